@@ -1,0 +1,128 @@
+"""Host-side mirror of the reference's analyser interface on top of the C ABI.
+
+One BatchAnalyser stands for `num_channels` AnalyserTrackControllers' analysis halves
+(ref AnalyserTrackController.h:199-206): per channel a RealTimeSpectralAnalyser, a
+RealTimeHarmonicAnalyser and the AudioFeatures they write.  Method names follow the reference
+(RealTimeAnalyser.h:111-114, :244-258; AudioDataCollector.h:124).
+"""
+import ctypes
+
+import numpy as np
+
+from . import capi
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class BatchAnalyser:
+    def __init__(self, num_channels, window_size=2048, sample_rate=48000.0, device=0,
+                 order=capi.ORDER_SPECTRAL_THEN_HARMONIC):
+        self._lib = capi.load_library()
+        self.num_channels = int(num_channels)
+        self.window_size = int(window_size)
+        self.device = int(device)
+        h = ctypes.c_void_p()
+        capi.check(self._lib.fx_create(ctypes.byref(h), self.device, self.num_channels, self.window_size,
+                                       float(sample_rate), int(order)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference setters ----
+    def sample_rate_changed(self, sr):                       # RealTimeAnalyser::sampleRateChanged
+        capi.check(self._lib.fx_set_sample_rate(self._h, float(sr)))
+
+    def set_onset_detection_sensitivity(self, s):            # RealTimeAnalyser.h:244
+        capi.check(self._lib.fx_set_onset_sensitivity(self._h, float(s)))
+
+    def set_onset_window_length(self, n):                    # RealTimeAnalyser.h:250
+        capi.check(self._lib.fx_set_onset_window(self._h, int(n)))
+
+    def set_onset_detection_type(self, t):                   # RealTimeAnalyser.h:258
+        capi.check(self._lib.fx_set_onset_type(self._h, int(t)))
+
+    def set_gain(self, g):                                   # AudioDataCollector::setGain
+        capi.check(self._lib.fx_set_gain(self._h, float(g)))
+
+    def reset_state(self):
+        capi.check(self._lib.fx_reset_state(self._h))
+
+    def sync(self):
+        capi.check(self._lib.fx_sync(self._h))
+
+    def last_kernel_ms(self):
+        a, b = ctypes.c_float(), ctypes.c_float()
+        capi.check(self._lib.fx_last_kernel_ms(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
+
+    def stream(self):
+        s = ctypes.c_void_p()
+        capi.check(self._lib.fx_get_stream(self._h, ctypes.byref(s)))
+        return s.value
+
+    # ---- analysis ----
+    def _run(self, fn, x, per_frame, want_raw, want_smoothed, out_raw=None, out_smoothed=None):
+        C = self.num_channels
+        if _is_torch(x):
+            import torch
+            if not x.is_cuda:
+                raise ValueError("torch input must live on the GPU (use numpy for host buffers)")
+            if not x.is_contiguous():
+                raise ValueError("device input must be contiguous")
+            if x.dtype == torch.float32:
+                fmt = capi.SAMPLE_F32
+            elif x.dtype == torch.float16:
+                fmt = capi.SAMPLE_F16
+            else:
+                raise ValueError("samples must be float32 or float16")
+            if x.numel() % (C * per_frame):
+                raise ValueError("input size is not a multiple of channels x samples per frame")
+            T = x.numel() // (C * per_frame)
+            raw = out_raw if out_raw is not None else (torch.empty((C, T, 12), dtype=torch.float32, device=x.device) if want_raw else None)
+            sm = out_smoothed if out_smoothed is not None else (torch.empty((C, T, 12), dtype=torch.float32, device=x.device) if want_smoothed else None)
+            # order our stream after the producer of x on torch's current stream
+            torch.cuda.current_stream(x.device).synchronize()
+            capi.check(fn(self._h, ctypes.c_void_p(x.data_ptr()), T, fmt, capi.MEM_DEVICE,
+                          ctypes.c_void_p(raw.data_ptr()) if raw is not None else None,
+                          ctypes.c_void_p(sm.data_ptr()) if sm is not None else None))
+            return raw, sm
+        x = np.ascontiguousarray(x)
+        if x.dtype == np.float16:
+            fmt = capi.SAMPLE_F16
+        else:
+            x = np.ascontiguousarray(x, np.float32)
+            fmt = capi.SAMPLE_F32
+        if x.size % (C * per_frame):
+            raise ValueError("input size is not a multiple of channels x samples per frame")
+        T = x.size // (C * per_frame)
+        raw = np.empty((C, T, 12), np.float32) if want_raw else None
+        sm = np.empty((C, T, 12), np.float32) if want_smoothed else None
+        capi.check(fn(self._h, x.ctypes.data_as(ctypes.c_void_p), T, fmt, capi.MEM_HOST,
+                      raw.ctypes.data_as(ctypes.c_void_p) if raw is not None else None,
+                      sm.ctypes.data_as(ctypes.c_void_p) if sm is not None else None))
+        return raw, sm
+
+    def push_hops(self, hops, want_raw=True, want_smoothed=True, out_raw=None, out_smoothed=None):
+        """hops [C][T][N/2] -> (raw [C][T][12], smoothed [C][T][12])."""
+        return self._run(self._lib.fx_push_hops, hops, self.window_size // 2, want_raw, want_smoothed, out_raw, out_smoothed)
+
+    def process_frames(self, frames, want_raw=True, want_smoothed=True, out_raw=None, out_smoothed=None):
+        """frames [C][T][N] -> (raw [C][T][12], smoothed [C][T][12])."""
+        return self._run(self._lib.fx_process_frames, frames, self.window_size, want_raw, want_smoothed, out_raw, out_smoothed)
+
+    def get_features(self):
+        """Latest AudioFeatures::getValue of every slot, [C][12] (host)."""
+        out = np.empty((self.num_channels, 12), np.float32)
+        capi.check(self._lib.fx_get_smoothed(self._h, out.ctypes.data_as(ctypes.c_void_p), capi.MEM_HOST))
+        return out

@@ -1,0 +1,103 @@
+"""ctypes binding of include/fx.h (libfx_hip.so)."""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+NUM_FEATURES = 12
+(ONSET, RMS, F0, CENTROID, SPREAD, FLATNESS, LER, FLUX, SLOPE, HER, OER, INHARM) = range(12)
+FEATURE_NAMES = ["onset", "rms", "f0", "centroid", "spread", "flatness", "ler", "flux",
+                 "slope", "her", "oer", "inharm"]
+ONSET_SPECTRAL, ONSET_AMPLITUDE, ONSET_COMBINATION = 0, 1, 2
+ORDER_SPECTRAL_THEN_HARMONIC, ORDER_HARMONIC_THEN_SPECTRAL, ORDER_ISOLATED = 0, 1, 2
+MEM_HOST, MEM_DEVICE = 0, 1
+SAMPLE_F32, SAMPLE_F16 = 0, 1
+FX_OK, FX_ERR_INVALID_ARGUMENT, FX_ERR_NO_DEVICE, FX_ERR_HIP, FX_ERR_OUT_OF_MEMORY, FX_ERR_UNSUPPORTED = range(6)
+
+# every symbol include/fx.h declares
+EXPORTS = ["fx_create", "fx_destroy", "fx_reset_state", "fx_set_sample_rate", "fx_set_onset_sensitivity",
+           "fx_set_onset_window", "fx_set_onset_type", "fx_set_gain", "fx_push_hops", "fx_process_frames",
+           "fx_get_smoothed", "fx_sync", "fx_get_stream", "fx_last_kernel_ms", "fx_pack_osc12",
+           "fx_pack_osc10", "fx_osc_encode", "fx_last_error", "fx_abi_version"]
+
+
+class FxError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("fx error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load_library(build_if_missing=True):
+    """Load libfx_hip.so; raises if it is missing and cannot be built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing:
+        _build.build()
+    if not os.path.exists(_build.LIB_PATH):
+        raise FxError(FX_ERR_UNSUPPORTED, "libfx_hip.so has not been built (run feature-extractor_amd/build.py)")
+    L = ctypes.CDLL(_build.LIB_PATH)
+    vp, fp, i, d, f, u = ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.c_double, ctypes.c_float, ctypes.c_uint
+    L.fx_create.argtypes = [ctypes.POINTER(vp), i, i, i, d, u]
+    L.fx_destroy.argtypes = [vp]
+    L.fx_reset_state.argtypes = [vp]
+    L.fx_set_sample_rate.argtypes = [vp, d]
+    L.fx_set_onset_sensitivity.argtypes = [vp, f]
+    L.fx_set_onset_window.argtypes = [vp, i]
+    L.fx_set_onset_type.argtypes = [vp, i]
+    L.fx_set_gain.argtypes = [vp, f]
+    L.fx_push_hops.argtypes = [vp, vp, i, i, i, vp, vp]
+    L.fx_process_frames.argtypes = [vp, vp, i, i, i, vp, vp]
+    L.fx_get_smoothed.argtypes = [vp, vp, i]
+    L.fx_sync.argtypes = [vp]
+    L.fx_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
+    L.fx_last_kernel_ms.argtypes = [vp, fp, fp]
+    L.fx_pack_osc12.argtypes = [fp, fp]
+    L.fx_pack_osc12.restype = None
+    L.fx_pack_osc10.argtypes = [fp, fp]
+    L.fx_pack_osc10.restype = None
+    L.fx_osc_encode.argtypes = [ctypes.c_char_p, fp, ctypes.POINTER(ctypes.c_ubyte), i]
+    L.fx_last_error.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != FX_OK:
+        raise FxError(status, load_library().fx_last_error().decode(errors="replace"))
+
+
+def _fp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def pack_osc12(features12):
+    v = np.ascontiguousarray(features12, np.float32)
+    out = np.empty(12, np.float32)
+    load_library().fx_pack_osc12(_fp(v), _fp(out))
+    return out
+
+
+def pack_osc10(features12):
+    v = np.ascontiguousarray(features12, np.float32)
+    out = np.empty(10, np.float32)
+    load_library().fx_pack_osc10(_fp(v), _fp(out))
+    return out
+
+
+def osc_encode(address, features12):
+    v = np.ascontiguousarray(features12, np.float32)
+    buf = (ctypes.c_ubyte * 512)()
+    n = load_library().fx_osc_encode(address.encode(), _fp(v), buf, 512)
+    if n < 0:
+        raise FxError(FX_ERR_INVALID_ARGUMENT, "OSC address too long")
+    return bytes(buf[:n])

@@ -1,0 +1,443 @@
+// fx_capi.cpp -- extern "C" shim declared in include/fx.h.  Host-side plumbing only: device
+// buffers, per-channel state residency in HBM, stream ordering, launch of the gfx950 kernels.
+// There is no CPU path: without a usable gfx950 device every entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fx_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+fx_status fail(fx_status code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP,          \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                        \
+    } while (0)
+
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+} // namespace
+
+struct fx_context {
+    int      device = 0;
+    int      C = 0, N = 0;
+    double   sample_rate = 48000.0;
+    unsigned flags = 0;
+    // settings (ref RealTimeAnalyser.h:244-258, SpectralCharacteristics.h:237-241,311, AudioDataCollector.h:129)
+    float    gain = 1.0f;
+    int      onset_window = 5;
+    int      onset_type = FX_ONSET_AMPLITUDE;
+    float    onset_multiplier = 1.7f;
+    long long frames_seen = 0;
+    long long onset_reset_frame = 0;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t  ev[3] = {nullptr, nullptr, nullptr};
+    bool        ev_valid = false;
+
+    float* d_tw = nullptr;        // [N][2]
+    float* d_prev = nullptr;      // [C][N/2]
+    float* d_tail[2] = {nullptr, nullptr};   // [C][N/2], ping-pong
+    float* d_hist[2] = {nullptr, nullptr};   // [C][HLEN][12], ping-pong
+    float* d_latest = nullptr;    // [C][12]
+    int    cur = 0;
+
+    float* d_raw = nullptr;       // [C][T_cap][12]
+    void*  d_in = nullptr;        // staging for host input
+    float* d_out_raw = nullptr;   // staging for host output
+    float* d_out_sm = nullptr;
+    size_t raw_cap = 0, in_cap = 0, out_cap = 0;
+
+    double bin_var = 0.0;
+    float  lpf_a = 0.0f, lpf_b = 0.0f;
+};
+
+namespace {
+
+fx_status zero_state(fx_context* c)
+{
+    const size_t half = (size_t) c->C * (c->N / 2);
+    HIP_TRY(hipMemsetAsync(c->d_prev, 0, half * sizeof(float), c->stream));
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipMemsetAsync(c->d_tail[i], 0, half * sizeof(float), c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_hist[i], 0, (size_t) c->C * fxk::HLEN * FX_NUM_FEATURES * sizeof(float), c->stream));
+    }
+    HIP_TRY(hipMemsetAsync(c->d_latest, 0, (size_t) c->C * FX_NUM_FEATURES * sizeof(float), c->stream));
+    c->frames_seen = 0;
+    c->onset_reset_frame = 0;
+    return FX_OK;
+}
+
+template <typename T> fx_status grow(T** ptr, size_t* cap, size_t need)
+{
+    if (need <= *cap) return FX_OK;
+    if (*ptr) HIP_TRY(hipFree(*ptr));
+    *ptr = nullptr;
+    *cap = 0;
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, need));
+    *ptr = static_cast<T*>(p);
+    *cap = need;
+    return FX_OK;
+}
+
+fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_kind, int hop_mode,
+              float* out_raw, float* out_smoothed)
+{
+    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (T < 0) return fail(FX_ERR_INVALID_ARGUMENT, "negative frame count");
+    if (T == 0) return FX_OK;
+    if (!in) return fail(FX_ERR_INVALID_ARGUMENT, "null input buffer");
+    if (sample_format != FX_SAMPLE_F32 && sample_format != FX_SAMPLE_F16)
+        return fail(FX_ERR_INVALID_ARGUMENT, "unknown sample format %d", sample_format);
+    if (mem_kind != FX_MEM_HOST && mem_kind != FX_MEM_DEVICE)
+        return fail(FX_ERR_INVALID_ARGUMENT, "unknown memory kind %d", mem_kind);
+    HIP_TRY(hipSetDevice(c->device));
+
+    const size_t esz = sample_format == FX_SAMPLE_F16 ? 2 : 4;
+    const size_t per_frame = hop_mode ? (size_t) c->N / 2 : (size_t) c->N;
+    const size_t in_bytes = (size_t) c->C * T * per_frame * esz;
+    const size_t out_elems = (size_t) c->C * T * FX_NUM_FEATURES;
+
+    fx_status st;
+    const size_t raw_bytes = out_elems * sizeof(float);
+    if ((st = grow(&c->d_raw, &c->raw_cap, raw_bytes)) != FX_OK) return st;
+
+    const void* d_in = in;
+    float* d_or = out_raw;
+    float* d_os = out_smoothed;
+    if (mem_kind == FX_MEM_HOST) {
+        if ((st = grow(reinterpret_cast<unsigned char**>(&c->d_in), &c->in_cap, in_bytes)) != FX_OK) return st;
+        if (out_raw || out_smoothed) {
+            // one allocation, two halves
+            if (2 * raw_bytes > c->out_cap) {
+                if (c->d_out_raw) HIP_TRY(hipFree(c->d_out_raw));
+                c->d_out_raw = nullptr; c->out_cap = 0;
+                void* p = nullptr;
+                HIP_TRY(hipMalloc(&p, 2 * raw_bytes));
+                c->d_out_raw = static_cast<float*>(p);
+                c->out_cap = 2 * raw_bytes;
+            }
+            c->d_out_sm = c->d_out_raw + out_elems;
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_in, in, in_bytes, hipMemcpyHostToDevice, c->stream));
+        d_in = c->d_in;
+        d_or = out_raw ? c->d_out_raw : nullptr;
+        d_os = out_smoothed ? c->d_out_sm : nullptr;
+    } else {
+        if (reinterpret_cast<uintptr_t>(in) % 16 != 0)
+            return fail(FX_ERR_INVALID_ARGUMENT, "device input must be 16-byte aligned");
+    }
+
+    fxk::FrameParams fp;
+    fp.in = d_in;
+    fp.sample_format = sample_format;
+    fp.hop_mode = hop_mode;
+    fp.T = T;
+    fp.C = c->C;
+    fp.gain = c->gain;
+    fp.tail_in = c->d_tail[c->cur];
+    fp.tail_out = c->d_tail[c->cur ^ 1];
+    fp.prev_re = c->d_prev;
+    fp.tw = c->d_tw;
+    fp.raw = c->d_raw;
+    fp.nyquist = c->sample_rate / 2.0;          // ref RealTimeAudioAnalysis.h:251, RealTimeAnalyser.h:113
+    fp.bin_var = c->bin_var;
+    fp.lpf_a = c->lpf_a;
+    fp.lpf_b = c->lpf_b;
+
+    int waves = T < 4 ? T : 4;
+    while (waves > 1 && fxk::frame_kernel_lds_bytes(c->N, waves) > 160 * 1024) waves--;
+    if (fxk::frame_kernel_lds_bytes(c->N, waves) > 160 * 1024)
+        return fail(FX_ERR_UNSUPPORTED, "window size %d does not fit the LDS", c->N);
+
+    fxk::EpilogueParams ep;
+    ep.raw = c->d_raw;
+    ep.hist_in = c->d_hist[c->cur];
+    ep.hist_out = c->d_hist[c->cur ^ 1];
+    ep.out_raw = d_or;
+    ep.out_smoothed = d_os;
+    ep.latest = c->d_latest;
+    ep.C = c->C;
+    ep.T = T;
+    ep.frames_before = c->frames_seen;
+    ep.onset_reset_frame = c->onset_reset_frame;
+    ep.onset_window = c->onset_window;
+    ep.onset_type = c->onset_type;
+    ep.onset_multiplier = c->onset_multiplier;
+    ep.order_mode = (int) (c->flags & FX_ORDER_MASK);
+
+    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    HIP_TRY(fxk::launch_frame_kernel(c->N, fp, waves, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(fxk::launch_epilogue_kernels(ep, c->stream));
+    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
+    c->ev_valid = true;
+    c->cur ^= 1;
+    c->frames_seen += T;
+
+    if (mem_kind == FX_MEM_HOST) {
+        if (out_raw) HIP_TRY(hipMemcpyAsync(out_raw, c->d_out_raw, raw_bytes, hipMemcpyDeviceToHost, c->stream));
+        if (out_smoothed) HIP_TRY(hipMemcpyAsync(out_smoothed, c->d_out_sm, raw_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return FX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int fx_abi_version(void) { return FX_ABI_VERSION; }
+const char* fx_last_error(void) { return g_err.c_str(); }
+
+fx_status fx_create(fx_context** out, int device_id, int num_channels, int window_size, double sample_rate, unsigned flags)
+{
+    if (!out) return fail(FX_ERR_INVALID_ARGUMENT, "null output pointer");
+    *out = nullptr;
+    if (num_channels <= 0) return fail(FX_ERR_INVALID_ARGUMENT, "num_channels must be positive");
+    if (!is_pow2(window_size) || window_size < 256 || window_size > 4096)
+        return fail(FX_ERR_INVALID_ARGUMENT, "window_size must be a power of two in [256, 4096], got %d", window_size);
+    if (!(sample_rate > 0.0)) return fail(FX_ERR_INVALID_ARGUMENT, "sample_rate must be positive");
+    if ((flags & FX_ORDER_MASK) == 3u || (flags & ~FX_ORDER_MASK)) return fail(FX_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", flags);
+
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void) hipGetLastError();
+        return fail(FX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    }
+    if (device_id < 0 || device_id >= count) return fail(FX_ERR_INVALID_ARGUMENT, "device_id %d out of range [0,%d)", device_id, count);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(FX_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device_id, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device_id));
+
+    fx_context* c = new (std::nothrow) fx_context();
+    if (!c) return fail(FX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    c->device = device_id;
+    c->C = num_channels;
+    c->N = window_size;
+    c->sample_rate = sample_rate;
+    c->flags = flags;
+
+    fx_status st = FX_OK;
+    auto cleanup = [&](fx_status s) { fx_destroy(c); return s; };
+    {
+        hipError_t e = fxk::prepare_kernels(window_size);
+        if (e != hipSuccess) return cleanup(fail(FX_ERR_HIP, "kernel preparation failed: %s", hipGetErrorString(e)));
+    }
+#define TRY_OR_CLEAN(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return cleanup(fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
+    TRY_OR_CLEAN(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < 3; i++) TRY_OR_CLEAN(hipEventCreate(&c->ev[i]));
+    const size_t half = (size_t) num_channels * (window_size / 2);
+    TRY_OR_CLEAN(hipMalloc((void**) &c->d_tw, sizeof(float) * 2 * window_size));
+    TRY_OR_CLEAN(hipMalloc((void**) &c->d_prev, sizeof(float) * half));
+    for (int i = 0; i < 2; i++) {
+        TRY_OR_CLEAN(hipMalloc((void**) &c->d_tail[i], sizeof(float) * half));
+        TRY_OR_CLEAN(hipMalloc((void**) &c->d_hist[i], sizeof(float) * (size_t) num_channels * fxk::HLEN * FX_NUM_FEATURES));
+    }
+    TRY_OR_CLEAN(hipMalloc((void**) &c->d_latest, sizeof(float) * (size_t) num_channels * FX_NUM_FEATURES));
+
+    // Twiddle table exactly as the reference's FFT builds it (JUCE 4.2 FFT::FFTConfig, SURVEY.md
+    // App. A.1): phase in double, entries rounded to float.  The inverse table is its conjugate.
+    {
+        std::vector<float> tw(2 * (size_t) window_size);
+        for (int i = 0; i < window_size; i++) {
+            const double phase = -2.0 * 3.14159265358979323846 * i / window_size;
+            tw[2 * i] = (float) std::cos(phase);
+            tw[2 * i + 1] = (float) std::sin(phase);
+        }
+        TRY_OR_CLEAN(hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    // ref SpectralCharacteristics.h:180-189: binVar does not depend on the signal
+    {
+        const int M = window_size / 2;
+        double bv = 0.0;
+        for (double i = 0.0; i < M; i++) {
+            const double ni = i / (double) M;
+            bv += (ni - 0.5) * (ni - 0.5);
+        }
+        c->bin_var = bv / (double) M;
+    }
+    // ref RealTimeAudioAnalysis.h:122,127: float_Pi / m and exp(-float_Pi / m), m = 2.0f, in fp32
+    {
+        const float float_pi = 3.14159265358979323846f;
+        c->lpf_a = float_pi / 2.0f;
+        c->lpf_b = std::exp(-float_pi / 2.0f);
+    }
+    if ((st = zero_state(c)) != FX_OK) return cleanup(st);
+    TRY_OR_CLEAN(hipStreamSynchronize(c->stream));
+#undef TRY_OR_CLEAN
+    *out = c;
+    return FX_OK;
+}
+
+fx_status fx_destroy(fx_context* c)
+{
+    if (!c) return FX_OK;
+    (void) hipSetDevice(c->device);
+    if (c->stream) (void) hipStreamSynchronize(c->stream);
+    void* bufs[] = {c->d_tw, c->d_prev, c->d_tail[0], c->d_tail[1], c->d_hist[0], c->d_hist[1], c->d_latest,
+                    c->d_raw, c->d_in, c->d_out_raw};
+    for (void* b : bufs) if (b) (void) hipFree(b);
+    for (int i = 0; i < 3; i++) if (c->ev[i]) (void) hipEventDestroy(c->ev[i]);
+    if (c->stream) (void) hipStreamDestroy(c->stream);
+    delete c;
+    return FX_OK;
+}
+
+fx_status fx_reset_state(fx_context* c)
+{
+    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    return zero_state(c);
+}
+
+fx_status fx_set_sample_rate(fx_context* c, double sr)
+{
+    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (!(sr > 0.0)) return fail(FX_ERR_INVALID_ARGUMENT, "sample_rate must be positive");
+    c->sample_rate = sr;
+    return FX_OK;
+}
+
+fx_status fx_set_onset_sensitivity(fx_context* c, float s)
+{
+    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (!(s >= 0.0f)) return fail(FX_ERR_INVALID_ARGUMENT, "sensitivity must be >= 0");   // jassert, RealTimeAnalyser.h:246
+    c->onset_multiplier = 1.0f + s;
+    return FX_OK;
+}
+
+fx_status fx_set_onset_window(fx_context* c, int length)
+{
+    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (length < 1 || length > fxk::MAX_ONSET_WINDOW)
+        return fail(FX_ERR_INVALID_ARGUMENT, "onset window must be in [1,%d]", fxk::MAX_ONSET_WINDOW);
+    c->onset_window = length;
+    c->onset_reset_frame = c->frames_seen;      // both histories emptied, RealTimeAudioAnalysis.h:73-81
+    return FX_OK;
+}
+
+fx_status fx_set_onset_type(fx_context* c, int type)
+{
+    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (type < FX_ONSET_SPECTRAL || type > FX_ONSET_COMBINATION) return fail(FX_ERR_INVALID_ARGUMENT, "unknown onset type %d", type);
+    c->onset_type = type;
+    return FX_OK;
+}
+
+fx_status fx_set_gain(fx_context* c, float gain)
+{
+    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    c->gain = gain;
+    return FX_OK;
+}
+
+fx_status fx_push_hops(fx_context* c, const void* hops, int num_hops, int sample_format, int mem_kind,
+                       float* out_raw, float* out_smoothed)
+{
+    return run(c, hops, num_hops, sample_format, mem_kind, 1, out_raw, out_smoothed);
+}
+
+fx_status fx_process_frames(fx_context* c, const void* frames, int num_frames, int sample_format, int mem_kind,
+                            float* out_raw, float* out_smoothed)
+{
+    return run(c, frames, num_frames, sample_format, mem_kind, 0, out_raw, out_smoothed);
+}
+
+fx_status fx_get_smoothed(fx_context* c, float* out, int mem_kind)
+{
+    if (!c || !out) return fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t) c->C * FX_NUM_FEATURES * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(out, c->d_latest, bytes,
+                           mem_kind == FX_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    if (mem_kind != FX_MEM_DEVICE) HIP_TRY(hipStreamSynchronize(c->stream));
+    return FX_OK;
+}
+
+fx_status fx_sync(fx_context* c)
+{
+    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return FX_OK;
+}
+
+fx_status fx_get_stream(fx_context* c, void** stream)
+{
+    if (!c || !stream) return fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    *stream = (void*) c->stream;
+    return FX_OK;
+}
+
+fx_status fx_last_kernel_ms(fx_context* c, float* frame_ms, float* epi_ms)
+{
+    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (!c->ev_valid) return fail(FX_ERR_INVALID_ARGUMENT, "no analysis call has been made yet");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(c->ev[2]));
+    float a = 0.f, b = 0.f;
+    HIP_TRY(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+    if (frame_ms) *frame_ms = a;
+    if (epi_ms) *epi_ms = b;
+    return FX_OK;
+}
+
+// ---- OSC sink helpers (ref OSCFeatureAnalysisOutput.h:107, README.md:57) ----
+static const int k_osc12[12] = {FX_ONSET, FX_RMS, FX_F0, FX_CENTROID, FX_SLOPE, FX_SPREAD,
+                                FX_FLATNESS, FX_LER, FX_FLUX, FX_HER, FX_OER, FX_INHARM};
+static const int k_osc10[10] = {FX_ONSET, FX_RMS, FX_F0, FX_CENTROID, FX_SLOPE, FX_SPREAD,
+                                FX_FLATNESS, FX_FLUX, FX_HER, FX_INHARM};
+
+void fx_pack_osc12(const float* f, float* out) { for (int i = 0; i < 12; i++) out[i] = f[k_osc12[i]]; }
+void fx_pack_osc10(const float* f, float* out) { for (int i = 0; i < 10; i++) out[i] = f[k_osc10[i]]; }
+
+int fx_osc_encode(const char* address, const float* f, unsigned char* out, int cap)
+{
+    if (!address || !f || !out) return -1;
+    const int alen = (int) strlen(address);
+    const int apad = (alen + 4) & ~3;           // NUL-terminated, padded to a multiple of 4
+    const int tpad = 16;                        // ",ffffffffffff" + NUL -> 16
+    const int total = apad + tpad + 48;
+    if (total > cap) return -1;
+    memset(out, 0, (size_t) total);
+    memcpy(out, address, (size_t) alen);
+    memcpy(out + apad, ",ffffffffffff", 13);
+    unsigned char* p = out + apad + tpad;
+    for (int i = 0; i < 12; i++) {
+        unsigned int bits;
+        memcpy(&bits, &f[k_osc12[i]], 4);
+        p[0] = (unsigned char) (bits >> 24); p[1] = (unsigned char) (bits >> 16);
+        p[2] = (unsigned char) (bits >> 8);  p[3] = (unsigned char) bits;
+        p += 4;
+    }
+    return total;
+}
+
+} // extern "C"

@@ -1,0 +1,56 @@
+// fx_kernels.h -- launch interface between the C-ABI shim (fx_capi.cpp) and the gfx950 kernels.
+#ifndef FX_KERNELS_H
+#define FX_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include "../../include/fx.h"
+
+namespace fxk {
+
+// Number of past frames of raw feature values kept per channel so that smoothing (10-deep
+// ValueHistory) and onset detection (<= 32-deep histories of a 10-push RMS mean) of frame t can be
+// evaluated without any sequential state: 32 + 9 rounded up.
+constexpr int HLEN = 48;
+constexpr int MAX_ONSET_WINDOW = 32;
+
+struct FrameParams {
+    const void*  in;            // frames [C][T][N] or hops [C][T][N/2]
+    int          sample_format; // FX_SAMPLE_F32 / FX_SAMPLE_F16
+    int          hop_mode;      // 1: `in` holds hops, windows are assembled from tail + hops
+    int          T;             // frames (= hops) per channel in this call
+    int          C;
+    float        gain;          // hop mode only (ref AudioDataCollector.h:88)
+    const float* tail_in;       // [C][N/2] second half of the previous window (already gained)
+    float*       tail_out;      // [C][N/2]
+    float*       prev_re;       // [C][N/2] real parts of the last accepted spectral frame (flux state)
+    const float* tw;            // [N][2] forward twiddle table, (float)cos/sin of a double phase
+    float*       raw;           // [C][T][12] raw per-frame values (onset slot left 0)
+    double       nyquist;
+    double       bin_var;       // sum_i (i/M - 0.5)^2 / M, summed serially on the host (ref SpectralCharacteristics.h:182-189)
+    float        lpf_a, lpf_b;  // ref RealTimeAudioAnalysis.h:122
+};
+
+struct EpilogueParams {
+    const float* raw;           // [C][T][12] from the frame kernel
+    const float* hist_in;       // [C][HLEN][12] raw values of the HLEN frames before this call
+    float*       hist_out;      // [C][HLEN][12]
+    float*       out_raw;       // [C][T][12] or nullptr
+    float*       out_smoothed;  // [C][T][12] or nullptr
+    float*       latest;        // [C][12] smoothed values after the last frame
+    int          C, T;
+    long long    frames_before; // frames analysed since the last state reset, before this call
+    long long    onset_reset_frame; // global index of the first frame after the last onset-window reset
+    int          onset_window;  // history length of the OnsetDetector (default 5)
+    int          onset_type;
+    float        onset_multiplier;
+    int          order_mode;    // FX_ORDER_*
+};
+
+size_t frame_kernel_lds_bytes(int window_size, int waves);
+// Chooses waves per workgroup and launches; returns hipSuccess or the launch error.
+hipError_t launch_frame_kernel(int window_size, const FrameParams& p, int waves, hipStream_t stream);
+hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t stream);
+hipError_t prepare_kernels(int window_size);   // raises the dynamic-LDS limit once per process
+
+} // namespace fxk
+#endif

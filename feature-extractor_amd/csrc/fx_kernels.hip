@@ -1,0 +1,1103 @@
+// fx_kernels.hip -- gfx950 (MI355X / CDNA4) kernels for the per-frame audio feature path
+//   RealTimeAnalyser -> SpectralCharacteristics / HarmonicCharacteristics / PitchAnalyser
+// of SeanSoraghan/Feature-Extractor.  "ref:" citations are relative to the reference's Source/.
+//
+// Mapping:
+//   * one workgroup per CHANNEL, K waves (64 lanes each); wave w analyses frames w, w+K, w+2K ...
+//     of its channel, so a whole analysis frame lives in ONE wavefront: no workgroup barriers
+//     inside a frame, only wave-local LDS exchanges.
+//   * the only frame-to-frame dependency on this path, the spectral-flux state
+//     (previousBinMagnitudes, ref SpectralCharacteristics.h:203), is handed from the wave of frame
+//     t-1 to the wave of frame t through LDS with a turn counter.
+//   * FFTs follow the exact rounding DAG of the reference's FFT (JUCE 4.2 kiss-style radix-4/2
+//     decimation in time, table twiddles, no fused multiply-add), executed as register-resident
+//     radix-16 / radix-8 / radix-4 passes over a padded LDS image, so spectra are bit-identical to
+//     the CPU path and every discrete decision downstream (pitch lag, peaks, onset) agrees.
+//   * reductions over bins run in fp64 with wavefront shuffles, as the reference accumulates in double.
+//   * smoothing (ValueHistory) + onset detection are sequential per channel and tiny: a second
+//     kernel runs them with one lane per channel.
+//
+// No MFMA: this is <=4096-point FFTs and reductions, not a dense contraction.
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "fx_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace fxk {
+
+typedef float  __attribute__((ext_vector_type(2))) f2;
+typedef float  __attribute__((ext_vector_type(4))) f4;
+
+__device__ __forceinline__ void wave_fence()
+{
+    // LDS operations of one wavefront execute in order; this only stops the compiler from moving
+    // LDS accesses of different lanes' data across the exchange point.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Re-materialise a lane-derived value so that nothing computed from it is hoisted out of the frame
+// loop (loop-invariant code motion would otherwise keep hundreds of addresses, window gains and
+// shuffle indices live across the whole loop and spill them).
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
+// ---------------------------------------------------------------------------------------------
+// wavefront reductions (all lanes receive the result)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ float wave_maxf(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS images
+//   complex image: position p at p + (p >> 4)            (one float2 of padding per 16)
+//   real image   : sample  n at n + 4 * (n >> 4)         (16 B of padding per 16 floats, keeps
+//                                                          16-byte alignment of 4-sample groups)
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int cpad(int p) { return p + (p >> 4); }
+__host__ __device__ constexpr int rpad(int n) { return n + ((n >> 4) << 2); }
+
+template <int N> struct Geo {
+    static constexpr int M      = N / 2;            // numMagnitudes (ref SpectralCharacteristics.h:104)
+    static constexpr int P      = N / 64;           // samples per lane
+    static constexpr int U      = M / 64;           // bins per lane
+    static constexpr int CBUF   = cpad(N) + 2;      // float2 elements
+    static constexpr int RBUF   = rpad(N) + 8;      // floats (holds N+1 values for the lag scan)
+    static constexpr int LOG2N  = (N == 256) ? 8 : (N == 512) ? 9 : (N == 1024) ? 10 : (N == 2048) ? 11 : 12;
+    static constexpr bool HAS_R2 = (LOG2N & 1) != 0;
+};
+
+// ---------------------------------------------------------------------------------------------
+// complex helpers -- separate multiplies and adds, never fused (ref FFT is plain a.r*b.r - a.i*b.i)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f2 cmul(f2 a, f2 b)
+{
+    const f2 p = f2{a.x, a.x} * b;                 // (a.r*b.r, a.r*b.i)
+    const f2 q = f2{a.y, a.y} * f2{b.y, b.x};      // (a.i*b.i, a.i*b.r)
+    return f2{p.x - q.x, p.y + q.y};
+}
+
+template <bool INV>
+__device__ __forceinline__ void bfly4(f2& d0, f2& d1, f2& d2, f2& d3, f2 t1, f2 t2, f2 t3, bool tw1, bool tw2, bool tw3)
+{
+    // JUCE FFT butterfly4; twX=false means the twiddle is exactly (1,0)
+    const f2 s0 = tw1 ? cmul(d1, t1) : d1;
+    const f2 s1 = tw2 ? cmul(d2, t2) : d2;
+    const f2 s2 = tw3 ? cmul(d3, t3) : d3;
+    const f2 s3 = s0 + s2;
+    const f2 s4 = s0 - s2;
+    const f2 s5 = d0 - s1;
+    f2 a = d0 + s1;
+    d2 = a - s3;
+    d0 = a + s3;
+    if (INV) {
+        d1 = f2{s5.x - s4.y, s5.y + s4.x};
+        d3 = f2{s5.x + s4.y, s5.y - s4.x};
+    } else {
+        d1 = f2{s5.x + s4.y, s5.y - s4.x};
+        d3 = f2{s5.x - s4.y, s5.y + s4.x};
+    }
+}
+
+__device__ __forceinline__ void bfly2(f2& d0, f2& d1, f2 t, bool tw)
+{
+    const f2 s = tw ? cmul(d1, t) : d1;
+    d1 = d0 - s;
+    d0 = d0 + s;
+}
+
+template <bool INV> __device__ __forceinline__ f2 twv(const f2* tw, int idx)
+{
+    const f2 t = tw[idx];
+    return INV ? f2{t.x, -t.y} : t;      // inverse table is the exact conjugate (cos even, sin odd)
+}
+
+// One stage over the R elements of an item.  Element i sits at position base + k + L0*i.
+//   RADIX : 2 or 4        LREL : (stage length) / L0        NTW = N / (RADIX * L0 * LREL)
+// Legs of one butterfly: i = jin + LREL*(q + RADIX*g), q = 0..RADIX-1; twiddle index (k + L0*jin)*NTW*q.
+template <int N, int R, int RADIX, int LREL, int L0, bool INV>
+__device__ __forceinline__ void stage(f2 (&e)[R], const f2* tw, int k)
+{
+    constexpr int NTW = N / (RADIX * L0 * LREL);
+    constexpr int GROUPS = R / (RADIX * LREL);
+#pragma unroll
+    for (int jin = 0; jin < LREL; jin++) {
+        const bool trivial = (L0 == 1) && (jin == 0);           // k == 0 whenever L0 == 1
+        const int kk = (L0 == 1) ? jin : (k + L0 * jin);
+        if (RADIX == 4) {
+            f2 t1 = f2{1.f, 0.f}, t2 = t1, t3 = t1;
+            if (!trivial) {
+                t1 = twv<INV>(tw, kk * NTW);
+                t2 = twv<INV>(tw, kk * NTW * 2);
+                t3 = twv<INV>(tw, kk * NTW * 3);
+            }
+#pragma unroll
+            for (int g = 0; g < GROUPS; g++) {
+                const int i0 = jin + LREL * (0 + 4 * g), i1 = jin + LREL * (1 + 4 * g);
+                const int i2 = jin + LREL * (2 + 4 * g), i3 = jin + LREL * (3 + 4 * g);
+                bfly4<INV>(e[i0], e[i1], e[i2], e[i3], t1, t2, t3, !trivial, !trivial, !trivial);
+            }
+        } else {
+            f2 t = f2{1.f, 0.f};
+            if (!trivial) t = twv<INV>(tw, kk * NTW);
+#pragma unroll
+            for (int g = 0; g < GROUPS; g++) {
+                const int i0 = jin + LREL * (0 + 2 * g), i1 = jin + LREL * (1 + 2 * g);
+                bfly2(e[i0], e[i1], t, !trivial);
+            }
+        }
+    }
+}
+
+// base-4 digit reversal of the low 2*DIGITS bits
+template <int DIGITS> __device__ __forceinline__ int rev4(int x)
+{
+    unsigned r = __builtin_bitreverse32((unsigned) x) >> (32 - 2 * DIGITS);
+    r = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+    return (int) r;
+}
+
+enum { WIN_NONE = 0, WIN_BARTLETT = 1 };
+
+// Bartlett gain, ref RealTimeAudioAnalysis.h:141-151: two JUCE gain ramps 0->1 and 1->0 whose
+// float accumulation is exact for power-of-two N: w[i] = 2i/N (i < N/2), 2 - 2i/N (i >= N/2).
+template <int N> __device__ __forceinline__ float bartlett_gain(int n)
+{
+    const float inc = 2.0f / N;
+    return n < N / 2 ? (float) n * inc : 1.0f - (float) (n - N / 2) * inc;
+}
+
+// A pass: every item of R elements is loaded, its 1 or 2 stages run in registers, and it is stored
+// back to the same positions.  FROM_REAL: first pass, reads the real input image through the
+// mixed-radix digit reversal (imag = 0) instead of the complex image.
+//   R = 16 : radix-4 at L0, radix-4 at 4*L0        R = 8 : radix-2 at L0 (=1), radix-4 at 2
+//   R = 4  : radix-4 at L0
+template <int N, int R, int L0, bool FROM_REAL, bool INV, int WIN>
+__device__ __forceinline__ void fft_pass(const float* rbuf, f2* cbuf, const f2* tw, int lane)
+{
+    lane = opaque(lane);
+    constexpr int ITEMS = N / R;
+    constexpr int R1 = (R == 8) ? 2 : 4;
+    for (int it = lane; it < ITEMS; it += 64) {
+        f2 e[R];
+        int k = 0, base = it * R;
+        if (L0 != 1) { k = it % L0; base = (it / L0) * (R * L0) + k; }
+        if (FROM_REAL) {
+            constexpr int IDIG = (Geo<N>::LOG2N - ((R == 8) ? 3 : 4)) / 2;    // base-4 digits of `it`
+            const int nlow = rev4<IDIG>(it);
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const int revj = (R == 8) ? ((j >> 1) + 4 * (j & 1)) : ((j >> 2) + 4 * (j & 3));
+                const int n = nlow + ITEMS * revj;
+                float x = rbuf[rpad(n)];
+                if (WIN == WIN_BARTLETT) x *= bartlett_gain<N>(n);
+                e[j] = f2{x, 0.0f};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < R; i++) e[i] = cbuf[cpad(base + L0 * i)];
+        }
+        stage<N, R, R1, 1, L0, INV>(e, tw, k);
+        if (R > R1) stage<N, R, 4, R1, L0, INV>(e, tw, k);
+#pragma unroll
+        for (int i = 0; i < R; i++) cbuf[cpad(base + L0 * i)] = e[i];
+    }
+    wave_fence();
+}
+
+// Whole transform of one wavefront: real image (N floats) -> complex image (N bins, natural order).
+// Same butterfly DAG as juce::FFT::perform for size N (factors 4,...,4[,2], outermost first).
+template <int N, bool INV, int WIN>
+__device__ __forceinline__ void fft_real_input(const float* rbuf, f2* cbuf, const f2* tw, int lane)
+{
+    if (N == 256) {
+        fft_pass<N, 16, 1,  true,  INV, WIN>(rbuf, cbuf, tw, lane);
+        fft_pass<N, 16, 16, false, INV, WIN>(rbuf, cbuf, tw, lane);
+    } else if (N == 512) {
+        fft_pass<N, 8,  1,   true,  INV, WIN>(rbuf, cbuf, tw, lane);
+        fft_pass<N, 16, 8,   false, INV, WIN>(rbuf, cbuf, tw, lane);
+        fft_pass<N, 4,  128, false, INV, WIN>(rbuf, cbuf, tw, lane);
+    } else if (N == 1024) {
+        fft_pass<N, 16, 1,   true,  INV, WIN>(rbuf, cbuf, tw, lane);
+        fft_pass<N, 16, 16,  false, INV, WIN>(rbuf, cbuf, tw, lane);
+        fft_pass<N, 4,  256, false, INV, WIN>(rbuf, cbuf, tw, lane);
+    } else if (N == 2048) {
+        fft_pass<N, 8,  1,   true,  INV, WIN>(rbuf, cbuf, tw, lane);
+        fft_pass<N, 16, 8,   false, INV, WIN>(rbuf, cbuf, tw, lane);
+        fft_pass<N, 16, 128, false, INV, WIN>(rbuf, cbuf, tw, lane);
+    } else {
+        fft_pass<N, 16, 1,   true,  INV, WIN>(rbuf, cbuf, tw, lane);
+        fft_pass<N, 16, 16,  false, INV, WIN>(rbuf, cbuf, tw, lane);
+        fft_pass<N, 16, 256, false, INV, WIN>(rbuf, cbuf, tw, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// frame load: global -> real LDS image, 16 B per lane, coalesced
+// ---------------------------------------------------------------------------------------------
+template <int HALF>
+__device__ __forceinline__ void load_half(const void* src, int sample_format, float gain, bool apply_gain,
+                                          float* rbuf, int dst_off, float* tail_out, int lane)
+{
+    // HALF is a multiple of 128 samples; 4 samples per lane per step
+    for (int i = lane * 4; i < HALF; i += 256) {
+        f4 v;
+        if (sample_format == FX_SAMPLE_F16) {
+            const uint2 raw = *reinterpret_cast<const uint2*>(static_cast<const __half*>(src) + i);
+            const __half2 a = *reinterpret_cast<const __half2*>(&raw.x);
+            const __half2 b = *reinterpret_cast<const __half2*>(&raw.y);
+            const float2 fa = __half22float2(a), fb = __half22float2(b);
+            v = f4{fa.x, fa.y, fb.x, fb.y};
+        } else {
+            v = *reinterpret_cast<const f4*>(static_cast<const float*>(src) + i);
+        }
+        if (apply_gain) v *= gain;                       // ref AudioDataCollector.h:88
+        *reinterpret_cast<f4*>(&rbuf[rpad(dst_off + i)]) = v;
+        if (tail_out) *reinterpret_cast<f4*>(tail_out + i) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the frame kernel
+// ---------------------------------------------------------------------------------------------
+struct FlatProd { double mant; int exp; };   // value = mant * 2^exp, mant in [0.5,1) (or 0)
+
+__device__ __forceinline__ FlatProd fp_mul(FlatProd a, double m)
+{
+    // multiply and renormalise; exact up to one rounding of the mantissa product
+    const double p = a.mant * m;
+    FlatProd r;
+    r.exp = a.exp + __builtin_amdgcn_frexp_exp(p);
+    r.mant = __builtin_amdgcn_frexp_mant(p);
+    return r;
+}
+__device__ __forceinline__ FlatProd fp_mul2(FlatProd a, FlatProd b)
+{
+    const double p = a.mant * b.mant;
+    FlatProd r;
+    r.exp = a.exp + b.exp + __builtin_amdgcn_frexp_exp(p);
+    r.mant = __builtin_amdgcn_frexp_mant(p);
+    return r;
+}
+
+// waves per SIMD the register allocator must leave room for (LDS bounds residency anyway)
+template <int N> struct Occ { static constexpr int WAVES_PER_SIMD = N <= 1024 ? 3 : (N == 2048 ? 2 : 1); };
+
+template <int N>
+__global__ void __launch_bounds__(256, Occ<N>::WAVES_PER_SIMD)
+fx_frame_kernel(const FrameParams p)
+{
+    typedef Geo<N> G;
+    constexpr int M = G::M, P = G::P, U = G::U, HALF = N / 2;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f2*    tw   = reinterpret_cast<f2*>(smem);                              // [N]
+    float* prev = reinterpret_cast<float*>(tw + N);                         // [M]  re of the last accepted frame
+    int*   turn = reinterpret_cast<int*>(prev + M);                         // [4]
+    unsigned char* per_wave = reinterpret_cast<unsigned char*>(turn + 4);
+    constexpr size_t WAVE_BYTES = sizeof(f2) * G::CBUF + sizeof(float) * G::RBUF;
+
+    const int nwaves = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6;
+    const int lane0 = threadIdx.x & 63;
+    const int c = blockIdx.x;
+    const int T = p.T;
+
+    f2*    cbuf = reinterpret_cast<f2*>(per_wave + WAVE_BYTES * wave);
+    float* rbuf = reinterpret_cast<float*>(cbuf + G::CBUF);
+
+    // workgroup prologue: twiddle table + this channel's flux state into LDS
+    for (int i = threadIdx.x; i < N; i += blockDim.x) tw[i] = reinterpret_cast<const f2*>(p.tw)[i];
+    for (int i = threadIdx.x; i < M; i += blockDim.x) prev[i] = p.prev_re[(size_t) c * M + i];
+    if (threadIdx.x == 0) turn[0] = 0;
+    __syncthreads();
+
+    const double nyquist = p.nyquist;
+    const double rnyq = 1.0 / nyquist;
+    const double frpb = nyquist / (double) M;          // ref SpectralCharacteristics.h:64,105
+    const float  scale = 1.0f / (float) N;             // JUCE inverse scale
+
+    for (int t = wave; t < T; t += nwaves) {
+        int lane = opaque(lane0);
+        float out[FX_NUM_FEATURES];
+#pragma unroll
+        for (int i = 0; i < FX_NUM_FEATURES; i++) out[i] = 0.0f;
+
+        // ---------------- a1: window assembly (ref RealTimeAudioAnalysis.h:205-219) ----------------
+        {
+            const size_t esz = p.sample_format == FX_SAMPLE_F16 ? 2 : 4;
+            const unsigned char* in = static_cast<const unsigned char*>(p.in);
+            float* tail_dst = (t == T - 1) ? p.tail_out + (size_t) c * HALF : nullptr;
+            if (p.hop_mode) {
+                if (t == 0) load_half<HALF>(p.tail_in + (size_t) c * HALF, FX_SAMPLE_F32, 1.0f, false, rbuf, 0, nullptr, lane);
+                else        load_half<HALF>(in + ((size_t) c * T + (t - 1)) * HALF * esz, p.sample_format, p.gain, true, rbuf, 0, nullptr, lane);
+                load_half<HALF>(in + ((size_t) c * T + t) * HALF * esz, p.sample_format, p.gain, true, rbuf, HALF, tail_dst, lane);
+            } else {
+                const unsigned char* f = in + ((size_t) c * T + t) * N * esz;
+                load_half<HALF>(f, p.sample_format, 1.0f, false, rbuf, 0, nullptr, lane);
+                load_half<HALF>(f + HALF * esz, p.sample_format, 1.0f, false, rbuf, HALF, tail_dst, lane);
+            }
+            wave_fence();
+        }
+
+        // ---------------- a2: RMS on the un-windowed frame (ref RealTimeAnalyser.h:207-208) ---------
+        float log_rms;
+        {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < P; i++) { const float x = rbuf[rpad(lane + 64 * i)]; s += (double) (x * x); }
+            s = wave_sum(s);
+            const float rms = (float) sqrt(s / (double) N);
+            log_rms = log10f(rms * 9.0f + 1.0f);
+            out[FX_RMS] = log_rms;
+        }
+
+        // ---------------- spectral analyser (ref RealTimeAnalyser.h:212-224) -----------------------
+        lane = opaque(lane);
+        fft_real_input<N, false, WIN_BARTLETT>(rbuf, cbuf, tw, lane);          // a3 + a4
+        {
+            // lane owns bins [U*lane, U*lane + U)
+            float re[U];
+            float maxabs = 0.0f;
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const f2 v = cbuf[cpad(U * lane + j)];
+                re[j] = v.x;
+                // ref SpectralCharacteristics.h:153: getMagnitude over the first M floats of the
+                // interleaved buffer = re and im of bins [0, M/2)
+                if (lane < 32) { maxabs = fmaxf(maxabs, fabsf(v.x)); maxabs = fmaxf(maxabs, fabsf(v.y)); }
+            }
+            const double eps = 0.01 * (double) log_rms;                        // :108
+            double mag_sum = 0.0, lhr = 0.0, wsum = 0.0, flat_sum = 0.0, max_mag = 0.0;
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < U; j++) {                                      // fillIntermediateValues :62-97
+                const int m = U * lane + j;
+                const double v = (double) re[j];
+                const double mag = v * v;
+                const double fc = (double) m * frpb + (frpb / 2.0);
+                mag_sum += mag;
+                if (m <= M / 5) lhr += mag;                                    // :86-87 (inclusive prefix)
+                if (mag > eps) { flat_sum += mag; cnt++; }
+                wsum += fc * mag;
+                max_mag = mag > max_mag ? mag : max_mag;
+            }
+            mag_sum = wave_sum(mag_sum);
+            lhr = wave_sum(lhr);
+            wsum = wave_sum(wsum);
+            flat_sum = wave_sum(flat_sum);
+            max_mag = wave_max(max_mag);
+            maxabs = wave_maxf(maxabs);
+            cnt = wave_sum_i(cnt);
+            const bool accepted = mag_sum > 0.05;                              // :121-123
+
+            // ---- flux against the previous accepted frame; hand-off between waves ----
+            double flux = 0.0;
+            {
+                while (__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t)
+                    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const double pv = (double) prev[U * lane + j];
+                    const double v = (double) re[j];
+                    const double diff = v * v - pv * pv;                       // :76
+                    if (diff > 0.0) flux += diff;                              // :77-79
+                    if (accepted) prev[U * lane + j] = re[j];                  // :138 (only on the accepted path)
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(turn, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            flux = wave_sum(flux);
+            const float max_flux = (float) (M * (M + 1)) / 2.0f;               // :111
+            flux /= (double) max_flux;
+
+            lane = opaque(lane);
+            // ---- flatness product: serial-order semantics of `magnitudeProduct *= binMagnitude` ----
+            // (ref :92) including IEEE overflow (sticky inf) and gradual underflow (sticky 0):
+            // exponent-extended prefix products locate the first prefix that leaves the normal
+            // range; an overflow decides at once, an underflow is finished serially in IEEE double.
+            double prod;
+            {
+                FlatProd loc = {0.5, 1};                                       // 1.0
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const double v = (double) re[j];
+                    const double mag = v * v;
+                    if (mag > eps) loc = fp_mul(loc, mag);
+                }
+                // exclusive scan of lane totals in lane (= bin) order
+                FlatProd inc = loc;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    FlatProd nb;
+                    nb.mant = __shfl_up(inc.mant, o, 64);
+                    nb.exp = __shfl_up(inc.exp, o, 64);
+                    if (lane >= o) inc = fp_mul2(nb, inc);
+                }
+                FlatProd exc;
+                exc.mant = __shfl_up(inc.mant, 1, 64);
+                exc.exp = __shfl_up(inc.exp, 1, 64);
+                if (lane == 0) { exc.mant = 0.5; exc.exp = 1; }
+                // replay the lane's chain from its true starting value, looking for the first prefix
+                // outside the normal range:  value = mant*2^exp with mant in [0.5,1)
+                //   overflow  : value >= 2^1024  <=> exp >= 1025
+                //   subnormal : value <  2^-1022 <=> exp <= -1022
+                int first_bad = 0x7fffffff;       // bin index of the first abnormal prefix
+                int bad_kind = 0;                 // 1 overflow, 2 subnormal
+                FlatProd run = exc;
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const double v = (double) re[j];
+                    const double mag = v * v;
+                    if (mag > eps) {
+                        run = fp_mul(run, mag);
+                        if (first_bad == 0x7fffffff && run.mant != 0.0) {
+                            if (run.exp >= 1025) { first_bad = U * lane + j; bad_kind = 1; }
+                            else if (run.exp <= -1022) { first_bad = U * lane + j; bad_kind = 2; }
+                        }
+                    }
+                }
+                const int fb = wave_min_i(first_bad);
+                const FlatProd total = {__shfl(inc.mant, 63, 64), __shfl(inc.exp, 63, 64)};
+                if (fb == 0x7fffffff) {
+                    prod = ldexp(total.mant, total.exp);
+                } else {
+                    // which lane owns bin fb, and what happened there
+                    const int owner = fb / U;
+                    const int kind = __shfl(bad_kind, owner, 64);
+                    if (kind == 1) {
+                        prod = __builtin_huge_val();                           // inf * positive finite stays inf
+                    } else {
+                        // value just before bin fb (normal), then IEEE double from fb onwards
+                        FlatProd before = exc;
+#pragma unroll
+                        for (int j = 0; j < U; j++) {
+                            const double v = (double) re[j];
+                            const double mag = v * v;
+                            if (mag > eps && (U * lane + j) < fb) before = fp_mul(before, mag);
+                        }
+                        const double start = ldexp(__shfl(before.mant, owner, 64), __shfl(before.exp, owner, 64));
+                        double pr = start;
+                        for (int m = fb; m < M; m++) {
+                            const double v = (double) cbuf[cpad(m)].x;
+                            const double mag = v * v;
+                            if (mag > eps) pr *= mag;
+                            if (pr == 0.0) break;                              // 0 * finite stays 0
+                        }
+                        prod = pr;
+                    }
+                }
+            }
+
+            if (accepted) {
+                // calculateSpectralCharacteristicsFromIntermediates :116-143
+                const float centroid = (float) (wsum / mag_sum);               // :127
+                const double dcnt = (double) cnt;
+                const double inv_n = 1.0 / (dcnt > 0.0 ? dcnt : 1.0);          // :129-130
+                const float flatness = flat_sum > eps ? (float) (pow(prod, inv_n) / (inv_n * flat_sum)) : 0.0f;
+                const float log_flat = (float) log10((double) flatness * 9.0 + 1.0);      // :132
+                const float cc = centroid / (float) (nyquist / 2.0);           // :133
+                const float log_centroid = log10f(cc * 9.0f + 1.0f);           // :134
+                const double cn = (double) centroid * rnyq;
+                double var = 0.0;
+#pragma unroll
+                for (int j = 0; j < U; j++) {                                  // :135-139
+                    const int m = U * lane + j;
+                    const double v = (double) re[j];
+                    const double mag = v * v;
+                    const double fc = (double) m * frpb + (frpb / 2.0);
+                    const double d = fc * rnyq - cn;
+                    var += (d * d) * mag;
+                }
+                var = wave_sum(var);
+                const double cn_exact = (double) centroid / nyquist;
+                const float max_spread = (float) (cn_exact * (1.0 - cn_exact)); // :140
+                const float spread = (float) ((var / mag_sum) / (double) max_spread);   // :141
+                out[FX_CENTROID] = log_centroid;
+                out[FX_SPREAD] = spread;
+                out[FX_FLATNESS] = log_flat;
+                out[FX_LER] = (float) (lhr / mag_sum);                         // :125
+                out[FX_FLUX] = (float) flux;
+            }
+
+            // ---- calculateNormalisedSpectralSlope (ref SpectralCharacteristics.h:145-200) ----
+            lane = opaque(lane);
+            {
+                double max_e = (double) maxabs;                                // :153
+                if (max_mag > max_e) max_e = max_mag;                          // :161-162
+                float slope = 0.0f;
+                if (max_e > 0.0001) {                                          // :165-167
+                    const double rmax = 1.0 / max_e;
+                    double se = 0.0, ps = 0.0;
+#pragma unroll
+                    for (int j = 0; j < U; j++) {
+                        const double v = (double) re[j];
+                        const double ne = (v * v) * rmax;
+                        se += ne;
+                        ps += (double) (U * lane + j) * ne;
+                    }
+                    se = wave_sum(se);
+                    ps = wave_sum(ps);
+                    const double mean_e = se / (double) M;
+                    double ev = 0.0;
+#pragma unroll
+                    for (int j = 0; j < U; j++) {
+                        const double v = (double) re[j];
+                        const double d = (v * v) * rmax - mean_e;
+                        ev += d * d;
+                    }
+                    ev = wave_sum(ev) / (double) M;
+                    const double bin_std = sqrt(p.bin_var), e_std = sqrt(ev);
+                    const double r = (ps - ((double) M * mean_e * 0.5)) / (double) ((float) M - 1.0f) * e_std * bin_std;   // :195
+                    slope = (float) (r * (bin_std / e_std));                   // :198
+                }
+                out[FX_SLOPE] = slope;
+            }
+        }
+        wave_fence();
+
+        // ---------------- harmonic analyser, part 1: raw (un-windowed) spectrum ---------------------
+        // ref RealTimeAnalyser.h:161 -- done before the low-pass overwrites the frame image
+        lane = opaque(lane);
+        fft_real_input<N, false, WIN_NONE>(rbuf, cbuf, tw, lane);
+        float hre[U];
+        float h_left2, h_left1, h_right1;          // |re| of bins U*lane-2, U*lane-1, U*lane+U
+        double h_sum = 0.0, h_max = 0.0;
+        {
+#pragma unroll
+            for (int j = 0; j < U; j++) {                                      // ref HarmonicCharacteristics.h:61-69
+                hre[j] = cbuf[cpad(U * lane + j)].x;
+                const double v = (double) hre[j];
+                const double mag = v * v;
+                h_sum += mag;
+                h_max = mag > h_max ? mag : h_max;
+            }
+            const int b0 = U * lane;
+            h_left2  = b0 >= 2 ? fabsf(cbuf[cpad(b0 - 2)].x) : 0.0f;
+            h_left1  = b0 >= 1 ? fabsf(cbuf[cpad(b0 - 1)].x) : 0.0f;
+            h_right1 = b0 + U < M ? fabsf(cbuf[cpad(b0 + U)].x) : 0.0f;
+            h_sum = wave_sum(h_sum);
+            h_max = wave_max(h_max);
+        }
+        wave_fence();
+
+        // ---------------- pitch: low-pass -> window -> FFT -> re^2 -> inverse FFT -> lag -------------
+        double f0;
+        lane = opaque(lane);
+        {
+            // a10 AudioFilter::filterAudio, ref RealTimeAudioAnalysis.h:106-125:
+            //   y[0] = x[0];  y[n] = (a*x[n]) + (b*y[n-1]) in fp32, strictly serial.
+            // Lane l owns samples [P*l, P*l+P).  It starts KW samples early from a guess, and the
+            // recurrence (|b| = 0.208) forgets the guess; the value it reaches at P*l-1 must be
+            // bit-identical to what lane l-1 produced there, otherwise the chunk is redone from the
+            // neighbour's value until every hand-over matches (exact by induction from lane 0).
+            constexpr int KW = 32;
+            const float a = p.lpf_a, b = p.lpf_b;
+            float x[P];
+#pragma unroll
+            for (int i = 0; i < P; i += 4) {
+                const f4 v = *reinterpret_cast<const f4*>(&rbuf[rpad(P * lane + i)]);
+                x[i] = v.x; x[i + 1] = v.y; x[i + 2] = v.z; x[i + 3] = v.w;
+            }
+            float yin;                                    // y[P*lane - 1] used as this chunk's input
+            {
+                const int first = P * lane;
+                int st = first - KW; if (st < 0) st = 0;
+                float y = rbuf[rpad(st)];                 // exact for st == 0, a guess otherwise
+                for (int n = st + 1; n < first; n++) y = (a * rbuf[rpad(n)]) + (b * y);
+                yin = y;
+            }
+            wave_fence();
+            float y[P];
+            float ylast;
+            {
+                float yy = yin;
+#pragma unroll
+                for (int i = 0; i < P; i++) {
+                    yy = (lane == 0 && i == 0) ? x[0] : (a * x[i]) + (b * yy);
+                    y[i] = yy;
+                }
+                ylast = yy;
+            }
+            for (int iter = 0; iter < 64; iter++) {
+                const float pe = __shfl_up(ylast, 1, 64);
+                const bool bad = lane > 0 && (__float_as_uint(pe) != __float_as_uint(yin));
+                if (!__any(bad)) break;
+                if (bad) {
+                    yin = pe;
+                    float yy = yin;
+#pragma unroll
+                    for (int i = 0; i < P; i++) { yy = (a * x[i]) + (b * yy); y[i] = yy; }
+                    ylast = yy;
+                }
+            }
+            // window the filtered frame (ref RealTimeAnalyser.h:157) and put it back in the real image
+            lane = opaque(lane);
+#pragma unroll
+            for (int i = 0; i < P; i += 4) {
+                f4 v;
+                v.x = y[i]     * bartlett_gain<N>(P * lane + i);
+                v.y = y[i + 1] * bartlett_gain<N>(P * lane + i + 1);
+                v.z = y[i + 2] * bartlett_gain<N>(P * lane + i + 2);
+                v.w = y[i + 3] * bartlett_gain<N>(P * lane + i + 3);
+                *reinterpret_cast<f4*>(&rbuf[rpad(P * lane + i)]) = v;
+            }
+            wave_fence();
+
+            fft_real_input<N, false, WIN_NONE>(rbuf, cbuf, tw, lane);          // ref RealTimeAnalyser.h:160
+            // a11 getComplexConjugateMultiplication, ref PitchAnalyser.h:83-108: re*re, imag := 0
+            lane = opaque(lane);
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                const int k = lane + 64 * i;
+                const float r = cbuf[cpad(k)].x;
+                rbuf[rpad(k)] = r * r;
+            }
+            wave_fence();
+            fft_real_input<N, true, WIN_NONE>(rbuf, cbuf, tw, lane);           // a12 inverse, ref :110-121
+            // v[s] = d[s]*d[s]*s, d = planar JUCE inverse output scaled by 1/N (ref :122-123).
+            // Only s in [1, N] is ever read by the lag search; v[N] comes from imag[0].
+            lane = opaque(lane);
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                const int s = lane + 64 * i;
+                const float d = cbuf[cpad(s)].x * scale;
+                rbuf[rpad(s)] = d * d * (float) s;
+            }
+            if (lane == 0) {
+                const float d = cbuf[cpad(0)].y * scale;
+                rbuf[rpad(N)] = d * d * (float) N;
+            }
+            wave_fence();
+            // a13 running fp32 sum, ref PitchAnalyser.h:138-150 -- serial by definition: one lane
+            float* sums = reinterpret_cast<float*>(cbuf);                      // complex image is free now
+            if (lane == 0) {
+                float sum = 0.0f;
+                for (int g = 0; g < N; g += 4) {
+                    const f4 v = *reinterpret_cast<const f4*>(&rbuf[rpad(g)]);
+                    f4 o;
+                    if (g != 0) sum += v.x;                                    // loop starts at sample 1
+                    o.x = sum;
+                    sum += v.y; o.y = sum;
+                    sum += v.z; o.z = sum;
+                    sum += v.w; o.w = sum;
+                    *reinterpret_cast<f4*>(&sums[rpad(g)]) = o;
+                }
+                sum += rbuf[rpad(N)];
+                sums[rpad(N)] = sum;
+            }
+            wave_fence();
+            // cnd[s] = sum != 0 ? v/sum : 0   (ref :146-154), written over v
+            lane = opaque(lane);
+            for (int s = lane; s <= N; s += 64) {
+                const float sm = sums[rpad(s)];
+                const float v = rbuf[rpad(s)];
+                rbuf[rpad(s)] = (sm != 0.0f) ? v / sm : 0.0f;
+            }
+            wave_fence();
+            // a14 getLagEstimateFromCumulativeDifference, ref PitchAnalyser.h:161-190
+            const float* cnd = rbuf;
+            lane = opaque(lane);
+            int first = 0x7fffffff;
+            for (int s = lane; s < N; s += 64)
+                if (s >= 2 && first == 0x7fffffff && cnd[rpad(s)] < 0.01f) first = s;
+            first = wave_min_i(first);
+            float lag;
+            if (first != 0x7fffffff) {
+                // walk right while cnd[s+1] < cnd[s] (ref :178-181), then :192-203 picks s or s+1
+                int stop = 0x7fffffff;
+                for (int s = lane; s < N; s += 64)
+                    if (s >= first && stop == 0x7fffffff && (s + 1 >= N || !(cnd[rpad(s + 1)] < cnd[rpad(s)]))) stop = s;
+                stop = wave_min_i(stop);
+                const int right = stop + 1;                                    // stop < N + 1 always
+                lag = (cnd[rpad(stop)] <= cnd[rpad(right)]) ? (float) stop : (float) right;
+            } else {
+                // global minimum, first occurrence (strict <, initial 100.0f), ref :171-175
+                float best = 100.0f; int best_i = 0x7fffffff;
+                for (int s = lane; s < N; s += 64) {
+                    const float v = cnd[rpad(s)];
+                    if (s >= 2 && v < best) { best = v; best_i = s; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(best, o, 64);
+                    const int oi = __shfl_xor(best_i, o, 64);
+                    if (ov < best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+                }
+                lag = best_i == 0x7fffffff ? -1.0f : (float) best_i;
+            }
+            f0 = (nyquist * 2.0) / (double) lag;                               // ref PitchAnalyser.h:57
+            out[FX_F0] = (float) (f0 / 5000.0);                                // ref RealTimeAnalyser.h:165-166
+        }
+        wave_fence();
+
+        // ---------------- harmonic analyser, part 2 (ref HarmonicCharacteristics.h:71-105) ----------
+        lane = opaque(lane);
+        if (!(h_sum < 0.005)) {                                                // :88-89
+            float* normed  = reinterpret_cast<float*>(cbuf);                   // [M] floats
+            int*   peaks   = reinterpret_cast<int*>(cbuf) + M;                 // [<= M] peak bins
+            float* peak_re = reinterpret_cast<float*>(cbuf) + 2 * M;           // [<= M] re of those bins
+            const double mean_mag = h_sum / (double) M;                        // :86
+            double sum_normed = 0.0;
+            unsigned peak_mask = 0;
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const double v = (double) hre[j];
+                const double mag = v * v;
+                const double nm = mag / h_max;                                 // :75
+                normed[U * lane + j] = (float) nm;
+                sum_normed += nm;
+                // binIsPeak :127-145: above the mean and none of bins -2,-1,+1 larger (windows are
+                // clipped at the ends, :136-138: no +1 neighbour for the last two bins).
+                // mag = (double) re^2 is exact, so comparing |re| compares magnitudes exactly.
+                const int m = U * lane + j;
+                const float me = fabsf(hre[j]);
+                const float l2 = j >= 2 ? fabsf(hre[j >= 2 ? j - 2 : 0]) : (j == 1 ? h_left1 : h_left2);
+                const float l1 = j >= 1 ? fabsf(hre[j >= 1 ? j - 1 : 0]) : h_left1;
+                const float r1 = j + 1 < U ? fabsf(hre[j + 1 < U ? j + 1 : 0]) : h_right1;
+                bool pk = mag > mean_mag;
+                if (m >= 2 && l2 > me) pk = false;
+                if (m >= 1 && l1 > me) pk = false;
+                if (m < M - 2 && r1 > me) pk = false;
+                if (pk) peak_mask |= 1u << j;
+            }
+            sum_normed = wave_sum(sum_normed);
+            // compact the peak list
+            const int npk_lane = __popc(peak_mask);
+            int pre = npk_lane;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(pre, o, 64); if (lane >= o) pre += v; }
+            const int total_peaks = __shfl(pre, 63, 64);
+            int woff = pre - npk_lane;
+#pragma unroll
+            for (int j = 0; j < U; j++)
+                if (peak_mask & (1u << j)) { peaks[woff] = U * lane + j; peak_re[woff] = hre[j]; woff++; }
+            wave_fence();
+
+            const double fr = nyquist / (double) M;                            // :93
+            const int f0_bin = (int) floor(f0 / fr);                           // getBinForFrequency :246-249
+            // calculateHarmonicEnergyCharacteristics :147-198 with numLower = 15, numHarmonics = 3:
+            // 18 probes, one lane each
+            double probe = 0.0;
+            {
+                int bin = -1;
+                if (lane < 15) {
+                    const double lf = f0 / (double) (2 << lane);               // f0 / pow(2, lane+1)
+                    bin = (int) floor(lf / fr);
+                    if (bin == f0_bin) bin = -1;                               // :163-164
+                } else if (lane < 18) {
+                    const double hf = f0 * (double) (lane - 14);
+                    bin = (int) floor(hf / fr);
+                    if (bin >= M) bin = -1;                                    // :174-175 (monotone, so break == skip)
+                }
+                if (bin >= 0 && bin < M) {
+                    // getMaxBinInNeighbourhood :200-210 : [max(0,c-2), min(c+2, M)), start value normed[c]
+                    const int s0 = bin - 2 >= 0 ? bin - 2 : 0;
+                    const int e0 = bin + 2 < M ? bin + 2 : M;
+                    float mx = normed[bin];
+                    for (int q = s0; q < e0; q++) { const float v = normed[q]; if (v > mx) mx = v; }
+                    probe = (double) mx;
+                }
+            }
+            const double score = wave_sum(probe);
+            double her = score / sum_normed;                                   // :186-188
+            if (her > 1.0) her = 1.0;
+            if (her < 0.0) her = 0.0;
+            const double her_f = (double) (float) her;                         // struct of floats, :197
+
+            // calculateInharmonicity :212-244
+            double inh = 0.0;
+            if (f0 > 0.0) {                                                    // :98
+                for (int i = lane; i < total_peaks; i += 64) {
+                    const int bin = peaks[i];
+                    if (bin == f0_bin) continue;                               // :220-221
+                    double fs = (double) bin * fr;
+                    if (fs == 0.0) fs = fr * 0.5;                              // :225-226
+                    const double fe = (double) (bin + 1) * fr;
+                    const double rs  = fs == f0 ? 1.0 : (fs > f0 ? fs / f0 : f0 / fs);   // getFrequencyRatio :251-259
+                    const double re_ = fe == f0 ? 1.0 : (fe > f0 ? fe / f0 : f0 / fe);
+                    if (floor(rs) != floor(re_)) continue;                     // :232-233
+                    const double r = rs < re_ ? rs : re_;
+                    const double v = (double) peak_re[i];
+                    inh += (r - floor(r)) * ((v * v) / h_sum);                 // :236-239
+                }
+            }
+            inh = wave_sum(inh);
+            const float log_her = (float) log10(her_f * 9.0 + 1.0);            // :101
+            out[FX_HER] = log_her;
+            out[FX_OER] = log_her;                                             // ref RealTimeAnalyser.h:171 writes HER into the OER slot
+            out[FX_INHARM] = (float) log10(inh * 9.0 + 1.0);                   // :102
+        }
+        wave_fence();
+
+        if (lane == 0) {
+            f4* dst = reinterpret_cast<f4*>(p.raw + ((size_t) c * T + t) * FX_NUM_FEATURES);
+            dst[0] = f4{out[0], out[1], out[2], out[3]};
+            dst[1] = f4{out[4], out[5], out[6], out[7]};
+            dst[2] = f4{out[8], out[9], out[10], out[11]};
+        }
+    }
+
+    __syncthreads();
+    for (int i = threadIdx.x; i < M; i += blockDim.x) p.prev_re[(size_t) c * M + i] = prev[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// smoothing (ValueHistory, ref RealTimeAudioAnalysis.h:40-96; AudioFeatures, ref
+// RealTimeAnalyser.h:70-88) and onset detection (ref SpectralCharacteristics.h:249-306,
+// RealTimeAnalyser.h:236-242).
+//
+// A ValueHistory of length L after its k-th insert holds the last min(k, L) inserted values,
+// oldest first, padded on the left with the zeros it was created with; getTotal() adds them left to
+// right in fp32.  Every smoothed value and every onset decision of frame t is therefore a pure
+// function of the raw values of frames t-HLEN+1 .. t, and all (channel, frame) pairs are evaluated
+// in parallel: thread = (channel, frame).  Frames before this call come from hist_in.
+// ---------------------------------------------------------------------------------------------
+struct RawView {
+    const float* raw; const float* hist; int T; long long frames_before;
+    // raw value of slot s at frame index tau relative to this call (tau may be negative);
+    // frames before the stream began read as "not recorded"
+    __device__ __forceinline__ bool valid(int tau) const { return frames_before + (long long) tau >= 0 && tau > -HLEN - 1; }
+    __device__ __forceinline__ float get(int tau, int s) const
+    {
+        return tau >= 0 ? raw[(size_t) tau * FX_NUM_FEATURES + s] : hist[(size_t) (HLEN + tau) * FX_NUM_FEATURES + s];
+    }
+};
+
+// smoothed RMS as AudioFeatures::getValue(enRMS) returns it when `pushes_after` of frame tau's
+// two RMS inserts have happened (shared AudioFeatures: two inserts per hop; isolated: one)
+__device__ __forceinline__ float rms_value(const RawView& v, int tau, int order_mode, int pushes_of_tau)
+{
+    float total = 0.0f;
+    long long recorded;
+    if (order_mode == FX_ORDER_ISOLATED) {
+        // spectral analyser's own AudioFeatures: one insert per frame, window = frames tau-9 .. tau
+#pragma unroll
+        for (int i = 0; i < 10; i++) { const int f = tau - 9 + i; total += v.valid(f) ? v.get(f, FX_RMS) : 0.0f; }
+        recorded = v.frames_before + tau + 1;
+    } else {
+        // inserts are numbered 2*g (first analyser of frame g) and 2*g+1; the newest insert present
+        // is 2*tau + pushes_of_tau - 1 and the history holds the 10 newest
+        const long long newest = 2 * (v.frames_before + tau) + pushes_of_tau - 1;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const long long q = newest - 9 + i;                     // global insert index
+            const long long g = q >> 1;                             // its frame (floor for q >= 0)
+            const int f = (int) (g - v.frames_before);
+            total += (q >= 0 && v.valid(f)) ? v.get(f, FX_RMS) : 0.0f;
+        }
+        recorded = newest + 1;
+    }
+    if (recorded > 10) recorded = 10;
+    return total / (float) recorded;
+}
+
+__global__ void __launch_bounds__(256)
+fx_epilogue_kernel(const EpilogueParams p)
+{
+    const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long) p.C * p.T) return;
+    const int c = (int) (idx / p.T), t = (int) (idx % p.T);
+    RawView v;
+    v.raw = p.raw + (size_t) c * p.T * FX_NUM_FEATURES;
+    v.hist = p.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES;
+    v.T = p.T;
+    v.frames_before = p.frames_before;
+
+    float sm[FX_NUM_FEATURES];
+    float rw[FX_NUM_FEATURES];
+#pragma unroll
+    for (int s = 0; s < FX_NUM_FEATURES; s++) rw[s] = v.get(t, s);
+
+    // 10-deep slots (ref RealTimeAnalyser.h:73)
+    long long rec10 = p.frames_before + t + 1; if (rec10 > 10) rec10 = 10;
+#pragma unroll
+    for (int s = 0; s < FX_NUM_FEATURES; s++) {
+        if (s == FX_ONSET || s == FX_FLUX || s == FX_RMS) continue;
+        float total = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 10; i++) { const int f = t - 9 + i; total += v.valid(f) ? v.get(f, s) : 0.0f; }
+        sm[s] = total / (float) rec10;
+    }
+    sm[FX_FLUX] = (0.0f + rw[FX_FLUX]) / 1.0f;                       // history length 1
+    // RMS after both analysers of this hop have inserted (what the OSC timer samples)
+    sm[FX_RMS] = rms_value(v, t, p.order_mode, 2);
+
+    // OnsetDetector::detectOnset, ref SpectralCharacteristics.h:249-306.  The detector's histories
+    // hold (getValue(enFlux), getValue(enRMS)) as seen by detectOnset() of each frame
+    // (ref RealTimeAnalyser.h:236-242): flux of that frame, and the RMS mean at that moment.
+    const int L = p.onset_window;
+    const int rms_pushes_at_detect = (p.order_mode == FX_ORDER_HARMONIC_THEN_SPECTRAL) ? 2 : 1;
+    const long long g = p.frames_before + t;
+    long long recorded = g - p.onset_reset_frame + 1;
+    if (recorded > L) recorded = L;
+    bool onset = false;
+    if (recorded >= L && L > 0) {                                   // :253-258 both histories full
+        int cand = L - 1;                                           // :263-266
+        const bool use_amp = p.onset_type == FX_ONSET_AMPLITUDE || p.onset_type == FX_ONSET_COMBINATION;
+        const bool use_flux = p.onset_type == FX_ONSET_SPECTRAL || p.onset_type == FX_ONSET_COMBINATION;
+        if (use_flux) cand = L / 2;
+        const float cand_amp = rms_value(v, t - L + 1 + cand, p.order_mode, rms_pushes_at_detect);
+        const float cand_sf = (0.0f + v.get(t - L + 1 + cand, FX_FLUX)) / 1.0f;
+        bool ok = !(cand_amp < 0.01f);                              // :271-274
+        float tot_amp = 0.0f, tot_flux = 0.0f;
+#pragma unroll 1
+        for (int i = 0; i < L; i++) {                               // :260-261 totals, :276-289 neighbours
+            const int f = t - L + 1 + i;
+            const float amp_i = rms_value(v, f, p.order_mode, rms_pushes_at_detect);
+            const float flx_i = (0.0f + v.get(f, FX_FLUX)) / 1.0f;
+            tot_amp += amp_i;
+            tot_flux += flx_i;
+            if (i != cand) {
+                if (amp_i >= cand_amp && use_amp) ok = false;
+                if (flx_i >= cand_sf && use_flux) ok = false;
+            }
+        }
+        const float mean_flux = tot_flux / (float) recorded;
+        const float mean_amp = tot_amp / (float) recorded;
+        const bool on_sf = cand_sf > mean_flux * p.onset_multiplier;    // :291-292
+        const bool on_amp = cand_amp > mean_amp * p.onset_multiplier;
+        bool res = false;
+        if (p.onset_type == FX_ONSET_AMPLITUDE) res = on_amp;
+        else if (p.onset_type == FX_ONSET_SPECTRAL) res = on_sf;
+        else if (p.onset_type == FX_ONSET_COMBINATION) res = on_amp && on_sf;
+        onset = ok && res;
+    }
+    rw[FX_ONSET] = onset ? 1.0f : 0.0f;
+    sm[FX_ONSET] = (0.0f + rw[FX_ONSET]) / 1.0f;                     // history length 1
+
+    const size_t o = ((size_t) c * p.T + t) * FX_NUM_FEATURES;
+    if (p.out_raw) {
+#pragma unroll
+        for (int s = 0; s < FX_NUM_FEATURES; s++) p.out_raw[o + s] = rw[s];
+    }
+    if (p.out_smoothed) {
+#pragma unroll
+        for (int s = 0; s < FX_NUM_FEATURES; s++) p.out_smoothed[o + s] = sm[s];
+    }
+    if (t == p.T - 1) {
+#pragma unroll
+        for (int s = 0; s < FX_NUM_FEATURES; s++) p.latest[(size_t) c * FX_NUM_FEATURES + s] = sm[s];
+    }
+}
+
+// carry the newest HLEN frames of raw values over to the next call
+__global__ void __launch_bounds__(256)
+fx_history_kernel(const EpilogueParams p)
+{
+    const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long) p.C * HLEN * FX_NUM_FEATURES;
+    if (idx >= total) return;
+    const int s = (int) (idx % FX_NUM_FEATURES);
+    const int h = (int) ((idx / FX_NUM_FEATURES) % HLEN);
+    const int c = (int) (idx / ((long long) FX_NUM_FEATURES * HLEN));
+    const int tau = p.T - HLEN + h;                                  // frame relative to this call
+    float val;
+    if (tau >= 0) val = p.raw[((size_t) c * p.T + tau) * FX_NUM_FEATURES + s];
+    else          val = p.hist_in[((size_t) c * HLEN + (HLEN + tau)) * FX_NUM_FEATURES + s];
+    p.hist_out[idx] = val;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+template <int N> static size_t lds_bytes_t(int waves)
+{
+    typedef Geo<N> G;
+    return sizeof(f2) * N + sizeof(float) * G::M + 16 + (size_t) waves * (sizeof(f2) * G::CBUF + sizeof(float) * G::RBUF);
+}
+
+size_t frame_kernel_lds_bytes(int n, int waves)
+{
+    switch (n) {
+        case 256:  return lds_bytes_t<256>(waves);
+        case 512:  return lds_bytes_t<512>(waves);
+        case 1024: return lds_bytes_t<1024>(waves);
+        case 2048: return lds_bytes_t<2048>(waves);
+        case 4096: return lds_bytes_t<4096>(waves);
+        default:   return 0;
+    }
+}
+
+template <int N> static hipError_t prepare_t()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+hipError_t prepare_kernels(int n)
+{
+    switch (n) {
+        case 256:  return prepare_t<256>();
+        case 512:  return prepare_t<512>();
+        case 1024: return prepare_t<1024>();
+        case 2048: return prepare_t<2048>();
+        case 4096: return prepare_t<4096>();
+        default:   return hipErrorInvalidValue;
+    }
+}
+
+template <int N> static hipError_t launch_t(const FrameParams& p, int waves, hipStream_t stream)
+{
+    const size_t lds = lds_bytes_t<N>(waves);
+    hipLaunchKernelGGL((fx_frame_kernel<N>), dim3((unsigned) p.C), dim3((unsigned) waves * 64), lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_frame_kernel(int n, const FrameParams& p, int waves, hipStream_t stream)
+{
+    if (p.C <= 0 || p.T <= 0) return hipSuccess;
+    switch (n) {
+        case 256:  return launch_t<256>(p, waves, stream);
+        case 512:  return launch_t<512>(p, waves, stream);
+        case 1024: return launch_t<1024>(p, waves, stream);
+        case 2048: return launch_t<2048>(p, waves, stream);
+        case 4096: return launch_t<4096>(p, waves, stream);
+        default:   return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t stream)
+{
+    if (p.C <= 0 || p.T <= 0) return hipSuccess;
+    const long long n1 = (long long) p.C * p.T;
+    hipLaunchKernelGGL(fx_epilogue_kernel, dim3((unsigned) ((n1 + 255) / 256)), dim3(256), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const long long n2 = (long long) p.C * HLEN * FX_NUM_FEATURES;
+    hipLaunchKernelGGL(fx_history_kernel, dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace fxk

@@ -1,0 +1,152 @@
+/*
+ * fx.h -- C ABI of libfx_hip.so: the MI355X (gfx950) implementation of the
+ * reference's per-frame audio feature path
+ *     RealTimeAnalyser -> SpectralCharacteristics / HarmonicCharacteristics /
+ *     PitchAnalyser  ->  AudioFeatures (12 floats)  ->  OSC feature message.
+ *
+ * The reference (SeanSoraghan/Feature-Extractor) has no FFI layer; the seam this
+ * library replaces is "analysis window in -> AudioFeatures::updateFeature out".
+ * Every entry point cites the reference interface it stands in for; paths are
+ * relative to the reference's Source/ directory.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an fx_status (0 = FX_OK) and
+ *     fx_last_error() returns a description of the last failure on this thread.
+ *   - a context analyses `num_channels` independent mono channels (one
+ *     AnalyserTrackController each, AnalyserTrackController.h:199-206) on ONE
+ *     GPU.  Calls on one context must be externally serialised.
+ *   - all work is enqueued on the context's HIP stream; fx_sync() waits for it.
+ *   - feature vectors use the AudioFeatures slot order (RealTimeAnalyser.h:19-30).
+ *   - numeric behaviour (NaN, inf, values > 1) is the reference's; nothing is
+ *     clamped or "fixed".
+ *   - there is NO CPU fallback: if no gfx950 device is usable every call fails
+ *     with FX_ERR_NO_DEVICE.
+ */
+#ifndef FX_H
+#define FX_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FX_ABI_VERSION 1
+
+typedef int fx_status;
+enum {
+    FX_OK = 0,
+    FX_ERR_INVALID_ARGUMENT = 1,
+    FX_ERR_NO_DEVICE = 2,
+    FX_ERR_HIP = 3,
+    FX_ERR_OUT_OF_MEMORY = 4,
+    FX_ERR_UNSUPPORTED = 5
+};
+
+/* AudioFeatures::eAudioFeature, RealTimeAnalyser.h:17-32 */
+enum {
+    FX_ONSET = 0, FX_RMS, FX_F0, FX_CENTROID, FX_SPREAD, FX_FLATNESS, FX_LER,
+    FX_FLUX, FX_SLOPE, FX_HER, FX_OER, FX_INHARM, FX_NUM_FEATURES
+};
+
+/* OnsetDetector::eOnsetDetectionType, SpectralCharacteristics.h:213-219 */
+enum { FX_ONSET_SPECTRAL = 0, FX_ONSET_AMPLITUDE = 1, FX_ONSET_COMBINATION = 2 };
+
+/* Where a caller buffer lives. */
+enum { FX_MEM_HOST = 0, FX_MEM_DEVICE = 1 };
+
+/* Sample formats accepted for audio input. */
+enum { FX_SAMPLE_F32 = 0, FX_SAMPLE_F16 = 1 };
+
+/* fx_create flags.  The first three fix the order in which the reference's two
+ * analysis threads write the ONE shared AudioFeatures object per hop
+ * (AnalyserTrackController.h:20-21; a data race in the reference):            */
+#define FX_ORDER_SPECTRAL_THEN_HARMONIC 0u   /* default */
+#define FX_ORDER_HARMONIC_THEN_SPECTRAL 1u
+#define FX_ORDER_ISOLATED               2u   /* one AudioFeatures per analyser */
+#define FX_ORDER_MASK                   3u
+
+typedef struct fx_context fx_context;
+
+/* Replaces the RealTimeSpectralAnalyser + RealTimeHarmonicAnalyser constructor
+ * pair, (AudioDataCollector&, AudioFeatures&, int windowSize, double sampleRate)
+ * -- RealTimeAnalyser.h:100,136,196 -- for `num_channels` channels at once.
+ * window_size: power of two in [256, 4096] (the collector ring is 4096,
+ * AudioDataCollector.h:24; the app uses 2048, AnalyserTrackController.h:20-21). */
+fx_status fx_create(fx_context** out, int device_id, int num_channels,
+                    int window_size, double sample_rate, unsigned flags);
+fx_status fx_destroy(fx_context* ctx);
+
+/* Zero overlap buffers, flux state and every ValueHistory (a freshly
+ * constructed AnalyserTrackController); settings are kept. */
+fx_status fx_reset_state(fx_context* ctx);
+
+/* RealTimeAnalyser::sampleRateChanged, RealTimeAnalyser.h:111-114 */
+fx_status fx_set_sample_rate(fx_context* ctx, double sample_rate);
+/* RealTimeSpectralAnalyser::setOnsetDetectionSensitivity, RealTimeAnalyser.h:244-248 */
+fx_status fx_set_onset_sensitivity(fx_context* ctx, float sensitivity);
+/* RealTimeSpectralAnalyser::setOnsetWindowLength, RealTimeAnalyser.h:250-254
+ * (both onset histories are emptied, as ValueHistory::setHistoryLength does);
+ * 1 <= length <= 32 (the GUI offers 3..21, AudioFeaturesListComponent.h:142-156) */
+fx_status fx_set_onset_window(fx_context* ctx, int length);
+/* RealTimeSpectralAnalyser::setOnsetDetectionType, RealTimeAnalyser.h:258 */
+fx_status fx_set_onset_type(fx_context* ctx, int type);
+/* AudioDataCollector::setGain, AudioDataCollector.h:124 (applied to hops only,
+ * as AudioDataCollector::getAnalysisBuffer does at :88) */
+fx_status fx_set_gain(fx_context* ctx, float gain);
+
+/* Replaces RealTimeAudioDataOverlapper::getNextBuffer (RealTimeAudioAnalysis.h:
+ * 205-228) + both run() loops (RealTimeAnalyser.h:141-177, :201-234) for
+ * `num_hops` consecutive hops of window_size/2 samples per channel.
+ *   hops         [num_channels][num_hops][window_size/2]  samples (sample_format)
+ *   out_raw      [num_channels][num_hops][12]  values passed to updateFeature,
+ *                or NULL
+ *   out_smoothed [num_channels][num_hops][12]  AudioFeatures::getValue of every
+ *                slot after each hop (RealTimeAnalyser.h:84-88), or NULL
+ * Buffers are caller-owned and, for FX_MEM_DEVICE, must stay valid until the
+ * stream reaches this call's work (fx_sync).  FX_MEM_HOST buffers are copied
+ * synchronously. */
+fx_status fx_push_hops(fx_context* ctx, const void* hops, int num_hops, int sample_format,
+                       int mem_kind, float* out_raw, float* out_smoothed);
+
+/* Same analysis on already assembled windows (the `audioWindow` each run()
+ * loop sees, RealTimeAnalyser.h:147,206): frames [num_channels][num_frames]
+ * [window_size].  Gain is not applied.  The overlap state is left holding the
+ * second half of each channel's last frame. */
+fx_status fx_process_frames(fx_context* ctx, const void* frames, int num_frames, int sample_format,
+                            int mem_kind, float* out_raw, float* out_smoothed);
+
+/* Latest AudioFeatures::getValue of every slot, [num_channels][12]
+ * (what OSCFeatureAnalysisOutput::sendSpectralFeaturesViaOSC samples,
+ * OSCFeatureAnalysisOutput.h:91-104). */
+fx_status fx_get_smoothed(fx_context* ctx, float* out, int mem_kind);
+
+/* Wait for all enqueued work of this context. */
+fx_status fx_sync(fx_context* ctx);
+
+/* The context's hipStream_t (as void*), so callers can order their own copies. */
+fx_status fx_get_stream(fx_context* ctx, void** stream);
+
+/* Device time of the analysis kernels of the most recent fx_push_hops /
+ * fx_process_frames call, measured with HIP events on the context's stream
+ * (milliseconds; synchronises). kernel 0 = frame kernel, 1 = smoothing/onset. */
+fx_status fx_last_kernel_ms(fx_context* ctx, float* frame_kernel_ms, float* epilogue_kernel_ms);
+
+/* ---- OSC sink helpers (host side, no GPU) ---- */
+/* Re-order one 12-slot vector into the wire order of
+ * sender.send(bundleAddress, onset, rms, f0, centroid, slope, spread, flatness,
+ * ler, flux, her, oer, inharm)  -- OSCFeatureAnalysisOutput.h:107 */
+void fx_pack_osc12(const float* features12, float* out12);
+/* README.md:57 order: onset, rms, f0, centroid, slope, spread, flatness, flux, her, inharm */
+void fx_pack_osc10(const float* features12, float* out10);
+/* Encode the OSC 1.0 message OSCSender::send(address, 12 floats) emits.
+ * Returns the byte count (76 for "/Audio/A0") or -1 if cap is too small. */
+int fx_osc_encode(const char* address, const float* features12, unsigned char* out, int cap);
+
+const char* fx_last_error(void);
+int fx_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FX_H */
