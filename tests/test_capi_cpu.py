@@ -1,0 +1,83 @@
+"""CPU-side checks of the C ABI: the library builds for gfx950, loads, exports every symbol
+include/fx.h declares, refuses to run without a GPU (no CPU fallback), and its host-only OSC helpers
+match the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_what_the_binding_expects(fx):
+    from importlib import import_module
+    capi = import_module("feature-extractor_amd.capi")
+    assert declared_symbols() == sorted(capi.EXPORTS)
+
+
+def test_library_builds_loads_and_exports_every_symbol(fx):
+    lib = fx.load_library()
+    assert os.path.exists(fx.library_path())
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.fx_abi_version() == 1
+
+
+def test_library_contains_gfx950_code(fx):
+    fx.load_library()
+    blob = open(fx.library_path(), "rb").read()
+    assert b"gfx950" in blob
+    assert b"fx_frame_kernel" in blob
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU error path")
+def test_no_cpu_fallback_without_device(fx):
+    with pytest.raises(fx.FxError) as e:
+        fx.BatchAnalyser(4, 1024)
+    assert e.value.code == 2                    # FX_ERR_NO_DEVICE
+
+
+def test_argument_validation_happens_before_device_use(fx):
+    lib = fx.load_library()
+    h = ctypes.c_void_p()
+    assert lib.fx_create(ctypes.byref(h), 0, 4, 1000, 48000.0, 0) == 1      # not a power of two
+    assert b"window_size" in lib.fx_last_error()
+    assert lib.fx_create(ctypes.byref(h), 0, 0, 1024, 48000.0, 0) == 1
+    assert lib.fx_create(ctypes.byref(h), 0, 4, 8192, 48000.0, 0) == 1
+    assert lib.fx_create(None, 0, 4, 1024, 48000.0, 0) == 1
+    assert lib.fx_push_hops(None, None, 1, 0, 0, None, None) == 1
+    assert lib.fx_sync(None) == 1
+
+
+def test_osc_helpers_match_oracle(fx, oracle):
+    v = np.random.default_rng(0).standard_normal(12).astype(np.float32)
+    assert fx.osc_encode("/Audio/A0", v) == oracle.osc_message("/Audio/A0", v)
+    assert len(fx.osc_encode("/Audio/A0", v)) == 76
+    assert fx.osc_encode("/Audio/A13", v) == oracle.osc_message("/Audio/A13", v)
+    o12 = fx.pack_osc12(v)
+    assert np.array_equal(o12, v[[0, 1, 2, 3, 8, 4, 5, 6, 7, 9, 10, 11]])
+    assert np.array_equal(fx.pack_osc10(v), v[[0, 1, 2, 3, 8, 4, 5, 7, 9, 11]])     # README.md:57 order
+
+
+def test_synth_is_deterministic_and_frames_match_hops(fx):
+    a = fx.synth.hops(3, 5, 1024, first_channel=7)
+    b = fx.synth.hops(3, 5, 1024, first_channel=7)
+    assert np.array_equal(a, b) and a.dtype == np.float32
+    c = fx.synth.hops(1, 5, 1024, first_channel=8)
+    assert np.array_equal(a[1], c[0])            # a channel's samples do not depend on the shard it is in
+    fr = fx.synth.frames(3, 5, 1024, first_channel=7)
+    assert np.array_equal(fr[:, 0, :512], np.zeros((3, 512), np.float32))
+    assert np.array_equal(fr[:, 2, :512], a[:, 1]) and np.array_equal(fr[:, 2, 512:], a[:, 2])

@@ -1,0 +1,216 @@
+"""GPU parity tests: the HIP path, called through the C ABI (include/fx.h), against the CPU oracle
+on the same inputs.  Bar: onset bit-exact; every other slot within 1e-5 relative (BASELINE.json
+north_star); NaN/inf must match exactly.  All tests here need a real MI355X."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import signals
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+SIZES = [256, 512, 1024, 2048, 4096]
+
+
+def close(got, want, what):
+    from oracle import fx_oracle as fo
+    return signals.assert_features_close(got, want, RTOL, fo.FEATURE_NAMES, what)
+
+
+@pytest.mark.parametrize("N", SIZES)
+@pytest.mark.parametrize("sig", sorted(signals.ALL))
+def test_hops_match_oracle(gpu_fx, oracle, sig, N):
+    C, T = 6, 14
+    hops = signals.ALL[sig](C, T, N)
+    an = gpu_fx.BatchAnalyser(C, N)
+    raw, sm = an.push_hops(hops)
+    oraw, osm = oracle.push_hops(hops, N)
+    close(raw, oraw, "%s N=%d raw" % (sig, N))
+    close(sm, osm, "%s N=%d smoothed" % (sig, N))
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p)[:-4] for p in GOLDEN])
+def test_committed_fixtures(gpu_fx, path):
+    g = np.load(path)
+    hops = g["hops"]
+    an = gpu_fx.BatchAnalyser(hops.shape[0], int(g["window_size"]), float(g["sample_rate"]), order=int(g["order"]))
+    raw, sm = an.push_hops(hops)
+    close(raw, g["raw"], "golden raw")
+    close(sm, g["smoothed"], "golden smoothed")
+
+
+@pytest.mark.parametrize("N", [1024, 2048])
+def test_preassembled_frames_match_oracle(gpu_fx, oracle, N):
+    frames = gpu_fx.synth.frames(5, 12, N, first_channel=3)
+    raw, sm = gpu_fx.BatchAnalyser(5, N).process_frames(frames)
+    oraw, osm = oracle.process_frames(frames, N)
+    close(raw, oraw, "frames raw")
+    close(sm, osm, "frames smoothed")
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_order_modes(gpu_fx, oracle, order):
+    hops = signals.bursts(4, 30, 1024, seed=21)
+    raw, sm = gpu_fx.BatchAnalyser(4, 1024, order=order).push_hops(hops)
+    oraw, osm = oracle.push_hops(hops, 1024, order=order)
+    close(raw, oraw, "order %d raw" % order)
+    close(sm, osm, "order %d smoothed" % order)
+
+
+@pytest.mark.parametrize("otype", [0, 1, 2])
+@pytest.mark.parametrize("window", [3, 5, 9, 21])
+def test_onset_settings(gpu_fx, oracle, otype, window):
+    hops = signals.bursts(6, 48, 1024, seed=100 + window)
+    an = gpu_fx.BatchAnalyser(6, 1024)
+    an.set_onset_detection_type(otype)
+    an.set_onset_window_length(window)
+    an.set_onset_detection_sensitivity(0.3)
+    raw, sm = an.push_hops(hops)
+    oraw, osm = oracle.push_hops(hops, 1024, onset_type=otype, onset_window=window, onset_sensitivity=0.3)
+    assert oraw[:, :, 0].sum() > 0 or otype == 2          # the case really contains onsets
+    close(raw, oraw, "onset raw")
+    close(sm, osm, "onset smoothed")
+
+
+def test_settings_changed_mid_stream(gpu_fx, oracle):
+    N, C = 1024, 3
+    hops = signals.bursts(C, 40, N, seed=33)
+    an = gpu_fx.BatchAnalyser(C, N)
+    chans = [oracle.Channel(N) for _ in range(C)]
+    got, want = [], []
+
+    def both(lo, hi):
+        got.append(an.push_hops(hops[:, lo:hi]))
+        want.append([ch.push_hops(hops[c, lo:hi]) for c, ch in enumerate(chans)])
+
+    both(0, 11)
+    an.set_onset_window_length(4)
+    an.set_gain(0.5)
+    [ch.set_onset_window(4) for ch in chans]
+    [ch.set_gain(0.5) for ch in chans]
+    both(11, 23)
+    an.set_onset_detection_type(0)
+    an.sample_rate_changed(44100.0)
+    [ch.set_onset_type(0) for ch in chans]
+    [ch.set_sample_rate(44100.0) for ch in chans]
+    both(23, 40)
+    for (raw, sm), w in zip(got, want):
+        close(raw, np.stack([x[0] for x in w]), "mid-stream raw")
+        close(sm, np.stack([x[1] for x in w]), "mid-stream smoothed")
+
+
+@pytest.mark.parametrize("N", [1024, 4096])
+def test_split_calls_equal_one_call_bitwise(gpu_fx, N):
+    C, T = 4, 21
+    hops = signals.bursts(C, T, N, seed=5)
+    one = gpu_fx.BatchAnalyser(C, N).push_hops(hops)
+    an = gpu_fx.BatchAnalyser(C, N)
+    parts = [an.push_hops(hops[:, a:b]) for a, b in ((0, 1), (1, 2), (2, 9), (9, 10), (10, 21))]
+    for k in (0, 1):
+        assert np.array_equal(np.concatenate([p[k] for p in parts], axis=1), one[k], equal_nan=True)
+    assert np.array_equal(an.get_features(), one[1][:, -1], equal_nan=True)
+
+
+def test_streaming_one_hop_per_call_matches_oracle(gpu_fx, oracle):
+    N, C, T = 2048, 3, 26
+    hops = signals.tone_vibrato_noise(C, T, N, seed=8)
+    an = gpu_fx.BatchAnalyser(C, N)
+    outs = [an.push_hops(hops[:, t:t + 1]) for t in range(T)]
+    oraw, osm = oracle.push_hops(hops, N)
+    close(np.concatenate([o[0] for o in outs], axis=1), oraw, "streaming raw")
+    close(np.concatenate([o[1] for o in outs], axis=1), osm, "streaming smoothed")
+
+
+def test_reset_state_restores_a_fresh_analyser(gpu_fx):
+    hops = signals.tone_vibrato_noise(2, 12, 1024)
+    an = gpu_fx.BatchAnalyser(2, 1024)
+    a = an.push_hops(hops)
+    an.push_hops(signals.loud_noise(2, 5, 1024))
+    an.reset_state()
+    b = an.push_hops(hops)
+    assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True)
+
+
+def test_fp16_samples(gpu_fx, oracle):
+    N, C, T = 4096, 2, 10                    # BASELINE config 5 shape: 4096-pt, fp16 samples
+    h16 = gpu_fx.synth.hops(C, T, N).astype(np.float16)
+    raw16, sm16 = gpu_fx.BatchAnalyser(C, N).push_hops(h16)
+    raw32, sm32 = gpu_fx.BatchAnalyser(C, N).push_hops(h16.astype(np.float32))
+    assert np.array_equal(raw16, raw32, equal_nan=True) and np.array_equal(sm16, sm32, equal_nan=True)
+    oraw, osm = oracle.push_hops(h16.astype(np.float32), N)
+    close(raw16, oraw, "fp16 raw")
+    close(sm16, osm, "fp16 smoothed")
+
+
+def test_device_buffers_equal_host_buffers(gpu_fx):
+    import torch
+    N, C, T = 1024, 8, 9
+    hops = gpu_fx.synth.hops(C, T, N)
+    host = gpu_fx.BatchAnalyser(C, N).push_hops(hops)
+    an = gpu_fx.BatchAnalyser(C, N)
+    d = torch.from_numpy(hops).cuda()
+    raw, sm = an.push_hops(d)
+    an.sync()
+    assert raw.is_cuda and np.array_equal(raw.cpu().numpy(), host[0], equal_nan=True)
+    assert np.array_equal(sm.cpu().numpy(), host[1], equal_nan=True)
+    fr = torch.from_numpy(gpu_fx.synth.frames(C, T, N)).cuda()
+    an2 = gpu_fx.BatchAnalyser(C, N)
+    raw2, sm2 = an2.process_frames(fr)
+    an2.sync()
+    assert np.array_equal(raw2.cpu().numpy(), host[0], equal_nan=True)      # frames of the same stream
+
+
+def test_error_paths(gpu_fx):
+    an = gpu_fx.BatchAnalyser(2, 1024)
+    with pytest.raises(gpu_fx.FxError):
+        an.set_onset_window_length(0)
+    with pytest.raises(gpu_fx.FxError):
+        an.set_onset_detection_type(7)
+    with pytest.raises(gpu_fx.FxError):
+        gpu_fx.BatchAnalyser(2, 1024, device=99)
+    raw, sm = an.push_hops(np.zeros((2, 0, 512), np.float32))       # empty input is a no-op
+    assert raw.shape == (2, 0, 12)
+
+
+def test_full_size_config_properties(gpu_fx, oracle):
+    """BASELINE configs[1] shape (1024 channels x 1024-pt frames): properties that do not need the
+    oracle at full size, plus an oracle spot check on a random subset of channels."""
+    N, C, T = 1024, 1024, 32
+    frames = gpu_fx.synth.frames(C, T, N)
+    an = gpu_fx.BatchAnalyser(C, N)
+    raw, sm = an.process_frames(frames)
+    # repeatable bit for bit
+    an.reset_state()
+    raw_b, sm_b = an.process_frames(frames)
+    assert np.array_equal(raw, raw_b, equal_nan=True) and np.array_equal(sm, sm_b, equal_nan=True)
+    # a channel's result does not depend on which shard / context it was analysed in
+    lo = gpu_fx.BatchAnalyser(C // 2, N).process_frames(frames[: C // 2])
+    hi = gpu_fx.BatchAnalyser(C // 2, N).process_frames(frames[C // 2:])
+    assert np.array_equal(np.concatenate([lo[0], hi[0]]), raw, equal_nan=True)
+    assert np.array_equal(np.concatenate([lo[1], hi[1]]), sm, equal_nan=True)
+    # channels 72 apart carry the same tone + different noise: f0 of the noiseless part agrees often,
+    # and OER is always a copy of HER
+    assert np.array_equal(raw[:, :, 10], raw[:, :, 9])
+    assert np.all(np.isfinite(raw[:, :, [1, 2, 3, 6, 7, 9, 11]]))
+    pick = np.random.default_rng(0).choice(C, 24, replace=False)
+    oraw, osm = oracle.process_frames(frames[pick], N)
+    close(raw[pick], oraw, "full-size spot check raw")
+    close(sm[pick], osm, "full-size spot check smoothed")
+
+
+def test_config3_shape_spot_check(gpu_fx, oracle):
+    """BASELINE configs[2]: 4096 channels x 2048-pt frames, flux state resident in HBM across calls."""
+    N, C, T = 2048, 4096, 6
+    an = gpu_fx.BatchAnalyser(C, N)
+    h1 = gpu_fx.synth.hops(C, T, N)
+    h2 = gpu_fx.synth.hops(C, T, N, first_hop=T)
+    a = an.push_hops(h1)
+    b = an.push_hops(h2)
+    pick = np.random.default_rng(1).choice(C, 12, replace=False)
+    oraw, osm = oracle.push_hops(np.concatenate([h1[pick], h2[pick]], axis=1), N)
+    close(np.concatenate([a[0][pick], b[0][pick]], axis=1), oraw, "config 3 raw")
+    close(np.concatenate([a[1][pick], b[1][pick]], axis=1), osm, "config 3 smoothed")
