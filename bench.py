@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the full 12-feature bundle on synthetic audio, per BASELINE.json.
+
+Workload at N=1 GPU: BASELINE.json configs[1] -- 1024 synthetic 48 kHz channels x 1024-pt fp32
+frames (50 % overlap, pre-assembled [C][T][1024], resident in HBM), the whole RealTimeAnalyser
+bundle (spectral + pitch + harmonic + RMS + smoothing + onset).  A "step" is one pass of the hot
+path over one batch of T consecutive frames per channel.  With N GPUs every rank analyses its own
+1024-channel shard (weak scaling; channels are independent, so there is no data-path collective)
+and the smoothed feature vectors are gathered to rank 0, the OSC sink, over RCCL.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(fx, window, frames_per_channel, seconds=12.0):
+    """The CPU oracle (a port of the reference's algorithm, oracle/fx_oracle.c) on this host's
+    cores, on a bounded sample of the same synthetic workload: one worker thread per core over
+    disjoint channel blocks, mirroring the reference's thread-pair-per-channel model."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import fx_oracle as fo
+    fo.lib()
+    cores = os.cpu_count() or 1
+    T = min(frames_per_channel, 16)
+    probe = fx.synth.frames(1, T, window)
+    t0 = time.perf_counter()
+    fo.Channel(window).process_frames(probe[0])
+    per_frame = (time.perf_counter() - t0) / T
+    chans_per_worker = max(1, int(seconds / (per_frame * T)))
+    chans_per_worker = min(chans_per_worker, 64)
+    data = fx.synth.frames(min(cores, 8) * 1, T, window)        # reuse a few channels' samples
+
+    def work(i):
+        n = 0
+        for k in range(chans_per_worker):
+            fo.Channel(window).process_frames(data[(i + k) % data.shape[0]])
+            n += T
+        return n
+
+    t0 = time.perf_counter()
+    one = work(0)
+    single = one / (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        total = sum(ex.map(work, range(cores)))
+    dt = time.perf_counter() - t0
+    return {"value": total / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "single_thread_value": single,
+            "sample": "%d worker threads x %d channels x %d frames of the %d-pt synthetic workload "
+                      "(oracle/fx_oracle.c, gcc -O2)" % (cores, chans_per_worker, T, window)}
+
+
+def load_traffic(window, channels, frames):
+    """HBM bytes per frame-kernel launch from committed PMC passes (profiles/pmc_traffic.json,
+    written by tools/pmc_traffic.py from rocprofv3 --pmc runs of this same command)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        rec = json.load(open(path))
+        if rec.get("window") == window and rec.get("channels") == channels and rec.get("frames") == frames:
+            return rec.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--channels-per-gpu", type=int, default=1024)
+    ap.add_argument("--frames", type=int, default=64, help="consecutive frames per channel per step")
+    ap.add_argument("--window", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    fx = importlib.import_module("feature-extractor_amd")
+    sharded = importlib.import_module("feature-extractor_amd.sharded")
+    C, T, N = args.channels_per_gpu, args.frames, args.window
+    total_channels = C * world
+    first, count = sharded.my_shard(total_channels, rank, world)
+
+    frames = torch.from_numpy(fx.synth.frames(count, T, N, first_channel=first)).cuda(local_rank)
+    an = fx.BatchAnalyser(count, N, device=local_rank)
+    raw = torch.empty((count, T, 12), dtype=torch.float32, device=frames.device)
+    sm = torch.empty((count, T, 12), dtype=torch.float32, device=frames.device)
+
+    def barrier():
+        an.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    pending = [None]
+
+    def step():
+        an.process_frames(frames, out_raw=raw, out_smoothed=sm)
+        if world > 1:
+            an.sync()                                    # features ready before RCCL reads them
+            if pending[0] is not None and pending[0][1] is not None:
+                pending[0][1].wait()
+            pending[0] = sharded.gather_features(sm, total_channels, dst=0, async_op=True)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    an.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if pending[0] is not None and pending[0][1] is not None:
+        pending[0][1].wait()
+    barrier()
+    dt = time.perf_counter() - t0
+    frame_ms, epi_ms, calls = an.profile_end()
+
+    t = torch.tensor([dt], dtype=torch.float64, device=frames.device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        frames_total = total_channels * T * args.steps
+        value = frames_total / dt
+        bytes_per_frame = 4 * N + 48                     # sample bytes + 12 floats out
+        launch_bytes = bytes_per_frame * count * T
+        avg_launch_s = frame_ms / 1e3 / max(calls, 1)
+        achieved = launch_bytes / avg_launch_s / 1e9
+        out = {
+            "metric": "frames/sec (1024-pt FFT, 10-feature bundle)" if N == 1024 else "frames/sec (%d-pt FFT, 10-feature bundle)" % N,
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d channels/GPU x %d-pt fp32 frames, %d consecutive frames per channel per step, "
+                                   "full 12-feature RealTimeAnalyser bundle (spectral+pitch+harmonic+RMS+smoothing+onset), "
+                                   "frames pre-assembled and resident in HBM" % (C, N, T),
+                       "channels_per_gpu": C, "frames_per_step": T, "window": N, "sample_rate": 48000,
+                       "sharding": "channels, contiguous blocks; RCCL gather of [C][T][12] smoothed vectors to rank 0" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(N, count, T),
+                         "kernel": "fx_frame_kernel<%d>" % N, "avg_launch_ms": avg_launch_s * 1e3,
+                         "algorithmic_bytes_per_launch": launch_bytes, "launches_timed": calls,
+                         "epilogue_ms_per_step": epi_ms / max(calls, 1),
+                         "note": "algorithmic bytes = (4*N + 48) B/frame x frames per launch; this kernel is VALU/LDS-bound, not HBM-bound (see DESIGN.md)"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(fx, N, T)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -66,6 +66,15 @@ class BatchAnalyser:
         capi.check(self._lib.fx_last_kernel_ms(self._h, ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
+    def profile_begin(self):
+        capi.check(self._lib.fx_profile_begin(self._h))
+
+    def profile_end(self):
+        """(frame kernel ms, smoothing/onset kernels ms, calls) summed since profile_begin()."""
+        a, b, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        capi.check(self._lib.fx_profile_end(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)))
+        return a.value, b.value, n.value
+
     def stream(self):
         s = ctypes.c_void_p()
         capi.check(self._lib.fx_get_stream(self._h, ctypes.byref(s)))

@@ -56,6 +56,9 @@ struct fx_context {
     hipStream_t stream = nullptr;
     hipEvent_t  ev[3] = {nullptr, nullptr, nullptr};
     bool        ev_valid = false;
+    bool        profiling = false;
+    std::vector<hipEvent_t> prof_events;     // 3 per recorded call
+    size_t      prof_used = 0;
 
     float* d_tw = nullptr;        // [N][2]
     float* d_prev = nullptr;      // [C][N/2]
@@ -189,12 +192,24 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     ep.onset_multiplier = c->onset_multiplier;
     ep.order_mode = (int) (c->flags & FX_ORDER_MASK);
 
-    HIP_TRY(hipEventRecord(c->ev[0], c->stream));
+    hipEvent_t e0 = c->ev[0], e1 = c->ev[1], e2 = c->ev[2];
+    bool last_valid = true;
+    if (c->profiling && c->prof_used + 3 <= 3 * 4096) {
+        while (c->prof_events.size() < c->prof_used + 3) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            c->prof_events.push_back(e);
+        }
+        e0 = c->prof_events[c->prof_used]; e1 = c->prof_events[c->prof_used + 1]; e2 = c->prof_events[c->prof_used + 2];
+        c->prof_used += 3;
+        last_valid = false;
+    }
+    HIP_TRY(hipEventRecord(e0, c->stream));
     HIP_TRY(fxk::launch_frame_kernel(c->N, fp, waves, c->stream));
-    HIP_TRY(hipEventRecord(c->ev[1], c->stream));
+    HIP_TRY(hipEventRecord(e1, c->stream));
     HIP_TRY(fxk::launch_epilogue_kernels(ep, c->stream));
-    HIP_TRY(hipEventRecord(c->ev[2], c->stream));
-    c->ev_valid = true;
+    HIP_TRY(hipEventRecord(e2, c->stream));
+    c->ev_valid = last_valid;
     c->cur ^= 1;
     c->frames_seen += T;
 
@@ -304,6 +319,7 @@ fx_status fx_destroy(fx_context* c)
                     c->d_raw, c->d_in, c->d_out_raw};
     for (void* b : bufs) if (b) (void) hipFree(b);
     for (int i = 0; i < 3; i++) if (c->ev[i]) (void) hipEventDestroy(c->ev[i]);
+    for (hipEvent_t e : c->prof_events) (void) hipEventDestroy(e);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
     return FX_OK;
@@ -406,6 +422,34 @@ fx_status fx_last_kernel_ms(fx_context* c, float* frame_ms, float* epi_ms)
     HIP_TRY(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
     if (frame_ms) *frame_ms = a;
     if (epi_ms) *epi_ms = b;
+    return FX_OK;
+}
+
+fx_status fx_profile_begin(fx_context* c)
+{
+    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    c->profiling = true;
+    c->prof_used = 0;
+    return FX_OK;
+}
+
+fx_status fx_profile_end(fx_context* c, double* frame_ms, double* epi_ms, int* calls)
+{
+    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    double a = 0.0, b = 0.0;
+    for (size_t i = 0; i + 3 <= c->prof_used; i += 3) {
+        float x = 0.f, y = 0.f;
+        HIP_TRY(hipEventElapsedTime(&x, c->prof_events[i], c->prof_events[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&y, c->prof_events[i + 1], c->prof_events[i + 2]));
+        a += x; b += y;
+    }
+    if (frame_ms) *frame_ms = a;
+    if (epi_ms) *epi_ms = b;
+    if (calls) *calls = (int) (c->prof_used / 3);
+    c->profiling = false;
+    c->prof_used = 0;
     return FX_OK;
 }
 

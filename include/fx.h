@@ -132,6 +132,13 @@ fx_status fx_get_stream(fx_context* ctx, void** stream);
  * (milliseconds; synchronises). kernel 0 = frame kernel, 1 = smoothing/onset. */
 fx_status fx_last_kernel_ms(fx_context* ctx, float* frame_kernel_ms, float* epilogue_kernel_ms);
 
+/* Kernel-time accounting over a region of calls: fx_profile_begin() starts recording a HIP event
+ * triple per analysis call on the context's stream (no synchronisation, at most 4096 calls);
+ * fx_profile_end() synchronises and returns the summed device time of the frame kernel and of the
+ * smoothing/onset kernels and the number of calls recorded. */
+fx_status fx_profile_begin(fx_context* ctx);
+fx_status fx_profile_end(fx_context* ctx, double* frame_kernel_ms, double* epilogue_kernel_ms, int* calls);
+
 /* ---- OSC sink helpers (host side, no GPU) ---- */
 /* Re-order one 12-slot vector into the wire order of
  * sender.send(bundleAddress, onset, rms, f0, centroid, slope, spread, flatness,
