@@ -27,39 +27,27 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 def cpu_baseline(fx, window, frames_per_channel, seconds=12.0):
     """The CPU oracle (a port of the reference's algorithm, oracle/fx_oracle.c) on this host's
-    cores, on a bounded sample of the same synthetic workload: one worker thread per core over
-    disjoint channel blocks, mirroring the reference's thread-pair-per-channel model."""
-    from concurrent.futures import ThreadPoolExecutor
+    cores, on a bounded sample of the same synthetic workload: one pthread per core over disjoint
+    channel blocks, mirroring the reference's thread-pair-per-channel model."""
     from oracle import fx_oracle as fo
     fo.lib()
     cores = os.cpu_count() or 1
     T = min(frames_per_channel, 16)
-    probe = fx.synth.frames(1, T, window)
+    probe = fx.synth.frames(4, T, window)
     t0 = time.perf_counter()
-    fo.Channel(window).process_frames(probe[0])
-    per_frame = (time.perf_counter() - t0) / T
-    chans_per_worker = max(1, int(seconds / (per_frame * T)))
-    chans_per_worker = min(chans_per_worker, 64)
-    data = fx.synth.frames(min(cores, 8) * 1, T, window)        # reuse a few channels' samples
-
-    def work(i):
-        n = 0
-        for k in range(chans_per_worker):
-            fo.Channel(window).process_frames(data[(i + k) % data.shape[0]])
-            n += T
-        return n
-
+    fo.batch_frames(probe, window, threads=1)
+    per_frame = (time.perf_counter() - t0) / (4 * T)
+    single = 1.0 / per_frame
+    chans = int(max(cores, min(seconds / (per_frame * T) * cores, 64 * cores)))
+    base = fx.synth.frames(min(chans, 64), T, window)
+    data = np.ascontiguousarray(np.tile(base, (-(-chans // base.shape[0]), 1, 1))[:chans])
     t0 = time.perf_counter()
-    one = work(0)
-    single = one / (time.perf_counter() - t0)
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        total = sum(ex.map(work, range(cores)))
+    fo.batch_frames(data, window, threads=cores)
     dt = time.perf_counter() - t0
-    return {"value": total / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": chans * T / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "single_thread_value": single,
-            "sample": "%d worker threads x %d channels x %d frames of the %d-pt synthetic workload "
-                      "(oracle/fx_oracle.c, gcc -O2)" % (cores, chans_per_worker, T, window)}
+            "sample": "%d channels x %d frames of the %d-pt synthetic workload on %d pthreads, %.1f s "
+                      "(oracle/fx_oracle.c, gcc -O2)" % (chans, T, window, cores, dt)}
 
 
 def load_traffic(window, channels, frames):

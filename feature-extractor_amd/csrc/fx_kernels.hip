@@ -29,6 +29,8 @@
 
 namespace fxk {
 
+#define FX_MARK(name) asm volatile("; FXMARK " name)
+
 typedef float  __attribute__((ext_vector_type(2))) f2;
 typedef float  __attribute__((ext_vector_type(4))) f4;
 
@@ -354,6 +356,7 @@ fx_frame_kernel(const FrameParams p)
 #pragma unroll
         for (int i = 0; i < FX_NUM_FEATURES; i++) out[i] = 0.0f;
 
+FX_MARK("load");
         // ---------------- a1: window assembly (ref RealTimeAudioAnalysis.h:205-219) ----------------
         {
             const size_t esz = p.sample_format == FX_SAMPLE_F16 ? 2 : 4;
@@ -371,6 +374,7 @@ fx_frame_kernel(const FrameParams p)
             wave_fence();
         }
 
+FX_MARK("rms");
         // ---------------- a2: RMS on the un-windowed frame (ref RealTimeAnalyser.h:207-208) ---------
         float log_rms;
         {
@@ -383,10 +387,12 @@ fx_frame_kernel(const FrameParams p)
             out[FX_RMS] = log_rms;
         }
 
+FX_MARK("spec_fft");
         // ---------------- spectral analyser (ref RealTimeAnalyser.h:212-224) -----------------------
         lane = opaque(lane);
         fft_real_input<N, false, WIN_BARTLETT>(rbuf, cbuf, tw, lane);          // a3 + a4
         {
+FX_MARK("spec_sums");
             // lane owns bins [U*lane, U*lane + U)
             float re[U];
             float maxabs = 0.0f;
@@ -422,6 +428,7 @@ fx_frame_kernel(const FrameParams p)
             cnt = wave_sum_i(cnt);
             const bool accepted = mag_sum > 0.05;                              // :121-123
 
+FX_MARK("flux");
             // ---- flux against the previous accepted frame; hand-off between waves ----
             double flux = 0.0;
             {
@@ -443,6 +450,7 @@ fx_frame_kernel(const FrameParams p)
             flux /= (double) max_flux;
 
             lane = opaque(lane);
+FX_MARK("flatprod");
             // ---- flatness product: serial-order semantics of `magnitudeProduct *= binMagnitude` ----
             // (ref :92) including IEEE overflow (sticky inf) and gradual underflow (sticky 0):
             // exponent-extended prefix products locate the first prefix that leaves the normal
@@ -520,6 +528,7 @@ fx_frame_kernel(const FrameParams p)
                 }
             }
 
+FX_MARK("spec_final");
             if (accepted) {
                 // calculateSpectralCharacteristicsFromIntermediates :116-143
                 const float centroid = (float) (wsum / mag_sum);               // :127
@@ -551,6 +560,7 @@ fx_frame_kernel(const FrameParams p)
                 out[FX_FLUX] = (float) flux;
             }
 
+FX_MARK("slope");
             // ---- calculateNormalisedSpectralSlope (ref SpectralCharacteristics.h:145-200) ----
             lane = opaque(lane);
             {
@@ -587,6 +597,7 @@ fx_frame_kernel(const FrameParams p)
         }
         wave_fence();
 
+FX_MARK("harm1");
         // ---------------- harmonic analyser, part 1: raw (un-windowed) spectrum ---------------------
         // ref RealTimeAnalyser.h:161 -- done before the low-pass overwrites the frame image
         lane = opaque(lane);
@@ -616,6 +627,7 @@ fx_frame_kernel(const FrameParams p)
         double f0;
         lane = opaque(lane);
         {
+FX_MARK("lpf");
             // a10 AudioFilter::filterAudio, ref RealTimeAudioAnalysis.h:106-125:
             //   y[0] = x[0];  y[n] = (a*x[n]) + (b*y[n-1]) in fp32, strictly serial.
             // Lane l owns samples [P*l, P*l+P).  It starts KW samples early from a guess, and the
@@ -675,7 +687,9 @@ fx_frame_kernel(const FrameParams p)
             }
             wave_fence();
 
+FX_MARK("pitch_fft");
             fft_real_input<N, false, WIN_NONE>(rbuf, cbuf, tw, lane);          // ref RealTimeAnalyser.h:160
+FX_MARK("power");
             // a11 getComplexConjugateMultiplication, ref PitchAnalyser.h:83-108: re*re, imag := 0
             lane = opaque(lane);
 #pragma unroll
@@ -685,7 +699,9 @@ fx_frame_kernel(const FrameParams p)
                 rbuf[rpad(k)] = r * r;
             }
             wave_fence();
+FX_MARK("ifft");
             fft_real_input<N, true, WIN_NONE>(rbuf, cbuf, tw, lane);           // a12 inverse, ref :110-121
+FX_MARK("vcalc");
             // v[s] = d[s]*d[s]*s, d = planar JUCE inverse output scaled by 1/N (ref :122-123).
             // Only s in [1, N] is ever read by the lag search; v[N] comes from imag[0].
             lane = opaque(lane);
@@ -700,6 +716,7 @@ fx_frame_kernel(const FrameParams p)
                 rbuf[rpad(N)] = d * d * (float) N;
             }
             wave_fence();
+FX_MARK("scan");
             // a13 running fp32 sum, ref PitchAnalyser.h:138-150 -- serial by definition: one lane
             float* sums = reinterpret_cast<float*>(cbuf);                      // complex image is free now
             if (lane == 0) {
@@ -718,6 +735,7 @@ fx_frame_kernel(const FrameParams p)
                 sums[rpad(N)] = sum;
             }
             wave_fence();
+FX_MARK("cnd");
             // cnd[s] = sum != 0 ? v/sum : 0   (ref :146-154), written over v
             lane = opaque(lane);
             for (int s = lane; s <= N; s += 64) {
@@ -726,6 +744,7 @@ fx_frame_kernel(const FrameParams p)
                 rbuf[rpad(s)] = (sm != 0.0f) ? v / sm : 0.0f;
             }
             wave_fence();
+FX_MARK("lag");
             // a14 getLagEstimateFromCumulativeDifference, ref PitchAnalyser.h:161-190
             const float* cnd = rbuf;
             lane = opaque(lane);
@@ -762,6 +781,7 @@ fx_frame_kernel(const FrameParams p)
         }
         wave_fence();
 
+FX_MARK("harm2");
         // ---------------- harmonic analyser, part 2 (ref HarmonicCharacteristics.h:71-105) ----------
         lane = opaque(lane);
         if (!(h_sum < 0.005)) {                                                // :88-89
@@ -861,6 +881,7 @@ fx_frame_kernel(const FrameParams p)
         }
         wave_fence();
 
+FX_MARK("store");
         if (lane == 0) {
             f4* dst = reinterpret_cast<f4*>(p.raw + ((size_t) c * T + t) * FX_NUM_FEATURES);
             dst[0] = f4{out[0], out[1], out[2], out[3]};

@@ -1,0 +1,163 @@
+// fx_realtime.hpp -- header-only C++ host side above the C ABI (fx.h).
+//
+// Mirrors the reference's own interface for this path so that existing C++ callers read the same:
+//   * AudioFeatures                 -- ref Source/RealTimeAnalyser.h:14-92 (same enum, updateFeature,
+//                                      getValue, getFeatureName minus juce::String)
+//   * fx::RealTimeBatchAnalyser     -- the pair RealTimeSpectralAnalyser + RealTimeHarmonicAnalyser
+//                                      (ref RealTimeAnalyser.h:133-269) for many channels on one GPU;
+//                                      setter names are the reference's.
+//   * fx::OSCFeatureMessage         -- ref Source/OSCFeatureAnalysisOutput.h:89-113 wire format.
+// No JUCE.  Errors are thrown as fx::Error (the reference only jasserts).
+#ifndef FX_REALTIME_HPP
+#define FX_REALTIME_HPP
+
+#include <cstddef>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "fx.h"
+
+// ---- ValueHistory, ref Source/RealTimeAudioAnalysis.h:40-96 -----------------------------------
+struct ValueHistory
+{
+    explicit ValueHistory (int historyLength) : recordedHistory (0) { setHistoryLength (historyLength); }
+
+    float getTotal() const
+    {
+        float total = 0.0f;
+        for (std::size_t i = 0; i < history.size(); i++) total += history[i];
+        return total;
+    }
+    void insertNewValueAndupdateHistory (float newValue)
+    {
+        for (std::size_t i = 0; i + 1 < history.size(); i++) history[i] = history[i + 1];
+        if (! history.empty()) history[history.size() - 1] = newValue;
+        if (recordedHistory < (int) history.size()) recordedHistory++;
+    }
+    void setHistoryLength (int historyLength)
+    {
+        recordedHistory = 0;
+        history.assign ((std::size_t) (historyLength > 0 ? historyLength : 0), 0.0f);
+    }
+    std::vector<float> history;
+    int recordedHistory;
+};
+
+// ---- AudioFeatures, ref Source/RealTimeAnalyser.h:14-92 ---------------------------------------
+struct AudioFeatures
+{
+    enum eAudioFeature
+    {
+        enOnset = FX_ONSET, enRMS = FX_RMS, enF0 = FX_F0, enCentroid = FX_CENTROID, enSpread = FX_SPREAD,
+        enFlatness = FX_FLATNESS, enLER = FX_LER, enFlux = FX_FLUX, enSlope = FX_SLOPE,
+        enHarmonicEnergyRatio = FX_HER, enOddEvenHarmonicRatio = FX_OER, enInharmonicity = FX_INHARM,
+        numFeatures = FX_NUM_FEATURES
+    };
+
+    static const char* getFeatureName (eAudioFeature f)          // ref :34-63
+    {
+        static const char* names[numFeatures] = { "Onset", "Amp.", "Pitch", "Centroid", "Spread", "Flatness",
+                                                  "L.E.R", "Flux", "Slope", "H.E.R", "O.E.R", "Inharm." };
+        return (f >= 0 && f < numFeatures) ? names[f] : "UNKNOWN";
+    }
+    static float getMaxValueForFeature (eAudioFeature) { return 1.0f; }     // ref :65-68
+
+    AudioFeatures()                                               // ref :70-74
+    {
+        for (int f = 0; f < numFeatures; f++)
+            smoothedFeatures.push_back (ValueHistory (f == enOnset || f == enFlux ? 1 : 10));
+    }
+    void updateFeature (eAudioFeature f, float v) { smoothedFeatures[(std::size_t) f].insertNewValueAndupdateHistory (v); }
+    float getValue (eAudioFeature f) const                        // ref :84-88
+    {
+        const ValueHistory& h = smoothedFeatures[(std::size_t) f];
+        return h.getTotal() / (float) h.recordedHistory;
+    }
+
+private:
+    std::vector<ValueHistory> smoothedFeatures;
+};
+
+namespace fx
+{
+struct Error : std::runtime_error
+{
+    Error (fx_status c, const char* what) : std::runtime_error (what), code (c) {}
+    fx_status code;
+};
+
+inline void check (fx_status s) { if (s != FX_OK) throw Error (s, fx_last_error()); }
+
+// OnsetDetector::eOnsetDetectionType, ref Source/SpectralCharacteristics.h:213-219
+enum eOnsetDetectionType { enSpectral = FX_ONSET_SPECTRAL, enAmplitude = FX_ONSET_AMPLITUDE, enCombination = FX_ONSET_COMBINATION };
+
+class RealTimeBatchAnalyser
+{
+public:
+    // ref RealTimeAnalyser.h:100 (AudioDataCollector&, AudioFeatures&, int windowSize, double sampleRate = 48000.0)
+    RealTimeBatchAnalyser (int numChannels, int windowSize = 2048, double sampleRate = 48000.0, int deviceId = 0,
+                           unsigned flags = FX_ORDER_SPECTRAL_THEN_HARMONIC)
+        : channels (numChannels), window (windowSize)
+    {
+        check (fx_create (&ctx, deviceId, numChannels, windowSize, sampleRate, flags));
+    }
+    ~RealTimeBatchAnalyser() { fx_destroy (ctx); }
+    RealTimeBatchAnalyser (const RealTimeBatchAnalyser&) = delete;
+    RealTimeBatchAnalyser& operator= (const RealTimeBatchAnalyser&) = delete;
+
+    void sampleRateChanged (double sr)                         { check (fx_set_sample_rate (ctx, sr)); }          // ref :111
+    void setOnsetDetectionSensitivity (float s)                { check (fx_set_onset_sensitivity (ctx, s)); }     // ref :244
+    void setOnsetWindowLength (int length)                     { check (fx_set_onset_window (ctx, length)); }     // ref :250
+    void setOnsetDetectionType (eOnsetDetectionType t)         { check (fx_set_onset_type (ctx, (int) t)); }      // ref :258
+    void setGain (float g)                                     { check (fx_set_gain (ctx, g)); }                  // AudioDataCollector.h:124
+    void reset()                                               { check (fx_reset_state (ctx)); }
+
+    // hops [channels][numHops][window/2] host floats -> raw / smoothed [channels][numHops][12]
+    void pushHops (const float* hops, int numHops, float* raw, float* smoothed)
+    {
+        check (fx_push_hops (ctx, hops, numHops, FX_SAMPLE_F32, FX_MEM_HOST, raw, smoothed));
+    }
+    void processFrames (const float* frames, int numFrames, float* raw, float* smoothed)
+    {
+        check (fx_process_frames (ctx, frames, numFrames, FX_SAMPLE_F32, FX_MEM_HOST, raw, smoothed));
+    }
+    // device-resident variants (pointers from hipMalloc); asynchronous until sync()
+    void pushHopsDevice (const void* hops, int numHops, int sampleFormat, float* raw, float* smoothed)
+    {
+        check (fx_push_hops (ctx, hops, numHops, sampleFormat, FX_MEM_DEVICE, raw, smoothed));
+    }
+    void sync() { check (fx_sync (ctx)); }
+
+    // latest AudioFeatures::getValue of every slot of one channel, as the OSC timer would read them
+    std::vector<float> getValues (int channel)
+    {
+        latest.resize ((std::size_t) channels * FX_NUM_FEATURES);
+        check (fx_get_smoothed (ctx, latest.data(), FX_MEM_HOST));
+        return std::vector<float> (latest.begin() + (std::ptrdiff_t) channel * FX_NUM_FEATURES,
+                                   latest.begin() + (std::ptrdiff_t) (channel + 1) * FX_NUM_FEATURES);
+    }
+    float getValue (int channel, AudioFeatures::eAudioFeature f) { return getValues (channel)[(std::size_t) f]; }
+
+    int getNumChannels() const { return channels; }
+    int getWindowSize() const  { return window; }
+    fx_context* handle()       { return ctx; }
+
+private:
+    fx_context* ctx = nullptr;
+    int channels, window;
+    std::vector<float> latest;
+};
+
+// The datagram OSCSender::send (bundleAddress, onset, rmsLevel, f0, centroid, slope, spread, flatness,
+// ler, flux, her, oer, inharm) emits -- ref Source/OSCFeatureAnalysisOutput.h:107
+inline std::string OSCFeatureMessage (const std::string& address, const float* features12)
+{
+    unsigned char buf[512];
+    const int n = fx_osc_encode (address.c_str(), features12, buf, (int) sizeof buf);
+    if (n < 0) throw Error (FX_ERR_INVALID_ARGUMENT, "OSC address too long");
+    return std::string (reinterpret_cast<const char*> (buf), (std::size_t) n);
+}
+} // namespace fx
+
+#endif // FX_REALTIME_HPP

@@ -23,6 +23,7 @@
 #include "fx_oracle.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -798,6 +799,52 @@ void fxo_push_hops(fxo_channel* c, const float* hops, int T, float* raw, float* 
         fxo_push_hop(c, hops + (size_t) t * (c->n / 2),
                      raw ? raw + (size_t) t * FXO_NUM_FEATURES : NULL,
                      smoothed ? smoothed + (size_t) t * FXO_NUM_FEATURES : NULL);
+}
+
+/* ------------------------------------------------------------------------- */
+/* batch driver for the CPU baseline                                          */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    int window, order, c0, c1, T;
+    double sr;
+    const float* frames;
+    float *raw, *smoothed;
+} batch_job;
+
+static void* batch_worker(void* arg)
+{
+    batch_job* j = (batch_job*) arg;
+    for (int c = j->c0; c < j->c1; c++) {
+        fxo_channel* ch = fxo_create(j->window, j->sr, j->order);
+        if (!ch) return NULL;
+        const size_t o = (size_t) c * j->T;
+        fxo_process_frames(ch, j->frames + o * j->window, j->T,
+                           j->raw ? j->raw + o * FXO_NUM_FEATURES : NULL,
+                           j->smoothed ? j->smoothed + o * FXO_NUM_FEATURES : NULL);
+        fxo_destroy(ch);
+    }
+    return NULL;
+}
+
+int fxo_batch_frames(int window_size, double sample_rate, int order_mode, const float* frames,
+                     int C, int T, float* raw, float* smoothed, int threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > C) threads = C;
+    if (C <= 0 || T <= 0) return 0;
+    pthread_t* th = (pthread_t*) malloc(sizeof(pthread_t) * (size_t) threads);
+    batch_job* jobs = (batch_job*) malloc(sizeof(batch_job) * (size_t) threads);
+    int started = 0, rc = 0;
+    for (int i = 0; i < threads; i++) {
+        batch_job j = { window_size, order_mode, (int) ((long long) C * i / threads),
+                        (int) ((long long) C * (i + 1) / threads), T, sample_rate, frames, raw, smoothed };
+        jobs[i] = j;
+        if (pthread_create(&th[i], NULL, batch_worker, &jobs[i]) != 0) { rc = -1; break; }
+        started++;
+    }
+    for (int i = 0; i < started; i++) pthread_join(th[i], NULL);
+    free(th); free(jobs);
+    return rc;
 }
 
 /* ------------------------------------------------------------------------- */

@@ -71,6 +71,12 @@ void fxo_process_frame(fxo_channel*, const float* frame, float* raw12, float* sm
 void fxo_process_frames(fxo_channel*, const float* frames, int T, float* raw, float* smoothed);
 void fxo_push_hops(fxo_channel*, const float* hops, int T, float* raw, float* smoothed);
 
+/* Many channels at once, one fresh fxo_channel per channel, `threads` worker threads over disjoint
+ * channel blocks (the reference runs one thread pair per channel, AnalyserTrackController.h:184-185).
+ * frames [C][T][N]; raw/smoothed [C][T][12] (either may be NULL).  Returns 0 on success. */
+int fxo_batch_frames(int window_size, double sample_rate, int order_mode, const float* frames,
+                     int C, int T, float* raw, float* smoothed, int threads);
+
 /* ---- taps (stateless building blocks, exposed for unit tests) ---- */
 /* JUCE 4.2 FFT restatement; in/out are interleaved complex, size n. */
 void fxo_fft_complex(int n, int inverse, const float* in, float* out);

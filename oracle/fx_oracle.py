@@ -52,6 +52,8 @@ def lib():
         L.fxo_set_gain.argtypes = [vp, ctypes.c_float]
         L.fxo_process_frames.argtypes = [vp, fp, ctypes.c_int, fp, fp]
         L.fxo_push_hops.argtypes = [vp, fp, ctypes.c_int, fp, fp]
+        L.fxo_batch_frames.restype = ctypes.c_int
+        L.fxo_batch_frames.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int, fp, fp, ctypes.c_int]
         L.fxo_fft_complex.argtypes = [ctypes.c_int, ctypes.c_int, fp, fp]
         L.fxo_forward_real.argtypes = [ctypes.c_int, fp, fp]
         L.fxo_bartlett.argtypes = [ctypes.c_int, fp]
@@ -148,6 +150,18 @@ def push_hops(hops, window_size, sample_rate=48000.0, order=ORDER_SPECTRAL_THEN_
         ch = Channel(window_size, sample_rate, order)
         _apply(ch, settings)
         raw[c], sm[c] = ch.push_hops(hops[c])
+    return raw, sm
+
+
+def batch_frames(frames, window_size, sample_rate=48000.0, order=ORDER_SPECTRAL_THEN_HARMONIC, threads=1):
+    """frames [C][T][N] -> (raw, smoothed), analysed by `threads` pthreads inside the C library."""
+    frames = _f32(frames)
+    C, T = frames.shape[0], frames.shape[1]
+    raw = np.empty((C, T, NUM_FEATURES), np.float32)
+    sm = np.empty((C, T, NUM_FEATURES), np.float32)
+    rc = lib().fxo_batch_frames(int(window_size), float(sample_rate), int(order), _fp(frames), C, T, _fp(raw), _fp(sm), int(threads))
+    if rc != 0:
+        raise RuntimeError("fxo_batch_frames failed")
     return raw, sm
 
 

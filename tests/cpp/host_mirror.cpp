@@ -1,0 +1,94 @@
+// Exercises include/fx_realtime.hpp the way a C++ caller of the reference would use it.
+//   host_mirror            : CPU-only checks (AudioFeatures mirror, OSC message, error without GPU)
+//   host_mirror --gpu      : additionally runs hops through the GPU and replays the raw values
+//                            through the AudioFeatures mirror; smoothed outputs must be identical.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "fx_realtime.hpp"
+
+static int failures = 0;
+#define EXPECT(cond) do { if (!(cond)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #cond); failures++; } } while (0)
+
+int main (int argc, char** argv)
+{
+    const bool gpu = argc > 1 && std::strcmp (argv[1], "--gpu") == 0;
+
+    AudioFeatures f;
+    EXPECT (std::isnan (f.getValue (AudioFeatures::enRMS)));              // 0/0 before the first insert, as in the reference
+    for (int i = 1; i <= 12; i++) f.updateFeature (AudioFeatures::enRMS, (float) i);
+    EXPECT (f.getValue (AudioFeatures::enRMS) == (3.f + 4 + 5 + 6 + 7 + 8 + 9 + 10 + 11 + 12) / 10.f);
+    f.updateFeature (AudioFeatures::enFlux, 0.25f);
+    f.updateFeature (AudioFeatures::enFlux, 0.5f);
+    EXPECT (f.getValue (AudioFeatures::enFlux) == 0.5f);                  // history length 1
+    EXPECT (std::strcmp (AudioFeatures::getFeatureName (AudioFeatures::enHarmonicEnergyRatio), "H.E.R") == 0);
+    EXPECT ((int) AudioFeatures::numFeatures == 12);
+
+    float v[12];
+    for (int i = 0; i < 12; i++) v[i] = (float) i;
+    const std::string msg = fx::OSCFeatureMessage ("/Audio/A0", v);
+    EXPECT (msg.size() == 76);
+    EXPECT (std::memcmp (msg.data(), "/Audio/A0\0\0\0,ffffffffffff\0\0\0", 28) == 0);
+    EXPECT ((unsigned char) msg[28 + 4 * 4] == 0x41 && (unsigned char) msg[28 + 4 * 4 + 1] == 0x00);   // 5th float is slope = 8.0f
+
+    if (! gpu)
+    {
+        bool threw = false;
+        try { fx::RealTimeBatchAnalyser a (2, 1000); } catch (const fx::Error& e) { threw = e.code == FX_ERR_INVALID_ARGUMENT; }
+        EXPECT (threw);
+        std::printf (failures ? "host_mirror: %d failure(s)\n" : "host_mirror: ok\n", failures);
+        return failures ? 1 : 0;
+    }
+
+    const int C = 3, T = 30, N = 1024, H = N / 2;
+    std::vector<float> hops ((size_t) C * T * H), raw ((size_t) C * T * 12), sm ((size_t) C * T * 12);
+    unsigned s = 12345;
+    for (int c = 0; c < C; c++)
+        for (int i = 0; i < T * H; i++)
+        {
+            s = s * 1664525u + 1013904223u;
+            const float gate = ((i / H) % 7 < 4) ? 1.0f : 0.0f;
+            hops[(size_t) c * T * H + i] = gate * (0.5f * std::sin (0.02f * (c + 1) * i) + 0.05f * ((s >> 8) / 16777216.0f - 0.5f));
+        }
+    fx::RealTimeBatchAnalyser an (C, N);
+    an.setOnsetDetectionType (fx::enAmplitude);
+    an.pushHops (hops.data(), T, raw.data(), sm.data());
+    // isolated-order replay is not what the default does; replay the default order by hand:
+    // spectral writes (RMS, 6 spectral slots, onset) then harmonic writes (RMS, F0, HER, OER, inharm)
+    for (int c = 0; c < C; c++)
+    {
+        AudioFeatures af;
+        for (int t = 0; t < T; t++)
+        {
+            const float* r = &raw[((size_t) c * T + t) * 12];
+            af.updateFeature (AudioFeatures::enRMS, r[FX_RMS]);
+            af.updateFeature (AudioFeatures::enCentroid, r[FX_CENTROID]);
+            af.updateFeature (AudioFeatures::enFlatness, r[FX_FLATNESS]);
+            af.updateFeature (AudioFeatures::enLER, r[FX_LER]);
+            af.updateFeature (AudioFeatures::enSpread, r[FX_SPREAD]);
+            af.updateFeature (AudioFeatures::enFlux, r[FX_FLUX]);
+            af.updateFeature (AudioFeatures::enSlope, r[FX_SLOPE]);
+            af.updateFeature (AudioFeatures::enOnset, r[FX_ONSET]);
+            af.updateFeature (AudioFeatures::enRMS, r[FX_RMS]);
+            af.updateFeature (AudioFeatures::enF0, r[FX_F0]);
+            af.updateFeature (AudioFeatures::enHarmonicEnergyRatio, r[FX_HER]);
+            af.updateFeature (AudioFeatures::enOddEvenHarmonicRatio, r[FX_OER]);
+            af.updateFeature (AudioFeatures::enInharmonicity, r[FX_INHARM]);
+            for (int k = 0; k < 12; k++)
+            {
+                const float got = sm[((size_t) c * T + t) * 12 + k], want = af.getValue ((AudioFeatures::eAudioFeature) k);
+                if (! (got == want || (std::isnan (got) && std::isnan (want))))
+                {
+                    std::printf ("smoothed mismatch c=%d t=%d slot=%d gpu=%g mirror=%g\n", c, t, k, got, want);
+                    failures++;
+                }
+            }
+        }
+        std::vector<float> latest = an.getValues (c);
+        for (int k = 0; k < 12; k++) EXPECT (latest[k] == sm[((size_t) c * T + T - 1) * 12 + k] || std::isnan (latest[k]));
+    }
+    std::printf (failures ? "host_mirror --gpu: %d failure(s)\n" : "host_mirror --gpu: ok\n", failures);
+    return failures ? 1 : 0;
+}

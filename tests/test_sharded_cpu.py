@@ -1,0 +1,77 @@
+"""N>1 path on CPU: two processes, gloo, world_size 2.  The sharding/gather code is the one bench.py
+uses with RCCL; here each rank's local analysis is done by the CPU oracle (tests may use it) so the
+check is: sharded + gathered result == unsharded result, bitwise, and the sink encodes per-channel OSC."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total_channels, T, N, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fx = importlib.import_module("feature-extractor_amd")
+    sharded = importlib.import_module("feature-extractor_amd.sharded")
+    from oracle import fx_oracle as fo
+    first, count = sharded.my_shard(total_channels, rank, world)
+    hops = fx.synth.hops(count, T, N, first_channel=first)
+    raw, sm = fo.push_hops(hops, N)
+    res, work = sharded.gather_features(torch.from_numpy(sm), total_channels, dst=0, async_op=True)
+    if work is not None:
+        work.wait()
+    if rank == 0:
+        np.save(out_path, sharded.resolve(res).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total_channels", [6, 7])
+def test_two_rank_gather_equals_unsharded(tmp_path, fx, oracle, total_channels):
+    T, N = 6, 1024
+    out = str(tmp_path / "gathered.npy")
+    mp.spawn(_worker, args=(2, _free_port(), total_channels, T, N, out), nprocs=2, join=True)
+    got = np.load(out)
+    _, want = oracle.push_hops(fx.synth.hops(total_channels, T, N), N)
+    assert got.shape == (total_channels, T, 12)
+    assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_shard_bounds_cover_all_channels():
+    sharded = importlib.import_module("feature-extractor_amd.sharded")
+    for C in (1, 7, 8, 1024, 65536, 65537):
+        for G in (1, 2, 3, 8):
+            b = sharded.shard_bounds(C, G)
+            assert sum(n for _, n in b) == C
+            pos = 0
+            for first, n in b:
+                assert first == pos or n == 0
+                pos += n
+    assert sharded.shard_bounds(65536, 8)[3] == (3 * 8192, 8192)        # BASELINE config 4: 8192 channels per GPU
+
+
+def test_sink_encodes_one_datagram_per_channel(fx, oracle):
+    sharded = importlib.import_module("feature-extractor_amd.sharded")
+    sm = np.random.default_rng(0).standard_normal((12, 12)).astype(np.float32)
+    sink = sharded.OscSink(fx.osc_encode)
+    msgs = sink.datagrams(sm)
+    assert len(msgs) == 12 and len(msgs[0]) == 76 and len(msgs[11]) == 76
+    assert msgs[10] == oracle.osc_message("/Audio/A10", sm[10])
+    assert sink.send(sm) == 12
