@@ -100,6 +100,35 @@ template <int N> struct Geo {
     static constexpr bool HAS_R2 = (LOG2N & 1) != 0;
 };
 
+// U consecutive floats of a lane, moved with the widest LDS access the alignment allows (a stride-U
+// ds_read_b32 pattern would be an 8-way bank conflict for U = 8)
+template <int U> __device__ __forceinline__ void lds_load_block(const float* base, float (&out)[U])
+{
+    if (U % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < U; j += 4) {
+            const f4 v = *reinterpret_cast<const f4*>(base + j);
+            out[j] = v.x; out[j + 1] = v.y; out[j + 2] = v.z; out[j + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < U; j += 2) {
+            const f2 v = *reinterpret_cast<const f2*>(base + j);
+            out[j] = v.x; out[j + 1] = v.y;
+        }
+    }
+}
+template <int U> __device__ __forceinline__ void lds_store_block(float* base, const float (&in)[U])
+{
+    if (U % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < U; j += 4) *reinterpret_cast<f4*>(base + j) = f4{in[j], in[j + 1], in[j + 2], in[j + 3]};
+    } else {
+#pragma unroll
+        for (int j = 0; j < U; j += 2) *reinterpret_cast<f2*>(base + j) = f2{in[j], in[j + 1]};
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // complex helpers -- separate multiplies and adds, never fused (ref FFT is plain a.r*b.r - a.i*b.i)
 // ---------------------------------------------------------------------------------------------
@@ -434,14 +463,16 @@ FX_MARK("flux");
             {
                 while (__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t)
                     __builtin_amdgcn_s_sleep(1);
+                float pvf[U];
+                lds_load_block<U>(prev + U * lane, pvf);
 #pragma unroll
                 for (int j = 0; j < U; j++) {
-                    const double pv = (double) prev[U * lane + j];
+                    const double pv = (double) pvf[j];
                     const double v = (double) re[j];
                     const double diff = v * v - pv * pv;                       // :76
                     if (diff > 0.0) flux += diff;                              // :77-79
-                    if (accepted) prev[U * lane + j] = re[j];                  // :138 (only on the accepted path)
                 }
+                if (accepted) lds_store_block<U>(prev + U * lane, re);         // :138 (only on the accepted path)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __hip_atomic_store(turn, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -634,7 +665,7 @@ FX_MARK("lpf");
             // recurrence (|b| = 0.208) forgets the guess; the value it reaches at P*l-1 must be
             // bit-identical to what lane l-1 produced there, otherwise the chunk is redone from the
             // neighbour's value until every hand-over matches (exact by induction from lane 0).
-            constexpr int KW = 32;
+            constexpr int KW = 16;
             const float a = p.lpf_a, b = p.lpf_b;
             float x[P];
 #pragma unroll
@@ -642,13 +673,20 @@ FX_MARK("lpf");
                 const f4 v = *reinterpret_cast<const f4*>(&rbuf[rpad(P * lane + i)]);
                 x[i] = v.x; x[i + 1] = v.y; x[i + 2] = v.z; x[i + 3] = v.w;
             }
-            float yin;                                    // y[P*lane - 1] used as this chunk's input
+            float yin = 0.0f;                             // y[P*lane - 1] used as this chunk's input
             {
                 const int first = P * lane;
-                int st = first - KW; if (st < 0) st = 0;
-                float y = rbuf[rpad(st)];                 // exact for st == 0, a guess otherwise
-                for (int n = st + 1; n < first; n++) y = (a * rbuf[rpad(n)]) + (b * y);
-                yin = y;
+#pragma unroll
+                for (int q = 0; q < KW / 4; q++) {
+                    const int n0 = first - KW + 4 * q;    // multiple of 4: the whole group is in range or not
+                    if (n0 >= 0) {
+                        const f4 v = *reinterpret_cast<const f4*>(&rbuf[rpad(n0)]);
+                        const float w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++)       // sample 0 starts the filter exactly; the first
+                            yin = (n0 + e == 0 || (q == 0 && e == 0)) ? w[e] : (a * w[e]) + (b * yin);   // warm-up sample is a guess
+                    }
+                }
             }
             wave_fence();
             float y[P];
@@ -705,76 +743,94 @@ FX_MARK("vcalc");
             // v[s] = d[s]*d[s]*s, d = planar JUCE inverse output scaled by 1/N (ref :122-123).
             // Only s in [1, N] is ever read by the lag search; v[N] comes from imag[0].
             lane = opaque(lane);
+            float* vbuf = rbuf;                                                // [N+1] plain layout
+            float* sums = reinterpret_cast<float*>(cbuf);                      // [N+1], written after the reads below
+            {
+                float vv[P];
 #pragma unroll
-            for (int i = 0; i < P; i++) {
-                const int s = lane + 64 * i;
-                const float d = cbuf[cpad(s)].x * scale;
-                rbuf[rpad(s)] = d * d * (float) s;
-            }
-            if (lane == 0) {
-                const float d = cbuf[cpad(0)].y * scale;
-                rbuf[rpad(N)] = d * d * (float) N;
+                for (int i = 0; i < P; i++) {
+                    const int s_ = lane + 64 * i;
+                    const float d = cbuf[cpad(s_)].x * scale;
+                    vv[i] = d * d * (float) s_;
+                }
+                const float dn = cbuf[cpad(0)].y * scale;
+                wave_fence();
+#pragma unroll
+                for (int i = 0; i < P; i++) vbuf[lane + 64 * i] = vv[i];
+                if (lane == 0) vbuf[N] = dn * dn * (float) N;
             }
             wave_fence();
 FX_MARK("scan");
-            // a13 running fp32 sum, ref PitchAnalyser.h:138-150 -- serial by definition: one lane
-            float* sums = reinterpret_cast<float*>(cbuf);                      // complex image is free now
-            if (lane == 0) {
-                float sum = 0.0f;
-                for (int g = 0; g < N; g += 4) {
-                    const f4 v = *reinterpret_cast<const f4*>(&rbuf[rpad(g)]);
-                    f4 o;
-                    if (g != 0) sum += v.x;                                    // loop starts at sample 1
-                    o.x = sum;
-                    sum += v.y; o.y = sum;
-                    sum += v.z; o.z = sum;
-                    sum += v.w; o.w = sum;
-                    *reinterpret_cast<f4*>(&sums[rpad(g)]) = o;
-                }
-                sum += rbuf[rpad(N)];
-                sums[rpad(N)] = sum;
-            }
-            wave_fence();
-FX_MARK("cnd");
-            // cnd[s] = sum != 0 ? v/sum : 0   (ref :146-154), written over v
-            lane = opaque(lane);
-            for (int s = lane; s <= N; s += 64) {
-                const float sm = sums[rpad(s)];
-                const float v = rbuf[rpad(s)];
-                rbuf[rpad(s)] = (sm != 0.0f) ? v / sm : 0.0f;
-            }
-            wave_fence();
-FX_MARK("lag");
-            // a14 getLagEstimateFromCumulativeDifference, ref PitchAnalyser.h:161-190
-            const float* cnd = rbuf;
-            lane = opaque(lane);
-            int first = 0x7fffffff;
-            for (int s = lane; s < N; s += 64)
-                if (s >= 2 && first == 0x7fffffff && cnd[rpad(s)] < 0.01f) first = s;
-            first = wave_min_i(first);
-            float lag;
-            if (first != 0x7fffffff) {
-                // walk right while cnd[s+1] < cnd[s] (ref :178-181), then :192-203 picks s or s+1
-                int stop = 0x7fffffff;
-                for (int s = lane; s < N; s += 64)
-                    if (s >= first && stop == 0x7fffffff && (s + 1 >= N || !(cnd[rpad(s + 1)] < cnd[rpad(s)]))) stop = s;
-                stop = wave_min_i(stop);
-                const int right = stop + 1;                                    // stop < N + 1 always
-                lag = (cnd[rpad(stop)] <= cnd[rpad(right)]) ? (float) stop : (float) right;
-            } else {
-                // global minimum, first occurrence (strict <, initial 100.0f), ref :171-175
+            // a13 running fp32 sum (ref PitchAnalyser.h:138-150) -- serial by definition, so one lane
+            // adds, 64 samples at a time; after each block all lanes form cnd = v/sum (ref :146-154) for
+            // that block and advance a14's search (ref :161-190), which usually ends long before N:
+            //   first  = first s >= 2 with cnd[s] < 0.01
+            //   stop   = first s' >= first with !(cnd[s'+1] < cnd[s'])   (or N-1)
+            //   lag    = cnd[stop] <= cnd[stop+1] ? stop : stop+1        (ref :192-203)
+            // otherwise the global minimum over [2, N), first occurrence (ref :171-175).
+            float lag = -1.0f;
+            {
+                float run = 0.0f;                 // lane 0: the running sum
+                float carry = 0.0f;               // cnd of the last sample of the previous block
+                int first = 0x7fffffff;
+                bool done = false;
                 float best = 100.0f; int best_i = 0x7fffffff;
-                for (int s = lane; s < N; s += 64) {
-                    const float v = cnd[rpad(s)];
-                    if (s >= 2 && v < best) { best = v; best_i = s; }
-                }
+                for (int blk = 0; blk < P && !done; blk++) {
+                    if (lane == 0) {
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(best, o, 64);
-                    const int oi = __shfl_xor(best_i, o, 64);
-                    if (ov < best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+                        for (int g = 0; g < 64; g += 4) {
+                            const f4 v = *reinterpret_cast<const f4*>(&vbuf[64 * blk + g]);
+                            f4 o;
+                            if (g != 0 || blk != 0) run += v.x;               // the sum starts at sample 1
+                            o.x = run;
+                            run += v.y; o.y = run;
+                            run += v.z; o.z = run;
+                            run += v.w; o.w = run;
+                            *reinterpret_cast<f4*>(&sums[64 * blk + g]) = o;
+                        }
+                    }
+                    wave_fence();
+                    const int s_ = 64 * blk + lane;
+                    const float sm = sums[s_];
+                    const float v = vbuf[s_];
+                    const float c_ = (sm != 0.0f) ? v / sm : 0.0f;
+                    float p_ = __shfl_up(c_, 1, 64);
+                    if (lane == 0) p_ = carry;
+                    carry = __shfl(c_, 63, 64);
+                    if (s_ >= 2 && c_ < best) { best = c_; best_i = s_; }
+                    if (first == 0x7fffffff) {
+                        const unsigned long long hit = __ballot(s_ >= 2 && c_ < 0.01f);
+                        if (hit) first = 64 * blk + (int) __builtin_ctzll(hit);
+                    }
+                    if (first != 0x7fffffff) {
+                        // sample s-1 ends the walk if it is past `first` and cnd does not keep falling
+                        const unsigned long long st = __ballot(s_ - 1 >= first && !(c_ < p_));
+                        if (st) {
+                            const int src = (int) __builtin_ctzll(st);
+                            const float pc = __shfl(p_, src, 64), cc = __shfl(c_, src, 64);
+                            const int sstar = 64 * blk + src;
+                            lag = (pc <= cc) ? (float) (sstar - 1) : (float) sstar;
+                            done = true;
+                        }
+                    }
                 }
-                lag = best_i == 0x7fffffff ? -1.0f : (float) best_i;
+                if (!done) {
+                    if (first != 0x7fffffff) {
+                        // the walk ran to N-1 (ref :178: sample + 1 < numSamples); compare with cnd[N]
+                        float cn = 0.0f;
+                        if (lane == 0) { run += vbuf[N]; cn = (run != 0.0f) ? vbuf[N] / run : 0.0f; }
+                        cn = __shfl(cn, 0, 64);
+                        lag = (carry <= cn) ? (float) (N - 1) : (float) N;
+                    } else {
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) {
+                            const float ov = __shfl_xor(best, o, 64);
+                            const int oi = __shfl_xor(best_i, o, 64);
+                            if (ov < best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+                        }
+                        lag = best_i == 0x7fffffff ? -1.0f : (float) best_i;
+                    }
+                }
             }
             f0 = (nyquist * 2.0) / (double) lag;                               // ref PitchAnalyser.h:57
             out[FX_F0] = (float) (f0 / 5000.0);                                // ref RealTimeAnalyser.h:165-166
@@ -791,12 +847,13 @@ FX_MARK("harm2");
             const double mean_mag = h_sum / (double) M;                        // :86
             double sum_normed = 0.0;
             unsigned peak_mask = 0;
+            float nrm[U];
 #pragma unroll
             for (int j = 0; j < U; j++) {
                 const double v = (double) hre[j];
                 const double mag = v * v;
                 const double nm = mag / h_max;                                 // :75
-                normed[U * lane + j] = (float) nm;
+                nrm[j] = (float) nm;
                 sum_normed += nm;
                 // binIsPeak :127-145: above the mean and none of bins -2,-1,+1 larger (windows are
                 // clipped at the ends, :136-138: no +1 neighbour for the last two bins).
@@ -812,6 +869,7 @@ FX_MARK("harm2");
                 if (m < M - 2 && r1 > me) pk = false;
                 if (pk) peak_mask |= 1u << j;
             }
+            lds_store_block<U>(normed + U * lane, nrm);
             sum_normed = wave_sum(sum_normed);
             // compact the peak list
             const int npk_lane = __popc(peak_mask);
