@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -171,7 +172,10 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     fp.lpf_a = c->lpf_a;
     fp.lpf_b = c->lpf_b;
 
-    int waves = T < 4 ? T : 4;
+    // waves per workgroup = frames of one channel in flight; FX_WAVES overrides for experiments
+    int want = 4;
+    if (const char* e = getenv("FX_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 4) want = v; }
+    int waves = T < want ? T : want;
     while (waves > 1 && fxk::frame_kernel_lds_bytes(c->N, waves) > 160 * 1024) waves--;
     if (fxk::frame_kernel_lds_bytes(c->N, waves) > 160 * 1024)
         return fail(FX_ERR_UNSUPPORTED, "window size %d does not fit the LDS", c->N);

@@ -94,10 +94,16 @@ template <int N> struct Geo {
     static constexpr int M      = N / 2;            // numMagnitudes (ref SpectralCharacteristics.h:104)
     static constexpr int P      = N / 64;           // samples per lane
     static constexpr int U      = M / 64;           // bins per lane
-    static constexpr int CBUF   = cpad(N) + 2;      // float2 elements
-    static constexpr int RBUF   = rpad(N) + 8;      // floats (holds N+1 values for the lag scan)
+    // ONE LDS buffer per wavefront, reused as: real image of the frame (rpad layout), complex image
+    // of each transform (cpad layout), v / running-sum arrays of the lag scan, harmonic scratch.
+    static constexpr int CBUF   = cpad(N) + 2;      // float2 elements (>= rpad(N)+8 floats, >= 2N+8 floats)
     static constexpr int LOG2N  = (N == 256) ? 8 : (N == 512) ? 9 : (N == 1024) ? 10 : (N == 2048) ? 11 : 12;
-    static constexpr bool HAS_R2 = (LOG2N & 1) != 0;
+    // first FFT pass: R inputs per item, G items per lane, R*G == P
+    static constexpr int RA     = (N == 256) ? 4 : ((N == 512 || N == 2048) ? 8 : 16);
+    static constexpr int LOG2RA = (RA == 4) ? 2 : (RA == 8) ? 3 : 4;
+    static constexpr int ITEMS_A = N / RA;
+    static constexpr int GA     = ITEMS_A / 64;
+    static constexpr int IDIG   = (LOG2N - LOG2RA) / 2;   // base-4 digits of an item index
 };
 
 // U consecutive floats of a lane, moved with the widest LDS access the alignment allows (a stride-U
@@ -219,8 +225,6 @@ template <int DIGITS> __device__ __forceinline__ int rev4(int x)
     return (int) r;
 }
 
-enum { WIN_NONE = 0, WIN_BARTLETT = 1 };
-
 // Bartlett gain, ref RealTimeAudioAnalysis.h:141-151: two JUCE gain ramps 0->1 and 1->0 whose
 // float accumulation is exact for power-of-two N: w[i] = 2i/N (i < N/2), 2 - 2i/N (i >= N/2).
 template <int N> __device__ __forceinline__ float bartlett_gain(int n)
@@ -229,68 +233,83 @@ template <int N> __device__ __forceinline__ float bartlett_gain(int n)
     return n < N / 2 ? (float) n * inc : 1.0f - (float) (n - N / 2) * inc;
 }
 
-// A pass: every item of R elements is loaded, its 1 or 2 stages run in registers, and it is stored
-// back to the same positions.  FROM_REAL: first pass, reads the real input image through the
-// mixed-radix digit reversal (imag = 0) instead of the complex image.
-//   R = 16 : radix-4 at L0, radix-4 at 4*L0        R = 8 : radix-2 at L0 (=1), radix-4 at 2
-//   R = 4  : radix-4 at L0
-template <int N, int R, int L0, bool FROM_REAL, bool INV, int WIN>
-__device__ __forceinline__ void fft_pass(const float* rbuf, f2* cbuf, const f2* tw, int lane)
+// Sample (or bin) index that feeds input j of this lane's g-th first-pass item: the mixed-radix
+// digit reversal of juce::FFT's decimation in time.  For a fixed (g, j) the 64 lanes cover 64
+// consecutive indices, so LDS / global accesses in this order are conflict-free / coalesced.
+template <int N> __device__ __forceinline__ int first_pass_index(int lane, int g, int j)
+{
+    typedef Geo<N> G;
+    const int revj = (G::RA == 4) ? j : (G::RA == 8) ? ((j >> 1) + 4 * (j & 1)) : ((j >> 2) + 4 * (j & 3));
+    return rev4<G::IDIG>(lane + 64 * g) + G::ITEMS_A * revj;
+}
+
+// First pass: the lane's P real inputs are already in registers in first_pass_index order
+// (imag = 0); 1 or 2 stages in registers, results to the complex image.
+template <int N, bool INV>
+__device__ __forceinline__ void fft_first_pass(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, int lane)
+{
+    typedef Geo<N> G;
+    constexpr int R = G::RA;
+    constexpr int R1 = (R == 8) ? 2 : 4;
+    lane = opaque(lane);
+#pragma unroll
+    for (int g = 0; g < G::GA; g++) {
+        f2 e[R];
+#pragma unroll
+        for (int j = 0; j < R; j++) e[j] = f2{xin[g * R + j], 0.0f};
+        stage<N, R, R1, 1, 1, INV>(e, tw, 0);
+        if (R > R1) stage<N, R, 4, R1, 1, INV>(e, tw, 0);
+        const int base = (lane + 64 * g) * R;
+#pragma unroll
+        for (int i = 0; i < R; i++) cbuf[cpad(base + i)] = e[i];
+    }
+    wave_fence();
+}
+
+// A later pass: every item of R elements (stride L0) is loaded from the complex image, its 1 or 2
+// stages run in registers, and it is stored back to the same positions.
+//   R = 16 : radix-4 at L0, radix-4 at 4*L0        R = 4  : radix-4 at L0
+template <int N, int R, int L0, bool INV>
+__device__ __forceinline__ void fft_pass(f2* cbuf, const f2* tw, int lane)
 {
     lane = opaque(lane);
     constexpr int ITEMS = N / R;
-    constexpr int R1 = (R == 8) ? 2 : 4;
     for (int it = lane; it < ITEMS; it += 64) {
         f2 e[R];
-        int k = 0, base = it * R;
-        if (L0 != 1) { k = it % L0; base = (it / L0) * (R * L0) + k; }
-        if (FROM_REAL) {
-            constexpr int IDIG = (Geo<N>::LOG2N - ((R == 8) ? 3 : 4)) / 2;    // base-4 digits of `it`
-            const int nlow = rev4<IDIG>(it);
+        const int k = it % L0;
+        const int base = (it / L0) * (R * L0) + k;
 #pragma unroll
-            for (int j = 0; j < R; j++) {
-                const int revj = (R == 8) ? ((j >> 1) + 4 * (j & 1)) : ((j >> 2) + 4 * (j & 3));
-                const int n = nlow + ITEMS * revj;
-                float x = rbuf[rpad(n)];
-                if (WIN == WIN_BARTLETT) x *= bartlett_gain<N>(n);
-                e[j] = f2{x, 0.0f};
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < R; i++) e[i] = cbuf[cpad(base + L0 * i)];
-        }
-        stage<N, R, R1, 1, L0, INV>(e, tw, k);
-        if (R > R1) stage<N, R, 4, R1, L0, INV>(e, tw, k);
+        for (int i = 0; i < R; i++) e[i] = cbuf[cpad(base + L0 * i)];
+        stage<N, R, 4, 1, L0, INV>(e, tw, k);
+        if (R > 4) stage<N, R, 4, 4, L0, INV>(e, tw, k);
 #pragma unroll
         for (int i = 0; i < R; i++) cbuf[cpad(base + L0 * i)] = e[i];
     }
     wave_fence();
 }
 
-// Whole transform of one wavefront: real image (N floats) -> complex image (N bins, natural order).
-// Same butterfly DAG as juce::FFT::perform for size N (factors 4,...,4[,2], outermost first).
-template <int N, bool INV, int WIN>
-__device__ __forceinline__ void fft_real_input(const float* rbuf, f2* cbuf, const f2* tw, int lane)
+// Whole transform of one wavefront: P real inputs per lane (first-pass order) -> complex image
+// (N bins, natural order).  Same butterfly DAG as juce::FFT::perform for size N (factors
+// 4,...,4[,2], outermost first); only the grouping of stages into passes is ours.
+template <int N, bool INV>
+__device__ __forceinline__ void fft_from_regs(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, int lane)
 {
-    if (N == 256) {
-        fft_pass<N, 16, 1,  true,  INV, WIN>(rbuf, cbuf, tw, lane);
-        fft_pass<N, 16, 16, false, INV, WIN>(rbuf, cbuf, tw, lane);
-    } else if (N == 512) {
-        fft_pass<N, 8,  1,   true,  INV, WIN>(rbuf, cbuf, tw, lane);
-        fft_pass<N, 16, 8,   false, INV, WIN>(rbuf, cbuf, tw, lane);
-        fft_pass<N, 4,  128, false, INV, WIN>(rbuf, cbuf, tw, lane);
-    } else if (N == 1024) {
-        fft_pass<N, 16, 1,   true,  INV, WIN>(rbuf, cbuf, tw, lane);
-        fft_pass<N, 16, 16,  false, INV, WIN>(rbuf, cbuf, tw, lane);
-        fft_pass<N, 4,  256, false, INV, WIN>(rbuf, cbuf, tw, lane);
-    } else if (N == 2048) {
-        fft_pass<N, 8,  1,   true,  INV, WIN>(rbuf, cbuf, tw, lane);
-        fft_pass<N, 16, 8,   false, INV, WIN>(rbuf, cbuf, tw, lane);
-        fft_pass<N, 16, 128, false, INV, WIN>(rbuf, cbuf, tw, lane);
-    } else {
-        fft_pass<N, 16, 1,   true,  INV, WIN>(rbuf, cbuf, tw, lane);
-        fft_pass<N, 16, 16,  false, INV, WIN>(rbuf, cbuf, tw, lane);
-        fft_pass<N, 16, 256, false, INV, WIN>(rbuf, cbuf, tw, lane);
+    fft_first_pass<N, INV>(xin, cbuf, tw, lane);
+    if (N == 256) {            // 4 | 4,4 | 4
+        fft_pass<N, 16, 4,   INV>(cbuf, tw, lane);
+        fft_pass<N, 4,  64,  INV>(cbuf, tw, lane);
+    } else if (N == 512) {     // 2,4 | 4,4 | 4
+        fft_pass<N, 16, 8,   INV>(cbuf, tw, lane);
+        fft_pass<N, 4,  128, INV>(cbuf, tw, lane);
+    } else if (N == 1024) {    // 4,4 | 4,4 | 4
+        fft_pass<N, 16, 16,  INV>(cbuf, tw, lane);
+        fft_pass<N, 4,  256, INV>(cbuf, tw, lane);
+    } else if (N == 2048) {    // 2,4 | 4,4 | 4,4
+        fft_pass<N, 16, 8,   INV>(cbuf, tw, lane);
+        fft_pass<N, 16, 128, INV>(cbuf, tw, lane);
+    } else {                   // 4,4 | 4,4 | 4,4
+        fft_pass<N, 16, 16,  INV>(cbuf, tw, lane);
+        fft_pass<N, 16, 256, INV>(cbuf, tw, lane);
     }
 }
 
@@ -357,7 +376,7 @@ fx_frame_kernel(const FrameParams p)
     float* prev = reinterpret_cast<float*>(tw + N);                         // [M]  re of the last accepted frame
     int*   turn = reinterpret_cast<int*>(prev + M);                         // [4]
     unsigned char* per_wave = reinterpret_cast<unsigned char*>(turn + 4);
-    constexpr size_t WAVE_BYTES = sizeof(f2) * G::CBUF + sizeof(float) * G::RBUF;
+    constexpr size_t WAVE_BYTES = sizeof(f2) * G::CBUF;
 
     const int nwaves = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6;
@@ -366,7 +385,7 @@ fx_frame_kernel(const FrameParams p)
     const int T = p.T;
 
     f2*    cbuf = reinterpret_cast<f2*>(per_wave + WAVE_BYTES * wave);
-    float* rbuf = reinterpret_cast<float*>(cbuf + G::CBUF);
+    float* rbuf = reinterpret_cast<float*>(cbuf);      // the same memory viewed as the real image
 
     // workgroup prologue: twiddle table + this channel's flux state into LDS
     for (int i = threadIdx.x; i < N; i += blockDim.x) tw[i] = reinterpret_cast<const f2*>(p.tw)[i];
@@ -405,11 +424,19 @@ FX_MARK("load");
 
 FX_MARK("rms");
         // ---------------- a2: RMS on the un-windowed frame (ref RealTimeAnalyser.h:207-208) ---------
+        // the frame, in registers, in the order the first FFT pass consumes it; the LDS buffer is
+        // free again after this read
+        float xr[P];
+#pragma unroll
+        for (int g = 0; g < G::GA; g++)
+#pragma unroll
+            for (int j = 0; j < G::RA; j++) xr[g * G::RA + j] = rbuf[rpad(first_pass_index<N>(lane, g, j))];
+        wave_fence();
         float log_rms;
         {
             double s = 0.0;
 #pragma unroll
-            for (int i = 0; i < P; i++) { const float x = rbuf[rpad(lane + 64 * i)]; s += (double) (x * x); }
+            for (int i = 0; i < P; i++) s += (double) (xr[i] * xr[i]);
             s = wave_sum(s);
             const float rms = (float) sqrt(s / (double) N);
             log_rms = log10f(rms * 9.0f + 1.0f);
@@ -419,9 +446,17 @@ FX_MARK("rms");
 FX_MARK("spec_fft");
         // ---------------- spectral analyser (ref RealTimeAnalyser.h:212-224) -----------------------
         lane = opaque(lane);
-        fft_real_input<N, false, WIN_BARTLETT>(rbuf, cbuf, tw, lane);          // a3 + a4
         {
+            float xw[P];                                                       // a3 Bartlett window
+#pragma unroll
+            for (int g = 0; g < G::GA; g++)
+#pragma unroll
+                for (int j = 0; j < G::RA; j++)
+                    xw[g * G::RA + j] = xr[g * G::RA + j] * bartlett_gain<N>(first_pass_index<N>(lane, g, j));
+            fft_from_regs<N, false>(xw, cbuf, tw, lane);                       // a4
+        }
 FX_MARK("spec_sums");
+        {
             // lane owns bins [U*lane, U*lane + U)
             float re[U];
             float maxabs = 0.0f;
@@ -632,7 +667,7 @@ FX_MARK("harm1");
         // ---------------- harmonic analyser, part 1: raw (un-windowed) spectrum ---------------------
         // ref RealTimeAnalyser.h:161 -- done before the low-pass overwrites the frame image
         lane = opaque(lane);
-        fft_real_input<N, false, WIN_NONE>(rbuf, cbuf, tw, lane);
+        fft_from_regs<N, false>(xr, cbuf, tw, lane);
         float hre[U];
         float h_left2, h_left1, h_right1;          // |re| of bins U*lane-2, U*lane-1, U*lane+U
         double h_sum = 0.0, h_max = 0.0;
@@ -667,6 +702,11 @@ FX_MARK("lpf");
             // neighbour's value until every hand-over matches (exact by induction from lane 0).
             constexpr int KW = 16;
             const float a = p.lpf_a, b = p.lpf_b;
+#pragma unroll
+            for (int g = 0; g < G::GA; g++)
+#pragma unroll
+                for (int j = 0; j < G::RA; j++) rbuf[rpad(first_pass_index<N>(lane, g, j))] = xr[g * G::RA + j];
+            wave_fence();
             float x[P];
 #pragma unroll
             for (int i = 0; i < P; i += 4) {
@@ -726,25 +766,34 @@ FX_MARK("lpf");
             wave_fence();
 
 FX_MARK("pitch_fft");
-            fft_real_input<N, false, WIN_NONE>(rbuf, cbuf, tw, lane);          // ref RealTimeAnalyser.h:160
+            lane = opaque(lane);
+            float xf[P];
+#pragma unroll
+            for (int g = 0; g < G::GA; g++)
+#pragma unroll
+                for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = rbuf[rpad(first_pass_index<N>(lane, g, j))];
+            wave_fence();
+            fft_from_regs<N, false>(xf, cbuf, tw, lane);                       // ref RealTimeAnalyser.h:160
 FX_MARK("power");
-            // a11 getComplexConjugateMultiplication, ref PitchAnalyser.h:83-108: re*re, imag := 0
+            // a11 getComplexConjugateMultiplication, ref PitchAnalyser.h:83-108: re*re, imag := 0,
+            // picked up directly in the order the inverse transform's first pass wants it
             lane = opaque(lane);
 #pragma unroll
-            for (int i = 0; i < P; i++) {
-                const int k = lane + 64 * i;
-                const float r = cbuf[cpad(k)].x;
-                rbuf[rpad(k)] = r * r;
-            }
+            for (int g = 0; g < G::GA; g++)
+#pragma unroll
+                for (int j = 0; j < G::RA; j++) {
+                    const float r = cbuf[cpad(first_pass_index<N>(lane, g, j))].x;
+                    xf[g * G::RA + j] = r * r;
+                }
             wave_fence();
 FX_MARK("ifft");
-            fft_real_input<N, true, WIN_NONE>(rbuf, cbuf, tw, lane);           // a12 inverse, ref :110-121
+            fft_from_regs<N, true>(xf, cbuf, tw, lane);                        // a12 inverse, ref :110-121
 FX_MARK("vcalc");
             // v[s] = d[s]*d[s]*s, d = planar JUCE inverse output scaled by 1/N (ref :122-123).
             // Only s in [1, N] is ever read by the lag search; v[N] comes from imag[0].
             lane = opaque(lane);
             float* vbuf = rbuf;                                                // [N+1] plain layout
-            float* sums = reinterpret_cast<float*>(cbuf);                      // [N+1], written after the reads below
+            float* sums = rbuf + N + 4;                                        // [N+1]; both fit in the buffer
             {
                 float vv[P];
 #pragma unroll
@@ -1114,7 +1163,7 @@ fx_history_kernel(const EpilogueParams p)
 template <int N> static size_t lds_bytes_t(int waves)
 {
     typedef Geo<N> G;
-    return sizeof(f2) * N + sizeof(float) * G::M + 16 + (size_t) waves * (sizeof(f2) * G::CBUF + sizeof(float) * G::RBUF);
+    return sizeof(f2) * N + sizeof(float) * G::M + 16 + (size_t) waves * (sizeof(f2) * G::CBUF);
 }
 
 size_t frame_kernel_lds_bytes(int n, int waves)
