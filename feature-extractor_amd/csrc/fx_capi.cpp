@@ -289,7 +289,9 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
             tw[2 * i] = (float) std::cos(phase);
             tw[2 * i + 1] = (float) std::sin(phase);
         }
-        TRY_OR_CLEAN(hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(float), hipMemcpyHostToDevice));
+        std::vector<float> ordered(tw.size());
+        fxk::build_pass_twiddles(window_size, tw.data(), ordered.data());    // same values, pass access order
+        TRY_OR_CLEAN(hipMemcpy(c->d_tw, ordered.data(), ordered.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     // ref SpectralCharacteristics.h:180-189: binVar does not depend on the signal
     {

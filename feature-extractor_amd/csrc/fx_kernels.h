@@ -23,7 +23,7 @@ struct FrameParams {
     const float* tail_in;       // [C][N/2] second half of the previous window (already gained)
     float*       tail_out;      // [C][N/2]
     float*       prev_re;       // [C][N/2] real parts of the last accepted spectral frame (flux state)
-    const float* tw;            // [N][2] forward twiddle table, (float)cos/sin of a double phase
+    const float* tw;            // [N][2] forward twiddles, (float)cos/sin of a double phase, in pass order (build_pass_twiddles)
     float*       raw;           // [C][T][12] raw per-frame values (onset slot left 0)
     double       nyquist;
     double       bin_var;       // sum_i (i/M - 0.5)^2 / M, summed serially on the host (ref SpectralCharacteristics.h:182-189)
@@ -45,6 +45,10 @@ struct EpilogueParams {
     float        onset_multiplier;
     int          order_mode;    // FX_ORDER_*
 };
+
+// Re-order the reference's N-entry twiddle table (canonical[i] = (re, im) of e^{-2*pi*i/N} as floats)
+// into the order the FFT passes read it; `out` has room for window_size complex entries.
+void build_pass_twiddles(int window_size, const float* canonical, float* out);
 
 size_t frame_kernel_lds_bytes(int window_size, int waves);
 // Chooses waves per workgroup and launches; returns hipSuccess or the launch error.

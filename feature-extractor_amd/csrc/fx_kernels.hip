@@ -136,26 +136,34 @@ template <int U> __device__ __forceinline__ void lds_store_block(float* base, co
 }
 
 // ---------------------------------------------------------------------------------------------
-// complex helpers -- separate multiplies and adds, never fused (ref FFT is plain a.r*b.r - a.i*b.i)
+// FFT: the butterfly DAG of juce::FFT (kiss-style decimation in time, factors 4,...,4[,2]; SURVEY.md
+// App. A.1), regrouped into register-resident passes.  Arithmetic is plain fp32 multiply / add /
+// subtract -- never fused -- on the same operands and the same table twiddles as the reference, so
+// every output is bit-identical to the CPU transform (up to the sign of an exact zero).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ f2 cmul(f2 a, f2 b)
+// a * t (forward) or a * conj(t) (inverse: the inverse table is the exact conjugate, cos being even
+// and sin odd).  Reference form: (a.r*t.r - a.i*t.i, a.r*t.i + a.i*t.r).
+template <bool INV> __device__ __forceinline__ f2 twmul(f2 a, f2 t)
 {
-    const f2 p = f2{a.x, a.x} * b;                 // (a.r*b.r, a.r*b.i)
-    const f2 q = f2{a.y, a.y} * f2{b.y, b.x};      // (a.i*b.i, a.i*b.r)
-    return f2{p.x - q.x, p.y + q.y};
+    const f2 p = f2{a.x, a.x} * t;                 // (a.r*t.r, a.r*t.i)
+    const f2 q = f2{a.y, a.y} * f2{t.y, t.x};      // (a.i*t.i, a.i*t.r)
+    return INV ? f2{p.x + q.x, q.y - p.y} : f2{p.x - q.x, p.y + q.y};
+}
+// the same for a purely real a = (r, 0): the products with 0 only contribute exact zeros
+template <bool INV> __device__ __forceinline__ f2 twmul_real(float r, f2 t)
+{
+    const f2 p = f2{r, r} * t;
+    return INV ? f2{p.x, -p.y} : p;
 }
 
+// butterfly4 after the three twiddle products s0, s1, s2
 template <bool INV>
-__device__ __forceinline__ void bfly4(f2& d0, f2& d1, f2& d2, f2& d3, f2 t1, f2 t2, f2 t3, bool tw1, bool tw2, bool tw3)
+__device__ __forceinline__ void bfly4_core(f2& d0, f2& d1, f2& d2, f2& d3, f2 s0, f2 s1, f2 s2)
 {
-    // JUCE FFT butterfly4; twX=false means the twiddle is exactly (1,0)
-    const f2 s0 = tw1 ? cmul(d1, t1) : d1;
-    const f2 s1 = tw2 ? cmul(d2, t2) : d2;
-    const f2 s2 = tw3 ? cmul(d3, t3) : d3;
     const f2 s3 = s0 + s2;
     const f2 s4 = s0 - s2;
     const f2 s5 = d0 - s1;
-    f2 a = d0 + s1;
+    const f2 a = d0 + s1;
     d2 = a - s3;
     d0 = a + s3;
     if (INV) {
@@ -166,55 +174,75 @@ __device__ __forceinline__ void bfly4(f2& d0, f2& d1, f2& d2, f2& d3, f2 t1, f2 
         d3 = f2{s5.x - s4.y, s5.y + s4.x};
     }
 }
-
-__device__ __forceinline__ void bfly2(f2& d0, f2& d1, f2 t, bool tw)
+// butterfly4 on four REAL inputs with unit twiddles (first stage of a real-input transform)
+template <bool INV>
+__device__ __forceinline__ void bfly4_real(float a0, float a1, float a2, float a3, f2& d0, f2& d1, f2& d2, f2& d3)
 {
-    const f2 s = tw ? cmul(d1, t) : d1;
-    d1 = d0 - s;
-    d0 = d0 + s;
+    const float s3 = a1 + a3, s4 = a1 - a3, s5 = a0 - a2, a = a0 + a2;
+    d2 = f2{a - s3, 0.0f};
+    d0 = f2{a + s3, 0.0f};
+    d1 = f2{s5, INV ? s4 : -s4};
+    d3 = f2{s5, INV ? -s4 : s4};
 }
 
-template <bool INV> __device__ __forceinline__ f2 twv(const f2* tw, int idx)
-{
-    const f2 t = tw[idx];
-    return INV ? f2{t.x, -t.y} : t;      // inverse table is the exact conjugate (cos even, sin odd)
-}
+// Twiddle storage.  The N-entry table of the reference, tw[i] = ((float)cos, (float)sin)(-2*pi*i/N),
+// is re-ordered on the host into the order the passes read it (fx_kernels.h, build_pass_twiddles), so
+// that the 64 lanes of a pass read consecutive entries (conflict-free) at compile-time offsets:
+//   later pass (R, L0), element index i = jin + LREL*(q + 4*g):
+//     stage 1 (LREL = 1): [OFF + (q-1)*L0 + k]                      = tw[k * N/(4*L0) * q]
+//     stage 2 (LREL = 4): [OFF + 3*L0 + (jin*3 + q-1)*L0 + k]       = tw[(k + L0*jin) * N/(16*L0) * q]
+//   first pass constants:  [OFFA + (jin-1)*3 + q-1]                 = tw[jin * N/(4*R1) * q]
+template <int N> struct Plan {
+    static constexpr int R1 = 16;
+    static constexpr int L1 = (N == 256) ? 4 : ((N == 512 || N == 2048) ? 8 : 16);
+    static constexpr int R2 = (N >= 2048) ? 16 : 4;
+    static constexpr int L2 = N / R2;
+    static constexpr int OFF1 = 0;
+    static constexpr int OFF2 = 15 * L1;
+    static constexpr int OFFA = OFF2 + (R2 == 16 ? 15 : 3) * L2;
+};
 
-// One stage over the R elements of an item.  Element i sits at position base + k + L0*i.
-//   RADIX : 2 or 4        LREL : (stage length) / L0        NTW = N / (RADIX * L0 * LREL)
-// Legs of one butterfly: i = jin + LREL*(q + RADIX*g), q = 0..RADIX-1; twiddle index (k + L0*jin)*NTW*q.
-template <int N, int R, int RADIX, int LREL, int L0, bool INV>
-__device__ __forceinline__ void stage(f2 (&e)[R], const f2* tw, int k)
+// offset of element i of an item inside the padded complex image, relative to cpad(base):
+// cpad(base + L0*i) - cpad(base) is a compile-time constant because base = blk*(R*L0) + k, k < L0
+__host__ __device__ constexpr int item_off(int L0, int i) { return L0 * i + (L0 >= 16 ? (L0 / 16) * i : ((L0 * i) >> 4)); }
+
+// A later pass: every item of R elements (stride L0) is loaded from the complex image, its 1 or 2
+// radix-4 stages run in registers, and it is stored back to the same positions.
+template <int N, int R, int L0, int TWOFF, bool INV>
+__device__ __forceinline__ void fft_pass(f2* cbuf, const f2* tw, int lane)
 {
-    constexpr int NTW = N / (RADIX * L0 * LREL);
-    constexpr int GROUPS = R / (RADIX * LREL);
+    lane = opaque(lane);
+    constexpr int ITEMS = N / R;
+    for (int it = lane; it < ITEMS; it += 64) {
+        f2 e[R];
+        const int k = it % L0;
+        const int base = (it / L0) * (R * L0) + k;
+        f2* img = cbuf + cpad(base);
+        const f2* t1 = tw + TWOFF + k;
 #pragma unroll
-    for (int jin = 0; jin < LREL; jin++) {
-        const bool trivial = (L0 == 1) && (jin == 0);           // k == 0 whenever L0 == 1
-        const int kk = (L0 == 1) ? jin : (k + L0 * jin);
-        if (RADIX == 4) {
-            f2 t1 = f2{1.f, 0.f}, t2 = t1, t3 = t1;
-            if (!trivial) {
-                t1 = twv<INV>(tw, kk * NTW);
-                t2 = twv<INV>(tw, kk * NTW * 2);
-                t3 = twv<INV>(tw, kk * NTW * 3);
-            }
+        for (int i = 0; i < R; i++) e[i] = img[item_off(L0, i)];
+        // stage 1: butterflies over i = q + 4*g
+        {
+            const f2 w1 = t1[0], w2 = t1[L0], w3 = t1[2 * L0];
 #pragma unroll
-            for (int g = 0; g < GROUPS; g++) {
-                const int i0 = jin + LREL * (0 + 4 * g), i1 = jin + LREL * (1 + 4 * g);
-                const int i2 = jin + LREL * (2 + 4 * g), i3 = jin + LREL * (3 + 4 * g);
-                bfly4<INV>(e[i0], e[i1], e[i2], e[i3], t1, t2, t3, !trivial, !trivial, !trivial);
-            }
-        } else {
-            f2 t = f2{1.f, 0.f};
-            if (!trivial) t = twv<INV>(tw, kk * NTW);
+            for (int g = 0; g < R / 4; g++)
+                bfly4_core<INV>(e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3],
+                                twmul<INV>(e[4 * g + 1], w1), twmul<INV>(e[4 * g + 2], w2), twmul<INV>(e[4 * g + 3], w3));
+        }
+        if constexpr (R == 16) {
+            // stage 2: butterflies over i = jin + 4*q
+            const f2* t2 = t1 + 3 * L0;
 #pragma unroll
-            for (int g = 0; g < GROUPS; g++) {
-                const int i0 = jin + LREL * (0 + 2 * g), i1 = jin + LREL * (1 + 2 * g);
-                bfly2(e[i0], e[i1], t, !trivial);
+            for (int jin = 0; jin < 4; jin++) {
+                const f2 w1 = t2[(jin * 3 + 0) * L0], w2 = t2[(jin * 3 + 1) * L0], w3 = t2[(jin * 3 + 2) * L0];
+                bfly4_core<INV>(e[jin], e[jin + 4], e[jin + 8], e[jin + 12],
+                                twmul<INV>(e[jin + 4], w1), twmul<INV>(e[jin + 8], w2), twmul<INV>(e[jin + 12], w3));
             }
         }
+#pragma unroll
+        for (int i = 0; i < R; i++) img[item_off(L0, i)] = e[i];
     }
+    wave_fence();
 }
 
 // base-4 digit reversal of the low 2*DIGITS bits
@@ -243,74 +271,63 @@ template <int N> __device__ __forceinline__ int first_pass_index(int lane, int g
     return rev4<G::IDIG>(lane + 64 * g) + G::ITEMS_A * revj;
 }
 
-// First pass: the lane's P real inputs are already in registers in first_pass_index order
-// (imag = 0); 1 or 2 stages in registers, results to the complex image.
+// First pass: the lane's P REAL inputs are already in registers in first_pass_index order (imag = 0,
+// as in performRealOnlyForwardTransform and in PitchAnalyser's re*re spectrum).  Stages at length 1
+// have unit twiddles and real operands; the stage after them sees real operands in half of its
+// butterflies.  Results go to the complex image.
 template <int N, bool INV>
 __device__ __forceinline__ void fft_first_pass(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, int lane)
 {
     typedef Geo<N> G;
     constexpr int R = G::RA;
-    constexpr int R1 = (R == 8) ? 2 : 4;
     lane = opaque(lane);
+    const f2* ta = tw + Plan<N>::OFFA;
 #pragma unroll
     for (int g = 0; g < G::GA; g++) {
+        const float* x = &xin[g * R];
         f2 e[R];
+        if constexpr (R == 4) {
+            bfly4_real<INV>(x[0], x[1], x[2], x[3], e[0], e[1], e[2], e[3]);
+        } else if constexpr (R == 8) {
+            // radix-2 at length 1 (unit twiddle, real): pairs (2g', 2g'+1)
+            float r[8];
 #pragma unroll
-        for (int j = 0; j < R; j++) e[j] = f2{xin[g * R + j], 0.0f};
-        stage<N, R, R1, 1, 1, INV>(e, tw, 0);
-        if (R > R1) stage<N, R, 4, R1, 1, INV>(e, tw, 0);
-        const int base = (lane + 64 * g) * R;
+            for (int h = 0; h < 4; h++) { r[2 * h] = x[2 * h] + x[2 * h + 1]; r[2 * h + 1] = x[2 * h] - x[2 * h + 1]; }
+            // radix-4 at length 2: legs i = jin + 2*q
+            bfly4_real<INV>(r[0], r[2], r[4], r[6], e[0], e[2], e[4], e[6]);
+            e[1] = f2{r[1], 0.0f};
+            bfly4_core<INV>(e[1], e[3], e[5], e[7], twmul_real<INV>(r[3], ta[0]), twmul_real<INV>(r[5], ta[1]), twmul_real<INV>(r[7], ta[2]));
+        } else {
+            // radix-4 at length 1: groups (4g', .., 4g'+3)
 #pragma unroll
-        for (int i = 0; i < R; i++) cbuf[cpad(base + i)] = e[i];
-    }
-    wave_fence();
-}
-
-// A later pass: every item of R elements (stride L0) is loaded from the complex image, its 1 or 2
-// stages run in registers, and it is stored back to the same positions.
-//   R = 16 : radix-4 at L0, radix-4 at 4*L0        R = 4  : radix-4 at L0
-template <int N, int R, int L0, bool INV>
-__device__ __forceinline__ void fft_pass(f2* cbuf, const f2* tw, int lane)
-{
-    lane = opaque(lane);
-    constexpr int ITEMS = N / R;
-    for (int it = lane; it < ITEMS; it += 64) {
-        f2 e[R];
-        const int k = it % L0;
-        const int base = (it / L0) * (R * L0) + k;
+            for (int h = 0; h < 4; h++)
+                bfly4_real<INV>(x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3], e[4 * h], e[4 * h + 1], e[4 * h + 2], e[4 * h + 3]);
+            // radix-4 at length 4: legs i = jin + 4*q; jin = 0 and 2 have real operands
+            {
+                f2 o0, o1, o2, o3;
+                bfly4_real<INV>(e[0].x, e[4].x, e[8].x, e[12].x, o0, o1, o2, o3);
+                e[0] = o0; e[4] = o1; e[8] = o2; e[12] = o3;
+            }
+            bfly4_core<INV>(e[1], e[5], e[9], e[13], twmul<INV>(e[5], ta[0]), twmul<INV>(e[9], ta[1]), twmul<INV>(e[13], ta[2]));
+            bfly4_core<INV>(e[2], e[6], e[10], e[14], twmul_real<INV>(e[6].x, ta[3]), twmul_real<INV>(e[10].x, ta[4]), twmul_real<INV>(e[14].x, ta[5]));
+            bfly4_core<INV>(e[3], e[7], e[11], e[15], twmul<INV>(e[7], ta[6]), twmul<INV>(e[11], ta[7]), twmul<INV>(e[15], ta[8]));
+        }
+        f2* img = cbuf + cpad((lane + 64 * g) * R);
 #pragma unroll
-        for (int i = 0; i < R; i++) e[i] = cbuf[cpad(base + L0 * i)];
-        stage<N, R, 4, 1, L0, INV>(e, tw, k);
-        if (R > 4) stage<N, R, 4, 4, L0, INV>(e, tw, k);
-#pragma unroll
-        for (int i = 0; i < R; i++) cbuf[cpad(base + L0 * i)] = e[i];
+        for (int i = 0; i < R; i++) img[i] = e[i];         // R <= 16 contiguous positions: no pad inside
     }
     wave_fence();
 }
 
 // Whole transform of one wavefront: P real inputs per lane (first-pass order) -> complex image
-// (N bins, natural order).  Same butterfly DAG as juce::FFT::perform for size N (factors
-// 4,...,4[,2], outermost first); only the grouping of stages into passes is ours.
+// (N bins, natural order).
 template <int N, bool INV>
 __device__ __forceinline__ void fft_from_regs(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, int lane)
 {
+    typedef Plan<N> PL;
     fft_first_pass<N, INV>(xin, cbuf, tw, lane);
-    if (N == 256) {            // 4 | 4,4 | 4
-        fft_pass<N, 16, 4,   INV>(cbuf, tw, lane);
-        fft_pass<N, 4,  64,  INV>(cbuf, tw, lane);
-    } else if (N == 512) {     // 2,4 | 4,4 | 4
-        fft_pass<N, 16, 8,   INV>(cbuf, tw, lane);
-        fft_pass<N, 4,  128, INV>(cbuf, tw, lane);
-    } else if (N == 1024) {    // 4,4 | 4,4 | 4
-        fft_pass<N, 16, 16,  INV>(cbuf, tw, lane);
-        fft_pass<N, 4,  256, INV>(cbuf, tw, lane);
-    } else if (N == 2048) {    // 2,4 | 4,4 | 4,4
-        fft_pass<N, 16, 8,   INV>(cbuf, tw, lane);
-        fft_pass<N, 16, 128, INV>(cbuf, tw, lane);
-    } else {                   // 4,4 | 4,4 | 4,4
-        fft_pass<N, 16, 16,  INV>(cbuf, tw, lane);
-        fft_pass<N, 16, 256, INV>(cbuf, tw, lane);
-    }
+    fft_pass<N, PL::R1, PL::L1, PL::OFF1, INV>(cbuf, tw, lane);
+    fft_pass<N, PL::R2, PL::L2, PL::OFF2, INV>(cbuf, tw, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1160,6 +1177,45 @@ fx_history_kernel(const EpilogueParams p)
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+template <int N> static void build_tw_t(const float* canon, float* out)
+{
+    typedef Plan<N> PL;
+    const f2* c = reinterpret_cast<const f2*>(canon);
+    f2* o = reinterpret_cast<f2*>(out);
+    for (int i = 0; i < N; i++) o[i] = f2{0.f, 0.f};
+    const int Rs[2] = {PL::R1, PL::R2}, Ls[2] = {PL::L1, PL::L2}, offs[2] = {PL::OFF1, PL::OFF2};
+    for (int ps = 0; ps < 2; ps++) {
+        const int R = Rs[ps], L0 = Ls[ps], off = offs[ps];
+        for (int q = 1; q <= 3; q++)
+            for (int k = 0; k < L0; k++) o[off + (q - 1) * L0 + k] = c[k * (N / (4 * L0)) * q];
+        if (R == 16)
+            for (int jin = 0; jin < 4; jin++)
+                for (int q = 1; q <= 3; q++)
+                    for (int k = 0; k < L0; k++)
+                        o[off + 3 * L0 + (jin * 3 + q - 1) * L0 + k] = c[(k + L0 * jin) * (N / (16 * L0)) * q];
+    }
+    typedef Geo<N> G;
+    if (G::RA == 16) {
+        for (int jin = 1; jin <= 3; jin++)
+            for (int q = 1; q <= 3; q++) o[PL::OFFA + (jin - 1) * 3 + q - 1] = c[jin * (N / 16) * q];
+    } else if (G::RA == 8) {
+        for (int q = 1; q <= 3; q++) o[PL::OFFA + q - 1] = c[(N / 8) * q];
+    }
+    static_assert(PL::OFFA + (G::RA == 16 ? 9 : (G::RA == 8 ? 3 : 0)) <= N, "pass-ordered twiddles must fit the N-entry table");
+}
+
+void build_pass_twiddles(int n, const float* canonical, float* out)
+{
+    switch (n) {
+        case 256:  build_tw_t<256>(canonical, out); break;
+        case 512:  build_tw_t<512>(canonical, out); break;
+        case 1024: build_tw_t<1024>(canonical, out); break;
+        case 2048: build_tw_t<2048>(canonical, out); break;
+        case 4096: build_tw_t<4096>(canonical, out); break;
+        default: break;
+    }
+}
+
 template <int N> static size_t lds_bytes_t(int waves)
 {
     typedef Geo<N> G;

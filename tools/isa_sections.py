@@ -1,0 +1,36 @@
+"""Static per-section instruction counts of fx_frame_kernel<N> from the FXMARK comments in the ISA."""
+import re, subprocess, sys, os, tempfile
+N = sys.argv[1] if len(sys.argv) > 1 else "1024"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+d = tempfile.mkdtemp()
+subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-mllvm", "-disable-machine-licm",
+                "-c", os.path.join(root, "feature-extractor_amd/csrc/fx_kernels.hip"), "-o", os.path.join(d, "fx.o"), "-save-temps"],
+               cwd=d, stderr=subprocess.DEVNULL)
+src = open(os.path.join(d, "fx_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
+start = src.index("_ZN3fxk15fx_frame_kernelILi%sEEEvNS_11FrameParamsE:" % N)
+body = src[start:src.index("s_endpgm", start)]
+sec = "pre"; counts = {}; order = []
+for line in body.splitlines():
+    l = line.strip()
+    m = re.match(r"; FXMARK (\w+)", l)
+    if m:
+        sec = m.group(1); continue
+    if not l or l.startswith(";") or l.startswith(".") or l.endswith(":"): continue
+    op = l.split()[0]
+    if sec not in counts:
+        counts[sec] = dict(v=0, pk=0, f64=0, s=0, ds=0, vmem=0); order.append(sec)
+    c = counts[sec]
+    if op.startswith("v_"):
+        c["v"] += 1
+        if op.startswith("v_pk_"): c["pk"] += 1
+        if "f64" in op: c["f64"] += 1
+    elif op.startswith("s_"): c["s"] += 1
+    elif op.startswith("ds_"): c["ds"] += 1
+    elif op.startswith(("global_", "buffer_", "scratch_", "flat_")): c["vmem"] += 1
+tot = dict(v=0, s=0, ds=0)
+print("%-12s %6s %6s %6s %6s %6s %6s" % ("section", "valu", "pk", "f64", "salu", "lds", "vmem"))
+for k in order:
+    c = counts[k]
+    print("%-12s %6d %6d %6d %6d %6d %6d" % (k, c["v"], c["pk"], c["f64"], c["s"], c["ds"], c["vmem"]))
+    for t in tot: tot[t] += c[t]
+print(tot)
