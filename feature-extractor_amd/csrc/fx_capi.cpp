@@ -69,6 +69,8 @@ struct fx_context {
     int    cur = 0;
 
     float* d_raw = nullptr;       // [C][T_cap][12]
+    fxk::FramePart* d_part = nullptr;   // [C][T_cap]
+    size_t part_cap = 0;
     void*  d_in = nullptr;        // staging for host input
     float* d_out_raw = nullptr;   // staging for host output
     float* d_out_sm = nullptr;
@@ -128,6 +130,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     fx_status st;
     const size_t raw_bytes = out_elems * sizeof(float);
     if ((st = grow(&c->d_raw, &c->raw_cap, raw_bytes)) != FX_OK) return st;
+    if ((st = grow(&c->d_part, &c->part_cap, (size_t) c->C * T * sizeof(fxk::FramePart))) != FX_OK) return st;
 
     const void* d_in = in;
     float* d_or = out_raw;
@@ -166,7 +169,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     fp.tail_out = c->d_tail[c->cur ^ 1];
     fp.prev_re = c->d_prev;
     fp.tw = c->d_tw;
-    fp.raw = c->d_raw;
+    fp.part = c->d_part;
     fp.nyquist = c->sample_rate / 2.0;          // ref RealTimeAudioAnalysis.h:251, RealTimeAnalyser.h:113
     fp.bin_var = c->bin_var;
     fp.lpf_a = c->lpf_a;
@@ -181,7 +184,11 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
         return fail(FX_ERR_UNSUPPORTED, "window size %d does not fit the LDS", c->N);
 
     fxk::EpilogueParams ep;
+    ep.part = c->d_part;
     ep.raw = c->d_raw;
+    ep.nyquist = c->sample_rate / 2.0;
+    ep.bin_var = c->bin_var;
+    ep.window = c->N;
     ep.hist_in = c->d_hist[c->cur];
     ep.hist_out = c->d_hist[c->cur ^ 1];
     ep.out_raw = d_or;
@@ -322,7 +329,7 @@ fx_status fx_destroy(fx_context* c)
     (void) hipSetDevice(c->device);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     void* bufs[] = {c->d_tw, c->d_prev, c->d_tail[0], c->d_tail[1], c->d_hist[0], c->d_hist[1], c->d_latest,
-                    c->d_raw, c->d_in, c->d_out_raw};
+                    c->d_raw, c->d_part, c->d_in, c->d_out_raw};
     for (void* b : bufs) if (b) (void) hipFree(b);
     for (int i = 0; i < 3; i++) if (c->ev[i]) (void) hipEventDestroy(c->ev[i]);
     for (hipEvent_t e : c->prof_events) (void) hipEventDestroy(e);

@@ -13,6 +13,30 @@ namespace fxk {
 constexpr int HLEN = 48;
 constexpr int MAX_ONSET_WINDOW = 32;
 
+// What the frame kernel leaves per frame: every reduction over samples / bins / lags is done, the
+// scalar tail (pow, log10, sqrt, a few divisions) is not.  One thread per frame finishes it in
+// fx_finalise_kernel, where 64 frames share an instruction instead of one.
+struct FramePart {
+    double mag_sum;     // sum of re^2 over the M bins of the windowed spectrum
+    double var;         // sum ((fc/nyq) - (centroid/nyq))^2 * mag          (ref SpectralCharacteristics.h:137)
+    double lhr;         // magnitudeSum at bin M/5 (inclusive)               (ref :86-87)
+    double flux;        // sum of rectified differences, not yet / maxFlux   (ref :76-79)
+    double flat_sum;    // flatnessMagnitudeSum                              (ref :91)
+    double prod;        // magnitudeProduct with the serial IEEE semantics   (ref :92)
+    double max_e;       // maxFFTMagnitude of the slope                      (ref :153-163)
+    double wsum;        // weightedMagnitudeSum                              (ref :95)
+    double vsum;        // sum (mag - mag_sum/M)^2
+    double inh;         // inharmonicity before the log                      (ref HarmonicCharacteristics.h:239)
+    double her;         // clamped harmonic energy ratio, rounded to float   (ref :186-197)
+    float  log_rms;     // ref RealTimeAnalyser.h:208
+    float  centroid;    // (float)(wsum / mag_sum)                           (ref SpectralCharacteristics.h:127)
+    float  cnt;         // numMagnitudesUsedInFlatnessCalculation
+    float  lag;         // ref PitchAnalyser.h:188-189
+    int    flags;       // bit 0: harmonic analyser ran past the 0.005 gate  (ref HarmonicCharacteristics.h:88)
+    int    pad_;
+};
+static_assert(sizeof(FramePart) == 112, "FramePart is written with 16-byte stores");
+
 struct FrameParams {
     const void*  in;            // frames [C][T][N] or hops [C][T][N/2]
     int          sample_format; // FX_SAMPLE_F32 / FX_SAMPLE_F16
@@ -24,14 +48,18 @@ struct FrameParams {
     float*       tail_out;      // [C][N/2]
     float*       prev_re;       // [C][N/2] real parts of the last accepted spectral frame (flux state)
     const float* tw;            // [N][2] forward twiddles, (float)cos/sin of a double phase, in pass order (build_pass_twiddles)
-    float*       raw;           // [C][T][12] raw per-frame values (onset slot left 0)
+    FramePart*   part;          // [C][T] per-frame partial results
     double       nyquist;
     double       bin_var;       // sum_i (i/M - 0.5)^2 / M, summed serially on the host (ref SpectralCharacteristics.h:182-189)
     float        lpf_a, lpf_b;  // ref RealTimeAudioAnalysis.h:122
 };
 
 struct EpilogueParams {
-    const float* raw;           // [C][T][12] from the frame kernel
+    const FramePart* part;      // [C][T] from the frame kernel
+    float*       raw;           // [C][T][12] raw values: written by fx_finalise_kernel, read by the smoothing kernel
+    double       nyquist;
+    double       bin_var;
+    int          window;
     const float* hist_in;       // [C][HLEN][12] raw values of the HLEN frames before this call
     float*       hist_out;      // [C][HLEN][12]
     float*       out_raw;       // [C][T][12] or nullptr

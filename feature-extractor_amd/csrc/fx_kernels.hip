@@ -417,9 +417,8 @@ fx_frame_kernel(const FrameParams p)
 
     for (int t = wave; t < T; t += nwaves) {
         int lane = opaque(lane0);
-        float out[FX_NUM_FEATURES];
-#pragma unroll
-        for (int i = 0; i < FX_NUM_FEATURES; i++) out[i] = 0.0f;
+        FramePart fp;
+        fp.var = 0.0; fp.vsum = 0.0; fp.inh = 0.0; fp.her = 0.0; fp.flags = 0; fp.pad_ = 0;
 
 FX_MARK("load");
         // ---------------- a1: window assembly (ref RealTimeAudioAnalysis.h:205-219) ----------------
@@ -457,7 +456,7 @@ FX_MARK("rms");
             s = wave_sum(s);
             const float rms = (float) sqrt(s / (double) N);
             log_rms = log10f(rms * 9.0f + 1.0f);
-            out[FX_RMS] = log_rms;
+            fp.log_rms = log_rms;
         }
 
 FX_MARK("spec_fft");
@@ -529,8 +528,6 @@ FX_MARK("flux");
                 if (lane == 0) __hip_atomic_store(turn, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             flux = wave_sum(flux);
-            const float max_flux = (float) (M * (M + 1)) / 2.0f;               // :111
-            flux /= (double) max_flux;
 
             lane = opaque(lane);
 FX_MARK("flatprod");
@@ -611,72 +608,34 @@ FX_MARK("flatprod");
                 }
             }
 
-FX_MARK("spec_final");
-            if (accepted) {
-                // calculateSpectralCharacteristicsFromIntermediates :116-143
+FX_MARK("spec_pass2");
+            // second pass over the lane's bins: spread needs the centroid, the slope needs the mean
+            // (ref SpectralCharacteristics.h:135-139 and :182-188); everything after these sums is
+            // scalar and is finished by fx_finalise_kernel
+            {
                 const float centroid = (float) (wsum / mag_sum);               // :127
-                const double dcnt = (double) cnt;
-                const double inv_n = 1.0 / (dcnt > 0.0 ? dcnt : 1.0);          // :129-130
-                const float flatness = flat_sum > eps ? (float) (pow(prod, inv_n) / (inv_n * flat_sum)) : 0.0f;
-                const float log_flat = (float) log10((double) flatness * 9.0 + 1.0);      // :132
-                const float cc = centroid / (float) (nyquist / 2.0);           // :133
-                const float log_centroid = log10f(cc * 9.0f + 1.0f);           // :134
                 const double cn = (double) centroid * rnyq;
-                double var = 0.0;
+                const double mu = mag_sum * (1.0 / (double) M);
+                double var = 0.0, vsum = 0.0;
 #pragma unroll
-                for (int j = 0; j < U; j++) {                                  // :135-139
+                for (int j = 0; j < U; j++) {
                     const int m = U * lane + j;
                     const double v = (double) re[j];
                     const double mag = v * v;
                     const double fc = (double) m * frpb + (frpb / 2.0);
                     const double d = fc * rnyq - cn;
                     var += (d * d) * mag;
+                    const double dv = mag - mu;
+                    vsum += dv * dv;
                 }
-                var = wave_sum(var);
-                const double cn_exact = (double) centroid / nyquist;
-                const float max_spread = (float) (cn_exact * (1.0 - cn_exact)); // :140
-                const float spread = (float) ((var / mag_sum) / (double) max_spread);   // :141
-                out[FX_CENTROID] = log_centroid;
-                out[FX_SPREAD] = spread;
-                out[FX_FLATNESS] = log_flat;
-                out[FX_LER] = (float) (lhr / mag_sum);                         // :125
-                out[FX_FLUX] = (float) flux;
+                fp.var = wave_sum(var);
+                fp.vsum = wave_sum(vsum);
+                fp.centroid = centroid;
             }
-
-FX_MARK("slope");
-            // ---- calculateNormalisedSpectralSlope (ref SpectralCharacteristics.h:145-200) ----
-            lane = opaque(lane);
-            {
-                double max_e = (double) maxabs;                                // :153
-                if (max_mag > max_e) max_e = max_mag;                          // :161-162
-                float slope = 0.0f;
-                if (max_e > 0.0001) {                                          // :165-167
-                    const double rmax = 1.0 / max_e;
-                    double se = 0.0, ps = 0.0;
-#pragma unroll
-                    for (int j = 0; j < U; j++) {
-                        const double v = (double) re[j];
-                        const double ne = (v * v) * rmax;
-                        se += ne;
-                        ps += (double) (U * lane + j) * ne;
-                    }
-                    se = wave_sum(se);
-                    ps = wave_sum(ps);
-                    const double mean_e = se / (double) M;
-                    double ev = 0.0;
-#pragma unroll
-                    for (int j = 0; j < U; j++) {
-                        const double v = (double) re[j];
-                        const double d = (v * v) * rmax - mean_e;
-                        ev += d * d;
-                    }
-                    ev = wave_sum(ev) / (double) M;
-                    const double bin_std = sqrt(p.bin_var), e_std = sqrt(ev);
-                    const double r = (ps - ((double) M * mean_e * 0.5)) / (double) ((float) M - 1.0f) * e_std * bin_std;   // :195
-                    slope = (float) (r * (bin_std / e_std));                   // :198
-                }
-                out[FX_SLOPE] = slope;
-            }
+            double max_e = (double) maxabs;                                    // :153
+            if (max_mag > max_e) max_e = max_mag;                              // :161-162
+            fp.mag_sum = mag_sum; fp.lhr = lhr; fp.flux = flux; fp.flat_sum = flat_sum; fp.prod = prod;
+            fp.max_e = max_e; fp.wsum = wsum; fp.cnt = (float) cnt;
         }
         wave_fence();
 
@@ -899,7 +858,7 @@ FX_MARK("scan");
                 }
             }
             f0 = (nyquist * 2.0) / (double) lag;                               // ref PitchAnalyser.h:57
-            out[FX_F0] = (float) (f0 / 5000.0);                                // ref RealTimeAnalyser.h:165-166
+            fp.lag = lag;
         }
         wave_fence();
 
@@ -997,25 +956,86 @@ FX_MARK("harm2");
                     inh += (r - floor(r)) * ((v * v) / h_sum);                 // :236-239
                 }
             }
-            inh = wave_sum(inh);
-            const float log_her = (float) log10(her_f * 9.0 + 1.0);            // :101
-            out[FX_HER] = log_her;
-            out[FX_OER] = log_her;                                             // ref RealTimeAnalyser.h:171 writes HER into the OER slot
-            out[FX_INHARM] = (float) log10(inh * 9.0 + 1.0);                   // :102
+            fp.inh = wave_sum(inh);
+            fp.her = her_f;
+            fp.flags = 1;
         }
         wave_fence();
 
 FX_MARK("store");
         if (lane == 0) {
-            f4* dst = reinterpret_cast<f4*>(p.raw + ((size_t) c * T + t) * FX_NUM_FEATURES);
-            dst[0] = f4{out[0], out[1], out[2], out[3]};
-            dst[1] = f4{out[4], out[5], out[6], out[7]};
-            dst[2] = f4{out[8], out[9], out[10], out[11]};
+            static_assert(sizeof(FramePart) % 16 == 0, "16-byte stores");
+            const uint4* src = reinterpret_cast<const uint4*>(&fp);
+            uint4* dst = reinterpret_cast<uint4*>(p.part + ((size_t) c * T + t));
+#pragma unroll
+            for (int i = 0; i < (int) (sizeof(FramePart) / 16); i++) dst[i] = src[i];
         }
     }
 
     __syncthreads();
     for (int i = threadIdx.x; i < M; i += blockDim.x) p.prev_re[(size_t) c * M + i] = prev[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// fx_finalise_kernel: thread = frame.  The scalar tail of calculateSpectralCharacteristicsFrom-
+// Intermediates (ref SpectralCharacteristics.h:116-143), calculateNormalisedSpectralSlope (:189-199),
+// the harmonic logs (ref HarmonicCharacteristics.h:101-105) and the slot mapping of
+// RealTimeAnalyser.h:165-172,219-224.  Output: raw[C][T][12] with the onset slot still 0.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+fx_finalise_kernel(const EpilogueParams p)
+{
+    const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long) p.C * p.T) return;
+    const FramePart f = p.part[idx];
+    const int M = p.window / 2;
+    const double nyquist = p.nyquist;
+    float out[FX_NUM_FEATURES];
+#pragma unroll
+    for (int i = 0; i < FX_NUM_FEATURES; i++) out[i] = 0.0f;
+    out[FX_RMS] = f.log_rms;
+    const double eps = 0.01 * (double) f.log_rms;                              // :108
+
+    if (f.mag_sum > 0.05) {                                                    // :121-123
+        const float centroid = f.centroid;
+        const double dcnt = (double) f.cnt;
+        const double inv_n = 1.0 / (dcnt > 0.0 ? dcnt : 1.0);                  // :129-130
+        const float flatness = f.flat_sum > eps ? (float) (pow(f.prod, inv_n) / (inv_n * f.flat_sum)) : 0.0f;   // :57-60
+        out[FX_FLATNESS] = (float) log10((double) flatness * 9.0 + 1.0);       // :132
+        const float cc = centroid / (float) (nyquist / 2.0);                   // :133
+        out[FX_CENTROID] = log10f(cc * 9.0f + 1.0f);                           // :134
+        const double cn = (double) centroid / nyquist;
+        const float max_spread = (float) (cn * (1.0 - cn));                    // :140
+        out[FX_SPREAD] = (float) ((f.var / f.mag_sum) / (double) max_spread);  // :141
+        out[FX_LER] = (float) (f.lhr / f.mag_sum);                             // :125
+        const float max_flux = (float) (M * (M + 1)) / 2.0f;                   // :111
+        out[FX_FLUX] = (float) (f.flux / (double) max_flux);
+    }
+    if (f.max_e > 0.0001) {                                                    // :165-167
+        // normedEnergy = mag / max (ref :172): the sums over bins were taken before the division
+        const double rmax = 1.0 / f.max_e;
+        const double se = f.mag_sum * rmax;
+        const double frpb = nyquist / (double) M;
+        const double s1 = (f.wsum - (frpb / 2.0) * f.mag_sum) / frpb;          // sum m * mag
+        const double ps = s1 * rmax;                                           // :175
+        const double mean_e = se / (double) M;                                 // :177
+        const double ev = f.vsum * rmax * rmax / (double) M;                   // :187,190
+        const double bin_std = sqrt(p.bin_var), e_std = sqrt(ev);              // :191-192
+        const double r = (ps - ((double) M * mean_e * 0.5)) / (double) ((float) M - 1.0f) * e_std * bin_std;   // :195
+        out[FX_SLOPE] = (float) (r * (bin_std / e_std));                       // :198
+    }
+    const double f0 = (nyquist * 2.0) / (double) f.lag;                        // ref PitchAnalyser.h:57
+    out[FX_F0] = (float) (f0 / 5000.0);                                        // ref RealTimeAnalyser.h:165-166
+    if (f.flags & 1) {
+        const float log_her = (float) log10(f.her * 9.0 + 1.0);                // ref HarmonicCharacteristics.h:101
+        out[FX_HER] = log_her;
+        out[FX_OER] = log_her;                                                 // ref RealTimeAnalyser.h:171 writes HER into the OER slot
+        out[FX_INHARM] = (float) log10(f.inh * 9.0 + 1.0);                     // :102
+    }
+    f4* dst = reinterpret_cast<f4*>(p.raw + idx * FX_NUM_FEATURES);
+    dst[0] = f4{out[0], out[1], out[2], out[3]};
+    dst[1] = f4{out[4], out[5], out[6], out[7]};
+    dst[2] = f4{out[8], out[9], out[10], out[11]};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1276,6 +1296,9 @@ hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t stream)
 {
     if (p.C <= 0 || p.T <= 0) return hipSuccess;
     const long long n1 = (long long) p.C * p.T;
+    hipLaunchKernelGGL(fx_finalise_kernel, dim3((unsigned) ((n1 + 255) / 256)), dim3(256), 0, stream, p);
+    hipError_t e0 = hipGetLastError();
+    if (e0 != hipSuccess) return e0;
     hipLaunchKernelGGL(fx_epilogue_kernel, dim3((unsigned) ((n1 + 255) / 256)), dim3(256), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
