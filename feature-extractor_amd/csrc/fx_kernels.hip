@@ -587,7 +587,9 @@ FX_MARK("flatprod");
                     if (kind == 1) {
                         prod = __builtin_huge_val();                           // inf * positive finite stays inf
                     } else {
-                        // value just before bin fb (normal), then IEEE double from fb onwards
+                        // value just before bin fb (normal), then IEEE double from fb onwards: the
+                        // owner of bin fb continues through its own bins, hands the product to the next
+                        // lane, and so on until it is exactly 0 (0 * finite stays 0) or the bins end
                         FlatProd before = exc;
 #pragma unroll
                         for (int j = 0; j < U; j++) {
@@ -595,13 +597,17 @@ FX_MARK("flatprod");
                             const double mag = v * v;
                             if (mag > eps && (U * lane + j) < fb) before = fp_mul(before, mag);
                         }
-                        const double start = ldexp(__shfl(before.mant, owner, 64), __shfl(before.exp, owner, 64));
-                        double pr = start;
-                        for (int m = fb; m < M; m++) {
-                            const double v = (double) cbuf[cpad(m)].x;
-                            const double mag = v * v;
-                            if (mag > eps) pr *= mag;
-                            if (pr == 0.0) break;                              // 0 * finite stays 0
+                        double pr = ldexp(__shfl(before.mant, owner, 64), __shfl(before.exp, owner, 64));
+                        for (int l = owner; l < 64; l++) {
+                            double mine = pr;
+#pragma unroll
+                            for (int j = 0; j < U; j++) {
+                                const double v = (double) re[j];
+                                const double mag = v * v;
+                                if (mag > eps && (U * lane + j) >= fb) mine *= mag;
+                            }
+                            pr = __shfl(mine, l, 64);
+                            if (pr == 0.0) break;
                         }
                         prod = pr;
                     }
@@ -873,11 +879,12 @@ FX_MARK("harm2");
             double sum_normed = 0.0;
             unsigned peak_mask = 0;
             float nrm[U];
+            const double r_hmax = 1.0 / h_max;
 #pragma unroll
             for (int j = 0; j < U; j++) {
                 const double v = (double) hre[j];
                 const double mag = v * v;
-                const double nm = mag / h_max;                                 // :75
+                const double nm = mag * r_hmax;                                // :75 (mag / max, via one reciprocal)
                 nrm[j] = (float) nm;
                 sum_normed += nm;
                 // binIsPeak :127-145: above the mean and none of bins -2,-1,+1 larger (windows are
