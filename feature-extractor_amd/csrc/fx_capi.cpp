@@ -175,12 +175,26 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     fp.lpf_a = c->lpf_a;
     fp.lpf_b = c->lpf_b;
 
-    // waves per workgroup = frames of one channel in flight; FX_WAVES overrides for experiments
-    int want = 4;
-    if (const char* e = getenv("FX_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 4) want = v; }
-    int waves = T < want ? T : want;
-    while (waves > 1 && fxk::frame_kernel_lds_bytes(c->N, waves) > 160 * 1024) waves--;
-    if (fxk::frame_kernel_lds_bytes(c->N, waves) > 160 * 1024)
+    // waves per workgroup = frames of one channel in flight.  Pick the count that keeps the most
+    // wavefronts resident per CU (LDS is the limiter: one twiddle table + flux state per workgroup,
+    // one transform buffer per wave); FX_WAVES overrides for experiments.
+    const size_t lds_cu = 160 * 1024;
+    int waves = 1;
+    {
+        int best_resident = 0;
+        const int kmax = T < 8 ? T : 8;
+        for (int k = 1; k <= kmax; k++) {
+            const size_t need = fxk::frame_kernel_lds_bytes(c->N, k);
+            if (need > lds_cu) break;
+            const int resident = k * (int) (lds_cu / need);
+            if (resident >= best_resident) { best_resident = resident; waves = k; }
+        }
+        if (const char* e = getenv("FX_WAVES")) {
+            const int v = atoi(e);
+            if (v >= 1 && v <= kmax && fxk::frame_kernel_lds_bytes(c->N, v) <= lds_cu) waves = v;
+        }
+    }
+    if (fxk::frame_kernel_lds_bytes(c->N, waves) > lds_cu)
         return fail(FX_ERR_UNSUPPORTED, "window size %d does not fit the LDS", c->N);
 
     fxk::EpilogueParams ep;

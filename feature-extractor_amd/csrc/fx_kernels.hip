@@ -378,11 +378,14 @@ __device__ __forceinline__ FlatProd fp_mul2(FlatProd a, FlatProd b)
     return r;
 }
 
-// waves per SIMD the register allocator must leave room for (LDS bounds residency anyway)
-template <int N> struct Occ { static constexpr int WAVES_PER_SIMD = N <= 1024 ? 3 : (N == 2048 ? 2 : 1); };
+// waves per SIMD the register allocator must leave room for (LDS bounds residency as well)
+#ifndef FX_OCC_SMALL
+#define FX_OCC_SMALL 4
+#endif
+template <int N> struct Occ { static constexpr int WAVES_PER_SIMD = N <= 1024 ? FX_OCC_SMALL : (N == 2048 ? 2 : 1); };
 
 template <int N>
-__global__ void __launch_bounds__(256, Occ<N>::WAVES_PER_SIMD)
+__global__ void __launch_bounds__(512, Occ<N>::WAVES_PER_SIMD)
 fx_frame_kernel(const FrameParams p)
 {
     typedef Geo<N> G;
@@ -392,7 +395,8 @@ fx_frame_kernel(const FrameParams p)
     f2*    tw   = reinterpret_cast<f2*>(smem);                              // [N]
     float* prev = reinterpret_cast<float*>(tw + N);                         // [M]  re of the last accepted frame
     int*   turn = reinterpret_cast<int*>(prev + M);                         // [4]
-    unsigned char* per_wave = reinterpret_cast<unsigned char*>(turn + 4);
+    FramePart* parts = reinterpret_cast<FramePart*>(turn + 4);              // [waves] per-frame results, filled as they appear
+    unsigned char* per_wave = reinterpret_cast<unsigned char*>(parts + (blockDim.x >> 6));
     constexpr size_t WAVE_BYTES = sizeof(f2) * G::CBUF;
 
     const int nwaves = blockDim.x >> 6;
@@ -417,8 +421,10 @@ fx_frame_kernel(const FrameParams p)
 
     for (int t = wave; t < T; t += nwaves) {
         int lane = opaque(lane0);
-        FramePart fp;
-        fp.var = 0.0; fp.vsum = 0.0; fp.inh = 0.0; fp.her = 0.0; fp.flags = 0; fp.pad_ = 0;
+        // uniform per-frame results go to LDS as soon as they exist instead of occupying ~28 VGPRs
+        // in every lane for the whole frame
+        FramePart* fpl = parts + wave;
+        if (lane == 0) { fpl->inh = 0.0; fpl->her = 0.0; fpl->flags = 0; fpl->pad_ = 0; }
 
 FX_MARK("load");
         // ---------------- a1: window assembly (ref RealTimeAudioAnalysis.h:205-219) ----------------
@@ -456,7 +462,7 @@ FX_MARK("rms");
             s = wave_sum(s);
             const float rms = (float) sqrt(s / (double) N);
             log_rms = log10f(rms * 9.0f + 1.0f);
-            fp.log_rms = log_rms;
+            if (lane == 0) fpl->log_rms = log_rms;
         }
 
 FX_MARK("spec_fft");
@@ -634,14 +640,16 @@ FX_MARK("spec_pass2");
                     const double dv = mag - mu;
                     vsum += dv * dv;
                 }
-                fp.var = wave_sum(var);
-                fp.vsum = wave_sum(vsum);
-                fp.centroid = centroid;
+                var = wave_sum(var);
+                vsum = wave_sum(vsum);
+                if (lane == 0) { fpl->var = var; fpl->vsum = vsum; fpl->centroid = centroid; }
             }
             double max_e = (double) maxabs;                                    // :153
             if (max_mag > max_e) max_e = max_mag;                              // :161-162
-            fp.mag_sum = mag_sum; fp.lhr = lhr; fp.flux = flux; fp.flat_sum = flat_sum; fp.prod = prod;
-            fp.max_e = max_e; fp.wsum = wsum; fp.cnt = (float) cnt;
+            if (lane == 0) {
+                fpl->mag_sum = mag_sum; fpl->lhr = lhr; fpl->flux = flux; fpl->flat_sum = flat_sum; fpl->prod = prod;
+                fpl->max_e = max_e; fpl->wsum = wsum; fpl->cnt = (float) cnt;
+            }
         }
         wave_fence();
 
@@ -864,7 +872,7 @@ FX_MARK("scan");
                 }
             }
             f0 = (nyquist * 2.0) / (double) lag;                               // ref PitchAnalyser.h:57
-            fp.lag = lag;
+            if (lane == 0) fpl->lag = lag;
         }
         wave_fence();
 
@@ -963,20 +971,17 @@ FX_MARK("harm2");
                     inh += (r - floor(r)) * ((v * v) / h_sum);                 // :236-239
                 }
             }
-            fp.inh = wave_sum(inh);
-            fp.her = her_f;
-            fp.flags = 1;
+            inh = wave_sum(inh);
+            if (lane == 0) { fpl->inh = inh; fpl->her = her_f; fpl->flags = 1; }
         }
         wave_fence();
 
 FX_MARK("store");
-        if (lane == 0) {
-            static_assert(sizeof(FramePart) % 16 == 0, "16-byte stores");
-            const uint4* src = reinterpret_cast<const uint4*>(&fp);
-            uint4* dst = reinterpret_cast<uint4*>(p.part + ((size_t) c * T + t));
-#pragma unroll
-            for (int i = 0; i < (int) (sizeof(FramePart) / 16); i++) dst[i] = src[i];
-        }
+        wave_fence();
+        static_assert(sizeof(FramePart) % 16 == 0, "16-byte stores");
+        if (lane < (int) (sizeof(FramePart) / 16))
+            reinterpret_cast<uint4*>(p.part + ((size_t) c * T + t))[lane] = reinterpret_cast<const uint4*>(fpl)[lane];
+        wave_fence();
     }
 
     __syncthreads();
@@ -1246,7 +1251,7 @@ void build_pass_twiddles(int n, const float* canonical, float* out)
 template <int N> static size_t lds_bytes_t(int waves)
 {
     typedef Geo<N> G;
-    return sizeof(f2) * N + sizeof(float) * G::M + 16 + (size_t) waves * (sizeof(f2) * G::CBUF);
+    return sizeof(f2) * N + sizeof(float) * G::M + 16 + (size_t) waves * (sizeof(FramePart) + sizeof(f2) * G::CBUF);
 }
 
 size_t frame_kernel_lds_bytes(int n, int waves)
