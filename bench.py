@@ -66,8 +66,8 @@ def load_traffic(window, channels, frames):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--channels-per-gpu", type=int, default=1024)
     ap.add_argument("--frames", type=int, default=64, help="consecutive frames per channel per step")
     ap.add_argument("--window", type=int, default=1024)
