@@ -48,37 +48,84 @@ __device__ __forceinline__ void wave_fence()
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 
 // ---------------------------------------------------------------------------------------------
-// wavefront reductions (all lanes receive the result)
+// wavefront reductions (all lanes receive the result, as a wave-uniform value).
+// DPP row operations instead of ds_bpermute shuffles: VALU latency instead of an LDS round trip per
+// step.  quad_perm xor1, xor2 -> row_half_mirror -> row_mirror give every lane its 16-lane row total;
+// row_bcast:15 / row_bcast:31 carry row totals forward so lane 63 holds the wave total.
 // ---------------------------------------------------------------------------------------------
+enum { DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143 };
+
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int dpp_i(int old, int v)
+{
+    return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_f(float old, float v)
+{
+    return __int_as_float(dpp_i<CTRL, ROW_MASK>(__float_as_int(old), __float_as_int(v)));
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_d(double old, double v)
+{
+    const int lo = dpp_i<CTRL, ROW_MASK>(__double2loint(old), __double2loint(v));
+    const int hi = dpp_i<CTRL, ROW_MASK>(__double2hiint(old), __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bcast63(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_d<DPP_XOR1, 0xF>(0.0, v);
+    v += dpp_d<DPP_XOR2, 0xF>(0.0, v);
+    v += dpp_d<DPP_HALF_MIRROR, 0xF>(0.0, v);
+    v += dpp_d<DPP_MIRROR, 0xF>(0.0, v);
+    v += dpp_d<DPP_BCAST15, 0xA>(0.0, v);
+    v += dpp_d<DPP_BCAST31, 0xC>(0.0, v);
+    return bcast63(v);
 }
 __device__ __forceinline__ double wave_max(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const double t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
-    return v;
+    double t;
+    t = dpp_d<DPP_XOR1, 0xF>(v, v);        v = t > v ? t : v;
+    t = dpp_d<DPP_XOR2, 0xF>(v, v);        v = t > v ? t : v;
+    t = dpp_d<DPP_HALF_MIRROR, 0xF>(v, v); v = t > v ? t : v;
+    t = dpp_d<DPP_MIRROR, 0xF>(v, v);      v = t > v ? t : v;
+    t = dpp_d<DPP_BCAST15, 0xA>(v, v);     v = t > v ? t : v;
+    t = dpp_d<DPP_BCAST31, 0xC>(v, v);     v = t > v ? t : v;
+    return bcast63(v);
 }
 __device__ __forceinline__ float wave_maxf(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
-    return v;
+    float t;
+    t = dpp_f<DPP_XOR1, 0xF>(v, v);        v = t > v ? t : v;
+    t = dpp_f<DPP_XOR2, 0xF>(v, v);        v = t > v ? t : v;
+    t = dpp_f<DPP_HALF_MIRROR, 0xF>(v, v); v = t > v ? t : v;
+    t = dpp_f<DPP_MIRROR, 0xF>(v, v);      v = t > v ? t : v;
+    t = dpp_f<DPP_BCAST15, 0xA>(v, v);     v = t > v ? t : v;
+    t = dpp_f<DPP_BCAST31, 0xC>(v, v);     v = t > v ? t : v;
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ int wave_min_i(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
-    return v;
+    int t;
+    t = dpp_i<DPP_XOR1, 0xF>(v, v);        v = t < v ? t : v;
+    t = dpp_i<DPP_XOR2, 0xF>(v, v);        v = t < v ? t : v;
+    t = dpp_i<DPP_HALF_MIRROR, 0xF>(v, v); v = t < v ? t : v;
+    t = dpp_i<DPP_MIRROR, 0xF>(v, v);      v = t < v ? t : v;
+    t = dpp_i<DPP_BCAST15, 0xA>(v, v);     v = t < v ? t : v;
+    t = dpp_i<DPP_BCAST31, 0xC>(v, v);     v = t < v ? t : v;
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_sum_i(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_i<DPP_XOR1, 0xF>(0, v);
+    v += dpp_i<DPP_XOR2, 0xF>(0, v);
+    v += dpp_i<DPP_HALF_MIRROR, 0xF>(0, v);
+    v += dpp_i<DPP_MIRROR, 0xF>(0, v);
+    v += dpp_i<DPP_BCAST15, 0xA>(0, v);
+    v += dpp_i<DPP_BCAST31, 0xC>(0, v);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 // ---------------------------------------------------------------------------------------------
