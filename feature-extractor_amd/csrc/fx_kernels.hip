@@ -192,9 +192,21 @@ template <int U> __device__ __forceinline__ void lds_store_block(float* base, co
 // and sin odd).  Reference form: (a.r*t.r - a.i*t.i, a.r*t.i + a.i*t.r).
 template <bool INV> __device__ __forceinline__ f2 twmul(f2 a, f2 t)
 {
-    const f2 p = f2{a.x, a.x} * t;                 // (a.r*t.r, a.r*t.i)
-    const f2 q = f2{a.y, a.y} * f2{t.y, t.x};      // (a.i*t.i, a.i*t.r)
-    return INV ? f2{p.x + q.x, q.y - p.y} : f2{p.x - q.x, p.y + q.y};
+    // Three packed instructions.  hipcc does not form the mixed per-half negation by itself (it emits
+    // two v_pk_add + a v_mov instead), so the VOP3P modifiers are spelled out:
+    //   forward: p = (a.r*t.r, a.r*t.i), q = (a.i*(-t.i), a.i*t.r), result = p + q
+    //   inverse: p = (a.r*t.r, a.r*(-t.i)), q = (a.i*t.i, a.i*t.r), result = p + q
+    // (-x)*y == -(x*y) and p + (-q) == p - q exactly, so the roundings are those of the reference form.
+    f2 p, q, r;
+    if (INV) {
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(p) : "v"(a), "v"(t));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(q) : "v"(a), "v"(t));
+    } else {
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "v"(a), "v"(t));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(q) : "v"(a), "v"(t));
+    }
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(p), "v"(q));
+    return r;
 }
 // the same for a purely real a = (r, 0): the products with 0 only contribute exact zeros
 template <bool INV> __device__ __forceinline__ f2 twmul_real(float r, f2 t)
