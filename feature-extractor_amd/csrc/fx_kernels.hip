@@ -520,7 +520,9 @@ FX_MARK("rms");
             for (int i = 0; i < P; i++) s += (double) (xr[i] * xr[i]);
             s = wave_sum(s);
             const float rms = (float) sqrt(s / (double) N);
-            log_rms = log10f(rms * 9.0f + 1.0f);
+            // log10 of a float, correctly rounded: this value gates bins (`mag > 0.01*logRMS`), so it must
+            // equal the CPU oracle's to the last bit (see oracle/fx_oracle.c)
+            log_rms = (float) log10((double) (rms * 9.0f + 1.0f));
             if (lane == 0) fpl->log_rms = log_rms;
         }
 
@@ -942,7 +944,30 @@ FX_MARK("harm2");
             float* normed  = reinterpret_cast<float*>(cbuf);                   // [M] floats
             int*   peaks   = reinterpret_cast<int*>(cbuf) + M;                 // [<= M] peak bins
             float* peak_re = reinterpret_cast<float*>(cbuf) + 2 * M;           // [<= M] re of those bins
-            const double mean_mag = h_sum / (double) M;                        // :86
+            double mean_mag = h_sum / (double) M;                              // :86
+            // binIsPeak's `mag > mean` (:132) is an exact tie when the spectrum is flat (an impulse at
+            // sample 0 or N/2 of the window): then the last bit of the reference's serial sum (:61-66)
+            // decides for every bin at once.  If any bin sits within rounding distance of the mean,
+            // redo the sum in the reference's order, handing the running value from lane to lane.
+            {
+                bool near = false;
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const double v = (double) hre[j];
+                    near |= fabs(v * v - mean_mag) <= 1e-12 * mean_mag;
+                }
+                if (__any(near)) {
+                    double run = 0.0;
+                    for (int l = 0; l < 64; l++) {
+                        double mine = run;
+#pragma unroll
+                        for (int j = 0; j < U; j++) { const double v = (double) hre[j]; mine += v * v; }
+                        run = __shfl(mine, l, 64);
+                    }
+                    h_sum = run;
+                    mean_mag = h_sum / (double) M;
+                }
+            }
             double sum_normed = 0.0;
             unsigned peak_mask = 0;
             float nrm[U];
@@ -1074,7 +1099,7 @@ fx_finalise_kernel(const EpilogueParams p)
         const float flatness = f.flat_sum > eps ? (float) (pow(f.prod, inv_n) / (inv_n * f.flat_sum)) : 0.0f;   // :57-60
         out[FX_FLATNESS] = (float) log10((double) flatness * 9.0 + 1.0);       // :132
         const float cc = centroid / (float) (nyquist / 2.0);                   // :133
-        out[FX_CENTROID] = log10f(cc * 9.0f + 1.0f);                           // :134
+        out[FX_CENTROID] = (float) log10((double) (cc * 9.0f + 1.0f));         // :134
         const double cn = (double) centroid / nyquist;
         const float max_spread = (float) (cn * (1.0 - cn));                    // :140
         out[FX_SPREAD] = (float) ((f.var / f.mag_sum) / (double) max_spread);  // :141

@@ -124,7 +124,7 @@ def log_rms(x):
     x = np.asarray(x, f32)
     s = np.sum((x * x).astype(f32).astype(f64))  # pairwise in numpy: ~1e-16 from the serial sum
     rms = f32(math.sqrt(s / x.shape[0]))
-    return f32(np.log10(f32(rms * f32(9.0) + f32(1.0)), dtype=f32))
+    return f32(math.log10(float(f32(rms * f32(9.0) + f32(1.0)))))      # correctly rounded float log10 (see fx_oracle.c)
 
 
 def spectral(re, im, prev_mag, lrms, nyquist):
@@ -179,7 +179,7 @@ def spectral(re, im, prev_mag, lrms, nyquist):
         flatness = f32(np.float64(prod) ** inv_n / (inv_n * flat_sum)) if flat_sum > eps else f32(0)
         log_flat = f32(np.log10(f64(flatness) * 9.0 + 1.0))
     c = f32(centroid / f32(nyquist / 2.0))
-    log_centroid = f32(np.log10(f32(c * f32(9.0) + f32(1.0)), dtype=f32))
+    log_centroid = f32(math.log10(float(f32(c * f32(9.0) + f32(1.0)))))
     var = float(np.sum(((fc / nyquist) - (f64(centroid) / nyquist)) ** 2 * mag))
     max_spread = f32((f64(centroid) / nyquist) * (1.0 - f64(centroid) / nyquist))
     with np.errstate(divide="ignore", invalid="ignore"):

@@ -14,6 +14,12 @@
  * pinned by Feature-Extractor.jucer:5 jucerVersion="4.2.3" -- is restated from
  * its published algorithm and marked "JUCE:".
  *
+ * log10 of a float argument (ref RealTimeAnalyser.h:149,208; SpectralCharacteristics.h:134): the
+ * original toolchains pick a float overload whose last bit differs between libms (and from
+ * glibc's log10f).  logRMS feeds the discrete test `binMagnitude > 0.01*logRMS`, so a 1-ulp
+ * difference can flip a bin.  The oracle therefore evaluates these as (float) log10((double) x) --
+ * the correctly rounded float, which every good log10f approximates -- and the GPU does the same.
+ *
  * Floating-point discipline: the original toolchains (VS2015 / Xcode, x86-64
  * SSE2) evaluate float expressions in float and double expressions in double
  * with no FMA contraction; unqualified log10/exp on a float argument resolve to
@@ -262,6 +268,9 @@ void fxo_bartlett(int n, float* x)
 /* ref: RealTimeAudioAnalysis.h:106-127.  float_Pi / m and exp(-float_Pi / m)
  * are float expressions (exp(float) -> expf). */
 static const float k_float_pi = 3.14159265358979323846f;
+
+/* log10 (float) -> float, correctly rounded (see the header comment) */
+static float log10_float(float x) { return (float) log10((double) x); }
 float fxo_lpf_a(void) { return k_float_pi / 2.0f; }
 float fxo_lpf_b(void) { return expf(-k_float_pi / 2.0f); }
 
@@ -453,7 +462,7 @@ static spectral_out spectral_characteristics(fxo_channel* c, const float* spec2n
         ? (float) (pow(prod, inv_n) / (inv_n * flat_sum)) : 0.0f;
     const float log_flat = (float) log10(flatness * 9.0 + 1.0);     /* :132 (double log10) */
     const float cc = centroid / (float) (nyquist / 2.0);            /* :133 */
-    const float log_centroid = log10f(cc * 9.0f + 1.0f);            /* :134 (float log10) */
+    const float log_centroid = log10_float(cc * 9.0f + 1.0f);       /* :134 (float log10) */
     for (int i = 0; i < M; i++) {                                   /* :135-139 */
         var += pow((c->fcs[i] / nyquist) - (centroid / nyquist), 2.0) * c->mags[i];
         c->prev_mag[i] = c->mags[i];
@@ -686,7 +695,7 @@ static spec_frame spectral_compute(fxo_channel* c)
 {
     spec_frame r;
     const float rms = buf_rms(c->overlap, c->n);                    /* :207 un-windowed */
-    r.log_rms = log10f(rms * 9.0f + 1.0f);                          /* :208 */
+    r.log_rms = log10_float(rms * 9.0f + 1.0f);                     /* :208 */
     memcpy(c->win, c->overlap, sizeof(float) * (size_t) c->n);      /* :206 copy */
     fxo_bartlett(c->n, c->win);                                     /* :212 */
     forward_real(&c->fwd, c->win, c->spec, c->scratch);             /* :215 */
@@ -702,7 +711,7 @@ static harm_frame harmonic_compute(fxo_channel* c)
 {
     harm_frame r;
     const float rms = buf_rms(c->overlap, c->n);                    /* :148 */
-    r.log_rms = log10f(rms * 9.0f + 1.0f);                          /* :149 */
+    r.log_rms = log10_float(rms * 9.0f + 1.0f);                     /* :149 */
     fxo_lowpass(c->n, c->overlap, c->filt);                         /* :152-154 */
     fxo_bartlett(c->n, c->filt);                                    /* :157 */
     forward_real(&c->fwd, c->filt, c->fspec, c->scratch);           /* :160 */

@@ -29,6 +29,7 @@ CASES = [
     ("levels_1024", "levels", 1024, 8, 8, 0),
     ("flat_edge_1024", "flat_edge", 1024, 12, 6, 0),
     ("impulse_1024", "impulse", 1024, 2, 16, 0),
+    ("impulse_on_boundary_512", "impulse_on_boundary", 512, 3, 12, 0),
     ("silence_2048", "silence", 2048, 1, 8, 0),
     ("loud_noise_2048", "loud_noise", 2048, 2, 8, 0),
     ("sine_512", "sine", 512, 2, 12, 0),

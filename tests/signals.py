@@ -34,6 +34,18 @@ def impulse(C, T, N, at_hop=6):
     return x
 
 
+def impulse_on_boundary(C, T, N):
+    """impulses exactly at the first sample of a hop: in one window the impulse is at sample N/2, in the
+    next at sample 0, and re^2 is perfectly flat -- every `mag > mean` of the peak picker is an exact tie
+    decided by the rounding of the reference's serial sum"""
+    x = np.zeros((C, T, N // 2), np.float32)
+    for c in range(C):
+        x[c, 2 + c % 3, 0] = 0.7 / (c + 1)
+        if T > 8:
+            x[c, 8, 0] = -0.31 * (c + 1)
+    return x
+
+
 def sine(C, T, N, amp=0.9, sr=48000.0):
     n = np.arange(T * N // 2)
     out = np.stack([amp * np.sin(2 * np.pi * (220.0 * (c + 1)) * n / sr) for c in range(C)])
@@ -78,7 +90,7 @@ def flat_edge(C, T, N, seed=6):
 ALL = {
     "tone": tone_vibrato_noise, "silence": silence, "loud_noise": loud_noise, "quiet_noise": quiet_noise,
     "impulse": impulse, "sine": sine, "dc": dc, "bursts": bursts, "levels": levels,
-    "flat_edge": flat_edge,
+    "flat_edge": flat_edge, "impulse_on_boundary": impulse_on_boundary,
 }
 
 

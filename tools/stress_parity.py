@@ -1,0 +1,103 @@
+"""Randomised parity stress: HIP path (through the C ABI) vs the CPU oracle over random signal mixes,
+levels, window sizes, batch shapes and settings.  Prints every mismatch beyond 1e-5 (onset: any)."""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+fx = importlib.import_module("feature-extractor_amd")
+from oracle import fx_oracle as fo
+
+
+def make_signal(rng, C, T, N):
+    n = T * N // 2
+    t = np.arange(n)
+    x = np.zeros((C, n))
+    for c in range(C):
+        kind = rng.integers(0, 8)
+        level = 10.0 ** rng.uniform(-5, 1.5)
+        if kind == 0:      # harmonic tone
+            f = rng.uniform(40, 6000)
+            ph = 2 * np.pi * f * t / 48000
+            x[c] = sum(rng.uniform(0, 1) / (h + 1) * np.sin((h + 1) * ph + rng.uniform(0, 6)) for h in range(rng.integers(1, 8)))
+        elif kind == 1:    # noise
+            x[c] = rng.normal(0, 1, n)
+        elif kind == 2:    # tone + noise
+            f = rng.uniform(40, 6000)
+            x[c] = np.sin(2 * np.pi * f * t / 48000) + rng.uniform(0, 0.3) * rng.normal(0, 1, n)
+        elif kind == 3:    # sparse impulses
+            x[c, rng.integers(0, n, max(1, n // 3000))] = rng.normal(0, 1, max(1, n // 3000))
+        elif kind == 4:    # gated bursts with exact silence
+            gate = (rng.random(T) > 0.5).repeat(N // 2)
+            x[c] = gate * np.sin(2 * np.pi * rng.uniform(80, 2000) * t / 48000)
+        elif kind == 5:    # chirp
+            f = np.linspace(rng.uniform(50, 500), rng.uniform(500, 12000), n)
+            x[c] = np.sin(2 * np.pi * np.cumsum(f) / 48000)
+        elif kind == 6:    # DC + tiny noise
+            x[c] = rng.uniform(-1, 1) + 1e-3 * rng.normal(0, 1, n)
+        else:              # silence with one loud hop
+            h = rng.integers(0, T)
+            x[c, h * N // 2:(h + 1) * N // 2] = rng.normal(0, 1, N // 2)
+        x[c] *= level
+    return x.astype(np.float32).reshape(C, T, N // 2)
+
+
+def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
+    """Returns (cases, frames, mismatching cases, worst finite relative error)."""
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + seconds
+    cases = frames = bad_cases = 0
+    worst = 0.0
+    while time.time() < t_end and (max_cases is None or cases < max_cases):
+        N = int(rng.choice([256, 512, 1024, 1024, 2048, 2048, 4096]))
+        C = int(rng.integers(1, 12))
+        T = int(rng.integers(1, 40))
+        order = int(rng.integers(0, 3))
+        otype = int(rng.integers(0, 3))
+        owin = int(rng.integers(1, 22))
+        sens = float(rng.uniform(0, 2))
+        gain = float(rng.choice([1.0, 1.0, 0.5, 3.0]))
+        hops = make_signal(rng, C, T, N)
+        an = fx.BatchAnalyser(C, N, order=order)
+        an.set_onset_detection_type(otype); an.set_onset_window_length(owin)
+        an.set_onset_detection_sensitivity(sens); an.set_gain(gain)
+        split = int(rng.integers(0, T + 1))
+        parts = [an.push_hops(hops[:, :split]), an.push_hops(hops[:, split:])]
+        raw = np.concatenate([p[0] for p in parts], 1); sm = np.concatenate([p[1] for p in parts], 1)
+        oraw, osm = fo.push_hops(hops, N, order=order, onset_type=otype, onset_window=owin, onset_sensitivity=sens, gain=gain)
+        cases += 1; frames += C * T
+        for name, g, w in (("raw", raw, oraw), ("smoothed", sm, osm)):
+            g64, w64 = g.astype(np.float64), w.astype(np.float64)
+            same = (g64 == w64) | (np.isnan(g64) & np.isnan(w64))
+            with np.errstate(invalid="ignore", divide="ignore"):
+                err = np.where(same, 0.0, np.abs(g64 - w64) / np.abs(w64))
+            err = np.where(np.isnan(err), np.inf, err)
+            tol = np.full(12, 1e-5); tol[0] = 0.0
+            bad = np.argwhere(err > tol)
+            worst = max(worst, float(np.max(np.where(np.isfinite(err), err, 0))))
+            if len(bad):
+                bad_cases += 1
+                if save_failures and bad_cases <= 6:
+                    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                    np.savez_compressed(os.path.join(ROOT, "gpurun_out", "stress_fail_%d.npz" % bad_cases), hops=hops, N=N, order=order,
+                                        otype=otype, owin=owin, sens=sens, gain=gain, split=split, gpu_raw=raw, oracle_raw=oraw, which=name)
+                c, t, f = bad[0]
+                if verbose:
+                    print("MISMATCH %s N=%d C=%d T=%d order=%d otype=%d owin=%d: %d values; first c=%d t=%d %s gpu=%r oracle=%r"
+                          % (name, N, C, T, order, otype, owin, len(bad), c, t, fx.FEATURE_NAMES[f], g[c, t, f], w[c, t, f]), flush=True)
+    return cases, frames, bad_cases, worst
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    cases, frames, bad_cases, worst = run(seconds, seed)
+    print("stress: %d cases, %d frames, %d mismatching cases, worst finite rel err %.3e" % (cases, frames, bad_cases, worst))
+
+
+if __name__ == "__main__":
+    main()
