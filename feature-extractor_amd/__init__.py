@@ -9,8 +9,8 @@ from .capi import (FEATURE_NAMES, NUM_FEATURES, FxError, load_library, library_p
                    ONSET_SPECTRAL, ONSET_AMPLITUDE, ONSET_COMBINATION,
                    ORDER_SPECTRAL_THEN_HARMONIC, ORDER_HARMONIC_THEN_SPECTRAL, ORDER_ISOLATED,
                    pack_osc12, pack_osc10, osc_encode)
-from .analyser import BatchAnalyser
+from .analyser import BatchAnalyser, HopStream
 from . import synth
 
-__all__ = ["BatchAnalyser", "FxError", "load_library", "library_path", "synth", "FEATURE_NAMES",
+__all__ = ["BatchAnalyser", "HopStream", "FxError", "load_library", "library_path", "synth", "FEATURE_NAMES",
            "NUM_FEATURES", "pack_osc12", "pack_osc10", "osc_encode"]

@@ -135,3 +135,61 @@ class BatchAnalyser:
         out = np.empty((self.num_channels, 12), np.float32)
         capi.check(self._lib.fx_get_smoothed(self._h, out.ctypes.data_as(ctypes.c_void_p), capi.MEM_HOST))
         return out
+
+
+class HopStream:
+    """Streaming ingest on top of a BatchAnalyser: the stand-in for AudioDataCollector's ring
+    (ref AudioDataCollector.h:36-94).  Batches of `hops_per_batch` hops per channel are written into
+    pinned host slots; the copy to the GPU runs on a side stream and overlaps the previous batch's
+    analysis; results come back in order."""
+
+    def __init__(self, analyser, hops_per_batch, slots=3, dtype=np.float32):
+        self._an = analyser
+        self._lib = analyser._lib
+        self.hops = int(hops_per_batch)
+        self.slots = int(slots)
+        self.dtype = np.dtype(dtype)
+        fmt = capi.SAMPLE_F16 if self.dtype == np.float16 else capi.SAMPLE_F32
+        h = ctypes.c_void_p()
+        capi.check(self._lib.fx_stream_create(analyser._h, self.hops, self.slots, fmt, ctypes.byref(h)))
+        self._h = h
+        self._shape = (analyser.num_channels, self.hops, analyser.window_size // 2)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fx_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def in_flight(self):
+        return int(self._lib.fx_stream_in_flight(self._h))
+
+    def slot(self):
+        """numpy view [C][hops][N/2] of the next pinned slot to fill."""
+        p = ctypes.c_void_p()
+        capi.check(self._lib.fx_stream_acquire(self._h, ctypes.byref(p)))
+        n = int(np.prod(self._shape))
+        buf = (ctypes.c_char * (n * self.dtype.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=self.dtype).reshape(self._shape)
+
+    def submit(self):
+        capi.check(self._lib.fx_stream_submit(self._h))
+
+    def push(self, hops):
+        """Copy one batch into the next slot and submit it."""
+        self.slot()[...] = np.asarray(hops, self.dtype).reshape(self._shape)
+        self.submit()
+
+    def collect(self, want_raw=True, want_smoothed=True):
+        C = self._shape[0]
+        raw = np.empty((C, self.hops, 12), np.float32) if want_raw else None
+        sm = np.empty((C, self.hops, 12), np.float32) if want_smoothed else None
+        capi.check(self._lib.fx_stream_collect(self._h,
+                                               raw.ctypes.data_as(ctypes.c_void_p) if raw is not None else None,
+                                               sm.ctypes.data_as(ctypes.c_void_p) if sm is not None else None))
+        return raw, sm

@@ -19,7 +19,8 @@ FX_OK, FX_ERR_INVALID_ARGUMENT, FX_ERR_NO_DEVICE, FX_ERR_HIP, FX_ERR_OUT_OF_MEMO
 # every symbol include/fx.h declares
 EXPORTS = ["fx_create", "fx_destroy", "fx_reset_state", "fx_set_sample_rate", "fx_set_onset_sensitivity",
            "fx_set_onset_window", "fx_set_onset_type", "fx_set_gain", "fx_push_hops", "fx_process_frames",
-           "fx_get_smoothed", "fx_sync", "fx_get_stream", "fx_last_kernel_ms", "fx_profile_begin", "fx_profile_end", "fx_pack_osc12",
+           "fx_get_smoothed", "fx_sync", "fx_get_stream", "fx_last_kernel_ms", "fx_profile_begin", "fx_profile_end",
+           "fx_stream_create", "fx_stream_destroy", "fx_stream_acquire", "fx_stream_submit", "fx_stream_collect", "fx_stream_in_flight", "fx_pack_osc12",
            "fx_pack_osc10", "fx_osc_encode", "fx_last_error", "fx_abi_version"]
 
 
@@ -61,6 +62,12 @@ def load_library(build_if_missing=True):
     L.fx_sync.argtypes = [vp]
     L.fx_get_stream.argtypes = [vp, ctypes.POINTER(vp)]
     L.fx_last_kernel_ms.argtypes = [vp, fp, fp]
+    L.fx_stream_create.argtypes = [vp, i, i, i, ctypes.POINTER(vp)]
+    L.fx_stream_destroy.argtypes = [vp]
+    L.fx_stream_acquire.argtypes = [vp, ctypes.POINTER(vp)]
+    L.fx_stream_submit.argtypes = [vp]
+    L.fx_stream_collect.argtypes = [vp, vp, vp]
+    L.fx_stream_in_flight.argtypes = [vp]
     L.fx_profile_begin.argtypes = [vp]
     L.fx_profile_end.argtypes = [vp, ctypes.POINTER(d), ctypes.POINTER(d), ctypes.POINTER(i)]
     L.fx_pack_osc12.argtypes = [fp, fp]

@@ -480,6 +480,135 @@ fx_status fx_profile_end(fx_context* c, double* frame_ms, double* epi_ms, int* c
     return FX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// streaming ingest (fx_stream_*): pinned host ring, H2D on a side stream, analysis behind an event
+// ---------------------------------------------------------------------------------------------
+} // extern "C"
+
+struct fx_stream {
+    fx_context* ctx = nullptr;
+    int hops = 0, slots = 0, fmt = FX_SAMPLE_F32;
+    size_t in_bytes = 0, out_bytes = 0;
+    hipStream_t copy = nullptr;
+    struct Slot {
+        void*  h_in = nullptr;  void* d_in = nullptr;
+        float* d_raw = nullptr; float* d_sm = nullptr;
+        float* h_raw = nullptr; float* h_sm = nullptr;
+        hipEvent_t copied = nullptr, done = nullptr, out = nullptr;
+    };
+    std::vector<Slot> ring;
+    int head = 0;        // next slot to acquire
+    int tail = 0;        // oldest slot in flight
+    int in_flight = 0;
+    bool acquired = false;
+};
+
+extern "C" {
+
+fx_status fx_stream_destroy(fx_stream* s)
+{
+    if (!s) return FX_OK;
+    if (s->ctx) (void) hipSetDevice(s->ctx->device);
+    if (s->copy) (void) hipStreamSynchronize(s->copy);
+    if (s->ctx && s->ctx->stream) (void) hipStreamSynchronize(s->ctx->stream);
+    for (auto& sl : s->ring) {
+        if (sl.h_in) (void) hipHostFree(sl.h_in);
+        if (sl.h_raw) (void) hipHostFree(sl.h_raw);
+        if (sl.h_sm) (void) hipHostFree(sl.h_sm);
+        if (sl.d_in) (void) hipFree(sl.d_in);
+        if (sl.d_raw) (void) hipFree(sl.d_raw);
+        if (sl.d_sm) (void) hipFree(sl.d_sm);
+        if (sl.copied) (void) hipEventDestroy(sl.copied);
+        if (sl.done) (void) hipEventDestroy(sl.done);
+        if (sl.out) (void) hipEventDestroy(sl.out);
+    }
+    if (s->copy) (void) hipStreamDestroy(s->copy);
+    delete s;
+    return FX_OK;
+}
+
+fx_status fx_stream_create(fx_context* c, int hops_per_batch, int slots, int sample_format, fx_stream** out)
+{
+    if (!c || !out) return fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    if (hops_per_batch < 1 || slots < 1 || slots > 64) return fail(FX_ERR_INVALID_ARGUMENT, "hops_per_batch >= 1 and 1 <= slots <= 64 required");
+    if (sample_format != FX_SAMPLE_F32 && sample_format != FX_SAMPLE_F16) return fail(FX_ERR_INVALID_ARGUMENT, "unknown sample format %d", sample_format);
+    HIP_TRY(hipSetDevice(c->device));
+    fx_stream* s = new (std::nothrow) fx_stream();
+    if (!s) return fail(FX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    s->ctx = c; s->hops = hops_per_batch; s->slots = slots; s->fmt = sample_format;
+    s->in_bytes = (size_t) c->C * hops_per_batch * (c->N / 2) * (sample_format == FX_SAMPLE_F16 ? 2 : 4);
+    s->out_bytes = (size_t) c->C * hops_per_batch * FX_NUM_FEATURES * sizeof(float);
+    s->ring.resize((size_t) slots);
+#define S_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fx_status st_ = fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); fx_stream_destroy(s); return st_; } } while (0)
+    S_TRY(hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
+    for (auto& sl : s->ring) {
+        S_TRY(hipHostMalloc(&sl.h_in, s->in_bytes, hipHostMallocDefault));
+        S_TRY(hipHostMalloc((void**) &sl.h_raw, s->out_bytes, hipHostMallocDefault));
+        S_TRY(hipHostMalloc((void**) &sl.h_sm, s->out_bytes, hipHostMallocDefault));
+        S_TRY(hipMalloc(&sl.d_in, s->in_bytes));
+        S_TRY(hipMalloc((void**) &sl.d_raw, s->out_bytes));
+        S_TRY(hipMalloc((void**) &sl.d_sm, s->out_bytes));
+        S_TRY(hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+        S_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        S_TRY(hipEventCreateWithFlags(&sl.out, hipEventDisableTiming));
+    }
+#undef S_TRY
+    *out = s;
+    return FX_OK;
+}
+
+int fx_stream_in_flight(fx_stream* s) { return s ? s->in_flight : 0; }
+
+fx_status fx_stream_acquire(fx_stream* s, void** host_slot)
+{
+    if (!s || !host_slot) return fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    if (s->acquired) return fail(FX_ERR_INVALID_ARGUMENT, "a slot is already acquired; submit it first");
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    if (s->in_flight == s->slots)
+        return fail(FX_ERR_INVALID_ARGUMENT, "all %d slots are in flight; collect a batch first", s->slots);
+    *host_slot = s->ring[(size_t) s->head].h_in;
+    s->acquired = true;
+    return FX_OK;
+}
+
+fx_status fx_stream_submit(fx_stream* s)
+{
+    if (!s) return fail(FX_ERR_INVALID_ARGUMENT, "null stream");
+    if (!s->acquired) return fail(FX_ERR_INVALID_ARGUMENT, "no slot acquired");
+    fx_context* c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    fx_stream::Slot& sl = s->ring[(size_t) s->head];
+    HIP_TRY(hipMemcpyAsync(sl.d_in, sl.h_in, s->in_bytes, hipMemcpyHostToDevice, s->copy));
+    HIP_TRY(hipEventRecord(sl.copied, s->copy));
+    HIP_TRY(hipStreamWaitEvent(c->stream, sl.copied, 0));
+    fx_status st = run(c, sl.d_in, s->hops, s->fmt, FX_MEM_DEVICE, 1, sl.d_raw, sl.d_sm);
+    if (st != FX_OK) return st;
+    HIP_TRY(hipEventRecord(sl.done, c->stream));
+    HIP_TRY(hipStreamWaitEvent(s->copy, sl.done, 0));
+    HIP_TRY(hipMemcpyAsync(sl.h_raw, sl.d_raw, s->out_bytes, hipMemcpyDeviceToHost, s->copy));
+    HIP_TRY(hipMemcpyAsync(sl.h_sm, sl.d_sm, s->out_bytes, hipMemcpyDeviceToHost, s->copy));
+    HIP_TRY(hipEventRecord(sl.out, s->copy));
+    s->head = (s->head + 1) % s->slots;
+    s->in_flight++;
+    s->acquired = false;
+    return FX_OK;
+}
+
+fx_status fx_stream_collect(fx_stream* s, float* out_raw, float* out_smoothed)
+{
+    if (!s) return fail(FX_ERR_INVALID_ARGUMENT, "null stream");
+    if (s->in_flight == 0) return fail(FX_ERR_INVALID_ARGUMENT, "nothing in flight");
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    fx_stream::Slot& sl = s->ring[(size_t) s->tail];
+    HIP_TRY(hipEventSynchronize(sl.out));
+    if (out_raw) memcpy(out_raw, sl.h_raw, s->out_bytes);
+    if (out_smoothed) memcpy(out_smoothed, sl.h_sm, s->out_bytes);
+    s->tail = (s->tail + 1) % s->slots;
+    s->in_flight--;
+    return FX_OK;
+}
+
 // ---- OSC sink helpers (ref OSCFeatureAnalysisOutput.h:107, README.md:57) ----
 static const int k_osc12[12] = {FX_ONSET, FX_RMS, FX_F0, FX_CENTROID, FX_SLOPE, FX_SPREAD,
                                 FX_FLATNESS, FX_LER, FX_FLUX, FX_HER, FX_OER, FX_INHARM};

@@ -132,6 +132,26 @@ fx_status fx_get_stream(fx_context* ctx, void** stream);
  * (milliseconds; synchronises). kernel 0 = frame kernel, 1 = smoothing/onset. */
 fx_status fx_last_kernel_ms(fx_context* ctx, float* frame_kernel_ms, float* epilogue_kernel_ms);
 
+/* ---- streaming ingest: replaces AudioDataCollector's ring + busy-wait reader ----
+ * (AudioDataCollector.h:24,36-94: audio thread writes a 4096-sample ring, the analysis thread spins
+ * until a hop is available.)  Here the producer owns a ring of `slots` PINNED host batches, each
+ * [num_channels][hops_per_batch][window_size/2] samples.  fx_stream_submit() enqueues the H2D copy of
+ * the filled slot on a side HIP stream and its analysis on the context's stream behind an event, so
+ * the copy of batch k+1 overlaps the kernels of batch k; results return in submission order. */
+typedef struct fx_stream fx_stream;
+fx_status fx_stream_create(fx_context* ctx, int hops_per_batch, int slots, int sample_format, fx_stream** out);
+fx_status fx_stream_destroy(fx_stream* s);
+/* Next free slot to fill (pinned host memory); blocks while every slot is still in flight. */
+fx_status fx_stream_acquire(fx_stream* s, void** host_slot);
+/* Hand the acquired slot to the GPU (asynchronous). */
+fx_status fx_stream_submit(fx_stream* s);
+/* Wait for the OLDEST submitted batch and copy its results out: raw / smoothed
+ * [num_channels][hops_per_batch][12] host floats (either may be NULL).  FX_ERR_INVALID_ARGUMENT
+ * if nothing is in flight. */
+fx_status fx_stream_collect(fx_stream* s, float* out_raw, float* out_smoothed);
+/* Number of submitted batches not yet collected. */
+int fx_stream_in_flight(fx_stream* s);
+
 /* Kernel-time accounting over a region of calls: fx_profile_begin() starts recording a HIP event
  * triple per analysis call on the context's stream (no synchronisation, at most 4096 calls);
  * fx_profile_end() synchronises and returns the summed device time of the frame kernel and of the

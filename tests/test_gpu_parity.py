@@ -214,3 +214,47 @@ def test_config3_shape_spot_check(gpu_fx, oracle):
     oraw, osm = oracle.push_hops(np.concatenate([h1[pick], h2[pick]], axis=1), N)
     close(np.concatenate([a[0][pick], b[0][pick]], axis=1), oraw, "config 3 raw")
     close(np.concatenate([a[1][pick], b[1][pick]], axis=1), osm, "config 3 smoothed")
+
+
+def test_hop_stream_equals_push_hops_bitwise(gpu_fx):
+    """Streaming ingest (pinned ring, H2D on a side stream) must give exactly what fx_push_hops gives,
+    in order, for ragged use of the ring (collect lagging behind submit)."""
+    N, C, B, nb = 2048, 5, 3, 7
+    hops = signals.bursts(C, B * nb, N, seed=77)
+    want = gpu_fx.BatchAnalyser(C, N).push_hops(hops)
+    an = gpu_fx.BatchAnalyser(C, N)
+    st = gpu_fx.HopStream(an, B, slots=3)
+    got_raw, got_sm = [], []
+    for b in range(nb):
+        if st.in_flight() == 3:
+            r, s = st.collect()
+            got_raw.append(r); got_sm.append(s)
+        st.push(hops[:, b * B:(b + 1) * B])
+    while st.in_flight():
+        r, s = st.collect()
+        got_raw.append(r); got_sm.append(s)
+    assert np.array_equal(np.concatenate(got_raw, 1), want[0], equal_nan=True)
+    assert np.array_equal(np.concatenate(got_sm, 1), want[1], equal_nan=True)
+    with pytest.raises(gpu_fx.FxError):
+        st.collect()                                   # nothing in flight
+    st.close()
+
+
+def test_hop_stream_fp16_4096(gpu_fx, oracle):
+    """BASELINE configs[4] shape: 4096-pt windows, fp16 samples streamed through the pinned ring."""
+    N, C, B, nb = 4096, 1, 1, 12
+    h16 = gpu_fx.synth.hops(C, B * nb, N).astype(np.float16)
+    an = gpu_fx.BatchAnalyser(C, N)
+    st = gpu_fx.HopStream(an, B, slots=2, dtype=np.float16)
+    outs = []
+    for b in range(nb):
+        if st.in_flight() == 2:
+            outs.append(st.collect())
+        slot = st.slot()
+        slot[...] = h16[:, b * B:(b + 1) * B]
+        st.submit()
+    while st.in_flight():
+        outs.append(st.collect())
+    oraw, osm = oracle.push_hops(h16.astype(np.float32), N)
+    close(np.concatenate([o[0] for o in outs], 1), oraw, "stream fp16 raw")
+    close(np.concatenate([o[1] for o in outs], 1), osm, "stream fp16 smoothed")
