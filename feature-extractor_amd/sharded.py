@@ -69,22 +69,86 @@ def resolve(result):
     return result.resolve() if isinstance(result, _LazySelect) else result
 
 
+def parse_osc_target(address, default_port=9000):
+    """'ip[:port]' -> (ip, port), as OSCFeatureAnalysisOutput::connectToAddress parses it
+    (ref OSCFeatureAnalysisOutput.h:115-123: text after the last ':' is the port, default 9000)."""
+    address = address.strip()
+    if ":" in address:
+        host, _, port = address.rpartition(":")
+        try:
+            return host.split(":")[0], int(port)
+        except ValueError:
+            return host.split(":")[0], 0
+    return address, default_port
+
+
 class OscSink:
-    """The sink side of the path: turns gathered smoothed vectors [C][12] into the datagrams
-    OSCFeatureAnalysisOutput would send, one per channel, address /Audio/A<channel>
-    (ref MainComponent.cpp:170, OSCFeatureAnalysisOutput.h:107).  `sock` is optional: tests and
-    the bench only encode."""
+    """The sink side of the path (ref OSCFeatureAnalysisOutput.h:84-136): holds the latest smoothed
+    vectors [C][12] and, paced by a 60 Hz timer (ref :133 startTimerHz (60)), sends one OSC message per
+    channel -- address /Audio/A<channel> (ref MainComponent.cpp:170), 12 big-endian floats in the order of
+    ref :107 -- to a primary and an optional secondary target (ref AnalyserTrackController.h:22-23).
+    Sampling is asynchronous to frame production, as in the reference: a value may be sent twice."""
 
-    def __init__(self, encode, host="127.0.0.1", port=9000, sock=None):
-        self.encode, self.addr, self.sock = encode, (host, port), sock
+    def __init__(self, encode, target="127.0.0.1:9000", secondary=None, bundle_prefix="/Audio/A", rate_hz=60.0, first_channel=0):
+        import socket
+        import threading
+        self.encode = encode
+        self.targets = [parse_osc_target(target)] + ([parse_osc_target(secondary)] if secondary else [])
+        self.prefix = bundle_prefix
+        self.first_channel = first_channel
+        self.period = 1.0 / rate_hz
+        self.sock = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        self._lock = threading.Lock()
+        self._latest = None
+        self._timer = None
+        self._stop = threading.Event()
+        self.sent = 0
 
-    def datagrams(self, smoothed):
+    def update(self, smoothed):
+        """Publish the newest AudioFeatures::getValue vectors [C][12] (what the timer will sample)."""
+        v = np.array(smoothed, np.float32).reshape(-1, 12)
+        with self._lock:
+            self._latest = v
+
+    def datagrams(self, smoothed=None):
+        if smoothed is None:
+            with self._lock:
+                smoothed = self._latest
+        if smoothed is None:
+            return []
         smoothed = np.asarray(smoothed, np.float32).reshape(-1, 12)
-        return [self.encode("/Audio/A%d" % c, smoothed[c]) for c in range(smoothed.shape[0])]
+        return [self.encode("%s%d" % (self.prefix, self.first_channel + c), smoothed[c]) for c in range(smoothed.shape[0])]
 
-    def send(self, smoothed):
+    def send(self, smoothed=None):
+        """One timer tick: sendSpectralFeaturesViaOSC for every channel (ref :89-113)."""
         msgs = self.datagrams(smoothed)
-        if self.sock is not None:
-            for m in msgs:
-                self.sock.sendto(m, self.addr)
+        for m in msgs:
+            for t in self.targets:
+                self.sock.sendto(m, t)
+        self.sent += len(msgs) * len(self.targets)
         return len(msgs)
+
+    def start(self):
+        import threading
+
+        def loop():
+            import time
+            nxt = time.perf_counter()
+            while not self._stop.is_set():
+                self.send()
+                nxt += self.period
+                self._stop.wait(max(0.0, nxt - time.perf_counter()))
+
+        self._stop.clear()
+        self._timer = threading.Thread(target=loop, daemon=True)
+        self._timer.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._timer is not None:
+            self._timer.join()
+            self._timer = None
+
+    def close(self):
+        self.stop()
+        self.sock.close()

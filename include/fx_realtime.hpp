@@ -12,6 +12,7 @@
 #define FX_REALTIME_HPP
 
 #include <cstddef>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -158,6 +159,53 @@ inline std::string OSCFeatureMessage (const std::string& address, const float* f
     if (n < 0) throw Error (FX_ERR_INVALID_ARGUMENT, "OSC address too long");
     return std::string (reinterpret_cast<const char*> (buf), (std::size_t) n);
 }
+} // namespace fx
+
+// ---- UDP sender for the feature message (POSIX sockets; ref OSCFeatureAnalysisOutput.h:115-136) ----
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+namespace fx
+{
+class OSCFeatureSender
+{
+public:
+    OSCFeatureSender() = default;
+    ~OSCFeatureSender() { if (fd >= 0) ::close (fd); }
+    OSCFeatureSender (const OSCFeatureSender&) = delete;
+    OSCFeatureSender& operator= (const OSCFeatureSender&) = delete;
+
+    // "ip[:port]", port defaults to 9000 -- same parsing as connectToAddress (ref :115-123)
+    bool connectToAddress (const std::string& newAddress)
+    {
+        int port = 9000;
+        const std::size_t sep = newAddress.rfind (':');
+        if (sep != std::string::npos) port = std::atoi (newAddress.c_str() + sep + 1);
+        const std::string ip = newAddress.substr (0, newAddress.find (':'));
+        if (fd < 0) fd = ::socket (AF_INET, SOCK_DGRAM, 0);
+        if (fd < 0) return false;
+        dest = sockaddr_in();
+        dest.sin_family = AF_INET;
+        dest.sin_port = htons ((unsigned short) port);
+        connected = ::inet_pton (AF_INET, ip.c_str(), &dest.sin_addr) == 1;
+        return connected;
+    }
+
+    // one sendSpectralFeaturesViaOSC (ref :89-113): features12 in AudioFeatures slot order
+    bool send (const std::string& bundleAddress, const float* features12)
+    {
+        if (! connected) return false;
+        const std::string msg = OSCFeatureMessage (bundleAddress, features12);
+        return ::sendto (fd, msg.data(), msg.size(), 0, reinterpret_cast<const sockaddr*> (&dest), sizeof dest) == (ssize_t) msg.size();
+    }
+
+private:
+    int fd = -1;
+    bool connected = false;
+    sockaddr_in dest {};
+};
 } // namespace fx
 
 #endif // FX_REALTIME_HPP

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "fx_realtime.hpp"
@@ -32,6 +33,27 @@ int main (int argc, char** argv)
     EXPECT (msg.size() == 76);
     EXPECT (std::memcmp (msg.data(), "/Audio/A0\0\0\0,ffffffffffff\0\0\0", 28) == 0);
     EXPECT ((unsigned char) msg[28 + 4 * 4] == 0x41 && (unsigned char) msg[28 + 4 * 4 + 1] == 0x00);   // 5th float is slope = 8.0f
+
+    {
+        // loopback: the sender's datagram is what OSCFeatureMessage builds
+        int rx = ::socket (AF_INET, SOCK_DGRAM, 0);
+        sockaddr_in a {};
+        a.sin_family = AF_INET; a.sin_port = 0; a.sin_addr.s_addr = htonl (INADDR_LOOPBACK);
+        EXPECT (::bind (rx, reinterpret_cast<sockaddr*> (&a), sizeof a) == 0);
+        socklen_t len = sizeof a;
+        ::getsockname (rx, reinterpret_cast<sockaddr*> (&a), &len);
+        fx::OSCFeatureSender sender;
+        EXPECT (sender.connectToAddress ("127.0.0.1:" + std::to_string ((int) ntohs (a.sin_port))));
+        EXPECT (sender.send ("/Audio/A0", v));
+        char buf[256];
+        timeval tv { 2, 0 };
+        ::setsockopt (rx, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+        const ssize_t n = ::recv (rx, buf, sizeof buf, 0);
+        EXPECT (n == 76 && std::memcmp (buf, msg.data(), 76) == 0);
+        ::close (rx);
+        fx::OSCFeatureSender dflt;
+        EXPECT (dflt.connectToAddress ("127.0.0.1"));          // default port 9000
+    }
 
     if (! gpu)
     {

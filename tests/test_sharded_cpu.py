@@ -74,4 +74,36 @@ def test_sink_encodes_one_datagram_per_channel(fx, oracle):
     msgs = sink.datagrams(sm)
     assert len(msgs) == 12 and len(msgs[0]) == 76 and len(msgs[11]) == 76
     assert msgs[10] == oracle.osc_message("/Audio/A10", sm[10])
-    assert sink.send(sm) == 12
+    sink.close()
+
+
+def test_osc_target_parsing_follows_the_reference():
+    sharded = importlib.import_module("feature-extractor_amd.sharded")
+    assert sharded.parse_osc_target("127.0.0.1") == ("127.0.0.1", 9000)        # default port, ref OSCFeatureAnalysisOutput.h:117
+    assert sharded.parse_osc_target("10.0.0.7:8001") == ("10.0.0.7", 8001)
+
+
+def test_sink_sends_udp_datagrams_at_60hz_to_both_targets(fx, oracle):
+    """Loopback UDP: primary + secondary receiver each get byte-exact 76-byte messages, paced ~60 Hz."""
+    import time
+    sharded = importlib.import_module("feature-extractor_amd.sharded")
+    rx = []
+    for _ in range(2):
+        r = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
+        r.bind(("127.0.0.1", 0))
+        r.settimeout(2.0)
+        rx.append(r)
+    sm = np.random.default_rng(1).standard_normal((3, 12)).astype(np.float32)
+    sink = sharded.OscSink(fx.osc_encode, "127.0.0.1:%d" % rx[0].getsockname()[1], "127.0.0.1:%d" % rx[1].getsockname()[1])
+    sink.update(sm)
+    t0 = time.perf_counter()
+    sink.start()
+    got = [[rx[k].recv(256) for _ in range(3 * 12)] for k in range(2)]        # 12 ticks x 3 channels
+    dt = time.perf_counter() - t0
+    sink.close()
+    want = [oracle.osc_message("/Audio/A%d" % c, sm[c]) for c in range(3)]
+    for k in range(2):
+        assert got[k][:3] == want and all(len(m) == 76 for m in got[k])
+    assert 0.12 < dt < 1.0                         # 11 periods of 1/60 s = 0.18 s, generous bounds for CI
+    for r in rx:
+        r.close()
