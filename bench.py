@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--frames", type=int, default=64, help="consecutive frames per channel per step")
     ap.add_argument("--window", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: debugging aid for boxes with fewer GPUs than ranks (ranks share devices, features are gathered through host memory)")
     ap.add_argument("--stream", action="store_true",
                     help="host-resident hops through the pinned ring (fx_stream_*): PCIe-inclusive rate, reported as an extra line")
     ap.add_argument("--fp16", action="store_true", help="--stream only: fp16 samples")
@@ -119,10 +121,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     fx = importlib.import_module("feature-extractor_amd")
     sharded = importlib.import_module("feature-extractor_amd.sharded")
@@ -135,7 +142,9 @@ def main():
     frames = torch.from_numpy(fx.synth.frames(count, T, N, first_channel=first)).cuda(local_rank)
     an = fx.BatchAnalyser(count, N, device=local_rank)
     raw = torch.empty((count, T, 12), dtype=torch.float32, device=frames.device)
-    sm = torch.empty((count, T, 12), dtype=torch.float32, device=frames.device)
+    # two output buffers: the gather of step i (RCCL, its own stream) reads one while the kernels of
+    # step i+1 (the library's stream) write the other
+    sm_bufs = [torch.empty((count, T, 12), dtype=torch.float32, device=frames.device) for _ in range(2)]
 
     def barrier():
         an.sync()
@@ -144,25 +153,37 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    pending = [None]
+    pending = [None, None]
+    counter = [0]
+
+    def drain(slot):
+        if pending[slot] is not None and pending[slot][1] is not None:
+            pending[slot][1].wait()
+            torch.cuda.current_stream().synchronize()
+        pending[slot] = None
 
     def step():
-        an.process_frames(frames, out_raw=raw, out_smoothed=sm)
+        slot = counter[0] & 1
+        counter[0] += 1
+        if world > 1:
+            drain(slot)                                  # the gather that last read this buffer has finished
+        an.process_frames(frames, out_raw=raw, out_smoothed=sm_bufs[slot])
         if world > 1:
             an.sync()                                    # features ready before RCCL reads them
-            if pending[0] is not None and pending[0][1] is not None:
-                pending[0][1].wait()
-            pending[0] = sharded.gather_features(sm, total_channels, dst=0, async_op=True)
+            src = sm_bufs[slot] if args.backend == "nccl" else sm_bufs[slot].cpu()
+            pending[slot] = sharded.gather_features(src, total_channels, dst=0, async_op=True)
 
     for _ in range(args.warmup):
         step()
+    drain(0)
+    drain(1)
     barrier()
     an.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if pending[0] is not None and pending[0][1] is not None:
-        pending[0][1].wait()
+    drain(0)
+    drain(1)
     barrier()
     dt = time.perf_counter() - t0
     frame_ms, epi_ms, calls = an.profile_end()
