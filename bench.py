@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--frames", type=int, default=64, help="consecutive frames per channel per step")
     ap.add_argument("--window", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--signal", default="synth", choices=["synth", "noise", "silence"],
+                    help="synth = the BASELINE synthetic mix (default); noise / silence probe data-dependent paths")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: debugging aid for boxes with fewer GPUs than ranks (ranks share devices, features are gathered through host memory)")
     ap.add_argument("--stream", action="store_true",
@@ -139,7 +141,12 @@ def main():
     total_channels = C * world
     first, count = sharded.my_shard(total_channels, rank, world)
 
-    frames = torch.from_numpy(fx.synth.frames(count, T, N, first_channel=first)).cuda(local_rank)
+    host_frames = fx.synth.frames(count, T, N, first_channel=first)
+    if args.signal == "noise":
+        host_frames = np.random.default_rng(first).normal(0, 0.1, host_frames.shape).astype(np.float32)
+    elif args.signal == "silence":
+        host_frames = np.zeros_like(host_frames)
+    frames = torch.from_numpy(host_frames).cuda(local_rank)
     an = fx.BatchAnalyser(count, N, device=local_rank)
     raw = torch.empty((count, T, 12), dtype=torch.float32, device=frames.device)
     # two output buffers: the gather of step i (RCCL, its own stream) reads one while the kernels of

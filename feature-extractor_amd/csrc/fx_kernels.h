@@ -52,6 +52,7 @@ struct FrameParams {
     double       nyquist;
     double       bin_var;       // sum_i (i/M - 0.5)^2 / M, summed serially on the host (ref SpectralCharacteristics.h:182-189)
     float        lpf_a, lpf_b;  // ref RealTimeAudioAnalysis.h:122
+    unsigned long long* debug;  // diagnostic builds (-DFX_STAMPS) only: [12] per-section cycle sums; else nullptr
 };
 
 struct EpilogueParams {

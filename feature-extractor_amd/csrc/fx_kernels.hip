@@ -31,6 +31,15 @@ namespace fxk {
 
 #define FX_MARK(name) asm volatile("; FXMARK " name)
 
+// Diagnostic build only (-DFX_STAMPS): per-section wave-cycle shares, summed into p.debug[section].
+// Never part of the shipped library; stamped builds are not timed (MI355X guide, "In-kernel stamps").
+#ifdef FX_STAMPS
+#define FX_STAMP(idx) do { unsigned long long now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
+                           stamp_acc[idx] += now_ - stamp_last; stamp_last = now_; } while (0)
+#else
+#define FX_STAMP(idx) do {} while (0)
+#endif
+
 typedef float  __attribute__((ext_vector_type(2))) f2;
 typedef float  __attribute__((ext_vector_type(4))) f4;
 
@@ -414,6 +423,50 @@ __device__ __forceinline__ void load_half(const void* src, int sample_format, fl
     }
 }
 
+// Both halves of a window with every global load issued before the first one is consumed (one memory
+// round trip per frame instead of one per 1 KB piece).  F16_A / F16_B: sample format of the source of
+// the first / second half (the carried-over tail is always fp32).  N >= 512.
+template <int N, bool F16_A, bool F16_B>
+__device__ __forceinline__ void load_window(const void* src_a, const void* src_b, float gain_a, float gain_b,
+                                            float* rbuf, float* tail_out, int lane)
+{
+    constexpr int HALF = N / 2, QH = HALF / 256;
+    uint4 ra[QH], rb[QH];
+#pragma unroll
+    for (int q = 0; q < QH; q++) {
+        const int i = 256 * q + 4 * lane;
+        if (F16_A) { const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const __half*>(src_a) + i); ra[q] = uint4{v.x, v.y, 0u, 0u}; }
+        else       ra[q] = *reinterpret_cast<const uint4*>(static_cast<const float*>(src_a) + i);
+    }
+#pragma unroll
+    for (int q = 0; q < QH; q++) {
+        const int i = 256 * q + 4 * lane;
+        if (F16_B) { const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const __half*>(src_b) + i); rb[q] = uint4{v.x, v.y, 0u, 0u}; }
+        else       rb[q] = *reinterpret_cast<const uint4*>(static_cast<const float*>(src_b) + i);
+    }
+    auto widen = [](uint4 r, bool f16) -> f4 {
+        if (f16) {
+            const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&r.x));
+            const float2 b = __half22float2(*reinterpret_cast<const __half2*>(&r.y));
+            return f4{a.x, a.y, b.x, b.y};
+        }
+        return f4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+    };
+#pragma unroll
+    for (int q = 0; q < QH; q++) {
+        const int i = 256 * q + 4 * lane;
+        const f4 v = widen(ra[q], F16_A) * gain_a;             // ref AudioDataCollector.h:88 (x * 1.0f is exact)
+        *reinterpret_cast<f4*>(&rbuf[rpad(i)]) = v;
+    }
+#pragma unroll
+    for (int q = 0; q < QH; q++) {
+        const int i = 256 * q + 4 * lane;
+        const f4 v = widen(rb[q], F16_B) * gain_b;
+        *reinterpret_cast<f4*>(&rbuf[rpad(HALF + i)]) = v;
+        if (tail_out) *reinterpret_cast<f4*>(tail_out + i) = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // the frame kernel
 // ---------------------------------------------------------------------------------------------
@@ -478,8 +531,14 @@ fx_frame_kernel(const FrameParams p)
     const double frpb = nyquist / (double) M;          // ref SpectralCharacteristics.h:64,105
     const float  scale = 1.0f / (float) N;             // JUCE inverse scale
 
+#ifdef FX_STAMPS
+    unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
+#endif
     for (int t = wave; t < T; t += nwaves) {
         int lane = opaque(lane0);
+        FX_STAMP(11);
         // uniform per-frame results go to LDS as soon as they exist instead of occupying ~28 VGPRs
         // in every lane for the whole frame
         FramePart* fpl = parts + wave;
@@ -491,19 +550,31 @@ FX_MARK("load");
             const size_t esz = p.sample_format == FX_SAMPLE_F16 ? 2 : 4;
             const unsigned char* in = static_cast<const unsigned char*>(p.in);
             float* tail_dst = (t == T - 1) ? p.tail_out + (size_t) c * HALF : nullptr;
+            const bool f16 = p.sample_format == FX_SAMPLE_F16;
+            const void* src_a; const void* src_b; float gain_a, gain_b; bool f16_a = f16;
             if (p.hop_mode) {
-                if (t == 0) load_half<HALF>(p.tail_in + (size_t) c * HALF, FX_SAMPLE_F32, 1.0f, false, rbuf, 0, nullptr, lane);
-                else        load_half<HALF>(in + ((size_t) c * T + (t - 1)) * HALF * esz, p.sample_format, p.gain, true, rbuf, 0, nullptr, lane);
-                load_half<HALF>(in + ((size_t) c * T + t) * HALF * esz, p.sample_format, p.gain, true, rbuf, HALF, tail_dst, lane);
+                gain_a = gain_b = p.gain;
+                src_b = in + ((size_t) c * T + t) * HALF * esz;
+                if (t == 0) { src_a = p.tail_in + (size_t) c * HALF; f16_a = false; gain_a = 1.0f; }   // tail is fp32, already gained
+                else        src_a = in + ((size_t) c * T + (t - 1)) * HALF * esz;
             } else {
-                const unsigned char* f = in + ((size_t) c * T + t) * N * esz;
-                load_half<HALF>(f, p.sample_format, 1.0f, false, rbuf, 0, nullptr, lane);
-                load_half<HALF>(f + HALF * esz, p.sample_format, 1.0f, false, rbuf, HALF, tail_dst, lane);
+                gain_a = gain_b = 1.0f;
+                src_a = in + ((size_t) c * T + t) * N * esz;
+                src_b = static_cast<const unsigned char*>(src_a) + HALF * esz;
+            }
+            if constexpr (N >= 512) {
+                if (f16_a && f16)       load_window<N, true,  true >(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane);
+                else if (f16)           load_window<N, false, true >(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane);
+                else                    load_window<N, false, false>(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane);
+            } else {
+                load_half<HALF>(src_a, f16_a ? FX_SAMPLE_F16 : FX_SAMPLE_F32, gain_a, gain_a != 1.0f, rbuf, 0, nullptr, lane);
+                load_half<HALF>(src_b, p.sample_format, gain_b, gain_b != 1.0f, rbuf, HALF, tail_dst, lane);
             }
             wave_fence();
         }
 
 FX_MARK("rms");
+        FX_STAMP(0);
         // ---------------- a2: RMS on the un-windowed frame (ref RealTimeAnalyser.h:207-208) ---------
         // the frame, in registers, in the order the first FFT pass consumes it; the LDS buffer is
         // free again after this read
@@ -527,6 +598,7 @@ FX_MARK("rms");
         }
 
 FX_MARK("spec_fft");
+        FX_STAMP(1);
         // ---------------- spectral analyser (ref RealTimeAnalyser.h:212-224) -----------------------
         lane = opaque(lane);
         {
@@ -539,6 +611,7 @@ FX_MARK("spec_fft");
             fft_from_regs<N, false>(xw, cbuf, tw, lane);                       // a4
         }
 FX_MARK("spec_sums");
+        FX_STAMP(2);
         {
             // lane owns bins [U*lane, U*lane + U)
             float re[U];
@@ -715,6 +788,7 @@ FX_MARK("spec_pass2");
         wave_fence();
 
 FX_MARK("harm1");
+        FX_STAMP(3);
         // ---------------- harmonic analyser, part 1: raw (un-windowed) spectrum ---------------------
         // ref RealTimeAnalyser.h:161 -- done before the low-pass overwrites the frame image
         lane = opaque(lane);
@@ -745,6 +819,7 @@ FX_MARK("harm1");
         lane = opaque(lane);
         {
 FX_MARK("lpf");
+        FX_STAMP(4);
             // a10 AudioFilter::filterAudio, ref RealTimeAudioAnalysis.h:106-125:
             //   y[0] = x[0];  y[n] = (a*x[n]) + (b*y[n-1]) in fp32, strictly serial.
             // Lane l owns samples [P*l, P*l+P).  It starts KW samples early from a guess, and the
@@ -817,6 +892,7 @@ FX_MARK("lpf");
             wave_fence();
 
 FX_MARK("pitch_fft");
+        FX_STAMP(5);
             lane = opaque(lane);
             float xf[P];
 #pragma unroll
@@ -826,6 +902,7 @@ FX_MARK("pitch_fft");
             wave_fence();
             fft_from_regs<N, false>(xf, cbuf, tw, lane);                       // ref RealTimeAnalyser.h:160
 FX_MARK("power");
+        FX_STAMP(6);
             // a11 getComplexConjugateMultiplication, ref PitchAnalyser.h:83-108: re*re, imag := 0,
             // picked up directly in the order the inverse transform's first pass wants it
             lane = opaque(lane);
@@ -840,6 +917,7 @@ FX_MARK("power");
 FX_MARK("ifft");
             fft_from_regs<N, true>(xf, cbuf, tw, lane);                        // a12 inverse, ref :110-121
 FX_MARK("vcalc");
+        FX_STAMP(7);
             // v[s] = d[s]*d[s]*s, d = planar JUCE inverse output scaled by 1/N (ref :122-123).
             // Only s in [1, N] is ever read by the lag search; v[N] comes from imag[0].
             lane = opaque(lane);
@@ -938,6 +1016,7 @@ FX_MARK("scan");
         wave_fence();
 
 FX_MARK("harm2");
+        FX_STAMP(8);
         // ---------------- harmonic analyser, part 2 (ref HarmonicCharacteristics.h:71-105) ----------
         lane = opaque(lane);
         if (!(h_sum < 0.005)) {                                                // :88-89
@@ -1061,13 +1140,21 @@ FX_MARK("harm2");
         wave_fence();
 
 FX_MARK("store");
+        FX_STAMP(9);
         wave_fence();
         static_assert(sizeof(FramePart) % 16 == 0, "16-byte stores");
+#ifndef FX_EXPERIMENT_NOSTORE
         if (lane < (int) (sizeof(FramePart) / 16))
             reinterpret_cast<uint4*>(p.part + ((size_t) c * T + t))[lane] = reinterpret_cast<const uint4*>(fpl)[lane];
+#endif
         wave_fence();
+        FX_STAMP(10);
     }
 
+#ifdef FX_STAMPS
+    if (lane0 == 0 && p.debug)
+        for (int i = 0; i < 16; i++) atomicAdd(p.debug + i, stamp_acc[i]);
+#endif
     __syncthreads();
     for (int i = threadIdx.x; i < M; i += blockDim.x) p.prev_re[(size_t) c * M + i] = prev[i];
 }
