@@ -258,3 +258,27 @@ def test_hop_stream_fp16_4096(gpu_fx, oracle):
     oraw, osm = oracle.push_hops(h16.astype(np.float32), N)
     close(np.concatenate([o[0] for o in outs], 1), oraw, "stream fp16 raw")
     close(np.concatenate([o[1] for o in outs], 1), osm, "stream fp16 smoothed")
+
+
+def test_non_finite_and_extreme_inputs_do_not_disturb_other_channels(gpu_fx, oracle):
+    """NaN / inf / 1e30 / denormal samples: the call must return, and channels without such samples
+    must be unaffected bit for bit.  (Parity is not claimed for the poisoned channels' harmonic slots:
+    the reference indexes out of bounds there, HarmonicCharacteristics.h:205.)"""
+    N, C, T = 1024, 6, 10
+    hops = signals.tone_vibrato_noise(C, T, N, seed=5)
+    clean = gpu_fx.BatchAnalyser(C, N).push_hops(hops)
+    bad = hops.copy()
+    bad[1, 3, 17] = np.nan
+    bad[2, 4, 100] = np.inf
+    bad[3, 5, :] = 1e30
+    bad[4, 2, :] = 1e-42                       # denormals
+    got = gpu_fx.BatchAnalyser(C, N).push_hops(bad)
+    for c in (0, 5):
+        assert np.array_equal(got[0][c], clean[0][c], equal_nan=True)
+        assert np.array_equal(got[1][c], clean[1][c], equal_nan=True)
+    assert np.array_equal(got[0][1, :3], clean[0][1, :3])          # frames before the NaN arrive are unaffected
+    assert np.isnan(got[0][1, 3, 1])                                  # RMS of the poisoned frame is NaN, as in the reference
+    # finite-but-extreme channels still match the oracle
+    oraw, osm = oracle.push_hops(bad[3:5], N)
+    close(got[0][3:5], oraw, "extreme raw")
+    close(got[1][3:5], osm, "extreme smoothed")
