@@ -3,19 +3,24 @@
 // of SeanSoraghan/Feature-Extractor.  "ref:" citations are relative to the reference's Source/.
 //
 // Mapping:
-//   * one workgroup per CHANNEL, K waves (64 lanes each); wave w analyses frames w, w+K, w+2K ...
-//     of its channel, so a whole analysis frame lives in ONE wavefront: no workgroup barriers
-//     inside a frame, only wave-local LDS exchanges.
+//   * fx_frame_kernel: one workgroup per CHANNEL, K <= 8 waves (64 lanes each); wave w analyses frames
+//     w, w+K, w+2K ... of its channel, so a whole analysis frame lives in ONE wavefront: no workgroup
+//     barriers inside a frame, only wave-local LDS exchanges through one buffer per wave.
 //   * the only frame-to-frame dependency on this path, the spectral-flux state
 //     (previousBinMagnitudes, ref SpectralCharacteristics.h:203), is handed from the wave of frame
 //     t-1 to the wave of frame t through LDS with a turn counter.
 //   * FFTs follow the exact rounding DAG of the reference's FFT (JUCE 4.2 kiss-style radix-4/2
-//     decimation in time, table twiddles, no fused multiply-add), executed as register-resident
-//     radix-16 / radix-8 / radix-4 passes over a padded LDS image, so spectra are bit-identical to
+//     decimation in time, table twiddles, no fused multiply-add), executed as three register-resident
+//     passes (radix 16/8/4 first pass on real input, then radix-16 / radix-4 passes) over a padded
+//     LDS image with compile-time offsets and pass-ordered twiddles, so spectra are bit-identical to
 //     the CPU path and every discrete decision downstream (pitch lag, peaks, onset) agrees.
-//   * reductions over bins run in fp64 with wavefront shuffles, as the reference accumulates in double.
-//   * smoothing (ValueHistory) + onset detection are sequential per channel and tiny: a second
-//     kernel runs them with one lane per channel.
+//   * reductions over bins run in fp64 (the reference accumulates in double) and are combined with
+//     DPP row operations; the few places where serial ORDER is semantics (flatness product, low-pass,
+//     lag scan, flat-spectrum ties) are handled exactly.
+//   * fx_finalise_kernel (thread = frame) runs the scalar tail (pow, log10, sqrt, divisions);
+//     fx_epilogue_kernel (thread = channel x frame) evaluates ValueHistory smoothing and onset
+//     detection, which depend only on a bounded window of past raw values; fx_history_kernel carries
+//     that window to the next call.
 //
 // No MFMA: this is <=4096-point FFTs and reductions, not a dense contraction.
 
