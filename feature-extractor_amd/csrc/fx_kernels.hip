@@ -142,6 +142,31 @@ __device__ __forceinline__ int wave_sum_i(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// value of a wave-uniform lane (readlane needs the index in an SGPR)
+__device__ __forceinline__ int lane_get(int v, int l) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(l)); }
+__device__ __forceinline__ float lane_get(float v, int l) { return __int_as_float(lane_get(__float_as_int(v), l)); }
+__device__ __forceinline__ double lane_get(double v, int l)
+{
+    return __hiloint2double(lane_get(__double2hiint(v), l), lane_get(__double2loint(v), l));
+}
+// lane i receives lane i-1's value (wave_shr:1); lane 0 receives `first`
+enum { DPP_WAVE_SHR1 = 0x138, DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118 };
+__device__ __forceinline__ int shift_up1(int v, int first) { return dpp_i<DPP_WAVE_SHR1, 0xF>(first, v); }
+__device__ __forceinline__ float shift_up1(float v, float first) { return dpp_f<DPP_WAVE_SHR1, 0xF>(first, v); }
+__device__ __forceinline__ double shift_up1(double v, double first) { return dpp_d<DPP_WAVE_SHR1, 0xF>(first, v); }
+
+// inclusive prefix sum over lanes (Kogge-Stone inside each 16-lane row, row totals carried by row_bcast)
+__device__ __forceinline__ int wave_scan_incl_i(int v)
+{
+    v += dpp_i<DPP_ROW_SHR1, 0xF>(0, v);
+    v += dpp_i<DPP_ROW_SHR2, 0xF>(0, v);
+    v += dpp_i<DPP_ROW_SHR4, 0xF>(0, v);
+    v += dpp_i<DPP_ROW_SHR8, 0xF>(0, v);
+    v += dpp_i<DPP_BCAST15, 0xA>(0, v);
+    v += dpp_i<DPP_BCAST31, 0xC>(0, v);
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // LDS images
 //   complex image: position p at p + (p >> 4)            (one float2 of padding per 16)
@@ -689,19 +714,19 @@ FX_MARK("flatprod");
                     const double mag = v * v;
                     if (mag > eps) loc = fp_mul(loc, mag);
                 }
-                // exclusive scan of lane totals in lane (= bin) order
+                // inclusive / exclusive scan of lane totals in lane (= bin) order; identity = 1.0 = (0.5, 1)
                 FlatProd inc = loc;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    FlatProd nb;
-                    nb.mant = __shfl_up(inc.mant, o, 64);
-                    nb.exp = __shfl_up(inc.exp, o, 64);
-                    if (lane >= o) inc = fp_mul2(nb, inc);
-                }
+#define FX_FP_STEP(CTRL, ROW_MASK) { FlatProd nb; nb.mant = dpp_d<CTRL, ROW_MASK>(0.5, inc.mant); nb.exp = dpp_i<CTRL, ROW_MASK>(1, inc.exp); inc = fp_mul2(nb, inc); }
+                FX_FP_STEP(DPP_ROW_SHR1, 0xF)
+                FX_FP_STEP(DPP_ROW_SHR2, 0xF)
+                FX_FP_STEP(DPP_ROW_SHR4, 0xF)
+                FX_FP_STEP(DPP_ROW_SHR8, 0xF)
+                FX_FP_STEP(DPP_BCAST15, 0xA)
+                FX_FP_STEP(DPP_BCAST31, 0xC)
+#undef FX_FP_STEP
                 FlatProd exc;
-                exc.mant = __shfl_up(inc.mant, 1, 64);
-                exc.exp = __shfl_up(inc.exp, 1, 64);
-                if (lane == 0) { exc.mant = 0.5; exc.exp = 1; }
+                exc.mant = shift_up1(inc.mant, 0.5);
+                exc.exp = shift_up1(inc.exp, 1);
                 // replay the lane's chain from its true starting value, looking for the first prefix
                 // outside the normal range:  value = mant*2^exp with mant in [0.5,1)
                 //   overflow  : value >= 2^1024  <=> exp >= 1025
@@ -722,13 +747,13 @@ FX_MARK("flatprod");
                     }
                 }
                 const int fb = wave_min_i(first_bad);
-                const FlatProd total = {__shfl(inc.mant, 63, 64), __shfl(inc.exp, 63, 64)};
+                const FlatProd total = {bcast63(inc.mant), __builtin_amdgcn_readlane(inc.exp, 63)};
                 if (fb == 0x7fffffff) {
                     prod = ldexp(total.mant, total.exp);
                 } else {
                     // which lane owns bin fb, and what happened there
                     const int owner = fb / U;
-                    const int kind = __shfl(bad_kind, owner, 64);
+                    const int kind = lane_get(bad_kind, owner);
                     if (kind == 1) {
                         prod = __builtin_huge_val();                           // inf * positive finite stays inf
                     } else {
@@ -742,7 +767,7 @@ FX_MARK("flatprod");
                             const double mag = v * v;
                             if (mag > eps && (U * lane + j) < fb) before = fp_mul(before, mag);
                         }
-                        double pr = ldexp(__shfl(before.mant, owner, 64), __shfl(before.exp, owner, 64));
+                        double pr = ldexp(lane_get(before.mant, owner), lane_get(before.exp, owner));
                         for (int l = owner; l < 64; l++) {
                             double mine = pr;
 #pragma unroll
@@ -751,7 +776,7 @@ FX_MARK("flatprod");
                                 const double mag = v * v;
                                 if (mag > eps && (U * lane + j) >= fb) mine *= mag;
                             }
-                            pr = __shfl(mine, l, 64);
+                            pr = lane_get(mine, l);
                             if (pr == 0.0) break;
                         }
                         prod = pr;
@@ -872,7 +897,7 @@ FX_MARK("lpf");
                 ylast = yy;
             }
             for (int iter = 0; iter < 64; iter++) {
-                const float pe = __shfl_up(ylast, 1, 64);
+                const float pe = shift_up1(ylast, 0.0f);
                 const bool bad = lane > 0 && (__float_as_uint(pe) != __float_as_uint(yin));
                 if (!__any(bad)) break;
                 if (bad) {
@@ -977,9 +1002,8 @@ FX_MARK("scan");
                     const float sm = sums[s_];
                     const float v = vbuf[s_];
                     const float c_ = (sm != 0.0f) ? v / sm : 0.0f;
-                    float p_ = __shfl_up(c_, 1, 64);
-                    if (lane == 0) p_ = carry;
-                    carry = __shfl(c_, 63, 64);
+                    const float p_ = shift_up1(c_, carry);                     // cnd of the previous sample
+                    carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_), 63));
                     if (s_ >= 2 && c_ < best) { best = c_; best_i = s_; }
                     if (first == 0x7fffffff) {
                         const unsigned long long hit = __ballot(s_ >= 2 && c_ < 0.01f);
@@ -990,7 +1014,7 @@ FX_MARK("scan");
                         const unsigned long long st = __ballot(s_ - 1 >= first && !(c_ < p_));
                         if (st) {
                             const int src = (int) __builtin_ctzll(st);
-                            const float pc = __shfl(p_, src, 64), cc = __shfl(c_, src, 64);
+                            const float pc = lane_get(p_, src), cc = lane_get(c_, src);
                             const int sstar = 64 * blk + src;
                             lag = (pc <= cc) ? (float) (sstar - 1) : (float) sstar;
                             done = true;
@@ -1002,7 +1026,7 @@ FX_MARK("scan");
                         // the walk ran to N-1 (ref :178: sample + 1 < numSamples); compare with cnd[N]
                         float cn = 0.0f;
                         if (lane == 0) { run += vbuf[N]; cn = (run != 0.0f) ? vbuf[N] / run : 0.0f; }
-                        cn = __shfl(cn, 0, 64);
+                        cn = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cn)));
                         lag = (carry <= cn) ? (float) (N - 1) : (float) N;
                     } else {
 #pragma unroll
@@ -1046,7 +1070,7 @@ FX_MARK("harm2");
                         double mine = run;
 #pragma unroll
                         for (int j = 0; j < U; j++) { const double v = (double) hre[j]; mine += v * v; }
-                        run = __shfl(mine, l, 64);
+                        run = lane_get(mine, l);
                     }
                     h_sum = run;
                     mean_mag = h_sum / (double) M;
@@ -1081,10 +1105,8 @@ FX_MARK("harm2");
             sum_normed = wave_sum(sum_normed);
             // compact the peak list
             const int npk_lane = __popc(peak_mask);
-            int pre = npk_lane;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(pre, o, 64); if (lane >= o) pre += v; }
-            const int total_peaks = __shfl(pre, 63, 64);
+            const int pre = wave_scan_incl_i(npk_lane);
+            const int total_peaks = __builtin_amdgcn_readlane(pre, 63);
             int woff = pre - npk_lane;
 #pragma unroll
             for (int j = 0; j < U; j++)
