@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--channels-per-gpu", type=int, default=1024)
-    ap.add_argument("--frames", type=int, default=64, help="consecutive frames per channel per step")
+    ap.add_argument("--frames", type=int, default=256, help="consecutive frames per channel per step (SURVEY 8d: T >= 64)")
     ap.add_argument("--window", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--signal", default="synth", choices=["synth", "noise", "silence"],

@@ -23,15 +23,21 @@ def channel_frequency(c):
 
 
 def samples(channels, num_samples, sample_rate=48000.0, first_channel=0, first_sample=0, dtype=np.float32):
-    """[channels][num_samples] synthetic stream, channel ids first_channel .. first_channel+channels-1."""
-    c = np.arange(first_channel, first_channel + channels, dtype=np.uint64)[:, None]
+    """[channels][num_samples] synthetic stream, channel ids first_channel .. first_channel+channels-1.
+    Generated in channel blocks so the fp64 temporaries stay small."""
+    out = np.empty((channels, num_samples), dtype)
     n = np.arange(first_sample, first_sample + num_samples, dtype=np.uint64)[None, :]
-    with np.errstate(over="ignore"):
-        key = np.uint64(0x5EED) ^ (c << np.uint64(32)) ^ n
-    u = (splitmix64(key) >> np.uint64(11)).astype(np.float64) * (2.0 ** -53) * 0.1 - 0.05
-    phase = 2.0 * np.pi * channel_frequency(c.astype(np.float64)) * n.astype(np.float64) / sample_rate
-    x = 0.4 * np.sin(phase) + 0.2 * np.sin(2 * phase) + 0.1 * np.sin(3 * phase) + u
-    return x.astype(dtype)
+    nf = n.astype(np.float64)
+    block = max(1, min(channels, (1 << 22) // max(1, num_samples)))
+    for c0 in range(0, channels, block):
+        c1 = min(channels, c0 + block)
+        c = np.arange(first_channel + c0, first_channel + c1, dtype=np.uint64)[:, None]
+        with np.errstate(over="ignore"):
+            key = np.uint64(0x5EED) ^ (c << np.uint64(32)) ^ n
+        u = (splitmix64(key) >> np.uint64(11)).astype(np.float64) * (2.0 ** -53) * 0.1 - 0.05
+        phase = 2.0 * np.pi * channel_frequency(c.astype(np.float64)) * nf / sample_rate
+        out[c0:c1] = (0.4 * np.sin(phase) + 0.2 * np.sin(2 * phase) + 0.1 * np.sin(3 * phase) + u).astype(dtype)
+    return out
 
 
 def hops(channels, num_hops, window_size, sample_rate=48000.0, first_channel=0, first_hop=0, dtype=np.float32):
