@@ -633,11 +633,21 @@ FX_MARK("spec_fft");
         lane = opaque(lane);
         {
             float xw[P];                                                       // a3 Bartlett window
+            // sample index of input j of item g is nlow + ITEMS_A*r(j) with nlow < ITEMS_A, so it lies in
+            // the rising half iff r(j) < RA/2 and the gain is base + r*2/RA there, (1-base) - (r-RA/2)*2/RA
+            // in the falling half -- exact dyadic arithmetic, identical to bartlett_gain<N>(index)
 #pragma unroll
-            for (int g = 0; g < G::GA; g++)
+            for (int g = 0; g < G::GA; g++) {
+                const float base = (float) rev4<G::IDIG>(lane + 64 * g) * (2.0f / N);
+                const float nbase = 1.0f - base;
 #pragma unroll
-                for (int j = 0; j < G::RA; j++)
-                    xw[g * G::RA + j] = xr[g * G::RA + j] * bartlett_gain<N>(first_pass_index<N>(lane, g, j));
+                for (int j = 0; j < G::RA; j++) {
+                    const int r = (G::RA == 4) ? j : (G::RA == 8) ? ((j >> 1) + 4 * (j & 1)) : ((j >> 2) + 4 * (j & 3));
+                    const float gain = r < G::RA / 2 ? base + (float) r * (2.0f / G::RA)
+                                                     : nbase - (float) (r - G::RA / 2) * (2.0f / G::RA);
+                    xw[g * G::RA + j] = xr[g * G::RA + j] * gain;
+                }
+            }
             fft_from_regs<N, false>(xw, cbuf, tw, lane);                       // a4
         }
 FX_MARK("spec_sums");
@@ -908,15 +918,19 @@ FX_MARK("lpf");
                     ylast = yy;
                 }
             }
-            // window the filtered frame (ref RealTimeAnalyser.h:157) and put it back in the real image
+            // window the filtered frame (ref RealTimeAnalyser.h:157) and put it back in the real image.
+            // A lane's P samples lie in one half of the window; the gains w0 + i*wstep are exact dyadic
+            // numbers (so the fma rounds nothing) and equal bartlett_gain<N>(P*lane + i).
             lane = opaque(lane);
+            const float w0 = bartlett_gain<N>(P * lane);
+            const float wstep = lane < 32 ? (2.0f / N) : -(2.0f / N);
 #pragma unroll
             for (int i = 0; i < P; i += 4) {
                 f4 v;
-                v.x = y[i]     * bartlett_gain<N>(P * lane + i);
-                v.y = y[i + 1] * bartlett_gain<N>(P * lane + i + 1);
-                v.z = y[i + 2] * bartlett_gain<N>(P * lane + i + 2);
-                v.w = y[i + 3] * bartlett_gain<N>(P * lane + i + 3);
+                v.x = y[i]     * __builtin_fmaf(wstep, (float) i, w0);
+                v.y = y[i + 1] * __builtin_fmaf(wstep, (float) (i + 1), w0);
+                v.z = y[i + 2] * __builtin_fmaf(wstep, (float) (i + 2), w0);
+                v.w = y[i + 3] * __builtin_fmaf(wstep, (float) (i + 3), w0);
                 *reinterpret_cast<f4*>(&rbuf[rpad(P * lane + i)]) = v;
             }
             wave_fence();
