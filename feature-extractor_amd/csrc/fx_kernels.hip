@@ -665,7 +665,8 @@ FX_MARK("spec_sums");
                 if (lane < 32) { maxabs = fmaxf(maxabs, fabsf(v.x)); maxabs = fmaxf(maxabs, fabsf(v.y)); }
             }
             const double eps = 0.01 * (double) log_rms;                        // :108
-            double mag_sum = 0.0, lhr = 0.0, wsum = 0.0, flat_sum = 0.0, max_mag = 0.0;
+            double mag_sum = 0.0, lhr = 0.0, wsum = 0.0, flat_sum = 0.0;
+            float max_re = 0.0f;       // max |re|: (double) re^2 is exact and monotone in |re|, so max mag = max_re^2
             int cnt = 0;
 #pragma unroll
             for (int j = 0; j < U; j++) {                                      // fillIntermediateValues :62-97
@@ -677,13 +678,14 @@ FX_MARK("spec_sums");
                 if (m <= M / 5) lhr += mag;                                    // :86-87 (inclusive prefix)
                 if (mag > eps) { flat_sum += mag; cnt++; }
                 wsum += fc * mag;
-                max_mag = mag > max_mag ? mag : max_mag;
+                max_re = fmaxf(max_re, fabsf(re[j]));
             }
             mag_sum = wave_sum(mag_sum);
             lhr = wave_sum(lhr);
             wsum = wave_sum(wsum);
             flat_sum = wave_sum(flat_sum);
-            max_mag = wave_max(max_mag);
+            max_re = wave_maxf(max_re);
+            const double max_mag = (double) max_re * (double) max_re;
             maxabs = wave_maxf(maxabs);
             cnt = wave_sum_i(cnt);
             const bool accepted = mag_sum > 0.05;                              // :121-123
@@ -835,7 +837,8 @@ FX_MARK("harm1");
         fft_from_regs<N, false>(xr, cbuf, tw, lane);
         float hre[U];
         float h_left2, h_left1, h_right1;          // |re| of bins U*lane-2, U*lane-1, U*lane+U
-        double h_sum = 0.0, h_max = 0.0;
+        double h_sum = 0.0, h_max;
+        float h_max_re = 0.0f;
         {
 #pragma unroll
             for (int j = 0; j < U; j++) {                                      // ref HarmonicCharacteristics.h:61-69
@@ -843,14 +846,15 @@ FX_MARK("harm1");
                 const double v = (double) hre[j];
                 const double mag = v * v;
                 h_sum += mag;
-                h_max = mag > h_max ? mag : h_max;
+                h_max_re = fmaxf(h_max_re, fabsf(hre[j]));
             }
             const int b0 = U * lane;
             h_left2  = b0 >= 2 ? fabsf(cbuf[cpad(b0 - 2)].x) : 0.0f;
             h_left1  = b0 >= 1 ? fabsf(cbuf[cpad(b0 - 1)].x) : 0.0f;
             h_right1 = b0 + U < M ? fabsf(cbuf[cpad(b0 + U)].x) : 0.0f;
             h_sum = wave_sum(h_sum);
-            h_max = wave_max(h_max);
+            h_max_re = wave_maxf(h_max_re);
+            h_max = (double) h_max_re * (double) h_max_re;
         }
         wave_fence();
 
@@ -1090,17 +1094,16 @@ FX_MARK("harm2");
                     mean_mag = h_sum / (double) M;
                 }
             }
-            double sum_normed = 0.0;
             unsigned peak_mask = 0;
             float nrm[U];
             const double r_hmax = 1.0 / h_max;
+            const double sum_normed = h_sum * r_hmax;                          // :77 sum of mag / max over all bins
 #pragma unroll
             for (int j = 0; j < U; j++) {
                 const double v = (double) hre[j];
                 const double mag = v * v;
                 const double nm = mag * r_hmax;                                // :75 (mag / max, via one reciprocal)
                 nrm[j] = (float) nm;
-                sum_normed += nm;
                 // binIsPeak :127-145: above the mean and none of bins -2,-1,+1 larger (windows are
                 // clipped at the ends, :136-138: no +1 neighbour for the last two bins).
                 // mag = (double) re^2 is exact, so comparing |re| compares magnitudes exactly.
@@ -1116,7 +1119,6 @@ FX_MARK("harm2");
                 if (pk) peak_mask |= 1u << j;
             }
             lds_store_block<U>(normed + U * lane, nrm);
-            sum_normed = wave_sum(sum_normed);
             // compact the peak list
             const int npk_lane = __popc(peak_mask);
             const int pre = wave_scan_incl_i(npk_lane);

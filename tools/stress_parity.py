@@ -54,8 +54,8 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
     worst = 0.0
     while time.time() < t_end and (max_cases is None or cases < max_cases):
         N = int(rng.choice([256, 512, 1024, 1024, 2048, 2048, 4096]))
-        C = int(rng.integers(1, 12))
-        T = int(rng.integers(1, 40))
+        C = int(rng.integers(1, 12)) if rng.random() < 0.9 else int(rng.integers(12, 80))
+        T = int(rng.integers(1, 40)) if rng.random() < 0.9 else int(rng.integers(40, 130))
         order = int(rng.integers(0, 3))
         otype = int(rng.integers(0, 3))
         owin = int(rng.integers(1, 22))
