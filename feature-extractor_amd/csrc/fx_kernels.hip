@@ -780,14 +780,17 @@ FX_MARK("flatprod");
                             if (mag > eps && (U * lane + j) < fb) before = fp_mul(before, mag);
                         }
                         double pr = ldexp(lane_get(before.mant, owner), lane_get(before.exp, owner));
+                        double tailf[U];           // this lane's factors from bin fb on (1.0 = not a factor; x * 1.0 is exact)
+#pragma unroll
+                        for (int j = 0; j < U; j++) {
+                            const double v = (double) re[j];
+                            const double mag = v * v;
+                            tailf[j] = (mag > eps && (U * lane + j) >= fb) ? mag : 1.0;
+                        }
                         for (int l = owner; l < 64; l++) {
                             double mine = pr;
 #pragma unroll
-                            for (int j = 0; j < U; j++) {
-                                const double v = (double) re[j];
-                                const double mag = v * v;
-                                if (mag > eps && (U * lane + j) >= fb) mine *= mag;
-                            }
+                            for (int j = 0; j < U; j++) mine *= tailf[j];
                             pr = lane_get(mine, l);
                             if (pr == 0.0) break;
                         }
