@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="consecutive frames per channel per step (SURVEY 8d: T >= 64)")
     ap.add_argument("--window", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the spectral-only extra measurement")
     ap.add_argument("--signal", default="synth", choices=["synth", "noise", "silence"],
                     help="synth = the BASELINE synthetic mix (default); noise / silence probe data-dependent paths")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -224,6 +225,26 @@ def main():
                          "epilogue_ms_per_step": epi_ms / max(calls, 1),
                          "note": "algorithmic bytes = (4*N + 48) B/frame x frames per launch; this kernel is VALU/LDS-bound, not HBM-bound (see DESIGN.md)"},
         }
+        if world == 1 and not args.no_extra:
+            # BASELINE configs[1] read literally is the spectral analyser alone ("fused window + FFT +
+            # magnitude + SpectralCharacteristics reductions in one kernel"); the same workload with only the
+            # RealTimeSpectralAnalyser constructed, as an extra (never `value`)
+            an_s = fx.BatchAnalyser(count, N, device=local_rank, analysers="spectral")
+            for _ in range(3):
+                an_s.process_frames(frames, out_raw=raw, out_smoothed=sm_bufs[0])
+            an_s.sync()
+            an_s.profile_begin()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                an_s.process_frames(frames, out_raw=raw, out_smoothed=sm_bufs[0])
+            an_s.sync()
+            dts = time.perf_counter() - t1
+            fms, _, calls_s = an_s.profile_end()
+            ach = launch_bytes / (fms / 1e3 / max(calls_s, 1)) / 1e9
+            out["spectral_only"] = {"value": total_channels * T * 10 / dts, "unit": "frames/s",
+                                    "kernel": "fx_frame_kernel<%d, spectral>" % N, "avg_launch_ms": fms / max(calls_s, 1),
+                                    "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS},
+                                    "note": "FX_SPECTRAL_ONLY: RMS, centroid, spread, flatness, LER, flux, slope, onset (8 of the 12 slots)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(fx, N, T)
         else:

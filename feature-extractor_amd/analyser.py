@@ -18,14 +18,15 @@ def _is_torch(x):
 
 class BatchAnalyser:
     def __init__(self, num_channels, window_size=2048, sample_rate=48000.0, device=0,
-                 order=capi.ORDER_SPECTRAL_THEN_HARMONIC):
+                 order=capi.ORDER_SPECTRAL_THEN_HARMONIC, analysers="both"):
         self._lib = capi.load_library()
         self.num_channels = int(num_channels)
         self.window_size = int(window_size)
         self.device = int(device)
         h = ctypes.c_void_p()
+        flags = int(order) | {"both": 0, "spectral": capi.SPECTRAL_ONLY, "harmonic": capi.HARMONIC_ONLY}[analysers]
         capi.check(self._lib.fx_create(ctypes.byref(h), self.device, self.num_channels, self.window_size,
-                                       float(sample_rate), int(order)))
+                                       float(sample_rate), flags))
         self._h = h
 
     def close(self):

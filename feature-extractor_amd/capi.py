@@ -12,6 +12,7 @@ FEATURE_NAMES = ["onset", "rms", "f0", "centroid", "spread", "flatness", "ler", 
                  "slope", "her", "oer", "inharm"]
 ONSET_SPECTRAL, ONSET_AMPLITUDE, ONSET_COMBINATION = 0, 1, 2
 ORDER_SPECTRAL_THEN_HARMONIC, ORDER_HARMONIC_THEN_SPECTRAL, ORDER_ISOLATED = 0, 1, 2
+SPECTRAL_ONLY, HARMONIC_ONLY = 4, 8
 MEM_HOST, MEM_DEVICE = 0, 1
 SAMPLE_F32, SAMPLE_F16 = 0, 1
 FX_OK, FX_ERR_INVALID_ARGUMENT, FX_ERR_NO_DEVICE, FX_ERR_HIP, FX_ERR_OUT_OF_MEMORY, FX_ERR_UNSUPPORTED = range(6)

@@ -218,6 +218,8 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     ep.onset_type = c->onset_type;
     ep.onset_multiplier = c->onset_multiplier;
     ep.order_mode = (int) (c->flags & FX_ORDER_MASK);
+    const int analysers = (c->flags & FX_SPECTRAL_ONLY) ? 1 : ((c->flags & FX_HARMONIC_ONLY) ? 2 : 3);
+    ep.analysers = analysers;
 
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1], e2 = c->ev[2];
     bool last_valid = true;
@@ -232,7 +234,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
         last_valid = false;
     }
     HIP_TRY(hipEventRecord(e0, c->stream));
-    HIP_TRY(fxk::launch_frame_kernel(c->N, fp, waves, c->stream));
+    HIP_TRY(fxk::launch_frame_kernel(c->N, fp, analysers, waves, c->stream));
     HIP_TRY(hipEventRecord(e1, c->stream));
     HIP_TRY(fxk::launch_epilogue_kernels(ep, c->stream));
     HIP_TRY(hipEventRecord(e2, c->stream));
@@ -263,7 +265,9 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
     if (!is_pow2(window_size) || window_size < 256 || window_size > 4096)
         return fail(FX_ERR_INVALID_ARGUMENT, "window_size must be a power of two in [256, 4096], got %d", window_size);
     if (!(sample_rate > 0.0)) return fail(FX_ERR_INVALID_ARGUMENT, "sample_rate must be positive");
-    if ((flags & FX_ORDER_MASK) == 3u || (flags & ~FX_ORDER_MASK)) return fail(FX_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", flags);
+    if ((flags & FX_ORDER_MASK) == 3u || (flags & ~(FX_ORDER_MASK | FX_SPECTRAL_ONLY | FX_HARMONIC_ONLY)) ||
+        ((flags & FX_SPECTRAL_ONLY) && (flags & FX_HARMONIC_ONLY)))
+        return fail(FX_ERR_INVALID_ARGUMENT, "unknown or contradictory flags 0x%x", flags);
 
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {

@@ -73,6 +73,7 @@ struct EpilogueParams {
     int          onset_type;
     float        onset_multiplier;
     int          order_mode;    // FX_ORDER_*
+    int          analysers;     // bit 0: spectral analyser runs, bit 1: harmonic analyser runs
 };
 
 // Re-order the reference's N-entry twiddle table (canonical[i] = (re, im) of e^{-2*pi*i/N} as floats)
@@ -81,7 +82,7 @@ void build_pass_twiddles(int window_size, const float* canonical, float* out);
 
 size_t frame_kernel_lds_bytes(int window_size, int waves);
 // Chooses waves per workgroup and launches; returns hipSuccess or the launch error.
-hipError_t launch_frame_kernel(int window_size, const FrameParams& p, int waves, hipStream_t stream);
+hipError_t launch_frame_kernel(int window_size, const FrameParams& p, int analysers, int waves, hipStream_t stream);
 hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t stream);
 hipError_t prepare_kernels(int window_size);   // raises the dynamic-LDS limit once per process
 

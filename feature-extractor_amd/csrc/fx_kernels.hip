@@ -526,7 +526,9 @@ __device__ __forceinline__ FlatProd fp_mul2(FlatProd a, FlatProd b)
 #endif
 template <int N> struct Occ { static constexpr int WAVES_PER_SIMD = N <= 1024 ? FX_OCC_SMALL : (N == 2048 ? 2 : 1); };
 
-template <int N>
+// SPEC / HARM: which of the reference's two analysers run (RealTimeSpectralAnalyser,
+// RealTimeHarmonicAnalyser -- both by default, as AnalyserTrackController constructs them)
+template <int N, bool SPEC, bool HARM>
 __global__ void __launch_bounds__(512, Occ<N>::WAVES_PER_SIMD)
 fx_frame_kernel(const FrameParams p)
 {
@@ -627,6 +629,7 @@ FX_MARK("rms");
             if (lane == 0) fpl->log_rms = log_rms;
         }
 
+        if constexpr (SPEC) {
 FX_MARK("spec_fft");
         FX_STAMP(1);
         // ---------------- spectral analyser (ref RealTimeAnalyser.h:212-224) -----------------------
@@ -831,7 +834,9 @@ FX_MARK("spec_pass2");
             }
         }
         wave_fence();
+        }
 
+        if constexpr (HARM) {
 FX_MARK("harm1");
         FX_STAMP(3);
         // ---------------- harmonic analyser, part 1: raw (un-windowed) spectrum ---------------------
@@ -1184,6 +1189,7 @@ FX_MARK("harm2");
             if (lane == 0) { fpl->inh = inh; fpl->her = her_f; fpl->flags = 1; }
         }
         wave_fence();
+        }
 
 FX_MARK("store");
         FX_STAMP(9);
@@ -1225,7 +1231,8 @@ fx_finalise_kernel(const EpilogueParams p)
     out[FX_RMS] = f.log_rms;
     const double eps = 0.01 * (double) f.log_rms;                              // :108
 
-    if (f.mag_sum > 0.05) {                                                    // :121-123
+    const bool spec = p.analysers & 1, harm = p.analysers & 2;
+    if (spec && f.mag_sum > 0.05) {                                            // :121-123
         const float centroid = f.centroid;
         const double dcnt = (double) f.cnt;
         const double inv_n = 1.0 / (dcnt > 0.0 ? dcnt : 1.0);                  // :129-130
@@ -1240,7 +1247,7 @@ fx_finalise_kernel(const EpilogueParams p)
         const float max_flux = (float) (M * (M + 1)) / 2.0f;                   // :111
         out[FX_FLUX] = (float) (f.flux / (double) max_flux);
     }
-    if (f.max_e > 0.0001) {                                                    // :165-167
+    if (spec && f.max_e > 0.0001) {                                            // :165-167
         // normedEnergy = mag / max (ref :172): the sums over bins were taken before the division
         const double rmax = 1.0 / f.max_e;
         const double se = f.mag_sum * rmax;
@@ -1253,9 +1260,11 @@ fx_finalise_kernel(const EpilogueParams p)
         const double r = (ps - ((double) M * mean_e * 0.5)) / (double) ((float) M - 1.0f) * e_std * bin_std;   // :195
         out[FX_SLOPE] = (float) (r * (bin_std / e_std));                       // :198
     }
-    const double f0 = (nyquist * 2.0) / (double) f.lag;                        // ref PitchAnalyser.h:57
-    out[FX_F0] = (float) (f0 / 5000.0);                                        // ref RealTimeAnalyser.h:165-166
-    if (f.flags & 1) {
+    if (harm) {
+        const double f0 = (nyquist * 2.0) / (double) f.lag;                    // ref PitchAnalyser.h:57
+        out[FX_F0] = (float) (f0 / 5000.0);                                    // ref RealTimeAnalyser.h:165-166
+    }
+    if (harm && (f.flags & 1)) {
         const float log_her = (float) log10(f.her * 9.0 + 1.0);                // ref HarmonicCharacteristics.h:101
         out[FX_HER] = log_her;
         out[FX_OER] = log_her;                                                 // ref RealTimeAnalyser.h:171 writes HER into the OER slot
@@ -1334,42 +1343,47 @@ fx_epilogue_kernel(const EpilogueParams p)
 #pragma unroll
     for (int s = 0; s < FX_NUM_FEATURES; s++) rw[s] = v.get(t, s);
 
+    const bool spec = p.analysers & 1, harm = p.analysers & 2;
+    // with a single analyser the RMS slot gets one insert per hop, like an isolated AudioFeatures
+    const int order_mode = (spec && harm) ? p.order_mode : FX_ORDER_ISOLATED;
+    const float never = __int_as_float(0x7fc00000);                  // getValue() of a slot nobody wrote: 0.0f / 0
     // 10-deep slots (ref RealTimeAnalyser.h:73)
     long long rec10 = p.frames_before + t + 1; if (rec10 > 10) rec10 = 10;
 #pragma unroll
     for (int s = 0; s < FX_NUM_FEATURES; s++) {
         if (s == FX_ONSET || s == FX_FLUX || s == FX_RMS) continue;
+        const bool harm_slot = s == FX_F0 || s == FX_HER || s == FX_OER || s == FX_INHARM;
         float total = 0.0f;
 #pragma unroll
         for (int i = 0; i < 10; i++) { const int f = t - 9 + i; total += v.valid(f) ? v.get(f, s) : 0.0f; }
-        sm[s] = total / (float) rec10;
+        sm[s] = (harm_slot ? harm : spec) ? total / (float) rec10 : never;
     }
-    sm[FX_FLUX] = (0.0f + rw[FX_FLUX]) / 1.0f;                       // history length 1
-    // RMS after both analysers of this hop have inserted (what the OSC timer samples)
-    sm[FX_RMS] = rms_value(v, t, p.order_mode, 2);
+    sm[FX_FLUX] = spec ? (0.0f + rw[FX_FLUX]) / 1.0f : never;        // history length 1
+    // RMS after every analyser of this hop has inserted (what the OSC timer samples)
+    sm[FX_RMS] = rms_value(v, t, order_mode, 2);
 
     // OnsetDetector::detectOnset, ref SpectralCharacteristics.h:249-306.  The detector's histories
     // hold (getValue(enFlux), getValue(enRMS)) as seen by detectOnset() of each frame
     // (ref RealTimeAnalyser.h:236-242): flux of that frame, and the RMS mean at that moment.
     const int L = p.onset_window;
-    const int rms_pushes_at_detect = (p.order_mode == FX_ORDER_HARMONIC_THEN_SPECTRAL) ? 2 : 1;
+    const int rms_pushes_at_detect = (order_mode == FX_ORDER_HARMONIC_THEN_SPECTRAL) ? 2 : 1;
     const long long g = p.frames_before + t;
     long long recorded = g - p.onset_reset_frame + 1;
     if (recorded > L) recorded = L;
     bool onset = false;
-    if (recorded >= L && L > 0) {                                   // :253-258 both histories full
+    if (spec && recorded >= L && L > 0) {                           // :253-258 both histories full
         int cand = L - 1;                                           // :263-266
         const bool use_amp = p.onset_type == FX_ONSET_AMPLITUDE || p.onset_type == FX_ONSET_COMBINATION;
         const bool use_flux = p.onset_type == FX_ONSET_SPECTRAL || p.onset_type == FX_ONSET_COMBINATION;
         if (use_flux) cand = L / 2;
-        const float cand_amp = rms_value(v, t - L + 1 + cand, p.order_mode, rms_pushes_at_detect);
+        const float cand_amp = rms_value(v, t - L + 1 + cand, order_mode, rms_pushes_at_detect);
         const float cand_sf = (0.0f + v.get(t - L + 1 + cand, FX_FLUX)) / 1.0f;
         bool ok = !(cand_amp < 0.01f);                              // :271-274
         float tot_amp = 0.0f, tot_flux = 0.0f;
 #pragma unroll 1
         for (int i = 0; i < L; i++) {                               // :260-261 totals, :276-289 neighbours
             const int f = t - L + 1 + i;
-            const float amp_i = rms_value(v, f, p.order_mode, rms_pushes_at_detect);
+            const float amp_i = rms_value(v, f, order_mode, rms_pushes_at_detect);
             const float flx_i = (0.0f + v.get(f, FX_FLUX)) / 1.0f;
             tot_amp += amp_i;
             tot_flux += flx_i;
@@ -1389,7 +1403,7 @@ fx_epilogue_kernel(const EpilogueParams p)
         onset = ok && res;
     }
     rw[FX_ONSET] = onset ? 1.0f : 0.0f;
-    sm[FX_ONSET] = (0.0f + rw[FX_ONSET]) / 1.0f;                     // history length 1
+    sm[FX_ONSET] = spec ? (0.0f + rw[FX_ONSET]) / 1.0f : never;      // history length 1
 
     const size_t o = ((size_t) c * p.T + t) * FX_NUM_FEATURES;
     if (p.out_raw) {
@@ -1485,7 +1499,13 @@ size_t frame_kernel_lds_bytes(int n, int waves)
 
 template <int N> static hipError_t prepare_t()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, true, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, true, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, false, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -1501,22 +1521,26 @@ hipError_t prepare_kernels(int n)
     }
 }
 
-template <int N> static hipError_t launch_t(const FrameParams& p, int waves, hipStream_t stream)
+template <int N> static hipError_t launch_t(const FrameParams& p, int analysers, int waves, hipStream_t stream)
 {
     const size_t lds = lds_bytes_t<N>(waves);
-    hipLaunchKernelGGL((fx_frame_kernel<N>), dim3((unsigned) p.C), dim3((unsigned) waves * 64), lds, stream, p);
+    const dim3 grid((unsigned) p.C), block((unsigned) waves * 64);
+    if (analysers == 3)      hipLaunchKernelGGL((fx_frame_kernel<N, true, true>), grid, block, lds, stream, p);
+    else if (analysers == 1) hipLaunchKernelGGL((fx_frame_kernel<N, true, false>), grid, block, lds, stream, p);
+    else if (analysers == 2) hipLaunchKernelGGL((fx_frame_kernel<N, false, true>), grid, block, lds, stream, p);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
-hipError_t launch_frame_kernel(int n, const FrameParams& p, int waves, hipStream_t stream)
+hipError_t launch_frame_kernel(int n, const FrameParams& p, int analysers, int waves, hipStream_t stream)
 {
     if (p.C <= 0 || p.T <= 0) return hipSuccess;
     switch (n) {
-        case 256:  return launch_t<256>(p, waves, stream);
-        case 512:  return launch_t<512>(p, waves, stream);
-        case 1024: return launch_t<1024>(p, waves, stream);
-        case 2048: return launch_t<2048>(p, waves, stream);
-        case 4096: return launch_t<4096>(p, waves, stream);
+        case 256:  return launch_t<256>(p, analysers, waves, stream);
+        case 512:  return launch_t<512>(p, analysers, waves, stream);
+        case 1024: return launch_t<1024>(p, analysers, waves, stream);
+        case 2048: return launch_t<2048>(p, analysers, waves, stream);
+        case 4096: return launch_t<4096>(p, analysers, waves, stream);
         default:   return hipErrorInvalidValue;
     }
 }

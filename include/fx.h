@@ -65,6 +65,11 @@ enum { FX_SAMPLE_F32 = 0, FX_SAMPLE_F16 = 1 };
 #define FX_ORDER_HARMONIC_THEN_SPECTRAL 1u
 #define FX_ORDER_ISOLATED               2u   /* one AudioFeatures per analyser */
 #define FX_ORDER_MASK                   3u
+/* Construct only one of the two analysers (the reference builds both, AnalyserTrackController.h:20-21).
+ * Slots the absent analyser would write keep their initial state: raw 0, getValue NaN (0.0f / 0, as
+ * AudioFeatures::getValue returns before any insert, RealTimeAnalyser.h:84-88). */
+#define FX_SPECTRAL_ONLY                4u   /* RealTimeSpectralAnalyser only: RMS, centroid..slope, onset */
+#define FX_HARMONIC_ONLY                8u   /* RealTimeHarmonicAnalyser only: RMS, F0, HER, OER, inharmonicity */
 
 typedef struct fx_context fx_context;
 

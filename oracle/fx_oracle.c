@@ -341,6 +341,7 @@ struct fxo_channel {
     double  nyquist;
     float   gain;
     int     order_mode;
+    int     analysers;         /* bit 0 spectral, bit 1 harmonic */
     fft_cfg fwd, inv;
     float*  overlap;           /* ref: RealTimeAudioAnalysis.h:236 overlappedAudio */
     double* prev_mag;          /* ref: SpectralCharacteristics.h:203 previousBinMagnitudes */
@@ -360,6 +361,7 @@ fxo_channel* fxo_create(int window_size, double sample_rate, int order_mode)
     c->nyquist = sample_rate / 2.0;                 /* ref: RealTimeAudioAnalysis.h:251 */
     c->gain = 1.0f;                                 /* ref: AudioDataCollector.h:129 */
     c->order_mode = order_mode;
+    c->analysers = 3;
     fft_cfg_init(&c->fwd, window_size, 0);
     fft_cfg_init(&c->inv, window_size, 1);
     const size_t n = (size_t) window_size;
@@ -416,6 +418,7 @@ void fxo_set_onset_window(fxo_channel* c, int length)
 void fxo_set_onset_type(fxo_channel* c, int t) { c->onset.type = t; }
 /* ref: AudioDataCollector.h:124 */
 void fxo_set_gain(fxo_channel* c, float g) { c->gain = g; }
+void fxo_set_analysers(fxo_channel* c, int mask) { c->analysers = mask & 3; }
 
 /* ------------------------------------------------------------------------- */
 /* SpectralCharacteristicsAnalyser, ref: SpectralCharacteristics.h:31-206     */
@@ -753,20 +756,23 @@ static void harmonic_writes(afeatures* f, const harm_frame* h)
 
 static void run_frame(fxo_channel* c, float* raw12, float* smoothed12)
 {
-    const spec_frame s = spectral_compute(c);
-    const harm_frame h = harmonic_compute(c);
+    const int do_spec = c->analysers & 1, do_harm = c->analysers & 2;
+    spec_frame s; harm_frame h;
+    memset(&s, 0, sizeof s); memset(&h, 0, sizeof h);
+    if (do_spec) s = spectral_compute(c);
+    if (do_harm) h = harmonic_compute(c);
     afeatures* fs = &c->feat;
     afeatures* fh = (c->order_mode == FXO_ORDER_ISOLATED) ? &c->feat_harm : &c->feat;
-    float onset;
+    float onset = 0.0f;
     if (c->order_mode == FXO_ORDER_HARMONIC_THEN_SPECTRAL) {
-        af_update(fh, FXO_RMS, h.log_rms);  harmonic_writes(fh, &h);
-        af_update(fs, FXO_RMS, s.log_rms);  onset = spectral_writes(c, fs, &s);
+        if (do_harm) { af_update(fh, FXO_RMS, h.log_rms);  harmonic_writes(fh, &h); }
+        if (do_spec) { af_update(fs, FXO_RMS, s.log_rms);  onset = spectral_writes(c, fs, &s); }
     } else {
-        af_update(fs, FXO_RMS, s.log_rms);  onset = spectral_writes(c, fs, &s);
-        af_update(fh, FXO_RMS, h.log_rms);  harmonic_writes(fh, &h);
+        if (do_spec) { af_update(fs, FXO_RMS, s.log_rms);  onset = spectral_writes(c, fs, &s); }
+        if (do_harm) { af_update(fh, FXO_RMS, h.log_rms);  harmonic_writes(fh, &h); }
     }
     if (raw12) {
-        raw12[FXO_ONSET] = onset;       raw12[FXO_RMS] = s.log_rms;   raw12[FXO_F0] = h.f0_feature;
+        raw12[FXO_ONSET] = onset;       raw12[FXO_RMS] = do_spec ? s.log_rms : h.log_rms;   raw12[FXO_F0] = h.f0_feature;
         raw12[FXO_CENTROID] = s.centroid; raw12[FXO_SPREAD] = s.spread; raw12[FXO_FLATNESS] = s.flatness;
         raw12[FXO_LER] = s.ler;         raw12[FXO_FLUX] = s.flux;     raw12[FXO_SLOPE] = s.slope;
         raw12[FXO_HER] = h.her;         raw12[FXO_OER] = h.oer;       raw12[FXO_INHARM] = h.inharm;
@@ -774,7 +780,10 @@ static void run_frame(fxo_channel* c, float* raw12, float* smoothed12)
     if (smoothed12) {
         for (int i = 0; i < FXO_NUM_FEATURES; i++) {
             const int harm_slot = (i == FXO_F0 || i == FXO_HER || i == FXO_OER || i == FXO_INHARM);
-            smoothed12[i] = af_value(harm_slot ? fh : fs, i);
+            /* with one analyser only, the RMS slot lives in that analyser's AudioFeatures */
+            const afeatures* src = harm_slot ? fh : fs;
+            if (i == FXO_RMS && !do_spec) src = fh;
+            smoothed12[i] = af_value(src, i);
         }
     }
 }

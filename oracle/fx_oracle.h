@@ -55,6 +55,10 @@ void fxo_set_onset_sensitivity(fxo_channel*, float s);
 void fxo_set_onset_window(fxo_channel*, int length);
 void fxo_set_onset_type(fxo_channel*, int type);
 void fxo_set_gain(fxo_channel*, float gain);
+/* Which of the two analyser threads exist (ref AnalyserTrackController.h:20-21 constructs both): bit 0 =
+ * RealTimeSpectralAnalyser, bit 1 = RealTimeHarmonicAnalyser.  Slots an absent analyser would write stay
+ * at their initial state (raw 0; getValue = 0/0 = NaN, as AudioFeatures::getValue returns before any insert). */
+void fxo_set_analysers(fxo_channel*, int mask);
 
 /* Push one hop of window_size/2 samples (ref: RealTimeAudioAnalysis.h:205-219)
  * and run one spectral + one harmonic frame.  raw12 = the 12 values passed to

@@ -50,6 +50,7 @@ def lib():
         L.fxo_set_onset_window.argtypes = [vp, ctypes.c_int]
         L.fxo_set_onset_type.argtypes = [vp, ctypes.c_int]
         L.fxo_set_gain.argtypes = [vp, ctypes.c_float]
+        L.fxo_set_analysers.argtypes = [vp, ctypes.c_int]
         L.fxo_process_frames.argtypes = [vp, fp, ctypes.c_int, fp, fp]
         L.fxo_push_hops.argtypes = [vp, fp, ctypes.c_int, fp, fp]
         L.fxo_batch_frames.restype = ctypes.c_int
@@ -107,6 +108,9 @@ class Channel:
 
     def set_gain(self, g):
         lib().fxo_set_gain(self._h, float(g))
+
+    def set_analysers(self, mask):
+        lib().fxo_set_analysers(self._h, int(mask))
 
     def process_frames(self, frames):
         """frames [T][N] pre-assembled windows -> (raw [T][12], smoothed [T][12])."""
@@ -174,6 +178,8 @@ def _apply(ch, settings):
         ch.set_onset_sensitivity(settings["onset_sensitivity"])
     if "onset_window" in settings:
         ch.set_onset_window(settings["onset_window"])
+    if "analysers" in settings:
+        ch.set_analysers(settings["analysers"])
 
 
 # ---- taps ----

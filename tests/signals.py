@@ -101,7 +101,7 @@ def assert_features_close(got, want, rtol=1e-5, names=None, what=""):
     assert got.shape == want.shape, (got.shape, want.shape)
     g = got.reshape(-1, 12).astype(np.float64)
     w = want.reshape(-1, 12).astype(np.float64)
-    assert np.array_equal(g[:, 0], w[:, 0]), "%s onset column differs at rows %s" % (what, np.nonzero(g[:, 0] != w[:, 0])[0][:8])
+    assert np.array_equal(g[:, 0], w[:, 0], equal_nan=True), "%s onset column differs at rows %s" % (what, np.nonzero(g[:, 0] != w[:, 0])[0][:8])
     same = (g == w) | (np.isnan(g) & np.isnan(w))
     with np.errstate(invalid="ignore", divide="ignore"):
         err = np.abs(g - w) / np.abs(w)

@@ -58,6 +58,8 @@ def test_argument_validation_happens_before_device_use(fx):
     assert lib.fx_create(ctypes.byref(h), 0, 0, 1024, 48000.0, 0) == 1
     assert lib.fx_create(ctypes.byref(h), 0, 4, 8192, 48000.0, 0) == 1
     assert lib.fx_create(None, 0, 4, 1024, 48000.0, 0) == 1
+    assert lib.fx_create(ctypes.byref(h), 0, 4, 1024, 48000.0, 4 | 8) == 1       # spectral-only AND harmonic-only
+    assert lib.fx_create(ctypes.byref(h), 0, 4, 1024, 48000.0, 3) == 1           # order 3 does not exist
     assert lib.fx_push_hops(None, None, 1, 0, 0, None, None) == 1
     assert lib.fx_sync(None) == 1
 

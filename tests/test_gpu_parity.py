@@ -284,3 +284,21 @@ def test_non_finite_and_extreme_inputs_do_not_disturb_other_channels(gpu_fx, ora
     oraw, osm = oracle.push_hops(bad[3:5], N)
     close(got[0][3:5], oraw, "extreme raw")
     close(got[1][3:5], osm, "extreme smoothed")
+
+
+@pytest.mark.parametrize("which,mask", [("spectral", 1), ("harmonic", 2)])
+@pytest.mark.parametrize("N", [512, 1024, 2048])
+def test_single_analyser_modes(gpu_fx, oracle, which, mask, N):
+    """Only one of the reference's two analyser threads constructed (FX_SPECTRAL_ONLY / FX_HARMONIC_ONLY):
+    the other analyser's slots keep raw 0 and getValue NaN."""
+    C, T = 5, 26
+    hops = signals.bursts(C, T, N, seed=N + mask)
+    an = gpu_fx.BatchAnalyser(C, N, analysers=which)
+    an.set_onset_detection_type(2)
+    a = an.push_hops(hops[:, :9])
+    b = an.push_hops(hops[:, 9:])
+    oraw, osm = oracle.push_hops(hops, N, analysers=mask, onset_type=2)
+    close(np.concatenate([a[0], b[0]], 1), oraw, which + " raw")
+    close(np.concatenate([a[1], b[1]], 1), osm, which + " smoothed")
+    absent = [2, 9, 10, 11] if which == "spectral" else [0, 3, 4, 5, 6, 7, 8]
+    assert np.isnan(b[1][:, :, absent]).all() and not b[0][:, :, absent].any()
