@@ -61,14 +61,16 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
         owin = int(rng.integers(1, 22))
         sens = float(rng.uniform(0, 2))
         gain = float(rng.choice([1.0, 1.0, 0.5, 3.0]))
+        which = str(rng.choice(["both", "both", "both", "spectral", "harmonic"]))
+        mask = {"both": 3, "spectral": 1, "harmonic": 2}[which]
         hops = make_signal(rng, C, T, N)
-        an = fx.BatchAnalyser(C, N, order=order)
+        an = fx.BatchAnalyser(C, N, order=order, analysers=which)
         an.set_onset_detection_type(otype); an.set_onset_window_length(owin)
         an.set_onset_detection_sensitivity(sens); an.set_gain(gain)
         split = int(rng.integers(0, T + 1))
         parts = [an.push_hops(hops[:, :split]), an.push_hops(hops[:, split:])]
         raw = np.concatenate([p[0] for p in parts], 1); sm = np.concatenate([p[1] for p in parts], 1)
-        oraw, osm = fo.push_hops(hops, N, order=order, onset_type=otype, onset_window=owin, onset_sensitivity=sens, gain=gain)
+        oraw, osm = fo.push_hops(hops, N, order=order, onset_type=otype, onset_window=owin, onset_sensitivity=sens, gain=gain, analysers=mask)
         cases += 1; frames += C * T
         for name, g, w in (("raw", raw, oraw), ("smoothed", sm, osm)):
             g64, w64 = g.astype(np.float64), w.astype(np.float64)
