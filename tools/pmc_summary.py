@@ -19,7 +19,7 @@ def main():
         for row in csv.DictReader(open(f)):
             print("  %-60s calls %6s total_ns %14s avg_ns %12s pct %s" % (
                 row.get("Name", "")[:60], row.get("Calls"), row.get("TotalDurationNs"), row.get("AverageNs"), row.get("Percentage")))
-            if "fx_frame_kernel" in row.get("Name", ""):
+            if "fx_frame_kernel" in row.get("Name", "") and "true, true" in row.get("Name", ""):
                 summary["frame_kernel_avg_ns"] = float(row["AverageNs"])
                 summary["frame_kernel_calls"] = int(row["Calls"])
     for f in find(os.path.join(out, "trace"), "*kernel_trace.csv"):
@@ -43,7 +43,7 @@ def main():
         print("== PMC per launch (mean over dispatches):", k[:70])
         for c in sorted(pmc[k]):
             print("   %-28s %18.1f   (%d dispatches)" % (c, pmc[k][c] / cnt[k][c], cnt[k][c]))
-        if "fx_frame_kernel" in k:
+        if "fx_frame_kernel" in k and "true, true" in k:
             summary["pmc_per_launch"] = {c: pmc[k][c] / cnt[k][c] for c in pmc[k]}
     json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
 
