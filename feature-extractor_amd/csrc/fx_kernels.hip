@@ -417,15 +417,75 @@ __device__ __forceinline__ void fft_first_pass(const float (&xin)[Geo<N>::P], f2
     wave_fence();
 }
 
-// Whole transform of one wavefront: P real inputs per lane (first-pass order) -> complex image
-// (N bins, natural order).
-template <int N, bool INV>
-__device__ __forceinline__ void fft_from_regs(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, int lane)
+// What the last pass leaves in the wave's LDS buffer.
+enum { OUT_COMPLEX = 0,       // the complex image (natural bin order, cpad layout)
+       OUT_RE_LOW = 1,        // float re[M] (plain layout): all the harmonic analyser reads (ref HarmonicCharacteristics.h:63)
+       OUT_RE_LOW_MAXABS = 2, // the same + max(|re|,|im|) over bins [0, M/2) returned per lane (ref SpectralCharacteristics.h:153)
+       OUT_POWER = 3,         // float re*re of all N bins in the real image (rpad layout): ref PitchAnalyser.h:97-103
+       OUT_LAG = 4 };         // float v[s] = (re_s/N)^2 * s, s in [0,N), and v[N] from imag[0] (plain layout): ref :119-123
+
+// Last pass for N <= 1024 -- radix 4 at length N/4, all of a lane's items in registers -- fused with
+// the consumer of the spectrum, so the full complex image is never written back and re-read: the
+// spectral / harmonic analysers only read re of bins < N/2, the pitch analyser only re*re, the lag
+// search only the squared, lag-weighted real part.
+template <int N, bool INV, int OUT>
+__device__ __forceinline__ float fft_last_pass_fused(f2* cbuf, const f2* tw, int lane, float scale)
+{
+    static_assert(N <= 1024, "needs every item of the lane in registers");
+    constexpr int L0 = N / 4, GI = (N / 4) / 64, TWOFF = Plan<N>::OFF2;
+    lane = opaque(lane);
+    f2 e[GI][4];
+#pragma unroll
+    for (int g = 0; g < GI; g++) {
+        const f2* img = cbuf + cpad(lane + 64 * g);
+#pragma unroll
+        for (int i = 0; i < 4; i++) e[g][i] = img[item_off(L0, i)];
+    }
+    wave_fence();                 // the wave has read the whole complex image; the buffer may be rewritten
+    float* fbuf = reinterpret_cast<float*>(cbuf);
+    float aux = 0.0f;
+#pragma unroll
+    for (int g = 0; g < GI; g++) {
+        const int k = lane + 64 * g;
+        const f2* t1 = tw + TWOFF + k;
+        bfly4_core<INV>(e[g][0], e[g][1], e[g][2], e[g][3],
+                        twmul<INV>(e[g][1], t1[0]), twmul<INV>(e[g][2], t1[L0]), twmul<INV>(e[g][3], t1[2 * L0]));
+        if (OUT == OUT_RE_LOW || OUT == OUT_RE_LOW_MAXABS) {
+            fbuf[k] = e[g][0].x;                       // bin k
+            fbuf[k + L0] = e[g][1].x;                  // bin k + N/4; bins >= N/2 are never read
+            if (OUT == OUT_RE_LOW_MAXABS) aux = fmaxf(aux, fmaxf(fabsf(e[g][0].x), fabsf(e[g][0].y)));
+        } else if (OUT == OUT_POWER) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) fbuf[rpad(k + L0 * i)] = e[g][i].x * e[g][i].x;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int s_ = k + L0 * i;
+                const float d = e[g][i].x * scale;
+                fbuf[s_] = d * d * (float) s_;
+            }
+            if (g == 0 && lane == 0) { const float d = e[0][0].y * scale; fbuf[N] = d * d * (float) N; }
+        }
+    }
+    wave_fence();
+    return aux;
+}
+
+// Whole transform of one wavefront: P real inputs per lane (first-pass order) -> OUT (see above).
+// For N > 1024 the last pass cannot hold every item in registers; it leaves the complex image and the
+// caller extracts what it needs.
+template <int N, bool INV, int OUT>
+__device__ __forceinline__ float fft_from_regs(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, int lane, float scale = 0.0f)
 {
     typedef Plan<N> PL;
     fft_first_pass<N, INV>(xin, cbuf, tw, lane);
     fft_pass<N, PL::R1, PL::L1, PL::OFF1, INV>(cbuf, tw, lane);
-    fft_pass<N, PL::R2, PL::L2, PL::OFF2, INV>(cbuf, tw, lane);
+    if constexpr (N <= 1024 && OUT != OUT_COMPLEX) {
+        return fft_last_pass_fused<N, INV, OUT>(cbuf, tw, lane, scale);
+    } else {
+        fft_pass<N, PL::R2, PL::L2, PL::OFF2, INV>(cbuf, tw, lane);
+        return 0.0f;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -629,7 +689,9 @@ FX_MARK("rms");
             if (lane == 0) fpl->log_rms = log_rms;
         }
 
+        constexpr bool FUSED = N <= 1024;          // last FFT pass fused with its consumer (fft_last_pass_fused)
         if constexpr (SPEC) {
+        float spec_aux = 0.0f;
 FX_MARK("spec_fft");
         FX_STAMP(1);
         // ---------------- spectral analyser (ref RealTimeAnalyser.h:212-224) -----------------------
@@ -651,21 +713,25 @@ FX_MARK("spec_fft");
                     xw[g * G::RA + j] = xr[g * G::RA + j] * gain;
                 }
             }
-            fft_from_regs<N, false>(xw, cbuf, tw, lane);                       // a4
+            spec_aux = fft_from_regs<N, false, OUT_RE_LOW_MAXABS>(xw, cbuf, tw, lane);   // a4
         }
 FX_MARK("spec_sums");
         FX_STAMP(2);
         {
             // lane owns bins [U*lane, U*lane + U)
             float re[U];
-            float maxabs = 0.0f;
+            // ref SpectralCharacteristics.h:153: getMagnitude over the first M floats of the interleaved
+            // buffer = max |re|, |im| over bins [0, M/2)
+            float maxabs = spec_aux;
+            if constexpr (FUSED) {
+                lds_load_block<U>(reinterpret_cast<const float*>(cbuf) + U * lane, re);
+            } else {
 #pragma unroll
-            for (int j = 0; j < U; j++) {
-                const f2 v = cbuf[cpad(U * lane + j)];
-                re[j] = v.x;
-                // ref SpectralCharacteristics.h:153: getMagnitude over the first M floats of the
-                // interleaved buffer = re and im of bins [0, M/2)
-                if (lane < 32) { maxabs = fmaxf(maxabs, fabsf(v.x)); maxabs = fmaxf(maxabs, fabsf(v.y)); }
+                for (int j = 0; j < U; j++) {
+                    const f2 v = cbuf[cpad(U * lane + j)];
+                    re[j] = v.x;
+                    if (lane < 32) { maxabs = fmaxf(maxabs, fabsf(v.x)); maxabs = fmaxf(maxabs, fabsf(v.y)); }
+                }
             }
             const double eps = 0.01 * (double) log_rms;                        // :108
             double mag_sum = 0.0, lhr = 0.0, wsum = 0.0, flat_sum = 0.0;
@@ -842,24 +908,33 @@ FX_MARK("harm1");
         // ---------------- harmonic analyser, part 1: raw (un-windowed) spectrum ---------------------
         // ref RealTimeAnalyser.h:161 -- done before the low-pass overwrites the frame image
         lane = opaque(lane);
-        fft_from_regs<N, false>(xr, cbuf, tw, lane);
+        fft_from_regs<N, false, OUT_RE_LOW>(xr, cbuf, tw, lane);
         float hre[U];
         float h_left2, h_left1, h_right1;          // |re| of bins U*lane-2, U*lane-1, U*lane+U
         double h_sum = 0.0, h_max;
         float h_max_re = 0.0f;
         {
+            const int b0 = U * lane;
+            if constexpr (FUSED) {
+                const float* relin = reinterpret_cast<const float*>(cbuf);
+                lds_load_block<U>(relin + b0, hre);
+                h_left2  = b0 >= 2 ? fabsf(relin[b0 - 2]) : 0.0f;
+                h_left1  = b0 >= 1 ? fabsf(relin[b0 - 1]) : 0.0f;
+                h_right1 = b0 + U < M ? fabsf(relin[b0 + U]) : 0.0f;
+            } else {
+#pragma unroll
+                for (int j = 0; j < U; j++) hre[j] = cbuf[cpad(b0 + j)].x;
+                h_left2  = b0 >= 2 ? fabsf(cbuf[cpad(b0 - 2)].x) : 0.0f;
+                h_left1  = b0 >= 1 ? fabsf(cbuf[cpad(b0 - 1)].x) : 0.0f;
+                h_right1 = b0 + U < M ? fabsf(cbuf[cpad(b0 + U)].x) : 0.0f;
+            }
 #pragma unroll
             for (int j = 0; j < U; j++) {                                      // ref HarmonicCharacteristics.h:61-69
-                hre[j] = cbuf[cpad(U * lane + j)].x;
                 const double v = (double) hre[j];
                 const double mag = v * v;
                 h_sum += mag;
                 h_max_re = fmaxf(h_max_re, fabsf(hre[j]));
             }
-            const int b0 = U * lane;
-            h_left2  = b0 >= 2 ? fabsf(cbuf[cpad(b0 - 2)].x) : 0.0f;
-            h_left1  = b0 >= 1 ? fabsf(cbuf[cpad(b0 - 1)].x) : 0.0f;
-            h_right1 = b0 + U < M ? fabsf(cbuf[cpad(b0 + U)].x) : 0.0f;
             h_sum = wave_sum(h_sum);
             h_max_re = wave_maxf(h_max_re);
             h_max = (double) h_max_re * (double) h_max_re;
@@ -956,7 +1031,7 @@ FX_MARK("pitch_fft");
 #pragma unroll
                 for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = rbuf[rpad(first_pass_index<N>(lane, g, j))];
             wave_fence();
-            fft_from_regs<N, false>(xf, cbuf, tw, lane);                       // ref RealTimeAnalyser.h:160
+            fft_from_regs<N, false, OUT_POWER>(xf, cbuf, tw, lane);            // ref RealTimeAnalyser.h:160
 FX_MARK("power");
         FX_STAMP(6);
             // a11 getComplexConjugateMultiplication, ref PitchAnalyser.h:83-108: re*re, imag := 0,
@@ -966,12 +1041,16 @@ FX_MARK("power");
             for (int g = 0; g < G::GA; g++)
 #pragma unroll
                 for (int j = 0; j < G::RA; j++) {
-                    const float r = cbuf[cpad(first_pass_index<N>(lane, g, j))].x;
-                    xf[g * G::RA + j] = r * r;
+                    if constexpr (FUSED) {
+                        xf[g * G::RA + j] = rbuf[rpad(first_pass_index<N>(lane, g, j))];     // already squared
+                    } else {
+                        const float r = cbuf[cpad(first_pass_index<N>(lane, g, j))].x;
+                        xf[g * G::RA + j] = r * r;
+                    }
                 }
             wave_fence();
 FX_MARK("ifft");
-            fft_from_regs<N, true>(xf, cbuf, tw, lane);                        // a12 inverse, ref :110-121
+            fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, lane, scale);        // a12 inverse, ref :110-121
 FX_MARK("vcalc");
         FX_STAMP(7);
             // v[s] = d[s]*d[s]*s, d = planar JUCE inverse output scaled by 1/N (ref :122-123).
@@ -979,7 +1058,7 @@ FX_MARK("vcalc");
             lane = opaque(lane);
             float* vbuf = rbuf;                                                // [N+1] plain layout
             float* sums = rbuf + N + 4;                                        // [N+1]; both fit in the buffer
-            {
+            if constexpr (!FUSED) {
                 float vv[P];
 #pragma unroll
                 for (int i = 0; i < P; i++) {
