@@ -79,6 +79,7 @@ struct fx_context {
     unsigned long long* d_debug = nullptr;   // FX_STAMPS diagnostic builds
     double bin_var = 0.0;
     float  lpf_a = 0.0f, lpf_b = 0.0f;
+    float  first_tw[18] = {0};
 };
 
 namespace {
@@ -176,6 +177,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     fp.lpf_a = c->lpf_a;
     fp.lpf_b = c->lpf_b;
     fp.debug = c->d_debug;
+    for (int i = 0; i < 18; i++) fp.first_tw[i] = c->first_tw[i];
 
     // waves per workgroup = frames of one channel in flight.  Pick the count that keeps the most
     // wavefronts resident per CU (LDS is the limiter: one twiddle table + flux state per workgroup,
@@ -318,6 +320,7 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
         }
         std::vector<float> ordered(tw.size());
         fxk::build_pass_twiddles(window_size, tw.data(), ordered.data());    // same values, pass access order
+        fxk::fill_first_pass_twiddles(window_size, ordered.data(), c->first_tw);
         TRY_OR_CLEAN(hipMemcpy(c->d_tw, ordered.data(), ordered.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     // ref SpectralCharacteristics.h:180-189: binVar does not depend on the signal

@@ -52,6 +52,8 @@ struct FrameParams {
     double       nyquist;
     double       bin_var;       // sum_i (i/M - 0.5)^2 / M, summed serially on the host (ref SpectralCharacteristics.h:182-189)
     float        lpf_a, lpf_b;  // ref RealTimeAudioAnalysis.h:122
+    float        first_tw[18];  // the <= 9 twiddles of the first FFT pass (re, im pairs): wave-uniform, so they travel as
+                                // kernel arguments (SGPRs) instead of LDS reads; filled by fill_first_pass_twiddles
     unsigned long long* debug;  // diagnostic builds (-DFX_STAMPS) only: [12] per-section cycle sums; else nullptr
 };
 
@@ -79,6 +81,8 @@ struct EpilogueParams {
 // Re-order the reference's N-entry twiddle table (canonical[i] = (re, im) of e^{-2*pi*i/N} as floats)
 // into the order the FFT passes read it; `out` has room for window_size complex entries.
 void build_pass_twiddles(int window_size, const float* canonical, float* out);
+// the first pass's constants, taken from the same pass-ordered table
+void fill_first_pass_twiddles(int window_size, const float* pass_ordered, float* out18);
 
 size_t frame_kernel_lds_bytes(int window_size, int waves);
 // Chooses waves per workgroup and launches; returns hipSuccess or the launch error.

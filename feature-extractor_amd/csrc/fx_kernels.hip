@@ -374,12 +374,14 @@ template <int N> __device__ __forceinline__ int first_pass_index(int lane, int g
 // have unit twiddles and real operands; the stage after them sees real operands in half of its
 // butterflies.  Results go to the complex image.
 template <int N, bool INV>
-__device__ __forceinline__ void fft_first_pass(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, int lane)
+__device__ __forceinline__ void fft_first_pass(const float (&xin)[Geo<N>::P], f2* cbuf, const float (&ftw)[18], int lane)
 {
     typedef Geo<N> G;
     constexpr int R = G::RA;
     lane = opaque(lane);
-    const f2* ta = tw + Plan<N>::OFFA;
+    f2 ta[9];                      // wave-uniform: kernel arguments, not LDS
+#pragma unroll
+    for (int i = 0; i < 9; i++) ta[i] = f2{ftw[2 * i], ftw[2 * i + 1]};
 #pragma unroll
     for (int g = 0; g < G::GA; g++) {
         const float* x = &xin[g * R];
@@ -475,10 +477,11 @@ __device__ __forceinline__ float fft_last_pass_fused(f2* cbuf, const f2* tw, int
 // For N > 1024 the last pass cannot hold every item in registers; it leaves the complex image and the
 // caller extracts what it needs.
 template <int N, bool INV, int OUT>
-__device__ __forceinline__ float fft_from_regs(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, int lane, float scale = 0.0f)
+__device__ __forceinline__ float fft_from_regs(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, const float (&ftw)[18],
+                                               int lane, float scale = 0.0f)
 {
     typedef Plan<N> PL;
-    fft_first_pass<N, INV>(xin, cbuf, tw, lane);
+    fft_first_pass<N, INV>(xin, cbuf, ftw, lane);
     fft_pass<N, PL::R1, PL::L1, PL::OFF1, INV>(cbuf, tw, lane);
     if constexpr (N <= 1024 && OUT != OUT_COMPLEX) {
         return fft_last_pass_fused<N, INV, OUT>(cbuf, tw, lane, scale);
@@ -713,7 +716,7 @@ FX_MARK("spec_fft");
                     xw[g * G::RA + j] = xr[g * G::RA + j] * gain;
                 }
             }
-            spec_aux = fft_from_regs<N, false, OUT_RE_LOW_MAXABS>(xw, cbuf, tw, lane);   // a4
+            spec_aux = fft_from_regs<N, false, OUT_RE_LOW_MAXABS>(xw, cbuf, tw, p.first_tw, lane);   // a4
         }
 FX_MARK("spec_sums");
         FX_STAMP(2);
@@ -908,7 +911,7 @@ FX_MARK("harm1");
         // ---------------- harmonic analyser, part 1: raw (un-windowed) spectrum ---------------------
         // ref RealTimeAnalyser.h:161 -- done before the low-pass overwrites the frame image
         lane = opaque(lane);
-        fft_from_regs<N, false, OUT_RE_LOW>(xr, cbuf, tw, lane);
+        fft_from_regs<N, false, OUT_RE_LOW>(xr, cbuf, tw, p.first_tw, lane);
         float hre[U];
         float h_left2, h_left1, h_right1;          // |re| of bins U*lane-2, U*lane-1, U*lane+U
         double h_sum = 0.0, h_max;
@@ -1031,7 +1034,7 @@ FX_MARK("pitch_fft");
 #pragma unroll
                 for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = rbuf[rpad(first_pass_index<N>(lane, g, j))];
             wave_fence();
-            fft_from_regs<N, false, OUT_POWER>(xf, cbuf, tw, lane);            // ref RealTimeAnalyser.h:160
+            fft_from_regs<N, false, OUT_POWER>(xf, cbuf, tw, p.first_tw, lane);            // ref RealTimeAnalyser.h:160
 FX_MARK("power");
         FX_STAMP(6);
             // a11 getComplexConjugateMultiplication, ref PitchAnalyser.h:83-108: re*re, imag := 0,
@@ -1050,7 +1053,7 @@ FX_MARK("power");
                 }
             wave_fence();
 FX_MARK("ifft");
-            fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, lane, scale);        // a12 inverse, ref :110-121
+            fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, p.first_tw, lane, scale);        // a12 inverse, ref :110-121
 FX_MARK("vcalc");
         FX_STAMP(7);
             // v[s] = d[s]*d[s]*s, d = planar JUCE inverse output scaled by 1/N (ref :122-123).
@@ -1544,6 +1547,25 @@ template <int N> static void build_tw_t(const float* canon, float* out)
         for (int q = 1; q <= 3; q++) o[PL::OFFA + q - 1] = c[(N / 8) * q];
     }
     static_assert(PL::OFFA + (G::RA == 16 ? 9 : (G::RA == 8 ? 3 : 0)) <= N, "pass-ordered twiddles must fit the N-entry table");
+}
+
+template <int N> static void fill_first_t(const float* ordered, float* out18)
+{
+    for (int i = 0; i < 18; i++) out18[i] = 0.0f;
+    constexpr int cnt = Geo<N>::RA == 16 ? 9 : (Geo<N>::RA == 8 ? 3 : 0);
+    for (int i = 0; i < 2 * cnt; i++) out18[i] = ordered[2 * Plan<N>::OFFA + i];
+}
+
+void fill_first_pass_twiddles(int n, const float* ordered, float* out18)
+{
+    switch (n) {
+        case 256:  fill_first_t<256>(ordered, out18); break;
+        case 512:  fill_first_t<512>(ordered, out18); break;
+        case 1024: fill_first_t<1024>(ordered, out18); break;
+        case 2048: fill_first_t<2048>(ordered, out18); break;
+        case 4096: fill_first_t<4096>(ordered, out18); break;
+        default: break;
+    }
 }
 
 void build_pass_twiddles(int n, const float* canonical, float* out)
