@@ -587,12 +587,17 @@ __device__ __forceinline__ FlatProd fp_mul2(FlatProd a, FlatProd b)
 #ifndef FX_OCC_SMALL
 #define FX_OCC_SMALL 4
 #endif
-template <int N> struct Occ { static constexpr int WAVES_PER_SIMD = N <= 1024 ? FX_OCC_SMALL : (N == 2048 ? 2 : 1); };
+template <int N> struct Occ {
+    static constexpr int WAVES_PER_SIMD = N <= 1024 ? FX_OCC_SMALL : (N == 2048 ? 2 : 1);
+    // N = 4096 fits at most 3 waves per workgroup in the LDS; a 256-thread bound lets it use the whole
+    // register file at one wave per SIMD instead of spilling
+    static constexpr int MAX_THREADS = N == 4096 ? 256 : 512;
+};
 
 // SPEC / HARM: which of the reference's two analysers run (RealTimeSpectralAnalyser,
 // RealTimeHarmonicAnalyser -- both by default, as AnalyserTrackController constructs them)
 template <int N, bool SPEC, bool HARM>
-__global__ void __launch_bounds__(512, Occ<N>::WAVES_PER_SIMD)
+__global__ void __launch_bounds__(Occ<N>::MAX_THREADS, Occ<N>::WAVES_PER_SIMD)
 fx_frame_kernel(const FrameParams p)
 {
     typedef Geo<N> G;
