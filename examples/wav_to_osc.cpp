@@ -1,0 +1,111 @@
+// wav_to_osc -- BASELINE configs[0]: one mono channel of a WAV file, windowSize-sample frames with 50 %
+// overlap through the analysers, smoothed AudioFeatures out as OSC feature messages.
+//
+// The reference does this with AudioFilePlayer -> AudioDataCollector -> the two analyser threads ->
+// OSCFeatureAnalysisOutput's 60 Hz timer (ref Source/AudioFilePlayer.h:41-61, AudioDataCollector.h:36-94,
+// RealTimeAnalyser.h:141-234, OSCFeatureAnalysisOutput.h:84-113).  Here the file is decoded by
+// include/fx_wav.hpp, analysed on the GPU through include/fx_realtime.hpp (C ABI underneath) and the
+// datagrams are written to a UDP target and/or a dump file (each record: u32 little-endian length + bytes).
+//
+//   wav_to_osc in.wav [--window 1024] [--channel 0] [--gain 1.0] [--address /Audio/A0]
+//                     [--target 127.0.0.1:9000] [--dump out.bin] [--rate 0] [--batch 64] [--device 0]
+//
+// --rate 0 (default) emits one message per hop.  --rate 60 emits what the reference's timer would read if
+// the file played in real time: at t = k/60 s, the smoothed values after the last hop completed by t.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fx_realtime.hpp"
+#include "fx_wav.hpp"
+
+int main (int argc, char** argv)
+{
+    std::string path, address = "/Audio/A0", target, dump;
+    int window = 1024, channel = 0, batch = 64, device = 0;
+    double rate = 0.0;
+    float gain = 1.0f;
+    for (int i = 1; i < argc; ++i)
+    {
+        const std::string a = argv[i];
+        auto next = [&] () -> const char* { if (i + 1 >= argc) { std::fprintf (stderr, "%s needs a value\n", a.c_str()); std::exit (2); } return argv[++i]; };
+        if      (a == "--window")  window = std::atoi (next());
+        else if (a == "--channel") channel = std::atoi (next());
+        else if (a == "--gain")    gain = (float) std::atof (next());
+        else if (a == "--address") address = next();
+        else if (a == "--target")  target = next();
+        else if (a == "--dump")    dump = next();
+        else if (a == "--rate")    rate = std::atof (next());
+        else if (a == "--batch")   batch = std::atoi (next());
+        else if (a == "--device")  device = std::atoi (next());
+        else if (a[0] != '-')      path = a;
+        else { std::fprintf (stderr, "unknown option %s\n", a.c_str()); return 2; }
+    }
+    if (path.empty()) { std::fprintf (stderr, "usage: wav_to_osc in.wav [--window N] [--channel c] [--gain g] [--address a] [--target ip[:port]] [--dump file] [--rate hz] [--batch hops]\n"); return 2; }
+
+    fx::WavData wav;
+    std::string error;
+    if (! fx::readWav (path, wav, error)) { std::fprintf (stderr, "%s\n", error.c_str()); return 1; }
+    if (channel < 0 || channel >= wav.numChannels) { std::fprintf (stderr, "channel %d not in file (%d channels)\n", channel, wav.numChannels); return 1; }
+    if (batch < 1) batch = 1;
+
+    int numHops = 0;
+    const std::vector<float> hops = fx::hopsOfChannel (wav, channel, window, numHops);
+    const std::size_t hop = (std::size_t) window / 2;
+
+    std::FILE* out = nullptr;
+    if (! dump.empty() && (out = std::fopen (dump.c_str(), "wb")) == nullptr) { std::fprintf (stderr, "cannot write %s\n", dump.c_str()); return 1; }
+    fx::OSCFeatureSender sender;
+    if (! target.empty() && ! sender.connectToAddress (target)) { std::fprintf (stderr, "bad target %s\n", target.c_str()); return 1; }
+
+    long sent = 0;
+    auto emit = [&] (const float* smoothed12)
+    {
+        const std::string msg = fx::OSCFeatureMessage (address, smoothed12);
+        if (out != nullptr)
+        {
+            const unsigned n = (unsigned) msg.size();
+            const unsigned char len[4] = { (unsigned char) n, (unsigned char) (n >> 8), (unsigned char) (n >> 16), (unsigned char) (n >> 24) };
+            std::fwrite (len, 1, 4, out);
+            std::fwrite (msg.data(), 1, msg.size(), out);
+        }
+        if (! target.empty()) sender.send (address, smoothed12);
+        ++sent;
+    };
+
+    try
+    {
+        fx::RealTimeBatchAnalyser analyser (1, window, (double) wav.sampleRate, device);
+        analyser.setGain (gain);
+        std::vector<float> raw ((std::size_t) batch * FX_NUM_FEATURES), smoothed ((std::size_t) batch * FX_NUM_FEATURES);
+        long tick = 1;                                               // next timer tick (k / rate seconds)
+        for (int done = 0; done < numHops; done += batch)
+        {
+            const int n = numHops - done < batch ? numHops - done : batch;
+            analyser.pushHops (hops.data() + (std::size_t) done * hop, n, raw.data(), smoothed.data());
+            for (int t = 0; t < n; ++t)
+            {
+                const float* v = smoothed.data() + (std::size_t) t * FX_NUM_FEATURES;
+                if (rate <= 0.0) { emit (v); continue; }
+                // hop (done + t) is complete at sample (done + t + 1) * hop; it is what every tick in
+                // [that time, completion of the next hop) reads
+                const double from = (double) (done + t + 1) * (double) hop / wav.sampleRate;
+                const double to   = (double) (done + t + 2) * (double) hop / wav.sampleRate;
+                while ((double) tick / rate < from) ++tick;          // ticks before the first result read nothing
+                while ((double) tick / rate < to) { emit (v); ++tick; }
+            }
+        }
+    }
+    catch (const fx::Error& e)
+    {
+        std::fprintf (stderr, "analysis failed: %s\n", e.what());
+        if (out != nullptr) std::fclose (out);
+        return 1;
+    }
+    if (out != nullptr) std::fclose (out);
+    std::printf ("%s: %d Hz, %d channel(s), %d-bit%s; %d hops of %zu samples; %ld OSC messages (%s)\n", path.c_str(), wav.sampleRate,
+                 wav.numChannels, wav.bitsPerSample, wav.isFloat ? " float" : "", numHops, hop, sent, address.c_str());
+    return 0;
+}

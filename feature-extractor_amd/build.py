@@ -18,6 +18,7 @@ HEADERS = ["fx_kernels.h", os.path.join("..", "..", "include", "fx.h")]
 #   per-frame loop and spilled (the loop body is ~9k instructions).
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                "-fno-fast-math", "-mllvm", "-disable-machine-licm", "-Wall", "-Wno-unused-function"]
+HIPCC_FLAGS += os.environ.get("FX_EXTRA_HIPCC_FLAGS", "").split()      # experiments only
 
 
 def _hipcc():

@@ -7,7 +7,8 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 BENCH="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
+# the trace pass runs the bench default step count so its per-kernel average is comparable with bench.py's own
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-extra $* > $OUT/trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- $BENCH > $OUT/pmc_$c.log 2>&1
 done
