@@ -88,36 +88,39 @@ __device__ __forceinline__ double bcast63(double v)
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+// Full-mask DPP read with bound_ctrl: lanes whose source does not exist receive 0 and nothing depends on
+// the destination's old contents, so the compiler needs no move to initialise it.  With every row
+// enabled row_bcast:15 gives rows 1..3 the total of the row before them and row_bcast:31 gives rows
+// 2..3 lane 31's value, so after both steps row 3 holds (r3 + r2) + (r1 + r0): lane 63 has the wave
+// total although rows 0..2 do not -- which is all a reduction needs.
+template <int CTRL> __device__ __forceinline__ int dppz_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
+template <int CTRL> __device__ __forceinline__ float dppz_f(float v) { return __int_as_float(dppz_i<CTRL>(__float_as_int(v))); }
+template <int CTRL> __device__ __forceinline__ double dppz_d(double v)
+{
+    const int lo = dppz_i<CTRL>(__double2loint(v));
+    const int hi = dppz_i<CTRL>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
-    v += dpp_d<DPP_XOR1, 0xF>(0.0, v);
-    v += dpp_d<DPP_XOR2, 0xF>(0.0, v);
-    v += dpp_d<DPP_HALF_MIRROR, 0xF>(0.0, v);
-    v += dpp_d<DPP_MIRROR, 0xF>(0.0, v);
-    v += dpp_d<DPP_BCAST15, 0xA>(0.0, v);
-    v += dpp_d<DPP_BCAST31, 0xC>(0.0, v);
+    v += dppz_d<DPP_XOR1>(v);
+    v += dppz_d<DPP_XOR2>(v);
+    v += dppz_d<DPP_HALF_MIRROR>(v);
+    v += dppz_d<DPP_MIRROR>(v);
+    v += dppz_d<DPP_BCAST15>(v);
+    v += dppz_d<DPP_BCAST31>(v);
     return bcast63(v);
 }
-__device__ __forceinline__ double wave_max(double v)
-{
-    double t;
-    t = dpp_d<DPP_XOR1, 0xF>(v, v);        v = t > v ? t : v;
-    t = dpp_d<DPP_XOR2, 0xF>(v, v);        v = t > v ? t : v;
-    t = dpp_d<DPP_HALF_MIRROR, 0xF>(v, v); v = t > v ? t : v;
-    t = dpp_d<DPP_MIRROR, 0xF>(v, v);      v = t > v ? t : v;
-    t = dpp_d<DPP_BCAST15, 0xA>(v, v);     v = t > v ? t : v;
-    t = dpp_d<DPP_BCAST31, 0xC>(v, v);     v = t > v ? t : v;
-    return bcast63(v);
-}
+// maximum of values that are >= 0 (or NaN, which never wins -- as in `if (x > max) max = x`)
 __device__ __forceinline__ float wave_maxf(float v)
 {
-    float t;
-    t = dpp_f<DPP_XOR1, 0xF>(v, v);        v = t > v ? t : v;
-    t = dpp_f<DPP_XOR2, 0xF>(v, v);        v = t > v ? t : v;
-    t = dpp_f<DPP_HALF_MIRROR, 0xF>(v, v); v = t > v ? t : v;
-    t = dpp_f<DPP_MIRROR, 0xF>(v, v);      v = t > v ? t : v;
-    t = dpp_f<DPP_BCAST15, 0xA>(v, v);     v = t > v ? t : v;
-    t = dpp_f<DPP_BCAST31, 0xC>(v, v);     v = t > v ? t : v;
+    v = fmaxf(v, dppz_f<DPP_XOR1>(v));
+    v = fmaxf(v, dppz_f<DPP_XOR2>(v));
+    v = fmaxf(v, dppz_f<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dppz_f<DPP_MIRROR>(v));
+    v = fmaxf(v, dppz_f<DPP_BCAST15>(v));
+    v = fmaxf(v, dppz_f<DPP_BCAST31>(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ int wave_min_i(int v)
@@ -254,6 +257,15 @@ template <bool INV> __device__ __forceinline__ f2 twmul_real(float r, f2 t)
     return INV ? f2{p.x, -p.y} : p;
 }
 
+// (a.x + b.y, a.y - b.x) if NEG_HI, else (a.x - b.y, a.y + b.x): a -/+ i*b
+template <bool NEG_HI> __device__ __forceinline__ f2 pk_add_rot(f2 a, f2 b)
+{
+    f2 r;
+    if (NEG_HI) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    else        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // butterfly4 after the three twiddle products s0, s1, s2
 template <bool INV>
 __device__ __forceinline__ void bfly4_core(f2& d0, f2& d1, f2& d2, f2& d3, f2 s0, f2 s1, f2 s2)
@@ -264,12 +276,15 @@ __device__ __forceinline__ void bfly4_core(f2& d0, f2& d1, f2& d2, f2& d3, f2 s0
     const f2 a = d0 + s1;
     d2 = a - s3;
     d0 = a + s3;
+    // d1 = s5 -/+ i*s4, d3 = s5 +/- i*s4: one packed add each with the second operand's halves swapped and
+    // one of them negated (x - y == x + (-y) exactly).  Left to itself hipcc computes all four sums and
+    // differences and re-pairs the halves with moves.
     if (INV) {
-        d1 = f2{s5.x - s4.y, s5.y + s4.x};
-        d3 = f2{s5.x + s4.y, s5.y - s4.x};
+        d1 = pk_add_rot<false>(s5, s4);     // (s5.x - s4.y, s5.y + s4.x)
+        d3 = pk_add_rot<true>(s5, s4);      // (s5.x + s4.y, s5.y - s4.x)
     } else {
-        d1 = f2{s5.x + s4.y, s5.y - s4.x};
-        d3 = f2{s5.x - s4.y, s5.y + s4.x};
+        d1 = pk_add_rot<true>(s5, s4);
+        d3 = pk_add_rot<false>(s5, s4);
     }
 }
 // butterfly4 on four REAL inputs with unit twiddles (first stage of a real-input transform)
@@ -744,7 +759,10 @@ FX_MARK("spec_sums");
             const double eps = 0.01 * (double) log_rms;                        // :108
             double mag_sum = 0.0, lhr = 0.0, wsum = 0.0, flat_sum = 0.0;
             float max_re = 0.0f;       // max |re|: (double) re^2 is exact and monotone in |re|, so max mag = max_re^2
-            int cnt = 0;
+            int cnt = 0;               // wave-uniform: bins that pass the flatness gate, counted from the compare masks
+            // bins m <= M/5 (:86-87, inclusive) are the lanes below LQ entirely and the first LR + 1 bins of lane LQ:
+            // the lane's share of `lhr` is its running magnitude sum at that point
+            constexpr int LQ = (M / 5) / U, LR = (M / 5) % U;
 #pragma unroll
             for (int j = 0; j < U; j++) {                                      // fillIntermediateValues :62-97
                 const int m = U * lane + j;
@@ -752,11 +770,14 @@ FX_MARK("spec_sums");
                 const double mag = v * v;
                 const double fc = (double) m * frpb + (frpb / 2.0);
                 mag_sum += mag;
-                if (m <= M / 5) lhr += mag;                                    // :86-87 (inclusive prefix)
-                if (mag > eps) { flat_sum += mag; cnt++; }
+                if (j == LR) lhr = mag_sum;
+                const bool gate = mag > eps;
+                cnt += __builtin_popcountll(__ballot(gate));
+                if (gate) flat_sum += mag;
                 wsum += fc * mag;
                 max_re = fmaxf(max_re, fabsf(re[j]));
             }
+            lhr = lane < LQ ? mag_sum : (lane == LQ ? lhr : 0.0);
             mag_sum = wave_sum(mag_sum);
             lhr = wave_sum(lhr);
             wsum = wave_sum(wsum);
@@ -764,15 +785,16 @@ FX_MARK("spec_sums");
             max_re = wave_maxf(max_re);
             const double max_mag = (double) max_re * (double) max_re;
             maxabs = wave_maxf(maxabs);
-            cnt = wave_sum_i(cnt);
             const bool accepted = mag_sum > 0.05;                              // :121-123
 
 FX_MARK("flux");
             // ---- flux against the previous accepted frame; hand-off between waves ----
             double flux = 0.0;
             {
+#ifndef FX_EXP_NOWAIT
                 while (__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t)
                     __builtin_amdgcn_s_sleep(1);
+#endif
                 float pvf[U];
                 lds_load_block<U>(prev + U * lane, pvf);
 #pragma unroll
@@ -1096,7 +1118,11 @@ FX_MARK("scan");
                 int first = 0x7fffffff;
                 bool done = false;
                 float best = 100.0f; int best_i = 0x7fffffff;
+#ifdef FX_EXP_SKIP_SCAN
+                for (int blk = 0; blk < (int) (scale * 0.5f) && !done; blk++) {
+#else
                 for (int blk = 0; blk < P && !done; blk++) {
+#endif
                     if (lane == 0) {
 #pragma unroll
                         for (int g = 0; g < 64; g += 4) {
@@ -1161,7 +1187,11 @@ FX_MARK("harm2");
         FX_STAMP(8);
         // ---------------- harmonic analyser, part 2 (ref HarmonicCharacteristics.h:71-105) ----------
         lane = opaque(lane);
+#ifdef FX_EXP_SKIP_HARM2
+        if (h_sum < -1.0) {
+#else
         if (!(h_sum < 0.005)) {                                                // :88-89
+#endif
             float* normed  = reinterpret_cast<float*>(cbuf);                   // [M] floats
             int*   peaks   = reinterpret_cast<int*>(cbuf) + M;                 // [<= M] peak bins
             float* peak_re = reinterpret_cast<float*>(cbuf) + 2 * M;           // [<= M] re of those bins
