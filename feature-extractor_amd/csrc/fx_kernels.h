@@ -27,7 +27,9 @@ struct FramePart {
     double wsum;        // weightedMagnitudeSum                              (ref :95)
     double vsum;        // sum (mag - mag_sum/M)^2
     double inh;         // inharmonicity before the log                      (ref HarmonicCharacteristics.h:239)
-    double her;         // clamped harmonic energy ratio, rounded to float   (ref :186-197)
+    double her_score;   // sum of the 18 probe maxima                        (ref :157-184)
+    double sum_normed;  // sum of mag / max over all bins                    (ref :77); her = score / sum_normed
+    double spare_;
     float  log_rms;     // ref RealTimeAnalyser.h:208
     float  centroid;    // (float)(wsum / mag_sum)                           (ref SpectralCharacteristics.h:127)
     float  cnt;         // numMagnitudesUsedInFlatnessCalculation
@@ -35,7 +37,7 @@ struct FramePart {
     int    flags;       // bit 0: harmonic analyser ran past the 0.005 gate  (ref HarmonicCharacteristics.h:88)
     int    pad_;
 };
-static_assert(sizeof(FramePart) == 112, "FramePart is written with 16-byte stores");
+static_assert(sizeof(FramePart) == 128, "FramePart is written with 16-byte stores");
 
 struct FrameParams {
     const void*  in;            // frames [C][T][N] or hops [C][T][N/2]

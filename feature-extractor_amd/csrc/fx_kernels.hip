@@ -657,7 +657,7 @@ fx_frame_kernel(const FrameParams p)
         // uniform per-frame results go to LDS as soon as they exist instead of occupying ~28 VGPRs
         // in every lane for the whole frame
         FramePart* fpl = parts + wave;
-        if (lane == 0) { fpl->inh = 0.0; fpl->her = 0.0; fpl->flags = 0; fpl->pad_ = 0; }
+        if (lane == 0) { fpl->inh = 0.0; fpl->her_score = 0.0; fpl->sum_normed = 1.0; fpl->flags = 0; fpl->pad_ = 0; fpl->spare_ = 0.0; }
 
 FX_MARK("load");
         // ---------------- a1: window assembly (ref RealTimeAudioAnalysis.h:205-219) ----------------
@@ -708,7 +708,11 @@ FX_MARK("rms");
             const float rms = (float) sqrt(s / (double) N);
             // log10 of a float, correctly rounded: this value gates bins (`mag > 0.01*logRMS`), so it must
             // equal the CPU oracle's to the last bit (see oracle/fx_oracle.c)
+#ifdef FX_EXP_SKIP_RMSLOG
+            log_rms = __log10f(rms * 9.0f + 1.0f);
+#else
             log_rms = (float) log10((double) (rms * 9.0f + 1.0f));
+#endif
             if (lane == 0) fpl->log_rms = log_rms;
         }
 
@@ -817,6 +821,10 @@ FX_MARK("flatprod");
             // exponent-extended prefix products locate the first prefix that leaves the normal
             // range; an overflow decides at once, an underflow is finished serially in IEEE double.
             double prod;
+#ifdef FX_EXP_SKIP_FLATPROD
+            prod = 1.0;
+            if (false)
+#endif
             {
                 FlatProd loc = {0.5, 1};                                       // 1.0
 #pragma unroll
@@ -1201,12 +1209,13 @@ FX_MARK("harm2");
             // decides for every bin at once.  If any bin sits within rounding distance of the mean,
             // redo the sum in the reference's order, handing the running value from lane to lane.
             {
+                // |re| within ~1e-6 of sqrt(mean) brackets every bin whose magnitude is within 1e-12 of the mean
+                // (a wider band only means the exact recomputation below runs a little more often)
+                const float root_mean = (float) sqrt(mean_mag);
+                const float band = root_mean * 1e-6f;
                 bool near = false;
 #pragma unroll
-                for (int j = 0; j < U; j++) {
-                    const double v = (double) hre[j];
-                    near |= fabs(v * v - mean_mag) <= 1e-12 * mean_mag;
-                }
+                for (int j = 0; j < U; j++) near |= fabsf(fabsf(hre[j]) - root_mean) <= band;
                 if (__any(near)) {
                     double run = 0.0;
                     for (int l = 0; l < 64; l++) {
@@ -1255,21 +1264,18 @@ FX_MARK("harm2");
             wave_fence();
 
             const double fr = nyquist / (double) M;                            // :93
-            const int f0_bin = (int) floor(f0 / fr);                           // getBinForFrequency :246-249
             // calculateHarmonicEnergyCharacteristics :147-198 with numLower = 15, numHarmonics = 3:
-            // 18 probes, one lane each
+            // 18 probes, one lane each; lane 18 divides f0 itself, which is getBinForFrequency(f0) (:246-249)
             double probe = 0.0;
+            int f0_bin;
             {
-                int bin = -1;
-                if (lane < 15) {
-                    const double lf = f0 / (double) (2 << lane);               // f0 / pow(2, lane+1)
-                    bin = (int) floor(lf / fr);
-                    if (bin == f0_bin) bin = -1;                               // :163-164
-                } else if (lane < 18) {
-                    const double hf = f0 * (double) (lane - 14);
-                    bin = (int) floor(hf / fr);
-                    if (bin >= M) bin = -1;                                    // :174-175 (monotone, so break == skip)
-                }
+                // f0 / pow(2, lane+1) is an exact scaling; f0 * h for the harmonics
+                const double freq = lane < 15 ? ldexp(f0, -(lane + 1)) : (lane < 18 ? f0 * (double) (lane - 14) : f0);
+                int bin = (int) floor(freq / fr);
+                f0_bin = __builtin_amdgcn_readlane(bin, 18);
+                if (lane < 15) { if (bin == f0_bin) bin = -1; }                // :163-164
+                else if (lane < 18) { if (bin >= M) bin = -1; }                // :174-175 (monotone, so break == skip)
+                else bin = -1;
                 if (bin >= 0 && bin < M) {
                     // getMaxBinInNeighbourhood :200-210 : [max(0,c-2), min(c+2, M)), start value normed[c]
                     const int s0 = bin - 2 >= 0 ? bin - 2 : 0;
@@ -1279,11 +1285,7 @@ FX_MARK("harm2");
                     probe = (double) mx;
                 }
             }
-            const double score = wave_sum(probe);
-            double her = score / sum_normed;                                   // :186-188
-            if (her > 1.0) her = 1.0;
-            if (her < 0.0) her = 0.0;
-            const double her_f = (double) (float) her;                         // struct of floats, :197
+            const double score = wave_sum(probe);                              // / sum_normed, clamped: fx_finalise_kernel
 
             // calculateInharmonicity :212-244
             double inh = 0.0;
@@ -1294,8 +1296,9 @@ FX_MARK("harm2");
                     double fs = (double) bin * fr;
                     if (fs == 0.0) fs = fr * 0.5;                              // :225-226
                     const double fe = (double) (bin + 1) * fr;
-                    const double rs  = fs == f0 ? 1.0 : (fs > f0 ? fs / f0 : f0 / fs);   // getFrequencyRatio :251-259
-                    const double re_ = fe == f0 ? 1.0 : (fe > f0 ? fe / f0 : f0 / fe);
+                    // getFrequencyRatio :251-259: higher / lower (1.0 when equal: x / x is exactly 1)
+                    const double rs  = (fs > f0 ? fs : f0) / (fs > f0 ? f0 : fs);
+                    const double re_ = (fe > f0 ? fe : f0) / (fe > f0 ? f0 : fe);
                     if (floor(rs) != floor(re_)) continue;                     // :232-233
                     const double r = rs < re_ ? rs : re_;
                     const double v = (double) peak_re[i];
@@ -1303,7 +1306,7 @@ FX_MARK("harm2");
                 }
             }
             inh = wave_sum(inh);
-            if (lane == 0) { fpl->inh = inh; fpl->her = her_f; fpl->flags = 1; }
+            if (lane == 0) { fpl->inh = inh; fpl->her_score = score; fpl->sum_normed = sum_normed; fpl->flags = 1; }
         }
         wave_fence();
         }
@@ -1382,7 +1385,11 @@ fx_finalise_kernel(const EpilogueParams p)
         out[FX_F0] = (float) (f0 / 5000.0);                                    // ref RealTimeAnalyser.h:165-166
     }
     if (harm && (f.flags & 1)) {
-        const float log_her = (float) log10(f.her * 9.0 + 1.0);                // ref HarmonicCharacteristics.h:101
+        double her = f.her_score / f.sum_normed;                               // ref HarmonicCharacteristics.h:186-188
+        if (her > 1.0) her = 1.0;
+        if (her < 0.0) her = 0.0;
+        her = (double) (float) her;                                            // struct of floats, :197
+        const float log_her = (float) log10(her * 9.0 + 1.0);                  // :101
         out[FX_HER] = log_her;
         out[FX_OER] = log_her;                                                 // ref RealTimeAnalyser.h:171 writes HER into the OER slot
         out[FX_INHARM] = (float) log10(f.inh * 9.0 + 1.0);                     // :102
