@@ -25,29 +25,58 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(fx, window, frames_per_channel, seconds=12.0):
+def usable_cores():
+    """Host threads this process can really run at once: the affinity mask, capped by the cgroup CPU quota
+    (the GPU boxes show 256 hardware threads under a 16-CPU quota; 256 runnable threads there only get
+    throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                       # cgroup v2: "<quota|max> <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
+def cpu_baseline(fx, window, frames_per_channel, seconds=30.0):
     """The CPU oracle (a port of the reference's algorithm, oracle/fx_oracle.c) on this host's
     cores, on a bounded sample of the same synthetic workload: one pthread per core over disjoint
     channel blocks, mirroring the reference's thread-pair-per-channel model."""
     from oracle import fx_oracle as fo
     fo.lib()
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     T = min(frames_per_channel, 16)
     probe = fx.synth.frames(4, T, window)
     t0 = time.perf_counter()
     fo.batch_frames(probe, window, threads=1)
     per_frame = (time.perf_counter() - t0) / (4 * T)
     single = 1.0 / per_frame
-    chans = int(max(cores, min(seconds / (per_frame * T) * cores, 64 * cores)))
-    base = fx.synth.frames(min(chans, 64), T, window)
-    data = np.ascontiguousarray(np.tile(base, (-(-chans // base.shape[0]), 1, 1))[:chans])
+    # about `seconds` of CPU work in total: a block of 64 channels per thread, analysed repeatedly
+    chans = 64 * cores
+    base = fx.synth.frames(64, T, window)
+    data = np.ascontiguousarray(np.tile(base, (cores, 1, 1)))
+    reps = int(max(1, round(seconds / (per_frame * T * 64 * cores))))
     t0 = time.perf_counter()
-    fo.batch_frames(data, window, threads=cores)
+    for _ in range(reps):
+        fo.batch_frames(data, window, threads=cores)
     dt = time.perf_counter() - t0
+    chans *= reps
     return {"value": chans * T / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "single_thread_value": single,
-            "sample": "%d channels x %d frames of the %d-pt synthetic workload on %d pthreads, %.1f s "
-                      "(oracle/fx_oracle.c, gcc -O2)" % (chans, T, window, cores, dt)}
+            "sample": "%d channels x %d frames of the %d-pt synthetic workload on %d pthreads (%d hardware threads visible, "
+                      "cgroup CPU quota applied), %.1f s wall = %.0f CPU-s (oracle/fx_oracle.c, gcc -O2)"
+                      % (chans, T, window, cores, os.cpu_count() or 1, dt, dt * cores)}
 
 
 def load_traffic(window, channels, frames):
