@@ -437,28 +437,27 @@ __device__ __forceinline__ void fft_first_pass(const float (&xin)[Geo<N>::P], f2
 }
 
 // What the last pass leaves in the wave's LDS buffer.
-enum { OUT_COMPLEX = 0,       // the complex image (natural bin order, cpad layout)
-       OUT_RE_LOW = 1,        // float re[M] (plain layout): all the harmonic analyser reads (ref HarmonicCharacteristics.h:63)
+enum { OUT_RE_LOW = 1,        // float re[M] (plain layout): all the harmonic analyser reads (ref HarmonicCharacteristics.h:63)
        OUT_RE_LOW_MAXABS = 2, // the same + max(|re|,|im|) over bins [0, M/2) returned per lane (ref SpectralCharacteristics.h:153)
        OUT_POWER = 3,         // float re*re of all N bins in the real image (rpad layout): ref PitchAnalyser.h:97-103
        OUT_LAG = 4 };         // float v[s] = (re_s/N)^2 * s, s in [0,N), and v[N] from imag[0] (plain layout): ref :119-123
 
-// Last pass for N <= 1024 -- radix 4 at length N/4, all of a lane's items in registers -- fused with
-// the consumer of the spectrum, so the full complex image is never written back and re-read: the
-// spectral / harmonic analysers only read re of bins < N/2, the pitch analyser only re*re, the lag
-// search only the squared, lag-weighted real part.
+// Last pass -- radix 4 at length N/4 (N <= 1024) or radix 16 at length N/16 -- with all of a lane's items in
+// registers (128 VGPRs of them at N = 4096, which runs one wave per SIMD anyway), fused with the consumer of the spectrum, so the full complex image is never written back and
+// re-read: the spectral / harmonic analysers only read re of bins < N/2, the pitch analyser only re*re, the
+// lag search only the squared, lag-weighted real part.
 template <int N, bool INV, int OUT>
 __device__ __forceinline__ float fft_last_pass_fused(f2* cbuf, const f2* tw, int lane, float scale)
 {
-    static_assert(N <= 1024, "needs every item of the lane in registers");
-    constexpr int L0 = N / 4, GI = (N / 4) / 64, TWOFF = Plan<N>::OFF2;
+    typedef Plan<N> PL;
+    constexpr int R = PL::R2, L0 = PL::L2, GI = (N / R) / 64, TWOFF = PL::OFF2, M = N / 2;
     lane = opaque(lane);
-    f2 e[GI][4];
+    f2 e[GI][R];
 #pragma unroll
     for (int g = 0; g < GI; g++) {
         const f2* img = cbuf + cpad(lane + 64 * g);
 #pragma unroll
-        for (int i = 0; i < 4; i++) e[g][i] = img[item_off(L0, i)];
+        for (int i = 0; i < R; i++) e[g][i] = img[item_off(L0, i)];
     }
     wave_fence();                 // the wave has read the whole complex image; the buffer may be rewritten
     float* fbuf = reinterpret_cast<float*>(cbuf);
@@ -467,32 +466,44 @@ __device__ __forceinline__ float fft_last_pass_fused(f2* cbuf, const f2* tw, int
     for (int g = 0; g < GI; g++) {
         const int k = lane + 64 * g;
         const f2* t1 = tw + TWOFF + k;
-        bfly4_core<INV>(e[g][0], e[g][1], e[g][2], e[g][3],
-                        twmul<INV>(e[g][1], t1[0]), twmul<INV>(e[g][2], t1[L0]), twmul<INV>(e[g][3], t1[2 * L0]));
-        if (OUT == OUT_RE_LOW || OUT == OUT_RE_LOW_MAXABS) {
-            fbuf[k] = e[g][0].x;                       // bin k
-            fbuf[k + L0] = e[g][1].x;                  // bin k + N/4; bins >= N/2 are never read
-            if (OUT == OUT_RE_LOW_MAXABS) aux = fmaxf(aux, fmaxf(fabsf(e[g][0].x), fabsf(e[g][0].y)));
-        } else if (OUT == OUT_POWER) {
+        {
+            const f2 w1 = t1[0], w2 = t1[L0], w3 = t1[2 * L0];
 #pragma unroll
-            for (int i = 0; i < 4; i++) fbuf[rpad(k + L0 * i)] = e[g][i].x * e[g][i].x;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int s_ = k + L0 * i;
-                const float d = e[g][i].x * scale;
-                fbuf[s_] = d * d * (float) s_;
-            }
-            if (g == 0 && lane == 0) { const float d = e[0][0].y * scale; fbuf[N] = d * d * (float) N; }
+            for (int h = 0; h < R / 4; h++)
+                bfly4_core<INV>(e[g][4 * h], e[g][4 * h + 1], e[g][4 * h + 2], e[g][4 * h + 3],
+                                twmul<INV>(e[g][4 * h + 1], w1), twmul<INV>(e[g][4 * h + 2], w2), twmul<INV>(e[g][4 * h + 3], w3));
         }
+        if constexpr (R == 16) {
+            const f2* t2 = t1 + 3 * L0;
+#pragma unroll
+            for (int jin = 0; jin < 4; jin++) {
+                const f2 w1 = t2[(jin * 3 + 0) * L0], w2 = t2[(jin * 3 + 1) * L0], w3 = t2[(jin * 3 + 2) * L0];
+                bfly4_core<INV>(e[g][jin], e[g][jin + 4], e[g][jin + 8], e[g][jin + 12],
+                                twmul<INV>(e[g][jin + 4], w1), twmul<INV>(e[g][jin + 8], w2), twmul<INV>(e[g][jin + 12], w3));
+            }
+        }
+        // e[g][i] is bin k + L0*i
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int bin = k + L0 * i;
+            if (OUT == OUT_RE_LOW || OUT == OUT_RE_LOW_MAXABS) {
+                if (i < R / 2) fbuf[bin] = e[g][i].x;                          // bins >= N/2 are never read
+                if (OUT == OUT_RE_LOW_MAXABS && i < R / 4) aux = fmaxf(aux, fmaxf(fabsf(e[g][i].x), fabsf(e[g][i].y)));
+            } else if (OUT == OUT_POWER) {
+                fbuf[rpad(bin)] = e[g][i].x * e[g][i].x;
+            } else {
+                const float d = e[g][i].x * scale;
+                fbuf[bin] = d * d * (float) bin;
+            }
+        }
+        if (OUT == OUT_LAG && g == 0 && lane == 0) { const float d = e[0][0].y * scale; fbuf[N] = d * d * (float) N; }
     }
+    (void) M;
     wave_fence();
     return aux;
 }
 
 // Whole transform of one wavefront: P real inputs per lane (first-pass order) -> OUT (see above).
-// For N > 1024 the last pass cannot hold every item in registers; it leaves the complex image and the
-// caller extracts what it needs.
 template <int N, bool INV, int OUT>
 __device__ __forceinline__ float fft_from_regs(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, const float (&ftw)[18],
                                                int lane, float scale = 0.0f)
@@ -500,12 +511,7 @@ __device__ __forceinline__ float fft_from_regs(const float (&xin)[Geo<N>::P], f2
     typedef Plan<N> PL;
     fft_first_pass<N, INV>(xin, cbuf, ftw, lane);
     fft_pass<N, PL::R1, PL::L1, PL::OFF1, INV>(cbuf, tw, lane);
-    if constexpr (N <= 1024 && OUT != OUT_COMPLEX) {
-        return fft_last_pass_fused<N, INV, OUT>(cbuf, tw, lane, scale);
-    } else {
-        fft_pass<N, PL::R2, PL::L2, PL::OFF2, INV>(cbuf, tw, lane);
-        return 0.0f;
-    }
+    return fft_last_pass_fused<N, INV, OUT>(cbuf, tw, lane, scale);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -718,7 +724,6 @@ FX_MARK("rms");
             if (lane == 0) fpl->log_rms = log_rms;
         }
 
-        constexpr bool FUSED = N <= 1024;          // last FFT pass fused with its consumer (fft_last_pass_fused)
         if constexpr (SPEC) {
         float spec_aux = 0.0f;
 FX_MARK("spec_fft");
@@ -752,16 +757,7 @@ FX_MARK("spec_sums");
             // ref SpectralCharacteristics.h:153: getMagnitude over the first M floats of the interleaved
             // buffer = max |re|, |im| over bins [0, M/2)
             float maxabs = spec_aux;
-            if constexpr (FUSED) {
-                lds_load_block<U>(reinterpret_cast<const float*>(cbuf) + U * lane, re);
-            } else {
-#pragma unroll
-                for (int j = 0; j < U; j++) {
-                    const f2 v = cbuf[cpad(U * lane + j)];
-                    re[j] = v.x;
-                    if (lane < 32) { maxabs = fmaxf(maxabs, fabsf(v.x)); maxabs = fmaxf(maxabs, fabsf(v.y)); }
-                }
-            }
+            lds_load_block<U>(reinterpret_cast<const float*>(cbuf) + U * lane, re);
             const double eps = 0.01 * (double) log_rms;                        // :108
             double mag_sum = 0.0, lhr = 0.0, wsum = 0.0, flat_sum = 0.0;
             float max_re = 0.0f;       // max |re|: (double) re^2 is exact and monotone in |re|, so max mag = max_re^2
@@ -955,19 +951,11 @@ FX_MARK("harm1");
         float h_max_re = 0.0f;
         {
             const int b0 = U * lane;
-            if constexpr (FUSED) {
-                const float* relin = reinterpret_cast<const float*>(cbuf);
-                lds_load_block<U>(relin + b0, hre);
-                h_left2  = b0 >= 2 ? fabsf(relin[b0 - 2]) : 0.0f;
-                h_left1  = b0 >= 1 ? fabsf(relin[b0 - 1]) : 0.0f;
-                h_right1 = b0 + U < M ? fabsf(relin[b0 + U]) : 0.0f;
-            } else {
-#pragma unroll
-                for (int j = 0; j < U; j++) hre[j] = cbuf[cpad(b0 + j)].x;
-                h_left2  = b0 >= 2 ? fabsf(cbuf[cpad(b0 - 2)].x) : 0.0f;
-                h_left1  = b0 >= 1 ? fabsf(cbuf[cpad(b0 - 1)].x) : 0.0f;
-                h_right1 = b0 + U < M ? fabsf(cbuf[cpad(b0 + U)].x) : 0.0f;
-            }
+            const float* relin = reinterpret_cast<const float*>(cbuf);
+            lds_load_block<U>(relin + b0, hre);
+            h_left2  = b0 >= 2 ? fabsf(relin[b0 - 2]) : 0.0f;
+            h_left1  = b0 >= 1 ? fabsf(relin[b0 - 1]) : 0.0f;
+            h_right1 = b0 + U < M ? fabsf(relin[b0 + U]) : 0.0f;
 #pragma unroll
             for (int j = 0; j < U; j++) {                                      // ref HarmonicCharacteristics.h:61-69
                 const double v = (double) hre[j];
@@ -1080,14 +1068,7 @@ FX_MARK("power");
 #pragma unroll
             for (int g = 0; g < G::GA; g++)
 #pragma unroll
-                for (int j = 0; j < G::RA; j++) {
-                    if constexpr (FUSED) {
-                        xf[g * G::RA + j] = rbuf[rpad(first_pass_index<N>(lane, g, j))];     // already squared
-                    } else {
-                        const float r = cbuf[cpad(first_pass_index<N>(lane, g, j))].x;
-                        xf[g * G::RA + j] = r * r;
-                    }
-                }
+                for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = rbuf[rpad(first_pass_index<N>(lane, g, j))];   // already squared
             wave_fence();
 FX_MARK("ifft");
             fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, p.first_tw, lane, scale);        // a12 inverse, ref :110-121
@@ -1098,20 +1079,6 @@ FX_MARK("vcalc");
             lane = opaque(lane);
             float* vbuf = rbuf;                                                // [N+1] plain layout
             float* sums = rbuf + N + 4;                                        // [N+1]; both fit in the buffer
-            if constexpr (!FUSED) {
-                float vv[P];
-#pragma unroll
-                for (int i = 0; i < P; i++) {
-                    const int s_ = lane + 64 * i;
-                    const float d = cbuf[cpad(s_)].x * scale;
-                    vv[i] = d * d * (float) s_;
-                }
-                const float dn = cbuf[cpad(0)].y * scale;
-                wave_fence();
-#pragma unroll
-                for (int i = 0; i < P; i++) vbuf[lane + 64 * i] = vv[i];
-                if (lane == 0) vbuf[N] = dn * dn * (float) N;
-            }
             wave_fence();
 FX_MARK("scan");
             // a13 running fp32 sum (ref PitchAnalyser.h:138-150) -- serial by definition, so one lane
