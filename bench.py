@@ -132,7 +132,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--channels-per-gpu", type=int, default=1024)
-    ap.add_argument("--frames", type=int, default=256, help="consecutive frames per channel per step (SURVEY 8d: T >= 64)")
+    ap.add_argument("--frames", type=int, default=512, help="consecutive frames per channel per step (SURVEY 8d: T >= 64)")
     ap.add_argument("--window", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the spectral-only extra measurement")
