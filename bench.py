@@ -210,6 +210,11 @@ def main():
             src = sm_bufs[slot] if args.backend == "nccl" else sm_bufs[slot].cpu()
             pending[slot] = sharded.gather_features(src, total_channels, dst=0, async_op=True)
 
+    if world > 1:
+        # one untimed exchange so that the RCCL communicator and the gather buffers exist even with --warmup 0
+        step()
+        drain(0)
+        drain(1)
     for _ in range(args.warmup):
         step()
     drain(0)
