@@ -386,6 +386,17 @@ template <int N> __device__ __forceinline__ int first_pass_index(int lane, int g
     return rev4<G::IDIG>(lane + 64 * g) + G::ITEMS_A * revj;
 }
 
+// The same position inside the padded real image, split into a per-lane base and a compile-time step:
+// ITEMS_A is a multiple of 16, so rpad(low + ITEMS_A*r) = rpad(low) + (ITEMS_A + ITEMS_A/4)*r and the
+// RA accesses of an item are one address register plus immediate offsets.
+template <int N> __device__ __forceinline__ int first_pass_rbase(int lane, int g) { return rpad(rev4<Geo<N>::IDIG>(lane + 64 * g)); }
+template <int N> __host__ __device__ constexpr int first_pass_rstep(int j)
+{
+    return (Geo<N>::ITEMS_A + Geo<N>::ITEMS_A / 4)
+         * ((Geo<N>::RA == 4) ? j : (Geo<N>::RA == 8) ? ((j >> 1) + 4 * (j & 1)) : ((j >> 2) + 4 * (j & 3)));
+}
+static_assert(Geo<256>::ITEMS_A % 16 == 0 && Geo<512>::ITEMS_A % 16 == 0 && Geo<1024>::ITEMS_A % 16 == 0, "rpad splits only at multiples of 16");
+
 // First pass: the lane's P REAL inputs are already in registers in first_pass_index order (imag = 0,
 // as in performRealOnlyForwardTransform and in PitchAnalyser's re*re spectrum).  Stages at length 1
 // have unit twiddles and real operands; the stage after them sees real operands in half of its
@@ -705,7 +716,7 @@ FX_MARK("rms");
 #pragma unroll
         for (int g = 0; g < G::GA; g++)
 #pragma unroll
-            for (int j = 0; j < G::RA; j++) xr[g * G::RA + j] = rbuf[rpad(first_pass_index<N>(lane, g, j))];
+            for (int j = 0; j < G::RA; j++) xr[g * G::RA + j] = (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)];
         wave_fence();
         float log_rms;
         {
@@ -986,7 +997,7 @@ FX_MARK("lpf");
 #pragma unroll
             for (int g = 0; g < G::GA; g++)
 #pragma unroll
-                for (int j = 0; j < G::RA; j++) rbuf[rpad(first_pass_index<N>(lane, g, j))] = xr[g * G::RA + j];
+                for (int j = 0; j < G::RA; j++) (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)] = xr[g * G::RA + j];
             wave_fence();
             float x[P];
 #pragma unroll
@@ -1057,7 +1068,7 @@ FX_MARK("pitch_fft");
 #pragma unroll
             for (int g = 0; g < G::GA; g++)
 #pragma unroll
-                for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = rbuf[rpad(first_pass_index<N>(lane, g, j))];
+                for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)];
             wave_fence();
             fft_from_regs<N, false, OUT_POWER>(xf, cbuf, tw, p.first_tw, lane);            // ref RealTimeAnalyser.h:160
 FX_MARK("power");
@@ -1068,7 +1079,7 @@ FX_MARK("power");
 #pragma unroll
             for (int g = 0; g < G::GA; g++)
 #pragma unroll
-                for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = rbuf[rpad(first_pass_index<N>(lane, g, j))];   // already squared
+                for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)];   // already squared
             wave_fence();
 FX_MARK("ifft");
             fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, p.first_tw, lane, scale);        // a12 inverse, ref :110-121
