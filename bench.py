@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--stream", action="store_true",
                     help="host-resident hops through the pinned ring (fx_stream_*): PCIe-inclusive rate, reported as an extra line")
     ap.add_argument("--fp16", action="store_true", help="--stream only: fp16 samples")
+    ap.add_argument("--debug-collective", action="store_true",
+                    help="with --gpus 1: create a one-rank RCCL group and run the N>1 code path (gather included), "
+                         "then check the gathered block against the local one")
     args = ap.parse_args()
 
     import torch
@@ -156,8 +159,10 @@ def main():
     if args.backend == "gloo":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    collective = world > 1 or args.debug_collective
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -179,38 +184,62 @@ def main():
     frames = torch.from_numpy(host_frames).cuda(local_rank)
     an = fx.BatchAnalyser(count, N, device=local_rank)
     raw = torch.empty((count, T, 12), dtype=torch.float32, device=frames.device)
-    # two output buffers: the gather of step i (RCCL, its own stream) reads one while the kernels of
-    # step i+1 (the library's stream) write the other
-    sm_bufs = [torch.empty((count, T, 12), dtype=torch.float32, device=frames.device) for _ in range(2)]
+    sm = torch.empty((count, T, 12), dtype=torch.float32, device=frames.device)
+    # What travels between GPUs is what the OSC sink samples (ref OSCFeatureAnalysisOutput.h:89-113): the latest
+    # smoothed vector of every channel, [C][12] per rank per step.  Two buffers: the gather of step i
+    # (RCCL, its own stream) reads one while step i+1 fills the other.
+    latest_bufs = [torch.empty((count, 12), dtype=torch.float32, device=frames.device) for _ in range(2)]
 
     def barrier():
         an.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
             torch.cuda.synchronize()
 
     pending = [None, None]
     counter = [0]
+    last = [None]
+    # RCCL path: everything is ordered on the device.  `lib_stream` wraps the library's hipStream_t, the gather runs
+    # on `side`; events make the gather wait for the step's kernels and make the kernels that next overwrite a
+    # feature buffer wait for the gather that read it.  The host never blocks inside the timed loop.
+    device_ordered = collective and args.backend == "nccl"
+    if device_ordered:
+        lib_stream = torch.cuda.ExternalStream(an.stream(), device=frames.device)
+        side = torch.cuda.Stream(device=frames.device)
 
     def drain(slot):
-        if pending[slot] is not None and pending[slot][1] is not None:
-            pending[slot][1].wait()
-            torch.cuda.current_stream().synchronize()
+        if pending[slot] is None:
+            return
+        work = pending[slot][1]
+        if device_ordered:
+            with torch.cuda.stream(side):
+                if work is not None:
+                    work.wait()                          # `side` waits for the collective
+            lib_stream.wait_stream(side)
+        elif work is not None:
+            work.wait()
         pending[slot] = None
 
     def step():
         slot = counter[0] & 1
         counter[0] += 1
-        if world > 1:
-            drain(slot)                                  # the gather that last read this buffer has finished
-        an.process_frames(frames, out_raw=raw, out_smoothed=sm_bufs[slot])
-        if world > 1:
-            an.sync()                                    # features ready before RCCL reads them
-            src = sm_bufs[slot] if args.backend == "nccl" else sm_bufs[slot].cpu()
-            pending[slot] = sharded.gather_features(src, total_channels, dst=0, async_op=True)
+        if collective:
+            drain(slot)                                  # the gather that last read this buffer is ordered before us
+        an.process_frames(frames, out_raw=raw, out_smoothed=sm)
+        if collective:
+            an.get_features(out=latest_bufs[slot])       # async device copy on the library's stream
+        if device_ordered:
+            side.wait_stream(lib_stream)                 # features ready before RCCL reads them
+            with torch.cuda.stream(side):
+                pending[slot] = sharded.gather_features(latest_bufs[slot], total_channels, dst=0, async_op=True, single_rank_collective=True)
+            last[0] = (slot, pending[slot][0])
+        elif collective:
+            an.sync()
+            pending[slot] = sharded.gather_features(latest_bufs[slot].cpu(), total_channels, dst=0, async_op=True, single_rank_collective=True)
+            last[0] = (slot, pending[slot][0])
 
-    if world > 1:
+    if collective:
         # one untimed exchange so that the RCCL communicator and the gather buffers exist even with --warmup 0
         step()
         drain(0)
@@ -231,9 +260,19 @@ def main():
     frame_ms, epi_ms, calls = an.profile_end()
 
     t = torch.tensor([dt], dtype=torch.float64, device=frames.device)
-    if world > 1:
+    if collective:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    if args.debug_collective and rank == 0:
+        slot, gathered = last[0]
+        got = sharded.resolve(gathered)[first:first + count].cpu()
+        want = latest_bufs[slot].cpu()
+        if not torch.equal(torch.nan_to_num(want), torch.nan_to_num(sm[:, -1, :].cpu())):
+            raise SystemExit("latest vectors differ from the last frame's smoothed vectors")
+        same = bool(torch.equal(torch.nan_to_num(got), torch.nan_to_num(want)))
+        print("debug-collective: gathered block %s the local features" % ("equals" if same else "DIFFERS FROM"), file=sys.stderr, flush=True)
+        if not same:
+            raise SystemExit(3)
 
     if rank == 0:
         frames_total = total_channels * T * args.steps
@@ -251,7 +290,7 @@ def main():
                                    "full 12-feature RealTimeAnalyser bundle (spectral+pitch+harmonic+RMS+smoothing+onset), "
                                    "frames pre-assembled and resident in HBM" % (C, N, T),
                        "channels_per_gpu": C, "frames_per_step": T, "window": N, "sample_rate": 48000,
-                       "sharding": "channels, contiguous blocks; RCCL gather of [C][T][12] smoothed vectors to rank 0" if world > 1 else "single GPU"},
+                       "sharding": "channels, contiguous blocks; per step an RCCL gather of the latest smoothed vectors [C][12] of every rank to rank 0 (the OSC sink)" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(N, count, T),
                          "kernel": "fx_frame_kernel<%d>" % N, "avg_launch_ms": avg_launch_s * 1e3,
@@ -265,12 +304,12 @@ def main():
             # RealTimeSpectralAnalyser constructed, as an extra (never `value`)
             an_s = fx.BatchAnalyser(count, N, device=local_rank, analysers="spectral")
             for _ in range(3):
-                an_s.process_frames(frames, out_raw=raw, out_smoothed=sm_bufs[0])
+                an_s.process_frames(frames, out_raw=raw, out_smoothed=sm)
             an_s.sync()
             an_s.profile_begin()
             t1 = time.perf_counter()
             for _ in range(10):
-                an_s.process_frames(frames, out_raw=raw, out_smoothed=sm_bufs[0])
+                an_s.process_frames(frames, out_raw=raw, out_smoothed=sm)
             an_s.sync()
             dts = time.perf_counter() - t1
             fms, _, calls_s = an_s.profile_end()
@@ -285,7 +324,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

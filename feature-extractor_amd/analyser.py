@@ -131,8 +131,16 @@ class BatchAnalyser:
         """frames [C][T][N] -> (raw [C][T][12], smoothed [C][T][12])."""
         return self._run(self._lib.fx_process_frames, frames, self.window_size, want_raw, want_smoothed, out_raw, out_smoothed)
 
-    def get_features(self):
-        """Latest AudioFeatures::getValue of every slot, [C][12] (host)."""
+    def get_features(self, out=None):
+        """Latest AudioFeatures::getValue of every slot, [C][12]: a host array, or -- with `out`, a contiguous
+        float32 CUDA tensor of that shape -- an asynchronous device copy on the library's stream (what the OSC
+        sink of a sharded run gathers)."""
+        if out is not None:
+            if not (_is_torch(out) and out.is_cuda and out.is_contiguous() and out.numel() == self.num_channels * 12
+                    and str(out.dtype) == "torch.float32"):
+                raise ValueError("out must be a contiguous float32 CUDA tensor with num_channels x 12 elements")
+            capi.check(self._lib.fx_get_smoothed(self._h, ctypes.c_void_p(out.data_ptr()), capi.MEM_DEVICE))
+            return out
         out = np.empty((self.num_channels, 12), np.float32)
         capi.check(self._lib.fx_get_smoothed(self._h, out.ctypes.data_as(ctypes.c_void_p), capi.MEM_HOST))
         return out

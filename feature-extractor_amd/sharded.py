@@ -23,7 +23,7 @@ def my_shard(num_channels, rank, world_size):
     return shard_bounds(num_channels, world_size)[rank]
 
 
-def gather_features(local, num_channels, dst=0, group=None, async_op=False):
+def gather_features(local, num_channels, dst=0, group=None, async_op=False, single_rank_collective=False):
     """Gather per-rank feature blocks [C_local][...][12] (torch tensors, CPU for gloo / CUDA for
     RCCL) to rank `dst`.  Returns (result, work): on dst `result` is the [num_channels][...][12]
     tensor in channel order (valid once work has completed), elsewhere None.  Ranks may own
@@ -41,7 +41,7 @@ def gather_features(local, num_channels, dst=0, group=None, async_op=False):
         pad = torch.zeros((per - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         local = torch.cat([local, pad], 0)
     local = local.contiguous()
-    if world == 1:
+    if world == 1 and not single_rank_collective:     # (a one-rank collective is only useful to exercise the backend)
         return local[:num_channels], None
     if rank == dst:
         out = torch.empty((world * per,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
