@@ -44,9 +44,15 @@ def main():
         # taps of the first channel's last frame, for debugging a failing port
         frame = np.concatenate([hops[0, T - 2], hops[0, T - 1]])
         spec = fo.forward_real(fo.bartlett(frame))
+        # pitch path of the same frame (ref RealTimeAnalyser.h:152-160): low-pass, window, spectrum, then
+        # PitchAnalyser's cumulative normalised difference and lag
+        low = fo.lowpass(frame)
+        pitch_spec = fo.forward_real(fo.bartlett(low))
+        f0, lag, cnd = fo.estimate_pitch(pitch_spec, 24000.0)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), hops=hops, raw=raw, smoothed=sm,
                             window_size=N, order=order, sample_rate=48000.0,
-                            tap_frame=frame, tap_spectrum=spec)
+                            tap_frame=frame, tap_spectrum=spec, tap_lowpass=low, tap_cnd=cnd,
+                            tap_lag=np.float32(lag), tap_f0=np.float64(f0))
         print(name, hops.shape, "->", raw.shape)
 
 

@@ -176,3 +176,15 @@ def test_oracle_reproduces_committed_fixtures(path):
     raw, sm = fo.push_hops(g["hops"], int(g["window_size"]), float(g["sample_rate"]), order=int(g["order"]))
     assert np.array_equal(raw, g["raw"], equal_nan=True)
     assert np.array_equal(sm, g["smoothed"], equal_nan=True)
+    # taps of channel 0's last frame
+    frame = g["tap_frame"]
+    assert np.array_equal(fo.forward_real(fo.bartlett(frame)), g["tap_spectrum"])
+    low = fo.lowpass(frame)
+    assert np.array_equal(low, g["tap_lowpass"])
+    f0, lag, cnd = fo.estimate_pitch(fo.forward_real(fo.bartlett(low)), float(g["sample_rate"]) / 2)
+    assert np.array_equal(cnd, g["tap_cnd"], equal_nan=True) and lag == float(g["tap_lag"])
+    assert f0 == float(g["tap_f0"]) or (np.isnan(f0) and np.isnan(float(g["tap_f0"])))
+    # the analyser's own F0 slot is that estimate / 5000 (ref RealTimeAnalyser.h:166) when the harmonic analyser ran last
+    T = g["hops"].shape[1]
+    if T >= 2:
+        assert raw[0, T - 1, fo.F0] == np.float32(f0 / 5000.0)
