@@ -11,7 +11,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfx_hip.so")
 SOURCES = ["fx_kernels.hip", "fx_capi.cpp"]
-HEADERS = ["fx_kernels.h", os.path.join("..", "..", "include", "fx.h")]
+HEADERS = ["fx_kernels.h", "fx_wave.hip.h", "fx_fft.hip.h", "fx_frame_kernel.hip.h", "fx_tail_kernels.hip.h",
+           os.path.join("..", "..", "include", "fx.h")]
 
 # -ffp-contract=off : the reference FFT never fuses a*b+c; spectra must be bit-identical.
 # -disable-machine-licm : keeps loop-invariant constants/addresses from being hoisted out of the

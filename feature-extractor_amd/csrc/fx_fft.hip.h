@@ -1,0 +1,356 @@
+// fx_fft.hip.h -- padded LDS images and the bit-exact JUCE-order FFT of one wavefront
+// Included by fx_kernels.hip inside namespace fxk (one translation unit: every kernel sees the same
+// inlined helpers); not a stand-alone header.
+
+// ---------------------------------------------------------------------------------------------
+// LDS images
+//   complex image: position p at p + (p >> 4)            (one float2 of padding per 16)
+//   real image   : sample  n at n + 4 * (n >> 4)         (16 B of padding per 16 floats, keeps
+//                                                          16-byte alignment of 4-sample groups)
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int cpad(int p) { return p + (p >> 4); }
+__host__ __device__ constexpr int rpad(int n) { return n + ((n >> 4) << 2); }
+
+template <int N> struct Geo {
+    static constexpr int M      = N / 2;            // numMagnitudes (ref SpectralCharacteristics.h:104)
+    static constexpr int P      = N / 64;           // samples per lane
+    static constexpr int U      = M / 64;           // bins per lane
+    // ONE LDS buffer per wavefront, reused as: real image of the frame (rpad layout), complex image
+    // of each transform (cpad layout), v / running-sum arrays of the lag scan, harmonic scratch.
+    static constexpr int CBUF   = cpad(N) + 2;      // float2 elements (>= rpad(N)+8 floats, >= 2N+8 floats)
+    static constexpr int LOG2N  = (N == 256) ? 8 : (N == 512) ? 9 : (N == 1024) ? 10 : (N == 2048) ? 11 : 12;
+    // first FFT pass: R inputs per item, G items per lane, R*G == P
+    static constexpr int RA     = (N == 256) ? 4 : ((N == 512 || N == 2048) ? 8 : 16);
+    static constexpr int LOG2RA = (RA == 4) ? 2 : (RA == 8) ? 3 : 4;
+    static constexpr int ITEMS_A = N / RA;
+    static constexpr int GA     = ITEMS_A / 64;
+    static constexpr int IDIG   = (LOG2N - LOG2RA) / 2;   // base-4 digits of an item index
+};
+
+// U consecutive floats of a lane, moved with the widest LDS access the alignment allows (a stride-U
+// ds_read_b32 pattern would be an 8-way bank conflict for U = 8)
+template <int U> __device__ __forceinline__ void lds_load_block(const float* base, float (&out)[U])
+{
+    if (U % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < U; j += 4) {
+            const f4 v = *reinterpret_cast<const f4*>(base + j);
+            out[j] = v.x; out[j + 1] = v.y; out[j + 2] = v.z; out[j + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < U; j += 2) {
+            const f2 v = *reinterpret_cast<const f2*>(base + j);
+            out[j] = v.x; out[j + 1] = v.y;
+        }
+    }
+}
+template <int U> __device__ __forceinline__ void lds_store_block(float* base, const float (&in)[U])
+{
+    if (U % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < U; j += 4) *reinterpret_cast<f4*>(base + j) = f4{in[j], in[j + 1], in[j + 2], in[j + 3]};
+    } else {
+#pragma unroll
+        for (int j = 0; j < U; j += 2) *reinterpret_cast<f2*>(base + j) = f2{in[j], in[j + 1]};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FFT: the butterfly DAG of juce::FFT (kiss-style decimation in time, factors 4,...,4[,2]; SURVEY.md
+// App. A.1), regrouped into register-resident passes.  Arithmetic is plain fp32 multiply / add /
+// subtract -- never fused -- on the same operands and the same table twiddles as the reference, so
+// every output is bit-identical to the CPU transform (up to the sign of an exact zero).
+// ---------------------------------------------------------------------------------------------
+// a * t (forward) or a * conj(t) (inverse: the inverse table is the exact conjugate, cos being even
+// and sin odd).  Reference form: (a.r*t.r - a.i*t.i, a.r*t.i + a.i*t.r).
+template <bool INV> __device__ __forceinline__ f2 twmul(f2 a, f2 t)
+{
+    // Three packed instructions.  hipcc does not form the mixed per-half negation by itself (it emits
+    // two v_pk_add + a v_mov instead), so the VOP3P modifiers are spelled out:
+    //   forward: p = (a.r*t.r, a.r*t.i), q = (a.i*(-t.i), a.i*t.r), result = p + q
+    //   inverse: p = (a.r*t.r, a.r*(-t.i)), q = (a.i*t.i, a.i*t.r), result = p + q
+    // (-x)*y == -(x*y) and p + (-q) == p - q exactly, so the roundings are those of the reference form.
+    f2 p, q, r;
+    if (INV) {
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(p) : "v"(a), "v"(t));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(q) : "v"(a), "v"(t));
+    } else {
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "v"(a), "v"(t));
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(q) : "v"(a), "v"(t));
+    }
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(p), "v"(q));
+    return r;
+}
+// the same for a purely real a = (r, 0): the products with 0 only contribute exact zeros
+template <bool INV> __device__ __forceinline__ f2 twmul_real(float r, f2 t)
+{
+    const f2 p = f2{r, r} * t;
+    return INV ? f2{p.x, -p.y} : p;
+}
+
+// (a.x + b.y, a.y - b.x) if NEG_HI, else (a.x - b.y, a.y + b.x): a -/+ i*b
+template <bool NEG_HI> __device__ __forceinline__ f2 pk_add_rot(f2 a, f2 b)
+{
+    f2 r;
+    if (NEG_HI) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    else        asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// butterfly4 after the three twiddle products s0, s1, s2
+template <bool INV>
+__device__ __forceinline__ void bfly4_core(f2& d0, f2& d1, f2& d2, f2& d3, f2 s0, f2 s1, f2 s2)
+{
+    const f2 s3 = s0 + s2;
+    const f2 s4 = s0 - s2;
+    const f2 s5 = d0 - s1;
+    const f2 a = d0 + s1;
+    d2 = a - s3;
+    d0 = a + s3;
+    // d1 = s5 -/+ i*s4, d3 = s5 +/- i*s4: one packed add each with the second operand's halves swapped and
+    // one of them negated (x - y == x + (-y) exactly).  Left to itself hipcc computes all four sums and
+    // differences and re-pairs the halves with moves.
+    if (INV) {
+        d1 = pk_add_rot<false>(s5, s4);     // (s5.x - s4.y, s5.y + s4.x)
+        d3 = pk_add_rot<true>(s5, s4);      // (s5.x + s4.y, s5.y - s4.x)
+    } else {
+        d1 = pk_add_rot<true>(s5, s4);
+        d3 = pk_add_rot<false>(s5, s4);
+    }
+}
+// butterfly4 on four REAL inputs with unit twiddles (first stage of a real-input transform)
+template <bool INV>
+__device__ __forceinline__ void bfly4_real(float a0, float a1, float a2, float a3, f2& d0, f2& d1, f2& d2, f2& d3)
+{
+    const float s3 = a1 + a3, s4 = a1 - a3, s5 = a0 - a2, a = a0 + a2;
+    d2 = f2{a - s3, 0.0f};
+    d0 = f2{a + s3, 0.0f};
+    d1 = f2{s5, INV ? s4 : -s4};
+    d3 = f2{s5, INV ? -s4 : s4};
+}
+
+// Twiddle storage.  The N-entry table of the reference, tw[i] = ((float)cos, (float)sin)(-2*pi*i/N),
+// is re-ordered on the host into the order the passes read it (fx_kernels.h, build_pass_twiddles), so
+// that the 64 lanes of a pass read consecutive entries (conflict-free) at compile-time offsets:
+//   later pass (R, L0), element index i = jin + LREL*(q + 4*g):
+//     stage 1 (LREL = 1): [OFF + (q-1)*L0 + k]                      = tw[k * N/(4*L0) * q]
+//     stage 2 (LREL = 4): [OFF + 3*L0 + (jin*3 + q-1)*L0 + k]       = tw[(k + L0*jin) * N/(16*L0) * q]
+//   first pass constants:  [OFFA + (jin-1)*3 + q-1]                 = tw[jin * N/(4*R1) * q]
+template <int N> struct Plan {
+    static constexpr int R1 = 16;
+    static constexpr int L1 = (N == 256) ? 4 : ((N == 512 || N == 2048) ? 8 : 16);
+    static constexpr int R2 = (N >= 2048) ? 16 : 4;
+    static constexpr int L2 = N / R2;
+    static constexpr int OFF1 = 0;
+    static constexpr int OFF2 = 15 * L1;
+    static constexpr int OFFA = OFF2 + (R2 == 16 ? 15 : 3) * L2;
+};
+
+// offset of element i of an item inside the padded complex image, relative to cpad(base):
+// cpad(base + L0*i) - cpad(base) is a compile-time constant because base = blk*(R*L0) + k, k < L0
+__host__ __device__ constexpr int item_off(int L0, int i) { return L0 * i + (L0 >= 16 ? (L0 / 16) * i : ((L0 * i) >> 4)); }
+
+// A later pass: every item of R elements (stride L0) is loaded from the complex image, its 1 or 2
+// radix-4 stages run in registers, and it is stored back to the same positions.
+template <int N, int R, int L0, int TWOFF, bool INV>
+__device__ __forceinline__ void fft_pass(f2* cbuf, const f2* tw, int lane)
+{
+    lane = opaque(lane);
+    constexpr int ITEMS = N / R;
+    for (int it = lane; it < ITEMS; it += 64) {
+        f2 e[R];
+        const int k = it % L0;
+        const int base = (it / L0) * (R * L0) + k;
+        f2* img = cbuf + cpad(base);
+        const f2* t1 = tw + TWOFF + k;
+#pragma unroll
+        for (int i = 0; i < R; i++) e[i] = img[item_off(L0, i)];
+        // stage 1: butterflies over i = q + 4*g
+        {
+            const f2 w1 = t1[0], w2 = t1[L0], w3 = t1[2 * L0];
+#pragma unroll
+            for (int g = 0; g < R / 4; g++)
+                bfly4_core<INV>(e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3],
+                                twmul<INV>(e[4 * g + 1], w1), twmul<INV>(e[4 * g + 2], w2), twmul<INV>(e[4 * g + 3], w3));
+        }
+        if constexpr (R == 16) {
+            // stage 2: butterflies over i = jin + 4*q
+            const f2* t2 = t1 + 3 * L0;
+#pragma unroll
+            for (int jin = 0; jin < 4; jin++) {
+                const f2 w1 = t2[(jin * 3 + 0) * L0], w2 = t2[(jin * 3 + 1) * L0], w3 = t2[(jin * 3 + 2) * L0];
+                bfly4_core<INV>(e[jin], e[jin + 4], e[jin + 8], e[jin + 12],
+                                twmul<INV>(e[jin + 4], w1), twmul<INV>(e[jin + 8], w2), twmul<INV>(e[jin + 12], w3));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < R; i++) img[item_off(L0, i)] = e[i];
+    }
+    wave_fence();
+}
+
+// base-4 digit reversal of the low 2*DIGITS bits
+template <int DIGITS> __device__ __forceinline__ int rev4(int x)
+{
+    unsigned r = __builtin_bitreverse32((unsigned) x) >> (32 - 2 * DIGITS);
+    r = ((r & 0x55555555u) << 1) | ((r >> 1) & 0x55555555u);
+    return (int) r;
+}
+
+// Bartlett gain, ref RealTimeAudioAnalysis.h:141-151: two JUCE gain ramps 0->1 and 1->0 whose
+// float accumulation is exact for power-of-two N: w[i] = 2i/N (i < N/2), 2 - 2i/N (i >= N/2).
+template <int N> __device__ __forceinline__ float bartlett_gain(int n)
+{
+    const float inc = 2.0f / N;
+    return n < N / 2 ? (float) n * inc : 1.0f - (float) (n - N / 2) * inc;
+}
+
+// Sample (or bin) index that feeds input j of this lane's g-th first-pass item: the mixed-radix
+// digit reversal of juce::FFT's decimation in time.  For a fixed (g, j) the 64 lanes cover 64
+// consecutive indices, so LDS / global accesses in this order are conflict-free / coalesced.
+template <int N> __device__ __forceinline__ int first_pass_index(int lane, int g, int j)
+{
+    typedef Geo<N> G;
+    const int revj = (G::RA == 4) ? j : (G::RA == 8) ? ((j >> 1) + 4 * (j & 1)) : ((j >> 2) + 4 * (j & 3));
+    return rev4<G::IDIG>(lane + 64 * g) + G::ITEMS_A * revj;
+}
+
+// The same position inside the padded real image, split into a per-lane base and a compile-time step:
+// ITEMS_A is a multiple of 16, so rpad(low + ITEMS_A*r) = rpad(low) + (ITEMS_A + ITEMS_A/4)*r and the
+// RA accesses of an item are one address register plus immediate offsets.
+template <int N> __device__ __forceinline__ int first_pass_rbase(int lane, int g) { return rpad(rev4<Geo<N>::IDIG>(lane + 64 * g)); }
+template <int N> __host__ __device__ constexpr int first_pass_rstep(int j)
+{
+    return (Geo<N>::ITEMS_A + Geo<N>::ITEMS_A / 4)
+         * ((Geo<N>::RA == 4) ? j : (Geo<N>::RA == 8) ? ((j >> 1) + 4 * (j & 1)) : ((j >> 2) + 4 * (j & 3)));
+}
+static_assert(Geo<256>::ITEMS_A % 16 == 0 && Geo<512>::ITEMS_A % 16 == 0 && Geo<1024>::ITEMS_A % 16 == 0, "rpad splits only at multiples of 16");
+
+// First pass: the lane's P REAL inputs are already in registers in first_pass_index order (imag = 0,
+// as in performRealOnlyForwardTransform and in PitchAnalyser's re*re spectrum).  Stages at length 1
+// have unit twiddles and real operands; the stage after them sees real operands in half of its
+// butterflies.  Results go to the complex image.
+template <int N, bool INV>
+__device__ __forceinline__ void fft_first_pass(const float (&xin)[Geo<N>::P], f2* cbuf, const float (&ftw)[18], int lane)
+{
+    typedef Geo<N> G;
+    constexpr int R = G::RA;
+    lane = opaque(lane);
+    f2 ta[9];                      // wave-uniform: kernel arguments, not LDS
+#pragma unroll
+    for (int i = 0; i < 9; i++) ta[i] = f2{ftw[2 * i], ftw[2 * i + 1]};
+#pragma unroll
+    for (int g = 0; g < G::GA; g++) {
+        const float* x = &xin[g * R];
+        f2 e[R];
+        if constexpr (R == 4) {
+            bfly4_real<INV>(x[0], x[1], x[2], x[3], e[0], e[1], e[2], e[3]);
+        } else if constexpr (R == 8) {
+            // radix-2 at length 1 (unit twiddle, real): pairs (2g', 2g'+1)
+            float r[8];
+#pragma unroll
+            for (int h = 0; h < 4; h++) { r[2 * h] = x[2 * h] + x[2 * h + 1]; r[2 * h + 1] = x[2 * h] - x[2 * h + 1]; }
+            // radix-4 at length 2: legs i = jin + 2*q
+            bfly4_real<INV>(r[0], r[2], r[4], r[6], e[0], e[2], e[4], e[6]);
+            e[1] = f2{r[1], 0.0f};
+            bfly4_core<INV>(e[1], e[3], e[5], e[7], twmul_real<INV>(r[3], ta[0]), twmul_real<INV>(r[5], ta[1]), twmul_real<INV>(r[7], ta[2]));
+        } else {
+            // radix-4 at length 1: groups (4g', .., 4g'+3)
+#pragma unroll
+            for (int h = 0; h < 4; h++)
+                bfly4_real<INV>(x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3], e[4 * h], e[4 * h + 1], e[4 * h + 2], e[4 * h + 3]);
+            // radix-4 at length 4: legs i = jin + 4*q; jin = 0 and 2 have real operands
+            {
+                f2 o0, o1, o2, o3;
+                bfly4_real<INV>(e[0].x, e[4].x, e[8].x, e[12].x, o0, o1, o2, o3);
+                e[0] = o0; e[4] = o1; e[8] = o2; e[12] = o3;
+            }
+            bfly4_core<INV>(e[1], e[5], e[9], e[13], twmul<INV>(e[5], ta[0]), twmul<INV>(e[9], ta[1]), twmul<INV>(e[13], ta[2]));
+            bfly4_core<INV>(e[2], e[6], e[10], e[14], twmul_real<INV>(e[6].x, ta[3]), twmul_real<INV>(e[10].x, ta[4]), twmul_real<INV>(e[14].x, ta[5]));
+            bfly4_core<INV>(e[3], e[7], e[11], e[15], twmul<INV>(e[7], ta[6]), twmul<INV>(e[11], ta[7]), twmul<INV>(e[15], ta[8]));
+        }
+        f2* img = cbuf + cpad((lane + 64 * g) * R);
+#pragma unroll
+        for (int i = 0; i < R; i++) img[i] = e[i];         // R <= 16 contiguous positions: no pad inside
+    }
+    wave_fence();
+}
+
+// What the last pass leaves in the wave's LDS buffer.
+enum { OUT_RE_LOW = 1,        // float re[M] (plain layout): all the harmonic analyser reads (ref HarmonicCharacteristics.h:63)
+       OUT_RE_LOW_MAXABS = 2, // the same + max(|re|,|im|) over bins [0, M/2) returned per lane (ref SpectralCharacteristics.h:153)
+       OUT_POWER = 3,         // float re*re of all N bins in the real image (rpad layout): ref PitchAnalyser.h:97-103
+       OUT_LAG = 4 };         // float v[s] = (re_s/N)^2 * s, s in [0,N), and v[N] from imag[0] (plain layout): ref :119-123
+
+// Last pass -- radix 4 at length N/4 (N <= 1024) or radix 16 at length N/16 -- with all of a lane's items in
+// registers (128 VGPRs of them at N = 4096, which runs one wave per SIMD anyway), fused with the consumer of the spectrum, so the full complex image is never written back and
+// re-read: the spectral / harmonic analysers only read re of bins < N/2, the pitch analyser only re*re, the
+// lag search only the squared, lag-weighted real part.
+template <int N, bool INV, int OUT>
+__device__ __forceinline__ float fft_last_pass_fused(f2* cbuf, const f2* tw, int lane, float scale)
+{
+    typedef Plan<N> PL;
+    constexpr int R = PL::R2, L0 = PL::L2, GI = (N / R) / 64, TWOFF = PL::OFF2, M = N / 2;
+    lane = opaque(lane);
+    f2 e[GI][R];
+#pragma unroll
+    for (int g = 0; g < GI; g++) {
+        const f2* img = cbuf + cpad(lane + 64 * g);
+#pragma unroll
+        for (int i = 0; i < R; i++) e[g][i] = img[item_off(L0, i)];
+    }
+    wave_fence();                 // the wave has read the whole complex image; the buffer may be rewritten
+    float* fbuf = reinterpret_cast<float*>(cbuf);
+    float aux = 0.0f;
+#pragma unroll
+    for (int g = 0; g < GI; g++) {
+        const int k = lane + 64 * g;
+        const f2* t1 = tw + TWOFF + k;
+        {
+            const f2 w1 = t1[0], w2 = t1[L0], w3 = t1[2 * L0];
+#pragma unroll
+            for (int h = 0; h < R / 4; h++)
+                bfly4_core<INV>(e[g][4 * h], e[g][4 * h + 1], e[g][4 * h + 2], e[g][4 * h + 3],
+                                twmul<INV>(e[g][4 * h + 1], w1), twmul<INV>(e[g][4 * h + 2], w2), twmul<INV>(e[g][4 * h + 3], w3));
+        }
+        if constexpr (R == 16) {
+            const f2* t2 = t1 + 3 * L0;
+#pragma unroll
+            for (int jin = 0; jin < 4; jin++) {
+                const f2 w1 = t2[(jin * 3 + 0) * L0], w2 = t2[(jin * 3 + 1) * L0], w3 = t2[(jin * 3 + 2) * L0];
+                bfly4_core<INV>(e[g][jin], e[g][jin + 4], e[g][jin + 8], e[g][jin + 12],
+                                twmul<INV>(e[g][jin + 4], w1), twmul<INV>(e[g][jin + 8], w2), twmul<INV>(e[g][jin + 12], w3));
+            }
+        }
+        // e[g][i] is bin k + L0*i
+#pragma unroll
+        for (int i = 0; i < R; i++) {
+            const int bin = k + L0 * i;
+            if (OUT == OUT_RE_LOW || OUT == OUT_RE_LOW_MAXABS) {
+                if (i < R / 2) fbuf[bin] = e[g][i].x;                          // bins >= N/2 are never read
+                if (OUT == OUT_RE_LOW_MAXABS && i < R / 4) aux = fmaxf(aux, fmaxf(fabsf(e[g][i].x), fabsf(e[g][i].y)));
+            } else if (OUT == OUT_POWER) {
+                fbuf[rpad(bin)] = e[g][i].x * e[g][i].x;
+            } else {
+                const float d = e[g][i].x * scale;
+                fbuf[bin] = d * d * (float) bin;
+            }
+        }
+        if (OUT == OUT_LAG && g == 0 && lane == 0) { const float d = e[0][0].y * scale; fbuf[N] = d * d * (float) N; }
+    }
+    (void) M;
+    wave_fence();
+    return aux;
+}
+
+// Whole transform of one wavefront: P real inputs per lane (first-pass order) -> OUT (see above).
+template <int N, bool INV, int OUT>
+__device__ __forceinline__ float fft_from_regs(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, const float (&ftw)[18],
+                                               int lane, float scale = 0.0f)
+{
+    typedef Plan<N> PL;
+    fft_first_pass<N, INV>(xin, cbuf, ftw, lane);
+    fft_pass<N, PL::R1, PL::L1, PL::OFF1, INV>(cbuf, tw, lane);
+    return fft_last_pass_fused<N, INV, OUT>(cbuf, tw, lane, scale);
+}

@@ -1,0 +1,789 @@
+// fx_frame_kernel.hip.h -- frame load and fx_frame_kernel: every reduction over samples, bins and lags of a frame
+// Included by fx_kernels.hip inside namespace fxk (one translation unit: every kernel sees the same
+// inlined helpers); not a stand-alone header.
+
+// ---------------------------------------------------------------------------------------------
+// frame load: global -> real LDS image, 16 B per lane, coalesced
+// ---------------------------------------------------------------------------------------------
+template <int HALF>
+__device__ __forceinline__ void load_half(const void* src, int sample_format, float gain, bool apply_gain,
+                                          float* rbuf, int dst_off, float* tail_out, int lane)
+{
+    // HALF is a multiple of 128 samples; 4 samples per lane per step
+    for (int i = lane * 4; i < HALF; i += 256) {
+        f4 v;
+        if (sample_format == FX_SAMPLE_F16) {
+            const uint2 raw = *reinterpret_cast<const uint2*>(static_cast<const __half*>(src) + i);
+            const __half2 a = *reinterpret_cast<const __half2*>(&raw.x);
+            const __half2 b = *reinterpret_cast<const __half2*>(&raw.y);
+            const float2 fa = __half22float2(a), fb = __half22float2(b);
+            v = f4{fa.x, fa.y, fb.x, fb.y};
+        } else {
+            v = *reinterpret_cast<const f4*>(static_cast<const float*>(src) + i);
+        }
+        if (apply_gain) v *= gain;                       // ref AudioDataCollector.h:88
+        *reinterpret_cast<f4*>(&rbuf[rpad(dst_off + i)]) = v;
+        if (tail_out) *reinterpret_cast<f4*>(tail_out + i) = v;
+    }
+}
+
+// Both halves of a window with every global load issued before the first one is consumed (one memory
+// round trip per frame instead of one per 1 KB piece).  F16_A / F16_B: sample format of the source of
+// the first / second half (the carried-over tail is always fp32).  N >= 512.
+template <int N, bool F16_A, bool F16_B>
+__device__ __forceinline__ void load_window(const void* src_a, const void* src_b, float gain_a, float gain_b,
+                                            float* rbuf, float* tail_out, int lane)
+{
+    constexpr int HALF = N / 2, QH = HALF / 256;
+    uint4 ra[QH], rb[QH];
+#pragma unroll
+    for (int q = 0; q < QH; q++) {
+        const int i = 256 * q + 4 * lane;
+        if (F16_A) { const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const __half*>(src_a) + i); ra[q] = uint4{v.x, v.y, 0u, 0u}; }
+        else       ra[q] = *reinterpret_cast<const uint4*>(static_cast<const float*>(src_a) + i);
+    }
+#pragma unroll
+    for (int q = 0; q < QH; q++) {
+        const int i = 256 * q + 4 * lane;
+        if (F16_B) { const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const __half*>(src_b) + i); rb[q] = uint4{v.x, v.y, 0u, 0u}; }
+        else       rb[q] = *reinterpret_cast<const uint4*>(static_cast<const float*>(src_b) + i);
+    }
+    auto widen = [](uint4 r, bool f16) -> f4 {
+        if (f16) {
+            const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&r.x));
+            const float2 b = __half22float2(*reinterpret_cast<const __half2*>(&r.y));
+            return f4{a.x, a.y, b.x, b.y};
+        }
+        return f4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+    };
+#pragma unroll
+    for (int q = 0; q < QH; q++) {
+        const int i = 256 * q + 4 * lane;
+        const f4 v = widen(ra[q], F16_A) * gain_a;             // ref AudioDataCollector.h:88 (x * 1.0f is exact)
+        *reinterpret_cast<f4*>(&rbuf[rpad(i)]) = v;
+    }
+#pragma unroll
+    for (int q = 0; q < QH; q++) {
+        const int i = 256 * q + 4 * lane;
+        const f4 v = widen(rb[q], F16_B) * gain_b;
+        *reinterpret_cast<f4*>(&rbuf[rpad(HALF + i)]) = v;
+        if (tail_out) *reinterpret_cast<f4*>(tail_out + i) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the frame kernel
+// ---------------------------------------------------------------------------------------------
+struct FlatProd { double mant; int exp; };   // value = mant * 2^exp, mant in [0.5,1) (or 0)
+
+__device__ __forceinline__ FlatProd fp_mul(FlatProd a, double m)
+{
+    // multiply and renormalise; exact up to one rounding of the mantissa product
+    const double p = a.mant * m;
+    FlatProd r;
+    r.exp = a.exp + __builtin_amdgcn_frexp_exp(p);
+    r.mant = __builtin_amdgcn_frexp_mant(p);
+    return r;
+}
+__device__ __forceinline__ FlatProd fp_mul2(FlatProd a, FlatProd b)
+{
+    const double p = a.mant * b.mant;
+    FlatProd r;
+    r.exp = a.exp + b.exp + __builtin_amdgcn_frexp_exp(p);
+    r.mant = __builtin_amdgcn_frexp_mant(p);
+    return r;
+}
+
+// waves per SIMD the register allocator must leave room for (LDS bounds residency as well)
+#ifndef FX_OCC_SMALL
+#define FX_OCC_SMALL 4
+#endif
+template <int N> struct Occ {
+    static constexpr int WAVES_PER_SIMD = N <= 1024 ? FX_OCC_SMALL : (N == 2048 ? 2 : 1);
+    // N = 4096 fits at most 3 waves per workgroup in the LDS; a 256-thread bound lets it use the whole
+    // register file at one wave per SIMD instead of spilling
+    static constexpr int MAX_THREADS = N == 4096 ? 256 : 512;
+};
+
+// SPEC / HARM: which of the reference's two analysers run (RealTimeSpectralAnalyser,
+// RealTimeHarmonicAnalyser -- both by default, as AnalyserTrackController constructs them)
+template <int N, bool SPEC, bool HARM>
+__global__ void __launch_bounds__(Occ<N>::MAX_THREADS, Occ<N>::WAVES_PER_SIMD)
+fx_frame_kernel(const FrameParams p)
+{
+    typedef Geo<N> G;
+    constexpr int M = G::M, P = G::P, U = G::U, HALF = N / 2;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f2*    tw   = reinterpret_cast<f2*>(smem);                              // [N]
+    float* prev = reinterpret_cast<float*>(tw + N);                         // [M]  re of the last accepted frame
+    int*   turn = reinterpret_cast<int*>(prev + M);                         // [4]
+    FramePart* parts = reinterpret_cast<FramePart*>(turn + 4);              // [waves] per-frame results, filled as they appear
+    unsigned char* per_wave = reinterpret_cast<unsigned char*>(parts + (blockDim.x >> 6));
+    constexpr size_t WAVE_BYTES = sizeof(f2) * G::CBUF;
+
+    const int nwaves = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6;
+    const int lane0 = threadIdx.x & 63;
+    const int c = blockIdx.x;
+    const int T = p.T;
+
+    f2*    cbuf = reinterpret_cast<f2*>(per_wave + WAVE_BYTES * wave);
+    float* rbuf = reinterpret_cast<float*>(cbuf);      // the same memory viewed as the real image
+
+    // workgroup prologue: twiddle table + this channel's flux state into LDS
+    for (int i = threadIdx.x; i < N; i += blockDim.x) tw[i] = reinterpret_cast<const f2*>(p.tw)[i];
+    for (int i = threadIdx.x; i < M; i += blockDim.x) prev[i] = p.prev_re[(size_t) c * M + i];
+    if (threadIdx.x == 0) turn[0] = 0;
+    __syncthreads();
+
+    const double nyquist = p.nyquist;
+    const double rnyq = 1.0 / nyquist;
+    const double frpb = nyquist / (double) M;          // ref SpectralCharacteristics.h:64,105
+    const float  scale = 1.0f / (float) N;             // JUCE inverse scale
+
+#ifdef FX_STAMPS
+    unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
+#endif
+    for (int t = wave; t < T; t += nwaves) {
+        int lane = opaque(lane0);
+        FX_STAMP(11);
+        // uniform per-frame results go to LDS as soon as they exist instead of occupying ~28 VGPRs
+        // in every lane for the whole frame
+        FramePart* fpl = parts + wave;
+        if (lane == 0) { fpl->inh = 0.0; fpl->her_score = 0.0; fpl->sum_normed = 1.0; fpl->flags = 0; fpl->pad_ = 0; fpl->spare_ = 0.0; }
+
+FX_MARK("load");
+        // ---------------- a1: window assembly (ref RealTimeAudioAnalysis.h:205-219) ----------------
+        {
+            const size_t esz = p.sample_format == FX_SAMPLE_F16 ? 2 : 4;
+            const unsigned char* in = static_cast<const unsigned char*>(p.in);
+            float* tail_dst = (t == T - 1) ? p.tail_out + (size_t) c * HALF : nullptr;
+            const bool f16 = p.sample_format == FX_SAMPLE_F16;
+            const void* src_a; const void* src_b; float gain_a, gain_b; bool f16_a = f16;
+            if (p.hop_mode) {
+                gain_a = gain_b = p.gain;
+                src_b = in + ((size_t) c * T + t) * HALF * esz;
+                if (t == 0) { src_a = p.tail_in + (size_t) c * HALF; f16_a = false; gain_a = 1.0f; }   // tail is fp32, already gained
+                else        src_a = in + ((size_t) c * T + (t - 1)) * HALF * esz;
+            } else {
+                gain_a = gain_b = 1.0f;
+                src_a = in + ((size_t) c * T + t) * N * esz;
+                src_b = static_cast<const unsigned char*>(src_a) + HALF * esz;
+            }
+            if constexpr (N >= 512) {
+                if (f16_a && f16)       load_window<N, true,  true >(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane);
+                else if (f16)           load_window<N, false, true >(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane);
+                else                    load_window<N, false, false>(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane);
+            } else {
+                load_half<HALF>(src_a, f16_a ? FX_SAMPLE_F16 : FX_SAMPLE_F32, gain_a, gain_a != 1.0f, rbuf, 0, nullptr, lane);
+                load_half<HALF>(src_b, p.sample_format, gain_b, gain_b != 1.0f, rbuf, HALF, tail_dst, lane);
+            }
+            wave_fence();
+        }
+
+FX_MARK("rms");
+        FX_STAMP(0);
+        // ---------------- a2: RMS on the un-windowed frame (ref RealTimeAnalyser.h:207-208) ---------
+        // the frame, in registers, in the order the first FFT pass consumes it; the LDS buffer is
+        // free again after this read
+        float xr[P];
+#pragma unroll
+        for (int g = 0; g < G::GA; g++)
+#pragma unroll
+            for (int j = 0; j < G::RA; j++) xr[g * G::RA + j] = (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)];
+        wave_fence();
+        float log_rms;
+        {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < P; i++) s += (double) (xr[i] * xr[i]);
+            s = wave_sum(s);
+            const float rms = (float) sqrt(s / (double) N);
+            // log10 of a float, correctly rounded: this value gates bins (`mag > 0.01*logRMS`), so it must
+            // equal the CPU oracle's to the last bit (see oracle/fx_oracle.c)
+#ifdef FX_EXP_SKIP_RMSLOG
+            log_rms = __log10f(rms * 9.0f + 1.0f);
+#else
+            log_rms = (float) log10((double) (rms * 9.0f + 1.0f));
+#endif
+            if (lane == 0) fpl->log_rms = log_rms;
+        }
+
+        if constexpr (SPEC) {
+        float spec_aux = 0.0f;
+FX_MARK("spec_fft");
+        FX_STAMP(1);
+        // ---------------- spectral analyser (ref RealTimeAnalyser.h:212-224) -----------------------
+        lane = opaque(lane);
+        {
+            float xw[P];                                                       // a3 Bartlett window
+            // sample index of input j of item g is nlow + ITEMS_A*r(j) with nlow < ITEMS_A, so it lies in
+            // the rising half iff r(j) < RA/2 and the gain is base + r*2/RA there, (1-base) - (r-RA/2)*2/RA
+            // in the falling half -- exact dyadic arithmetic, identical to bartlett_gain<N>(index)
+#pragma unroll
+            for (int g = 0; g < G::GA; g++) {
+                const float base = (float) rev4<G::IDIG>(lane + 64 * g) * (2.0f / N);
+                const float nbase = 1.0f - base;
+#pragma unroll
+                for (int j = 0; j < G::RA; j++) {
+                    const int r = (G::RA == 4) ? j : (G::RA == 8) ? ((j >> 1) + 4 * (j & 1)) : ((j >> 2) + 4 * (j & 3));
+                    const float gain = r < G::RA / 2 ? base + (float) r * (2.0f / G::RA)
+                                                     : nbase - (float) (r - G::RA / 2) * (2.0f / G::RA);
+                    xw[g * G::RA + j] = xr[g * G::RA + j] * gain;
+                }
+            }
+            spec_aux = fft_from_regs<N, false, OUT_RE_LOW_MAXABS>(xw, cbuf, tw, p.first_tw, lane);   // a4
+        }
+FX_MARK("spec_sums");
+        FX_STAMP(2);
+        {
+            // lane owns bins [U*lane, U*lane + U)
+            float re[U];
+            // ref SpectralCharacteristics.h:153: getMagnitude over the first M floats of the interleaved
+            // buffer = max |re|, |im| over bins [0, M/2)
+            float maxabs = spec_aux;
+            lds_load_block<U>(reinterpret_cast<const float*>(cbuf) + U * lane, re);
+            const double eps = 0.01 * (double) log_rms;                        // :108
+            double mag_sum = 0.0, lhr = 0.0, wsum = 0.0, flat_sum = 0.0;
+            float max_re = 0.0f;       // max |re|: (double) re^2 is exact and monotone in |re|, so max mag = max_re^2
+            int cnt = 0;               // wave-uniform: bins that pass the flatness gate, counted from the compare masks
+            // bins m <= M/5 (:86-87, inclusive) are the lanes below LQ entirely and the first LR + 1 bins of lane LQ:
+            // the lane's share of `lhr` is its running magnitude sum at that point
+            constexpr int LQ = (M / 5) / U, LR = (M / 5) % U;
+#pragma unroll
+            for (int j = 0; j < U; j++) {                                      // fillIntermediateValues :62-97
+                const int m = U * lane + j;
+                const double v = (double) re[j];
+                const double mag = v * v;
+                const double fc = (double) m * frpb + (frpb / 2.0);
+                mag_sum += mag;
+                if (j == LR) lhr = mag_sum;
+                const bool gate = mag > eps;
+                cnt += __builtin_popcountll(__ballot(gate));
+                if (gate) flat_sum += mag;
+                wsum += fc * mag;
+                max_re = fmaxf(max_re, fabsf(re[j]));
+            }
+            lhr = lane < LQ ? mag_sum : (lane == LQ ? lhr : 0.0);
+            mag_sum = wave_sum(mag_sum);
+            lhr = wave_sum(lhr);
+            wsum = wave_sum(wsum);
+            flat_sum = wave_sum(flat_sum);
+            max_re = wave_maxf(max_re);
+            const double max_mag = (double) max_re * (double) max_re;
+            maxabs = wave_maxf(maxabs);
+            const bool accepted = mag_sum > 0.05;                              // :121-123
+
+FX_MARK("flux");
+            // ---- flux against the previous accepted frame; hand-off between waves ----
+            double flux = 0.0;
+            {
+#ifndef FX_EXP_NOWAIT
+                while (__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t)
+                    __builtin_amdgcn_s_sleep(1);
+#endif
+                float pvf[U];
+                lds_load_block<U>(prev + U * lane, pvf);
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const double pv = (double) pvf[j];
+                    const double v = (double) re[j];
+                    const double diff = v * v - pv * pv;                       // :76
+                    if (diff > 0.0) flux += diff;                              // :77-79
+                }
+                if (accepted) lds_store_block<U>(prev + U * lane, re);         // :138 (only on the accepted path)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(turn, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            flux = wave_sum(flux);
+
+            lane = opaque(lane);
+FX_MARK("flatprod");
+            // ---- flatness product: serial-order semantics of `magnitudeProduct *= binMagnitude` ----
+            // (ref :92) including IEEE overflow (sticky inf) and gradual underflow (sticky 0):
+            // exponent-extended prefix products locate the first prefix that leaves the normal
+            // range; an overflow decides at once, an underflow is finished serially in IEEE double.
+            double prod;
+#ifdef FX_EXP_SKIP_FLATPROD
+            prod = 1.0;
+            if (false)
+#endif
+            {
+                FlatProd loc = {0.5, 1};                                       // 1.0
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const double v = (double) re[j];
+                    const double mag = v * v;
+                    if (mag > eps) loc = fp_mul(loc, mag);
+                }
+                // inclusive / exclusive scan of lane totals in lane (= bin) order; identity = 1.0 = (0.5, 1)
+                FlatProd inc = loc;
+#define FX_FP_STEP(CTRL, ROW_MASK) { FlatProd nb; nb.mant = dpp_d<CTRL, ROW_MASK>(0.5, inc.mant); nb.exp = dpp_i<CTRL, ROW_MASK>(1, inc.exp); inc = fp_mul2(nb, inc); }
+                FX_FP_STEP(DPP_ROW_SHR1, 0xF)
+                FX_FP_STEP(DPP_ROW_SHR2, 0xF)
+                FX_FP_STEP(DPP_ROW_SHR4, 0xF)
+                FX_FP_STEP(DPP_ROW_SHR8, 0xF)
+                FX_FP_STEP(DPP_BCAST15, 0xA)
+                FX_FP_STEP(DPP_BCAST31, 0xC)
+#undef FX_FP_STEP
+                FlatProd exc;
+                exc.mant = shift_up1(inc.mant, 0.5);
+                exc.exp = shift_up1(inc.exp, 1);
+                // replay the lane's chain from its true starting value, looking for the first prefix
+                // outside the normal range:  value = mant*2^exp with mant in [0.5,1)
+                //   overflow  : value >= 2^1024  <=> exp >= 1025
+                //   subnormal : value <  2^-1022 <=> exp <= -1022
+                int first_bad = 0x7fffffff;       // bin index of the first abnormal prefix
+                int bad_kind = 0;                 // 1 overflow, 2 subnormal
+                FlatProd run = exc;
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const double v = (double) re[j];
+                    const double mag = v * v;
+                    if (mag > eps) {
+                        run = fp_mul(run, mag);
+                        if (first_bad == 0x7fffffff && run.mant != 0.0) {
+                            if (run.exp >= 1025) { first_bad = U * lane + j; bad_kind = 1; }
+                            else if (run.exp <= -1022) { first_bad = U * lane + j; bad_kind = 2; }
+                        }
+                    }
+                }
+                const int fb = wave_min_i(first_bad);
+                const FlatProd total = {bcast63(inc.mant), __builtin_amdgcn_readlane(inc.exp, 63)};
+                if (fb == 0x7fffffff) {
+                    prod = ldexp(total.mant, total.exp);
+                } else {
+                    // which lane owns bin fb, and what happened there
+                    const int owner = fb / U;
+                    const int kind = lane_get(bad_kind, owner);
+                    if (kind == 1) {
+                        prod = __builtin_huge_val();                           // inf * positive finite stays inf
+                    } else {
+                        // value just before bin fb (normal), then IEEE double from fb onwards: the
+                        // owner of bin fb continues through its own bins, hands the product to the next
+                        // lane, and so on until it is exactly 0 (0 * finite stays 0) or the bins end
+                        FlatProd before = exc;
+#pragma unroll
+                        for (int j = 0; j < U; j++) {
+                            const double v = (double) re[j];
+                            const double mag = v * v;
+                            if (mag > eps && (U * lane + j) < fb) before = fp_mul(before, mag);
+                        }
+                        double pr = ldexp(lane_get(before.mant, owner), lane_get(before.exp, owner));
+                        double tailf[U];           // this lane's factors from bin fb on (1.0 = not a factor; x * 1.0 is exact)
+#pragma unroll
+                        for (int j = 0; j < U; j++) {
+                            const double v = (double) re[j];
+                            const double mag = v * v;
+                            tailf[j] = (mag > eps && (U * lane + j) >= fb) ? mag : 1.0;
+                        }
+                        for (int l = owner; l < 64; l++) {
+                            double mine = pr;
+#pragma unroll
+                            for (int j = 0; j < U; j++) mine *= tailf[j];
+                            pr = lane_get(mine, l);
+                            if (pr == 0.0) break;
+                        }
+                        prod = pr;
+                    }
+                }
+            }
+
+FX_MARK("spec_pass2");
+            // second pass over the lane's bins: spread needs the centroid, the slope needs the mean
+            // (ref SpectralCharacteristics.h:135-139 and :182-188); everything after these sums is
+            // scalar and is finished by fx_finalise_kernel
+            {
+                const float centroid = (float) (wsum / mag_sum);               // :127
+                const double cn = (double) centroid * rnyq;
+                const double mu = mag_sum * (1.0 / (double) M);
+                double var = 0.0, vsum = 0.0;
+#pragma unroll
+                for (int j = 0; j < U; j++) {
+                    const int m = U * lane + j;
+                    const double v = (double) re[j];
+                    const double mag = v * v;
+                    const double fc = (double) m * frpb + (frpb / 2.0);
+                    const double d = fc * rnyq - cn;
+                    var += (d * d) * mag;
+                    const double dv = mag - mu;
+                    vsum += dv * dv;
+                }
+                var = wave_sum(var);
+                vsum = wave_sum(vsum);
+                if (lane == 0) { fpl->var = var; fpl->vsum = vsum; fpl->centroid = centroid; }
+            }
+            double max_e = (double) maxabs;                                    // :153
+            if (max_mag > max_e) max_e = max_mag;                              // :161-162
+            if (lane == 0) {
+                fpl->mag_sum = mag_sum; fpl->lhr = lhr; fpl->flux = flux; fpl->flat_sum = flat_sum; fpl->prod = prod;
+                fpl->max_e = max_e; fpl->wsum = wsum; fpl->cnt = (float) cnt;
+            }
+        }
+        wave_fence();
+        }
+
+        if constexpr (HARM) {
+FX_MARK("harm1");
+        FX_STAMP(3);
+        // ---------------- harmonic analyser, part 1: raw (un-windowed) spectrum ---------------------
+        // ref RealTimeAnalyser.h:161 -- done before the low-pass overwrites the frame image
+        lane = opaque(lane);
+        fft_from_regs<N, false, OUT_RE_LOW>(xr, cbuf, tw, p.first_tw, lane);
+        float hre[U];
+        float h_left2, h_left1, h_right1;          // |re| of bins U*lane-2, U*lane-1, U*lane+U
+        double h_sum = 0.0, h_max;
+        float h_max_re = 0.0f;
+        {
+            const int b0 = U * lane;
+            const float* relin = reinterpret_cast<const float*>(cbuf);
+            lds_load_block<U>(relin + b0, hre);
+            h_left2  = b0 >= 2 ? fabsf(relin[b0 - 2]) : 0.0f;
+            h_left1  = b0 >= 1 ? fabsf(relin[b0 - 1]) : 0.0f;
+            h_right1 = b0 + U < M ? fabsf(relin[b0 + U]) : 0.0f;
+#pragma unroll
+            for (int j = 0; j < U; j++) {                                      // ref HarmonicCharacteristics.h:61-69
+                const double v = (double) hre[j];
+                const double mag = v * v;
+                h_sum += mag;
+                h_max_re = fmaxf(h_max_re, fabsf(hre[j]));
+            }
+            h_sum = wave_sum(h_sum);
+            h_max_re = wave_maxf(h_max_re);
+            h_max = (double) h_max_re * (double) h_max_re;
+        }
+        wave_fence();
+
+        // ---------------- pitch: low-pass -> window -> FFT -> re^2 -> inverse FFT -> lag -------------
+        double f0;
+        lane = opaque(lane);
+        {
+FX_MARK("lpf");
+        FX_STAMP(4);
+            // a10 AudioFilter::filterAudio, ref RealTimeAudioAnalysis.h:106-125:
+            //   y[0] = x[0];  y[n] = (a*x[n]) + (b*y[n-1]) in fp32, strictly serial.
+            // Lane l owns samples [P*l, P*l+P).  It starts KW samples early from a guess, and the
+            // recurrence (|b| = 0.208) forgets the guess; the value it reaches at P*l-1 must be
+            // bit-identical to what lane l-1 produced there, otherwise the chunk is redone from the
+            // neighbour's value until every hand-over matches (exact by induction from lane 0).
+            constexpr int KW = 16;
+            const float a = p.lpf_a, b = p.lpf_b;
+#pragma unroll
+            for (int g = 0; g < G::GA; g++)
+#pragma unroll
+                for (int j = 0; j < G::RA; j++) (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)] = xr[g * G::RA + j];
+            wave_fence();
+            float x[P];
+#pragma unroll
+            for (int i = 0; i < P; i += 4) {
+                const f4 v = *reinterpret_cast<const f4*>(&rbuf[rpad(P * lane + i)]);
+                x[i] = v.x; x[i + 1] = v.y; x[i + 2] = v.z; x[i + 3] = v.w;
+            }
+            float yin = 0.0f;                             // y[P*lane - 1] used as this chunk's input
+            {
+                const int first = P * lane;
+#pragma unroll
+                for (int q = 0; q < KW / 4; q++) {
+                    const int n0 = first - KW + 4 * q;    // multiple of 4: the whole group is in range or not
+                    if (n0 >= 0) {
+                        const f4 v = *reinterpret_cast<const f4*>(&rbuf[rpad(n0)]);
+                        const float w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++)       // sample 0 starts the filter exactly; the first
+                            yin = (n0 + e == 0 || (q == 0 && e == 0)) ? w[e] : (a * w[e]) + (b * yin);   // warm-up sample is a guess
+                    }
+                }
+            }
+            wave_fence();
+            float y[P];
+            float ylast;
+            {
+                float yy = yin;
+#pragma unroll
+                for (int i = 0; i < P; i++) {
+                    yy = (lane == 0 && i == 0) ? x[0] : (a * x[i]) + (b * yy);
+                    y[i] = yy;
+                }
+                ylast = yy;
+            }
+            for (int iter = 0; iter < 64; iter++) {
+                const float pe = shift_up1(ylast, 0.0f);
+                const bool bad = lane > 0 && (__float_as_uint(pe) != __float_as_uint(yin));
+                if (!__any(bad)) break;
+                if (bad) {
+                    yin = pe;
+                    float yy = yin;
+#pragma unroll
+                    for (int i = 0; i < P; i++) { yy = (a * x[i]) + (b * yy); y[i] = yy; }
+                    ylast = yy;
+                }
+            }
+            // window the filtered frame (ref RealTimeAnalyser.h:157) and put it back in the real image.
+            // A lane's P samples lie in one half of the window; the gains w0 + i*wstep are exact dyadic
+            // numbers (so the fma rounds nothing) and equal bartlett_gain<N>(P*lane + i).
+            lane = opaque(lane);
+            const float w0 = bartlett_gain<N>(P * lane);
+            const float wstep = lane < 32 ? (2.0f / N) : -(2.0f / N);
+#pragma unroll
+            for (int i = 0; i < P; i += 4) {
+                f4 v;
+                v.x = y[i]     * __builtin_fmaf(wstep, (float) i, w0);
+                v.y = y[i + 1] * __builtin_fmaf(wstep, (float) (i + 1), w0);
+                v.z = y[i + 2] * __builtin_fmaf(wstep, (float) (i + 2), w0);
+                v.w = y[i + 3] * __builtin_fmaf(wstep, (float) (i + 3), w0);
+                *reinterpret_cast<f4*>(&rbuf[rpad(P * lane + i)]) = v;
+            }
+            wave_fence();
+
+FX_MARK("pitch_fft");
+        FX_STAMP(5);
+            lane = opaque(lane);
+            float xf[P];
+#pragma unroll
+            for (int g = 0; g < G::GA; g++)
+#pragma unroll
+                for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)];
+            wave_fence();
+            fft_from_regs<N, false, OUT_POWER>(xf, cbuf, tw, p.first_tw, lane);            // ref RealTimeAnalyser.h:160
+FX_MARK("power");
+        FX_STAMP(6);
+            // a11 getComplexConjugateMultiplication, ref PitchAnalyser.h:83-108: re*re, imag := 0,
+            // picked up directly in the order the inverse transform's first pass wants it
+            lane = opaque(lane);
+#pragma unroll
+            for (int g = 0; g < G::GA; g++)
+#pragma unroll
+                for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)];   // already squared
+            wave_fence();
+FX_MARK("ifft");
+            fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, p.first_tw, lane, scale);        // a12 inverse, ref :110-121
+FX_MARK("vcalc");
+        FX_STAMP(7);
+            // v[s] = d[s]*d[s]*s, d = planar JUCE inverse output scaled by 1/N (ref :122-123).
+            // Only s in [1, N] is ever read by the lag search; v[N] comes from imag[0].
+            lane = opaque(lane);
+            float* vbuf = rbuf;                                                // [N+1] plain layout
+            float* sums = rbuf + N + 4;                                        // [N+1]; both fit in the buffer
+            wave_fence();
+FX_MARK("scan");
+            // a13 running fp32 sum (ref PitchAnalyser.h:138-150) -- serial by definition, so one lane
+            // adds, 64 samples at a time; after each block all lanes form cnd = v/sum (ref :146-154) for
+            // that block and advance a14's search (ref :161-190), which usually ends long before N:
+            //   first  = first s >= 2 with cnd[s] < 0.01
+            //   stop   = first s' >= first with !(cnd[s'+1] < cnd[s'])   (or N-1)
+            //   lag    = cnd[stop] <= cnd[stop+1] ? stop : stop+1        (ref :192-203)
+            // otherwise the global minimum over [2, N), first occurrence (ref :171-175).
+            float lag = -1.0f;
+            {
+                float run = 0.0f;                 // lane 0: the running sum
+                float carry = 0.0f;               // cnd of the last sample of the previous block
+                int first = 0x7fffffff;
+                bool done = false;
+                float best = 100.0f; int best_i = 0x7fffffff;
+#ifdef FX_EXP_SKIP_SCAN
+                for (int blk = 0; blk < (int) (scale * 0.5f) && !done; blk++) {
+#else
+                for (int blk = 0; blk < P && !done; blk++) {
+#endif
+                    if (lane == 0) {
+#pragma unroll
+                        for (int g = 0; g < 64; g += 4) {
+                            const f4 v = *reinterpret_cast<const f4*>(&vbuf[64 * blk + g]);
+                            f4 o;
+                            if (g != 0 || blk != 0) run += v.x;               // the sum starts at sample 1
+                            o.x = run;
+                            run += v.y; o.y = run;
+                            run += v.z; o.z = run;
+                            run += v.w; o.w = run;
+                            *reinterpret_cast<f4*>(&sums[64 * blk + g]) = o;
+                        }
+                    }
+                    wave_fence();
+                    const int s_ = 64 * blk + lane;
+                    const float sm = sums[s_];
+                    const float v = vbuf[s_];
+                    const float c_ = (sm != 0.0f) ? v / sm : 0.0f;
+                    const float p_ = shift_up1(c_, carry);                     // cnd of the previous sample
+                    carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_), 63));
+                    if (s_ >= 2 && c_ < best) { best = c_; best_i = s_; }
+                    if (first == 0x7fffffff) {
+                        const unsigned long long hit = __ballot(s_ >= 2 && c_ < 0.01f);
+                        if (hit) first = 64 * blk + (int) __builtin_ctzll(hit);
+                    }
+                    if (first != 0x7fffffff) {
+                        // sample s-1 ends the walk if it is past `first` and cnd does not keep falling
+                        const unsigned long long st = __ballot(s_ - 1 >= first && !(c_ < p_));
+                        if (st) {
+                            const int src = (int) __builtin_ctzll(st);
+                            const float pc = lane_get(p_, src), cc = lane_get(c_, src);
+                            const int sstar = 64 * blk + src;
+                            lag = (pc <= cc) ? (float) (sstar - 1) : (float) sstar;
+                            done = true;
+                        }
+                    }
+                }
+                if (!done) {
+                    if (first != 0x7fffffff) {
+                        // the walk ran to N-1 (ref :178: sample + 1 < numSamples); compare with cnd[N]
+                        float cn = 0.0f;
+                        if (lane == 0) { run += vbuf[N]; cn = (run != 0.0f) ? vbuf[N] / run : 0.0f; }
+                        cn = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cn)));
+                        lag = (carry <= cn) ? (float) (N - 1) : (float) N;
+                    } else {
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) {
+                            const float ov = __shfl_xor(best, o, 64);
+                            const int oi = __shfl_xor(best_i, o, 64);
+                            if (ov < best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+                        }
+                        lag = best_i == 0x7fffffff ? -1.0f : (float) best_i;
+                    }
+                }
+            }
+            f0 = (nyquist * 2.0) / (double) lag;                               // ref PitchAnalyser.h:57
+            if (lane == 0) fpl->lag = lag;
+        }
+        wave_fence();
+
+FX_MARK("harm2");
+        FX_STAMP(8);
+        // ---------------- harmonic analyser, part 2 (ref HarmonicCharacteristics.h:71-105) ----------
+        lane = opaque(lane);
+#ifdef FX_EXP_SKIP_HARM2
+        if (h_sum < -1.0) {
+#else
+        if (!(h_sum < 0.005)) {                                                // :88-89
+#endif
+            float* normed  = reinterpret_cast<float*>(cbuf);                   // [M] floats
+            int*   peaks   = reinterpret_cast<int*>(cbuf) + M;                 // [<= M] peak bins
+            float* peak_re = reinterpret_cast<float*>(cbuf) + 2 * M;           // [<= M] re of those bins
+            double mean_mag = h_sum / (double) M;                              // :86
+            // binIsPeak's `mag > mean` (:132) is an exact tie when the spectrum is flat (an impulse at
+            // sample 0 or N/2 of the window): then the last bit of the reference's serial sum (:61-66)
+            // decides for every bin at once.  If any bin sits within rounding distance of the mean,
+            // redo the sum in the reference's order, handing the running value from lane to lane.
+            {
+                // |re| within ~1e-6 of sqrt(mean) brackets every bin whose magnitude is within 1e-12 of the mean
+                // (a wider band only means the exact recomputation below runs a little more often)
+                const float root_mean = (float) sqrt(mean_mag);
+                const float band = root_mean * 1e-6f;
+                bool near = false;
+#pragma unroll
+                for (int j = 0; j < U; j++) near |= fabsf(fabsf(hre[j]) - root_mean) <= band;
+                if (__any(near)) {
+                    double run = 0.0;
+                    for (int l = 0; l < 64; l++) {
+                        double mine = run;
+#pragma unroll
+                        for (int j = 0; j < U; j++) { const double v = (double) hre[j]; mine += v * v; }
+                        run = lane_get(mine, l);
+                    }
+                    h_sum = run;
+                    mean_mag = h_sum / (double) M;
+                }
+            }
+            unsigned peak_mask = 0;
+            float nrm[U];
+            const double r_hmax = 1.0 / h_max;
+            const double sum_normed = h_sum * r_hmax;                          // :77 sum of mag / max over all bins
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const double v = (double) hre[j];
+                const double mag = v * v;
+                const double nm = mag * r_hmax;                                // :75 (mag / max, via one reciprocal)
+                nrm[j] = (float) nm;
+                // binIsPeak :127-145: above the mean and none of bins -2,-1,+1 larger (windows are
+                // clipped at the ends, :136-138: no +1 neighbour for the last two bins).
+                // mag = (double) re^2 is exact, so comparing |re| compares magnitudes exactly.
+                const int m = U * lane + j;
+                const float me = fabsf(hre[j]);
+                const float l2 = j >= 2 ? fabsf(hre[j >= 2 ? j - 2 : 0]) : (j == 1 ? h_left1 : h_left2);
+                const float l1 = j >= 1 ? fabsf(hre[j >= 1 ? j - 1 : 0]) : h_left1;
+                const float r1 = j + 1 < U ? fabsf(hre[j + 1 < U ? j + 1 : 0]) : h_right1;
+                bool pk = mag > mean_mag;
+                if (m >= 2 && l2 > me) pk = false;
+                if (m >= 1 && l1 > me) pk = false;
+                if (m < M - 2 && r1 > me) pk = false;
+                if (pk) peak_mask |= 1u << j;
+            }
+            lds_store_block<U>(normed + U * lane, nrm);
+            // compact the peak list
+            const int npk_lane = __popc(peak_mask);
+            const int pre = wave_scan_incl_i(npk_lane);
+            const int total_peaks = __builtin_amdgcn_readlane(pre, 63);
+            int woff = pre - npk_lane;
+#pragma unroll
+            for (int j = 0; j < U; j++)
+                if (peak_mask & (1u << j)) { peaks[woff] = U * lane + j; peak_re[woff] = hre[j]; woff++; }
+            wave_fence();
+
+            const double fr = nyquist / (double) M;                            // :93
+            // calculateHarmonicEnergyCharacteristics :147-198 with numLower = 15, numHarmonics = 3:
+            // 18 probes, one lane each; lane 18 divides f0 itself, which is getBinForFrequency(f0) (:246-249)
+            double probe = 0.0;
+            int f0_bin;
+            {
+                // f0 / pow(2, lane+1) is an exact scaling; f0 * h for the harmonics
+                const double freq = lane < 15 ? ldexp(f0, -(lane + 1)) : (lane < 18 ? f0 * (double) (lane - 14) : f0);
+                int bin = (int) floor(freq / fr);
+                f0_bin = __builtin_amdgcn_readlane(bin, 18);
+                if (lane < 15) { if (bin == f0_bin) bin = -1; }                // :163-164
+                else if (lane < 18) { if (bin >= M) bin = -1; }                // :174-175 (monotone, so break == skip)
+                else bin = -1;
+                if (bin >= 0 && bin < M) {
+                    // getMaxBinInNeighbourhood :200-210 : [max(0,c-2), min(c+2, M)), start value normed[c]
+                    const int s0 = bin - 2 >= 0 ? bin - 2 : 0;
+                    const int e0 = bin + 2 < M ? bin + 2 : M;
+                    float mx = normed[bin];
+                    for (int q = s0; q < e0; q++) { const float v = normed[q]; if (v > mx) mx = v; }
+                    probe = (double) mx;
+                }
+            }
+            const double score = wave_sum(probe);                              // / sum_normed, clamped: fx_finalise_kernel
+
+            // calculateInharmonicity :212-244
+            double inh = 0.0;
+            if (f0 > 0.0) {                                                    // :98
+                for (int i = lane; i < total_peaks; i += 64) {
+                    const int bin = peaks[i];
+                    if (bin == f0_bin) continue;                               // :220-221
+                    double fs = (double) bin * fr;
+                    if (fs == 0.0) fs = fr * 0.5;                              // :225-226
+                    const double fe = (double) (bin + 1) * fr;
+                    // getFrequencyRatio :251-259: higher / lower (1.0 when equal: x / x is exactly 1)
+                    const double rs  = (fs > f0 ? fs : f0) / (fs > f0 ? f0 : fs);
+                    const double re_ = (fe > f0 ? fe : f0) / (fe > f0 ? f0 : fe);
+                    if (floor(rs) != floor(re_)) continue;                     // :232-233
+                    const double r = rs < re_ ? rs : re_;
+                    const double v = (double) peak_re[i];
+                    inh += (r - floor(r)) * ((v * v) / h_sum);                 // :236-239
+                }
+            }
+            inh = wave_sum(inh);
+            if (lane == 0) { fpl->inh = inh; fpl->her_score = score; fpl->sum_normed = sum_normed; fpl->flags = 1; }
+        }
+        wave_fence();
+        }
+
+FX_MARK("store");
+        FX_STAMP(9);
+        wave_fence();
+        static_assert(sizeof(FramePart) % 16 == 0, "16-byte stores");
+#ifndef FX_EXPERIMENT_NOSTORE
+        if (lane < (int) (sizeof(FramePart) / 16))
+            reinterpret_cast<uint4*>(p.part + ((size_t) c * T + t))[lane] = reinterpret_cast<const uint4*>(fpl)[lane];
+#endif
+        wave_fence();
+        FX_STAMP(10);
+    }
+
+#ifdef FX_STAMPS
+    if (lane0 == 0 && p.debug)
+        for (int i = 0; i < 16; i++) atomicAdd(p.debug + i, stamp_acc[i]);
+#endif
+    __syncthreads();
+    for (int i = threadIdx.x; i < M; i += blockDim.x) p.prev_re[(size_t) c * M + i] = prev[i];
+}

@@ -1,0 +1,233 @@
+// fx_tail_kernels.hip.h -- fx_finalise_kernel, fx_epilogue_kernel, fx_history_kernel: scalar tails, smoothing, onset
+// Included by fx_kernels.hip inside namespace fxk (one translation unit: every kernel sees the same
+// inlined helpers); not a stand-alone header.
+
+// ---------------------------------------------------------------------------------------------
+// fx_finalise_kernel: thread = frame.  The scalar tail of calculateSpectralCharacteristicsFrom-
+// Intermediates (ref SpectralCharacteristics.h:116-143), calculateNormalisedSpectralSlope (:189-199),
+// the harmonic logs (ref HarmonicCharacteristics.h:101-105) and the slot mapping of
+// RealTimeAnalyser.h:165-172,219-224.  Output: raw[C][T][12] with the onset slot still 0.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+fx_finalise_kernel(const EpilogueParams p)
+{
+    const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long) p.C * p.T) return;
+    const FramePart f = p.part[idx];
+    const int M = p.window / 2;
+    const double nyquist = p.nyquist;
+    float out[FX_NUM_FEATURES];
+#pragma unroll
+    for (int i = 0; i < FX_NUM_FEATURES; i++) out[i] = 0.0f;
+    out[FX_RMS] = f.log_rms;
+    const double eps = 0.01 * (double) f.log_rms;                              // :108
+
+    const bool spec = p.analysers & 1, harm = p.analysers & 2;
+    if (spec && f.mag_sum > 0.05) {                                            // :121-123
+        const float centroid = f.centroid;
+        const double dcnt = (double) f.cnt;
+        const double inv_n = 1.0 / (dcnt > 0.0 ? dcnt : 1.0);                  // :129-130
+        const float flatness = f.flat_sum > eps ? (float) (pow(f.prod, inv_n) / (inv_n * f.flat_sum)) : 0.0f;   // :57-60
+        out[FX_FLATNESS] = (float) log10((double) flatness * 9.0 + 1.0);       // :132
+        const float cc = centroid / (float) (nyquist / 2.0);                   // :133
+        out[FX_CENTROID] = (float) log10((double) (cc * 9.0f + 1.0f));         // :134
+        const double cn = (double) centroid / nyquist;
+        const float max_spread = (float) (cn * (1.0 - cn));                    // :140
+        out[FX_SPREAD] = (float) ((f.var / f.mag_sum) / (double) max_spread);  // :141
+        out[FX_LER] = (float) (f.lhr / f.mag_sum);                             // :125
+        const float max_flux = (float) (M * (M + 1)) / 2.0f;                   // :111
+        out[FX_FLUX] = (float) (f.flux / (double) max_flux);
+    }
+    if (spec && f.max_e > 0.0001) {                                            // :165-167
+        // normedEnergy = mag / max (ref :172): the sums over bins were taken before the division
+        const double rmax = 1.0 / f.max_e;
+        const double se = f.mag_sum * rmax;
+        const double frpb = nyquist / (double) M;
+        const double s1 = (f.wsum - (frpb / 2.0) * f.mag_sum) / frpb;          // sum m * mag
+        const double ps = s1 * rmax;                                           // :175
+        const double mean_e = se / (double) M;                                 // :177
+        const double ev = f.vsum * rmax * rmax / (double) M;                   // :187,190
+        const double bin_std = sqrt(p.bin_var), e_std = sqrt(ev);              // :191-192
+        const double r = (ps - ((double) M * mean_e * 0.5)) / (double) ((float) M - 1.0f) * e_std * bin_std;   // :195
+        out[FX_SLOPE] = (float) (r * (bin_std / e_std));                       // :198
+    }
+    if (harm) {
+        const double f0 = (nyquist * 2.0) / (double) f.lag;                    // ref PitchAnalyser.h:57
+        out[FX_F0] = (float) (f0 / 5000.0);                                    // ref RealTimeAnalyser.h:165-166
+    }
+    if (harm && (f.flags & 1)) {
+        double her = f.her_score / f.sum_normed;                               // ref HarmonicCharacteristics.h:186-188
+        if (her > 1.0) her = 1.0;
+        if (her < 0.0) her = 0.0;
+        her = (double) (float) her;                                            // struct of floats, :197
+        const float log_her = (float) log10(her * 9.0 + 1.0);                  // :101
+        out[FX_HER] = log_her;
+        out[FX_OER] = log_her;                                                 // ref RealTimeAnalyser.h:171 writes HER into the OER slot
+        out[FX_INHARM] = (float) log10(f.inh * 9.0 + 1.0);                     // :102
+    }
+    f4* dst = reinterpret_cast<f4*>(p.raw + idx * FX_NUM_FEATURES);
+    dst[0] = f4{out[0], out[1], out[2], out[3]};
+    dst[1] = f4{out[4], out[5], out[6], out[7]};
+    dst[2] = f4{out[8], out[9], out[10], out[11]};
+}
+
+// ---------------------------------------------------------------------------------------------
+// smoothing (ValueHistory, ref RealTimeAudioAnalysis.h:40-96; AudioFeatures, ref
+// RealTimeAnalyser.h:70-88) and onset detection (ref SpectralCharacteristics.h:249-306,
+// RealTimeAnalyser.h:236-242).
+//
+// A ValueHistory of length L after its k-th insert holds the last min(k, L) inserted values,
+// oldest first, padded on the left with the zeros it was created with; getTotal() adds them left to
+// right in fp32.  Every smoothed value and every onset decision of frame t is therefore a pure
+// function of the raw values of frames t-HLEN+1 .. t, and all (channel, frame) pairs are evaluated
+// in parallel: thread = (channel, frame).  Frames before this call come from hist_in.
+// ---------------------------------------------------------------------------------------------
+struct RawView {
+    const float* raw; const float* hist; int T; long long frames_before;
+    // raw value of slot s at frame index tau relative to this call (tau may be negative);
+    // frames before the stream began read as "not recorded"
+    __device__ __forceinline__ bool valid(int tau) const { return frames_before + (long long) tau >= 0 && tau > -HLEN - 1; }
+    __device__ __forceinline__ float get(int tau, int s) const
+    {
+        return tau >= 0 ? raw[(size_t) tau * FX_NUM_FEATURES + s] : hist[(size_t) (HLEN + tau) * FX_NUM_FEATURES + s];
+    }
+};
+
+// smoothed RMS as AudioFeatures::getValue(enRMS) returns it when `pushes_after` of frame tau's
+// two RMS inserts have happened (shared AudioFeatures: two inserts per hop; isolated: one)
+__device__ __forceinline__ float rms_value(const RawView& v, int tau, int order_mode, int pushes_of_tau)
+{
+    float total = 0.0f;
+    long long recorded;
+    if (order_mode == FX_ORDER_ISOLATED) {
+        // spectral analyser's own AudioFeatures: one insert per frame, window = frames tau-9 .. tau
+#pragma unroll
+        for (int i = 0; i < 10; i++) { const int f = tau - 9 + i; total += v.valid(f) ? v.get(f, FX_RMS) : 0.0f; }
+        recorded = v.frames_before + tau + 1;
+    } else {
+        // inserts are numbered 2*g (first analyser of frame g) and 2*g+1; the newest insert present
+        // is 2*tau + pushes_of_tau - 1 and the history holds the 10 newest
+        const long long newest = 2 * (v.frames_before + tau) + pushes_of_tau - 1;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const long long q = newest - 9 + i;                     // global insert index
+            const long long g = q >> 1;                             // its frame (floor for q >= 0)
+            const int f = (int) (g - v.frames_before);
+            total += (q >= 0 && v.valid(f)) ? v.get(f, FX_RMS) : 0.0f;
+        }
+        recorded = newest + 1;
+    }
+    if (recorded > 10) recorded = 10;
+    return total / (float) recorded;
+}
+
+__global__ void __launch_bounds__(256)
+fx_epilogue_kernel(const EpilogueParams p)
+{
+    const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long) p.C * p.T) return;
+    const int c = (int) (idx / p.T), t = (int) (idx % p.T);
+    RawView v;
+    v.raw = p.raw + (size_t) c * p.T * FX_NUM_FEATURES;
+    v.hist = p.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES;
+    v.T = p.T;
+    v.frames_before = p.frames_before;
+
+    float sm[FX_NUM_FEATURES];
+    float rw[FX_NUM_FEATURES];
+#pragma unroll
+    for (int s = 0; s < FX_NUM_FEATURES; s++) rw[s] = v.get(t, s);
+
+    const bool spec = p.analysers & 1, harm = p.analysers & 2;
+    // with a single analyser the RMS slot gets one insert per hop, like an isolated AudioFeatures
+    const int order_mode = (spec && harm) ? p.order_mode : FX_ORDER_ISOLATED;
+    const float never = __int_as_float(0x7fc00000);                  // getValue() of a slot nobody wrote: 0.0f / 0
+    // 10-deep slots (ref RealTimeAnalyser.h:73)
+    long long rec10 = p.frames_before + t + 1; if (rec10 > 10) rec10 = 10;
+#pragma unroll
+    for (int s = 0; s < FX_NUM_FEATURES; s++) {
+        if (s == FX_ONSET || s == FX_FLUX || s == FX_RMS) continue;
+        const bool harm_slot = s == FX_F0 || s == FX_HER || s == FX_OER || s == FX_INHARM;
+        float total = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 10; i++) { const int f = t - 9 + i; total += v.valid(f) ? v.get(f, s) : 0.0f; }
+        sm[s] = (harm_slot ? harm : spec) ? total / (float) rec10 : never;
+    }
+    sm[FX_FLUX] = spec ? (0.0f + rw[FX_FLUX]) / 1.0f : never;        // history length 1
+    // RMS after every analyser of this hop has inserted (what the OSC timer samples)
+    sm[FX_RMS] = rms_value(v, t, order_mode, 2);
+
+    // OnsetDetector::detectOnset, ref SpectralCharacteristics.h:249-306.  The detector's histories
+    // hold (getValue(enFlux), getValue(enRMS)) as seen by detectOnset() of each frame
+    // (ref RealTimeAnalyser.h:236-242): flux of that frame, and the RMS mean at that moment.
+    const int L = p.onset_window;
+    const int rms_pushes_at_detect = (order_mode == FX_ORDER_HARMONIC_THEN_SPECTRAL) ? 2 : 1;
+    const long long g = p.frames_before + t;
+    long long recorded = g - p.onset_reset_frame + 1;
+    if (recorded > L) recorded = L;
+    bool onset = false;
+    if (spec && recorded >= L && L > 0) {                           // :253-258 both histories full
+        int cand = L - 1;                                           // :263-266
+        const bool use_amp = p.onset_type == FX_ONSET_AMPLITUDE || p.onset_type == FX_ONSET_COMBINATION;
+        const bool use_flux = p.onset_type == FX_ONSET_SPECTRAL || p.onset_type == FX_ONSET_COMBINATION;
+        if (use_flux) cand = L / 2;
+        const float cand_amp = rms_value(v, t - L + 1 + cand, order_mode, rms_pushes_at_detect);
+        const float cand_sf = (0.0f + v.get(t - L + 1 + cand, FX_FLUX)) / 1.0f;
+        bool ok = !(cand_amp < 0.01f);                              // :271-274
+        float tot_amp = 0.0f, tot_flux = 0.0f;
+#pragma unroll 1
+        for (int i = 0; i < L; i++) {                               // :260-261 totals, :276-289 neighbours
+            const int f = t - L + 1 + i;
+            const float amp_i = rms_value(v, f, order_mode, rms_pushes_at_detect);
+            const float flx_i = (0.0f + v.get(f, FX_FLUX)) / 1.0f;
+            tot_amp += amp_i;
+            tot_flux += flx_i;
+            if (i != cand) {
+                if (amp_i >= cand_amp && use_amp) ok = false;
+                if (flx_i >= cand_sf && use_flux) ok = false;
+            }
+        }
+        const float mean_flux = tot_flux / (float) recorded;
+        const float mean_amp = tot_amp / (float) recorded;
+        const bool on_sf = cand_sf > mean_flux * p.onset_multiplier;    // :291-292
+        const bool on_amp = cand_amp > mean_amp * p.onset_multiplier;
+        bool res = false;
+        if (p.onset_type == FX_ONSET_AMPLITUDE) res = on_amp;
+        else if (p.onset_type == FX_ONSET_SPECTRAL) res = on_sf;
+        else if (p.onset_type == FX_ONSET_COMBINATION) res = on_amp && on_sf;
+        onset = ok && res;
+    }
+    rw[FX_ONSET] = onset ? 1.0f : 0.0f;
+    sm[FX_ONSET] = spec ? (0.0f + rw[FX_ONSET]) / 1.0f : never;      // history length 1
+
+    const size_t o = ((size_t) c * p.T + t) * FX_NUM_FEATURES;
+    if (p.out_raw) {
+#pragma unroll
+        for (int s = 0; s < FX_NUM_FEATURES; s++) p.out_raw[o + s] = rw[s];
+    }
+    if (p.out_smoothed) {
+#pragma unroll
+        for (int s = 0; s < FX_NUM_FEATURES; s++) p.out_smoothed[o + s] = sm[s];
+    }
+    if (t == p.T - 1) {
+#pragma unroll
+        for (int s = 0; s < FX_NUM_FEATURES; s++) p.latest[(size_t) c * FX_NUM_FEATURES + s] = sm[s];
+    }
+}
+
+// carry the newest HLEN frames of raw values over to the next call
+__global__ void __launch_bounds__(256)
+fx_history_kernel(const EpilogueParams p)
+{
+    const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long) p.C * HLEN * FX_NUM_FEATURES;
+    if (idx >= total) return;
+    const int s = (int) (idx % FX_NUM_FEATURES);
+    const int h = (int) ((idx / FX_NUM_FEATURES) % HLEN);
+    const int c = (int) (idx / ((long long) FX_NUM_FEATURES * HLEN));
+    const int tau = p.T - HLEN + h;                                  // frame relative to this call
+    float val;
+    if (tau >= 0) val = p.raw[((size_t) c * p.T + tau) * FX_NUM_FEATURES + s];
+    else          val = p.hist_in[((size_t) c * HLEN + (HLEN + tau)) * FX_NUM_FEATURES + s];
+    p.hist_out[idx] = val;
+}
