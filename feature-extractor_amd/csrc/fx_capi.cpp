@@ -76,7 +76,6 @@ struct fx_context {
     float* d_out_sm = nullptr;
     size_t raw_cap = 0, in_cap = 0, out_cap = 0;
 
-    unsigned long long* d_debug = nullptr;   // FX_STAMPS diagnostic builds
     double bin_var = 0.0;
     float  lpf_a = 0.0f, lpf_b = 0.0f;
     float  first_tw[18] = {0};
@@ -176,7 +175,6 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     fp.bin_var = c->bin_var;
     fp.lpf_a = c->lpf_a;
     fp.lpf_b = c->lpf_b;
-    fp.debug = c->d_debug;
     for (int i = 0; i < 18; i++) fp.first_tw[i] = c->first_tw[i];
 
     // waves per workgroup = frames of one channel in flight.  Pick the count that keeps the most
@@ -339,10 +337,6 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
         c->lpf_a = float_pi / 2.0f;
         c->lpf_b = std::exp(-float_pi / 2.0f);
     }
-#ifdef FX_STAMPS
-    TRY_OR_CLEAN(hipMalloc((void**) &c->d_debug, 16 * sizeof(unsigned long long)));
-    TRY_OR_CLEAN(hipMemset(c->d_debug, 0, 16 * sizeof(unsigned long long)));
-#endif
     if ((st = zero_state(c)) != FX_OK) return cleanup(st);
     TRY_OR_CLEAN(hipStreamSynchronize(c->stream));
 #undef TRY_OR_CLEAN
@@ -436,16 +430,6 @@ fx_status fx_get_smoothed(fx_context* c, float* out, int mem_kind)
     return FX_OK;
 }
 
-#ifdef FX_STAMPS
-extern "C" fx_status fx_debug_stamps(fx_context* c, unsigned long long* out12, int reset)
-{
-    if (!c || !out12) return fail(FX_ERR_INVALID_ARGUMENT, "null argument");
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out12, c->d_debug, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(c->d_debug, 0, 16 * sizeof(unsigned long long)));
-    return FX_OK;
-}
-#endif
 
 fx_status fx_sync(fx_context* c)
 {

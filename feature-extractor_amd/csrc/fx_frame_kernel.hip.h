@@ -105,56 +105,29 @@ template <int N> struct Occ {
     static constexpr int MAX_THREADS = N == 4096 ? 256 : 512;
 };
 
-// SPEC / HARM: which of the reference's two analysers run (RealTimeSpectralAnalyser,
-// RealTimeHarmonicAnalyser -- both by default, as AnalyserTrackController constructs them)
-template <int N, bool SPEC, bool HARM>
-__global__ void __launch_bounds__(Occ<N>::MAX_THREADS, Occ<N>::WAVES_PER_SIMD)
-fx_frame_kernel(const FrameParams p)
-{
+// One wavefront's view of the frame it is analysing: where its buffers are and the constants every section
+// uses.  The member functions are the sections of the reference's two run() loops in the order the kernel
+// calls them; all of them are inlined into fx_frame_kernel.
+template <int N> struct FrameWave {
     typedef Geo<N> G;
-    constexpr int M = G::M, P = G::P, U = G::U, HALF = N / 2;
+    static constexpr int M = G::M, P = G::P, U = G::U, HALF = N / 2;
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    f2*    tw   = reinterpret_cast<f2*>(smem);                              // [N]
-    float* prev = reinterpret_cast<float*>(tw + N);                         // [M]  re of the last accepted frame
-    int*   turn = reinterpret_cast<int*>(prev + M);                         // [4]
-    FramePart* parts = reinterpret_cast<FramePart*>(turn + 4);              // [waves] per-frame results, filled as they appear
-    unsigned char* per_wave = reinterpret_cast<unsigned char*>(parts + (blockDim.x >> 6));
-    constexpr size_t WAVE_BYTES = sizeof(f2) * G::CBUF;
+    const FrameParams& p;
+    f2*    tw;          // [N] pass-ordered twiddles (workgroup LDS)
+    float* prev;        // [M] re of the channel's last accepted spectral frame (workgroup LDS)
+    int*   turn;        // index of the frame whose turn it is to read / replace `prev`
+    f2*    cbuf;        // this wave's transform buffer ...
+    float* rbuf;        // ... and the same memory viewed as the real image
+    FramePart* fpl;     // this wave's result record (LDS), filled as the values appear
+    double nyquist, rnyq, frpb;   // frpb: ref SpectralCharacteristics.h:64,105
+    float  scale;       // JUCE inverse-transform scale 1/N
+    int    c, T, t;     // channel, frames in this call, this frame
 
-    const int nwaves = blockDim.x >> 6;
-    const int wave = threadIdx.x >> 6;
-    const int lane0 = threadIdx.x & 63;
-    const int c = blockIdx.x;
-    const int T = p.T;
+    // |re| of the raw spectrum around and inside the lane's bins, kept from the harmonic FFT to the harmonic tail
+    struct HarmonicSpectrum { float hre[U]; float left2, left1, right1; double sum, max; };
 
-    f2*    cbuf = reinterpret_cast<f2*>(per_wave + WAVE_BYTES * wave);
-    float* rbuf = reinterpret_cast<float*>(cbuf);      // the same memory viewed as the real image
-
-    // workgroup prologue: twiddle table + this channel's flux state into LDS
-    for (int i = threadIdx.x; i < N; i += blockDim.x) tw[i] = reinterpret_cast<const f2*>(p.tw)[i];
-    for (int i = threadIdx.x; i < M; i += blockDim.x) prev[i] = p.prev_re[(size_t) c * M + i];
-    if (threadIdx.x == 0) turn[0] = 0;
-    __syncthreads();
-
-    const double nyquist = p.nyquist;
-    const double rnyq = 1.0 / nyquist;
-    const double frpb = nyquist / (double) M;          // ref SpectralCharacteristics.h:64,105
-    const float  scale = 1.0f / (float) N;             // JUCE inverse scale
-
-#ifdef FX_STAMPS
-    unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long stamp_last;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
-#endif
-    for (int t = wave; t < T; t += nwaves) {
-        int lane = opaque(lane0);
-        FX_STAMP(11);
-        // uniform per-frame results go to LDS as soon as they exist instead of occupying ~28 VGPRs
-        // in every lane for the whole frame
-        FramePart* fpl = parts + wave;
-        if (lane == 0) { fpl->inh = 0.0; fpl->her_score = 0.0; fpl->sum_normed = 1.0; fpl->flags = 0; fpl->pad_ = 0; fpl->spare_ = 0.0; }
-
+    __device__ __forceinline__ void load_frame(int lane) const
+    {
 FX_MARK("load");
         // ---------------- a1: window assembly (ref RealTimeAudioAnalysis.h:205-219) ----------------
         {
@@ -183,19 +156,21 @@ FX_MARK("load");
             }
             wave_fence();
         }
+    }
 
+    // fills xr with the raw frame in first-pass order and returns log10(rms * 9 + 1)
+    __device__ __forceinline__ float rms(int lane, float (&xr)[P]) const
+    {
+        float log_rms;
 FX_MARK("rms");
-        FX_STAMP(0);
         // ---------------- a2: RMS on the un-windowed frame (ref RealTimeAnalyser.h:207-208) ---------
         // the frame, in registers, in the order the first FFT pass consumes it; the LDS buffer is
         // free again after this read
-        float xr[P];
 #pragma unroll
         for (int g = 0; g < G::GA; g++)
 #pragma unroll
             for (int j = 0; j < G::RA; j++) xr[g * G::RA + j] = (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)];
         wave_fence();
-        float log_rms;
         {
             double s = 0.0;
 #pragma unroll
@@ -211,11 +186,13 @@ FX_MARK("rms");
 #endif
             if (lane == 0) fpl->log_rms = log_rms;
         }
+        return log_rms;
+    }
 
-        if constexpr (SPEC) {
+    __device__ __forceinline__ void spectral(int lane, const float (&xr)[P], float log_rms) const
+    {
         float spec_aux = 0.0f;
 FX_MARK("spec_fft");
-        FX_STAMP(1);
         // ---------------- spectral analyser (ref RealTimeAnalyser.h:212-224) -----------------------
         lane = opaque(lane);
         {
@@ -238,7 +215,6 @@ FX_MARK("spec_fft");
             spec_aux = fft_from_regs<N, false, OUT_RE_LOW_MAXABS>(xw, cbuf, tw, p.first_tw, lane);   // a4
         }
 FX_MARK("spec_sums");
-        FX_STAMP(2);
         {
             // lane owns bins [U*lane, U*lane + U)
             float re[U];
@@ -424,19 +400,20 @@ FX_MARK("spec_pass2");
             }
         }
         wave_fence();
-        }
+    }
 
-        if constexpr (HARM) {
+    __device__ __forceinline__ void harmonic_spectrum(int lane, const float (&xr)[P], HarmonicSpectrum& hs) const
+    {
+        float (&hre)[U] = hs.hre;
+        float &h_left2 = hs.left2, &h_left1 = hs.left1, &h_right1 = hs.right1;          // |re| of bins U*lane-2, U*lane-1, U*lane+U
+        double &h_sum = hs.sum, &h_max = hs.max;
+        h_sum = 0.0;
+        float h_max_re = 0.0f;
 FX_MARK("harm1");
-        FX_STAMP(3);
         // ---------------- harmonic analyser, part 1: raw (un-windowed) spectrum ---------------------
         // ref RealTimeAnalyser.h:161 -- done before the low-pass overwrites the frame image
         lane = opaque(lane);
         fft_from_regs<N, false, OUT_RE_LOW>(xr, cbuf, tw, p.first_tw, lane);
-        float hre[U];
-        float h_left2, h_left1, h_right1;          // |re| of bins U*lane-2, U*lane-1, U*lane+U
-        double h_sum = 0.0, h_max;
-        float h_max_re = 0.0f;
         {
             const int b0 = U * lane;
             const float* relin = reinterpret_cast<const float*>(cbuf);
@@ -456,13 +433,16 @@ FX_MARK("harm1");
             h_max = (double) h_max_re * (double) h_max_re;
         }
         wave_fence();
+    }
 
-        // ---------------- pitch: low-pass -> window -> FFT -> re^2 -> inverse FFT -> lag -------------
+    // returns f0 = sampleRate / lag (ref PitchAnalyser.h:57) and records the lag
+    __device__ __forceinline__ double pitch(int lane, const float (&xr)[P]) const
+    {
         double f0;
+        // ---------------- pitch: low-pass -> window -> FFT -> re^2 -> inverse FFT -> lag -------------
         lane = opaque(lane);
         {
 FX_MARK("lpf");
-        FX_STAMP(4);
             // a10 AudioFilter::filterAudio, ref RealTimeAudioAnalysis.h:106-125:
             //   y[0] = x[0];  y[n] = (a*x[n]) + (b*y[n-1]) in fp32, strictly serial.
             // Lane l owns samples [P*l, P*l+P).  It starts KW samples early from a guess, and the
@@ -539,7 +519,6 @@ FX_MARK("lpf");
             wave_fence();
 
 FX_MARK("pitch_fft");
-        FX_STAMP(5);
             lane = opaque(lane);
             float xf[P];
 #pragma unroll
@@ -549,7 +528,6 @@ FX_MARK("pitch_fft");
             wave_fence();
             fft_from_regs<N, false, OUT_POWER>(xf, cbuf, tw, p.first_tw, lane);            // ref RealTimeAnalyser.h:160
 FX_MARK("power");
-        FX_STAMP(6);
             // a11 getComplexConjugateMultiplication, ref PitchAnalyser.h:83-108: re*re, imag := 0,
             // picked up directly in the order the inverse transform's first pass wants it
             lane = opaque(lane);
@@ -561,7 +539,6 @@ FX_MARK("power");
 FX_MARK("ifft");
             fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, p.first_tw, lane, scale);        // a12 inverse, ref :110-121
 FX_MARK("vcalc");
-        FX_STAMP(7);
             // v[s] = d[s]*d[s]*s, d = planar JUCE inverse output scaled by 1/N (ref :122-123).
             // Only s in [1, N] is ever read by the lag search; v[N] comes from imag[0].
             lane = opaque(lane);
@@ -647,9 +624,16 @@ FX_MARK("scan");
             if (lane == 0) fpl->lag = lag;
         }
         wave_fence();
+        return f0;
+    }
 
+    __device__ __forceinline__ void harmonic_tail(int lane, HarmonicSpectrum& hs, double f0) const
+    {
+        float (&hre)[U] = hs.hre;
+        const float h_left2 = hs.left2, h_left1 = hs.left1, h_right1 = hs.right1;
+        double &h_sum = hs.sum;
+        const double h_max = hs.max;
 FX_MARK("harm2");
-        FX_STAMP(8);
         // ---------------- harmonic analyser, part 2 (ref HarmonicCharacteristics.h:71-105) ----------
         lane = opaque(lane);
 #ifdef FX_EXP_SKIP_HARM2
@@ -766,10 +750,11 @@ FX_MARK("harm2");
             if (lane == 0) { fpl->inh = inh; fpl->her_score = score; fpl->sum_normed = sum_normed; fpl->flags = 1; }
         }
         wave_fence();
-        }
+    }
 
+    __device__ __forceinline__ void store(int lane) const
+    {
 FX_MARK("store");
-        FX_STAMP(9);
         wave_fence();
         static_assert(sizeof(FramePart) % 16 == 0, "16-byte stores");
 #ifndef FX_EXPERIMENT_NOSTORE
@@ -777,13 +762,67 @@ FX_MARK("store");
             reinterpret_cast<uint4*>(p.part + ((size_t) c * T + t))[lane] = reinterpret_cast<const uint4*>(fpl)[lane];
 #endif
         wave_fence();
-        FX_STAMP(10);
+    }
+};
+
+// SPEC / HARM: which of the reference's two analysers run (RealTimeSpectralAnalyser,
+// RealTimeHarmonicAnalyser -- both by default, as AnalyserTrackController constructs them)
+template <int N, bool SPEC, bool HARM>
+__global__ void __launch_bounds__(Occ<N>::MAX_THREADS, Occ<N>::WAVES_PER_SIMD)
+fx_frame_kernel(const FrameParams p)
+{
+    typedef Geo<N> G;
+    constexpr int M = G::M, P = G::P;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f2*    tw   = reinterpret_cast<f2*>(smem);                              // [N]
+    float* prev = reinterpret_cast<float*>(tw + N);                         // [M]  re of the last accepted frame
+    int*   turn = reinterpret_cast<int*>(prev + M);                         // [4]
+    FramePart* parts = reinterpret_cast<FramePart*>(turn + 4);              // [waves] per-frame results, filled as they appear
+    unsigned char* per_wave = reinterpret_cast<unsigned char*>(parts + (blockDim.x >> 6));
+    constexpr size_t WAVE_BYTES = sizeof(f2) * G::CBUF;
+
+    const int nwaves = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6;
+    const int lane0 = threadIdx.x & 63;
+    const int c = blockIdx.x;
+    const int T = p.T;
+
+    f2*    cbuf = reinterpret_cast<f2*>(per_wave + WAVE_BYTES * wave);
+    float* rbuf = reinterpret_cast<float*>(cbuf);      // the same memory viewed as the real image
+
+    // workgroup prologue: twiddle table + this channel's flux state into LDS
+    for (int i = threadIdx.x; i < N; i += blockDim.x) tw[i] = reinterpret_cast<const f2*>(p.tw)[i];
+    for (int i = threadIdx.x; i < M; i += blockDim.x) prev[i] = p.prev_re[(size_t) c * M + i];
+    if (threadIdx.x == 0) turn[0] = 0;
+    __syncthreads();
+
+    const double nyquist = p.nyquist;
+    const double rnyq = 1.0 / nyquist;
+    const double frpb = nyquist / (double) M;          // ref SpectralCharacteristics.h:64,105
+    const float  scale = 1.0f / (float) N;             // JUCE inverse scale
+
+    for (int t = wave; t < T; t += nwaves) {
+        const int lane = opaque(lane0);
+        // uniform per-frame results go to LDS as soon as they exist instead of occupying ~28 VGPRs
+        // in every lane for the whole frame
+        FramePart* fpl = parts + wave;
+        if (lane == 0) { fpl->inh = 0.0; fpl->her_score = 0.0; fpl->sum_normed = 1.0; fpl->flags = 0; fpl->pad_ = 0; fpl->spare_ = 0.0; }
+        const FrameWave<N> w{p, tw, prev, turn, cbuf, rbuf, fpl, nyquist, rnyq, frpb, scale, c, T, t};
+
+        w.load_frame(lane);
+        float xr[P];
+        const float log_rms = w.rms(lane, xr);
+        if constexpr (SPEC) w.spectral(lane, xr, log_rms);
+        if constexpr (HARM) {
+            typename FrameWave<N>::HarmonicSpectrum hs;
+            w.harmonic_spectrum(lane, xr, hs);
+            const double f0 = w.pitch(lane, xr);
+            w.harmonic_tail(lane, hs, f0);
+        }
+        w.store(lane);
     }
 
-#ifdef FX_STAMPS
-    if (lane0 == 0 && p.debug)
-        for (int i = 0; i < 16; i++) atomicAdd(p.debug + i, stamp_acc[i]);
-#endif
     __syncthreads();
     for (int i = threadIdx.x; i < M; i += blockDim.x) p.prev_re[(size_t) c * M + i] = prev[i];
 }

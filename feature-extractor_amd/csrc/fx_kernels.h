@@ -56,7 +56,6 @@ struct FrameParams {
     float        lpf_a, lpf_b;  // ref RealTimeAudioAnalysis.h:122
     float        first_tw[18];  // the <= 9 twiddles of the first FFT pass (re, im pairs): wave-uniform, so they travel as
                                 // kernel arguments (SGPRs) instead of LDS reads; filled by fill_first_pass_twiddles
-    unsigned long long* debug;  // diagnostic builds (-DFX_STAMPS) only: [12] per-section cycle sums; else nullptr
 };
 
 struct EpilogueParams {

@@ -3,14 +3,6 @@
 // inlined helpers); not a stand-alone header.
 #define FX_MARK(name) asm volatile("; FXMARK " name)
 
-// Diagnostic build only (-DFX_STAMPS): per-section wave-cycle shares, summed into p.debug[section].
-// Never part of the shipped library; stamped builds are not timed (MI355X guide, "In-kernel stamps").
-#ifdef FX_STAMPS
-#define FX_STAMP(idx) do { unsigned long long now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
-                           stamp_acc[idx] += now_ - stamp_last; stamp_last = now_; } while (0)
-#else
-#define FX_STAMP(idx) do {} while (0)
-#endif
 
 typedef float  __attribute__((ext_vector_type(2))) f2;
 typedef float  __attribute__((ext_vector_type(4))) f4;
