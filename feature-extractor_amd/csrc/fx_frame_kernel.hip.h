@@ -189,6 +189,101 @@ FX_MARK("rms");
         return log_rms;
     }
 
+    // The flatness product with the serial-order semantics of `magnitudeProduct *= binMagnitude` (ref
+    // SpectralCharacteristics.h:92) over the bins whose magnitude exceeds eps, including IEEE overflow (sticky inf)
+    // and gradual underflow (sticky 0): exponent-extended prefix products locate the first prefix that leaves the
+    // normal range; an overflow decides at once, an underflow is finished serially in IEEE double.
+    __device__ __forceinline__ double flatness_product(int lane, const float (&re)[U], double eps) const
+    {
+FX_MARK("flatprod");
+        double prod;
+#ifdef FX_EXP_SKIP_FLATPROD
+        prod = 1.0;
+        if (false)
+#endif
+        {
+            FlatProd loc = {0.5, 1};                                       // 1.0
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const double v = (double) re[j];
+                const double mag = v * v;
+                if (mag > eps) loc = fp_mul(loc, mag);
+            }
+            // inclusive / exclusive scan of lane totals in lane (= bin) order; identity = 1.0 = (0.5, 1)
+            FlatProd inc = loc;
+#define FX_FP_STEP(CTRL, ROW_MASK) { FlatProd nb; nb.mant = dpp_d<CTRL, ROW_MASK>(0.5, inc.mant); nb.exp = dpp_i<CTRL, ROW_MASK>(1, inc.exp); inc = fp_mul2(nb, inc); }
+            FX_FP_STEP(DPP_ROW_SHR1, 0xF)
+            FX_FP_STEP(DPP_ROW_SHR2, 0xF)
+            FX_FP_STEP(DPP_ROW_SHR4, 0xF)
+            FX_FP_STEP(DPP_ROW_SHR8, 0xF)
+            FX_FP_STEP(DPP_BCAST15, 0xA)
+            FX_FP_STEP(DPP_BCAST31, 0xC)
+#undef FX_FP_STEP
+            FlatProd exc;
+            exc.mant = shift_up1(inc.mant, 0.5);
+            exc.exp = shift_up1(inc.exp, 1);
+            // replay the lane's chain from its true starting value, looking for the first prefix
+            // outside the normal range:  value = mant*2^exp with mant in [0.5,1)
+            //   overflow  : value >= 2^1024  <=> exp >= 1025
+            //   subnormal : value <  2^-1022 <=> exp <= -1022
+            int first_bad = 0x7fffffff;       // bin index of the first abnormal prefix
+            int bad_kind = 0;                 // 1 overflow, 2 subnormal
+            FlatProd run = exc;
+#pragma unroll
+            for (int j = 0; j < U; j++) {
+                const double v = (double) re[j];
+                const double mag = v * v;
+                if (mag > eps) {
+                    run = fp_mul(run, mag);
+                    if (first_bad == 0x7fffffff && run.mant != 0.0) {
+                        if (run.exp >= 1025) { first_bad = U * lane + j; bad_kind = 1; }
+                        else if (run.exp <= -1022) { first_bad = U * lane + j; bad_kind = 2; }
+                    }
+                }
+            }
+            const int fb = wave_min_i(first_bad);
+            const FlatProd total = {bcast63(inc.mant), __builtin_amdgcn_readlane(inc.exp, 63)};
+            if (fb == 0x7fffffff) {
+                prod = ldexp(total.mant, total.exp);
+            } else {
+                // which lane owns bin fb, and what happened there
+                const int owner = fb / U;
+                const int kind = lane_get(bad_kind, owner);
+                if (kind == 1) {
+                    prod = __builtin_huge_val();                           // inf * positive finite stays inf
+                } else {
+                    // value just before bin fb (normal), then IEEE double from fb onwards: the
+                    // owner of bin fb continues through its own bins, hands the product to the next
+                    // lane, and so on until it is exactly 0 (0 * finite stays 0) or the bins end
+                    FlatProd before = exc;
+#pragma unroll
+                    for (int j = 0; j < U; j++) {
+                        const double v = (double) re[j];
+                        const double mag = v * v;
+                        if (mag > eps && (U * lane + j) < fb) before = fp_mul(before, mag);
+                    }
+                    double pr = ldexp(lane_get(before.mant, owner), lane_get(before.exp, owner));
+                    double tailf[U];           // this lane's factors from bin fb on (1.0 = not a factor; x * 1.0 is exact)
+#pragma unroll
+                    for (int j = 0; j < U; j++) {
+                        const double v = (double) re[j];
+                        const double mag = v * v;
+                        tailf[j] = (mag > eps && (U * lane + j) >= fb) ? mag : 1.0;
+                    }
+                    for (int l = owner; l < 64; l++) {
+                        double mine = pr;
+#pragma unroll
+                        for (int j = 0; j < U; j++) mine *= tailf[j];
+                        pr = lane_get(mine, l);
+                        if (pr == 0.0) break;
+                    }
+                    prod = pr;
+                }
+            }
+        }
+        return prod;
+    }
+
     __device__ __forceinline__ void spectral(int lane, const float (&xr)[P], float log_rms) const
     {
         float spec_aux = 0.0f;
@@ -277,96 +372,7 @@ FX_MARK("flux");
             flux = wave_sum(flux);
 
             lane = opaque(lane);
-FX_MARK("flatprod");
-            // ---- flatness product: serial-order semantics of `magnitudeProduct *= binMagnitude` ----
-            // (ref :92) including IEEE overflow (sticky inf) and gradual underflow (sticky 0):
-            // exponent-extended prefix products locate the first prefix that leaves the normal
-            // range; an overflow decides at once, an underflow is finished serially in IEEE double.
-            double prod;
-#ifdef FX_EXP_SKIP_FLATPROD
-            prod = 1.0;
-            if (false)
-#endif
-            {
-                FlatProd loc = {0.5, 1};                                       // 1.0
-#pragma unroll
-                for (int j = 0; j < U; j++) {
-                    const double v = (double) re[j];
-                    const double mag = v * v;
-                    if (mag > eps) loc = fp_mul(loc, mag);
-                }
-                // inclusive / exclusive scan of lane totals in lane (= bin) order; identity = 1.0 = (0.5, 1)
-                FlatProd inc = loc;
-#define FX_FP_STEP(CTRL, ROW_MASK) { FlatProd nb; nb.mant = dpp_d<CTRL, ROW_MASK>(0.5, inc.mant); nb.exp = dpp_i<CTRL, ROW_MASK>(1, inc.exp); inc = fp_mul2(nb, inc); }
-                FX_FP_STEP(DPP_ROW_SHR1, 0xF)
-                FX_FP_STEP(DPP_ROW_SHR2, 0xF)
-                FX_FP_STEP(DPP_ROW_SHR4, 0xF)
-                FX_FP_STEP(DPP_ROW_SHR8, 0xF)
-                FX_FP_STEP(DPP_BCAST15, 0xA)
-                FX_FP_STEP(DPP_BCAST31, 0xC)
-#undef FX_FP_STEP
-                FlatProd exc;
-                exc.mant = shift_up1(inc.mant, 0.5);
-                exc.exp = shift_up1(inc.exp, 1);
-                // replay the lane's chain from its true starting value, looking for the first prefix
-                // outside the normal range:  value = mant*2^exp with mant in [0.5,1)
-                //   overflow  : value >= 2^1024  <=> exp >= 1025
-                //   subnormal : value <  2^-1022 <=> exp <= -1022
-                int first_bad = 0x7fffffff;       // bin index of the first abnormal prefix
-                int bad_kind = 0;                 // 1 overflow, 2 subnormal
-                FlatProd run = exc;
-#pragma unroll
-                for (int j = 0; j < U; j++) {
-                    const double v = (double) re[j];
-                    const double mag = v * v;
-                    if (mag > eps) {
-                        run = fp_mul(run, mag);
-                        if (first_bad == 0x7fffffff && run.mant != 0.0) {
-                            if (run.exp >= 1025) { first_bad = U * lane + j; bad_kind = 1; }
-                            else if (run.exp <= -1022) { first_bad = U * lane + j; bad_kind = 2; }
-                        }
-                    }
-                }
-                const int fb = wave_min_i(first_bad);
-                const FlatProd total = {bcast63(inc.mant), __builtin_amdgcn_readlane(inc.exp, 63)};
-                if (fb == 0x7fffffff) {
-                    prod = ldexp(total.mant, total.exp);
-                } else {
-                    // which lane owns bin fb, and what happened there
-                    const int owner = fb / U;
-                    const int kind = lane_get(bad_kind, owner);
-                    if (kind == 1) {
-                        prod = __builtin_huge_val();                           // inf * positive finite stays inf
-                    } else {
-                        // value just before bin fb (normal), then IEEE double from fb onwards: the
-                        // owner of bin fb continues through its own bins, hands the product to the next
-                        // lane, and so on until it is exactly 0 (0 * finite stays 0) or the bins end
-                        FlatProd before = exc;
-#pragma unroll
-                        for (int j = 0; j < U; j++) {
-                            const double v = (double) re[j];
-                            const double mag = v * v;
-                            if (mag > eps && (U * lane + j) < fb) before = fp_mul(before, mag);
-                        }
-                        double pr = ldexp(lane_get(before.mant, owner), lane_get(before.exp, owner));
-                        double tailf[U];           // this lane's factors from bin fb on (1.0 = not a factor; x * 1.0 is exact)
-#pragma unroll
-                        for (int j = 0; j < U; j++) {
-                            const double v = (double) re[j];
-                            const double mag = v * v;
-                            tailf[j] = (mag > eps && (U * lane + j) >= fb) ? mag : 1.0;
-                        }
-                        for (int l = owner; l < 64; l++) {
-                            double mine = pr;
-#pragma unroll
-                            for (int j = 0; j < U; j++) mine *= tailf[j];
-                            pr = lane_get(mine, l);
-                            if (pr == 0.0) break;
-                        }
-                        prod = pr;
-                    }
-                }
-            }
+            const double prod = flatness_product(lane, re, eps);
 
 FX_MARK("spec_pass2");
             // second pass over the lane's bins: spread needs the centroid, the slope needs the mean
@@ -436,195 +442,202 @@ FX_MARK("harm1");
     }
 
     // returns f0 = sampleRate / lag (ref PitchAnalyser.h:57) and records the lag
-    __device__ __forceinline__ double pitch(int lane, const float (&xr)[P]) const
+    // a10 + ref RealTimeAnalyser.h:157: the one-pole low-pass of the raw frame, windowed, left in the real image
+    __device__ __forceinline__ void lowpass_window(int lane, const float (&xr)[P]) const
     {
-        double f0;
-        // ---------------- pitch: low-pass -> window -> FFT -> re^2 -> inverse FFT -> lag -------------
-        lane = opaque(lane);
-        {
 FX_MARK("lpf");
-            // a10 AudioFilter::filterAudio, ref RealTimeAudioAnalysis.h:106-125:
-            //   y[0] = x[0];  y[n] = (a*x[n]) + (b*y[n-1]) in fp32, strictly serial.
-            // Lane l owns samples [P*l, P*l+P).  It starts KW samples early from a guess, and the
-            // recurrence (|b| = 0.208) forgets the guess; the value it reaches at P*l-1 must be
-            // bit-identical to what lane l-1 produced there, otherwise the chunk is redone from the
-            // neighbour's value until every hand-over matches (exact by induction from lane 0).
-            constexpr int KW = 16;
-            const float a = p.lpf_a, b = p.lpf_b;
+        // a10 AudioFilter::filterAudio, ref RealTimeAudioAnalysis.h:106-125:
+        //   y[0] = x[0];  y[n] = (a*x[n]) + (b*y[n-1]) in fp32, strictly serial.
+        // Lane l owns samples [P*l, P*l+P).  It starts KW samples early from a guess, and the
+        // recurrence (|b| = 0.208) forgets the guess; the value it reaches at P*l-1 must be
+        // bit-identical to what lane l-1 produced there, otherwise the chunk is redone from the
+        // neighbour's value until every hand-over matches (exact by induction from lane 0).
+        constexpr int KW = 16;
+        const float a = p.lpf_a, b = p.lpf_b;
 #pragma unroll
-            for (int g = 0; g < G::GA; g++)
+        for (int g = 0; g < G::GA; g++)
 #pragma unroll
-                for (int j = 0; j < G::RA; j++) (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)] = xr[g * G::RA + j];
-            wave_fence();
-            float x[P];
+            for (int j = 0; j < G::RA; j++) (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)] = xr[g * G::RA + j];
+        wave_fence();
+        float x[P];
 #pragma unroll
-            for (int i = 0; i < P; i += 4) {
-                const f4 v = *reinterpret_cast<const f4*>(&rbuf[rpad(P * lane + i)]);
-                x[i] = v.x; x[i + 1] = v.y; x[i + 2] = v.z; x[i + 3] = v.w;
-            }
-            float yin = 0.0f;                             // y[P*lane - 1] used as this chunk's input
-            {
-                const int first = P * lane;
+        for (int i = 0; i < P; i += 4) {
+            const f4 v = *reinterpret_cast<const f4*>(&rbuf[rpad(P * lane + i)]);
+            x[i] = v.x; x[i + 1] = v.y; x[i + 2] = v.z; x[i + 3] = v.w;
+        }
+        float yin = 0.0f;                             // y[P*lane - 1] used as this chunk's input
+        {
+            const int first = P * lane;
 #pragma unroll
-                for (int q = 0; q < KW / 4; q++) {
-                    const int n0 = first - KW + 4 * q;    // multiple of 4: the whole group is in range or not
-                    if (n0 >= 0) {
-                        const f4 v = *reinterpret_cast<const f4*>(&rbuf[rpad(n0)]);
-                        const float w[4] = {v.x, v.y, v.z, v.w};
+            for (int q = 0; q < KW / 4; q++) {
+                const int n0 = first - KW + 4 * q;    // multiple of 4: the whole group is in range or not
+                if (n0 >= 0) {
+                    const f4 v = *reinterpret_cast<const f4*>(&rbuf[rpad(n0)]);
+                    const float w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                        for (int e = 0; e < 4; e++)       // sample 0 starts the filter exactly; the first
-                            yin = (n0 + e == 0 || (q == 0 && e == 0)) ? w[e] : (a * w[e]) + (b * yin);   // warm-up sample is a guess
-                    }
+                    for (int e = 0; e < 4; e++)       // sample 0 starts the filter exactly; the first
+                        yin = (n0 + e == 0 || (q == 0 && e == 0)) ? w[e] : (a * w[e]) + (b * yin);   // warm-up sample is a guess
                 }
             }
-            wave_fence();
-            float y[P];
-            float ylast;
-            {
-                float yy = yin;
-#pragma unroll
-                for (int i = 0; i < P; i++) {
-                    yy = (lane == 0 && i == 0) ? x[0] : (a * x[i]) + (b * yy);
-                    y[i] = yy;
-                }
-                ylast = yy;
-            }
-            for (int iter = 0; iter < 64; iter++) {
-                const float pe = shift_up1(ylast, 0.0f);
-                const bool bad = lane > 0 && (__float_as_uint(pe) != __float_as_uint(yin));
-                if (!__any(bad)) break;
-                if (bad) {
-                    yin = pe;
-                    float yy = yin;
-#pragma unroll
-                    for (int i = 0; i < P; i++) { yy = (a * x[i]) + (b * yy); y[i] = yy; }
-                    ylast = yy;
-                }
-            }
-            // window the filtered frame (ref RealTimeAnalyser.h:157) and put it back in the real image.
-            // A lane's P samples lie in one half of the window; the gains w0 + i*wstep are exact dyadic
-            // numbers (so the fma rounds nothing) and equal bartlett_gain<N>(P*lane + i).
-            lane = opaque(lane);
-            const float w0 = bartlett_gain<N>(P * lane);
-            const float wstep = lane < 32 ? (2.0f / N) : -(2.0f / N);
-#pragma unroll
-            for (int i = 0; i < P; i += 4) {
-                f4 v;
-                v.x = y[i]     * __builtin_fmaf(wstep, (float) i, w0);
-                v.y = y[i + 1] * __builtin_fmaf(wstep, (float) (i + 1), w0);
-                v.z = y[i + 2] * __builtin_fmaf(wstep, (float) (i + 2), w0);
-                v.w = y[i + 3] * __builtin_fmaf(wstep, (float) (i + 3), w0);
-                *reinterpret_cast<f4*>(&rbuf[rpad(P * lane + i)]) = v;
-            }
-            wave_fence();
-
-FX_MARK("pitch_fft");
-            lane = opaque(lane);
-            float xf[P];
-#pragma unroll
-            for (int g = 0; g < G::GA; g++)
-#pragma unroll
-                for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)];
-            wave_fence();
-            fft_from_regs<N, false, OUT_POWER>(xf, cbuf, tw, p.first_tw, lane);            // ref RealTimeAnalyser.h:160
-FX_MARK("power");
-            // a11 getComplexConjugateMultiplication, ref PitchAnalyser.h:83-108: re*re, imag := 0,
-            // picked up directly in the order the inverse transform's first pass wants it
-            lane = opaque(lane);
-#pragma unroll
-            for (int g = 0; g < G::GA; g++)
-#pragma unroll
-                for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)];   // already squared
-            wave_fence();
-FX_MARK("ifft");
-            fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, p.first_tw, lane, scale);        // a12 inverse, ref :110-121
-FX_MARK("vcalc");
-            // v[s] = d[s]*d[s]*s, d = planar JUCE inverse output scaled by 1/N (ref :122-123).
-            // Only s in [1, N] is ever read by the lag search; v[N] comes from imag[0].
-            lane = opaque(lane);
-            float* vbuf = rbuf;                                                // [N+1] plain layout
-            float* sums = rbuf + N + 4;                                        // [N+1]; both fit in the buffer
-            wave_fence();
-FX_MARK("scan");
-            // a13 running fp32 sum (ref PitchAnalyser.h:138-150) -- serial by definition, so one lane
-            // adds, 64 samples at a time; after each block all lanes form cnd = v/sum (ref :146-154) for
-            // that block and advance a14's search (ref :161-190), which usually ends long before N:
-            //   first  = first s >= 2 with cnd[s] < 0.01
-            //   stop   = first s' >= first with !(cnd[s'+1] < cnd[s'])   (or N-1)
-            //   lag    = cnd[stop] <= cnd[stop+1] ? stop : stop+1        (ref :192-203)
-            // otherwise the global minimum over [2, N), first occurrence (ref :171-175).
-            float lag = -1.0f;
-            {
-                float run = 0.0f;                 // lane 0: the running sum
-                float carry = 0.0f;               // cnd of the last sample of the previous block
-                int first = 0x7fffffff;
-                bool done = false;
-                float best = 100.0f; int best_i = 0x7fffffff;
-#ifdef FX_EXP_SKIP_SCAN
-                for (int blk = 0; blk < (int) (scale * 0.5f) && !done; blk++) {
-#else
-                for (int blk = 0; blk < P && !done; blk++) {
-#endif
-                    if (lane == 0) {
-#pragma unroll
-                        for (int g = 0; g < 64; g += 4) {
-                            const f4 v = *reinterpret_cast<const f4*>(&vbuf[64 * blk + g]);
-                            f4 o;
-                            if (g != 0 || blk != 0) run += v.x;               // the sum starts at sample 1
-                            o.x = run;
-                            run += v.y; o.y = run;
-                            run += v.z; o.z = run;
-                            run += v.w; o.w = run;
-                            *reinterpret_cast<f4*>(&sums[64 * blk + g]) = o;
-                        }
-                    }
-                    wave_fence();
-                    const int s_ = 64 * blk + lane;
-                    const float sm = sums[s_];
-                    const float v = vbuf[s_];
-                    const float c_ = (sm != 0.0f) ? v / sm : 0.0f;
-                    const float p_ = shift_up1(c_, carry);                     // cnd of the previous sample
-                    carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_), 63));
-                    if (s_ >= 2 && c_ < best) { best = c_; best_i = s_; }
-                    if (first == 0x7fffffff) {
-                        const unsigned long long hit = __ballot(s_ >= 2 && c_ < 0.01f);
-                        if (hit) first = 64 * blk + (int) __builtin_ctzll(hit);
-                    }
-                    if (first != 0x7fffffff) {
-                        // sample s-1 ends the walk if it is past `first` and cnd does not keep falling
-                        const unsigned long long st = __ballot(s_ - 1 >= first && !(c_ < p_));
-                        if (st) {
-                            const int src = (int) __builtin_ctzll(st);
-                            const float pc = lane_get(p_, src), cc = lane_get(c_, src);
-                            const int sstar = 64 * blk + src;
-                            lag = (pc <= cc) ? (float) (sstar - 1) : (float) sstar;
-                            done = true;
-                        }
-                    }
-                }
-                if (!done) {
-                    if (first != 0x7fffffff) {
-                        // the walk ran to N-1 (ref :178: sample + 1 < numSamples); compare with cnd[N]
-                        float cn = 0.0f;
-                        if (lane == 0) { run += vbuf[N]; cn = (run != 0.0f) ? vbuf[N] / run : 0.0f; }
-                        cn = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cn)));
-                        lag = (carry <= cn) ? (float) (N - 1) : (float) N;
-                    } else {
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) {
-                            const float ov = __shfl_xor(best, o, 64);
-                            const int oi = __shfl_xor(best_i, o, 64);
-                            if (ov < best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
-                        }
-                        lag = best_i == 0x7fffffff ? -1.0f : (float) best_i;
-                    }
-                }
-            }
-            f0 = (nyquist * 2.0) / (double) lag;                               // ref PitchAnalyser.h:57
-            if (lane == 0) fpl->lag = lag;
         }
         wave_fence();
-        return f0;
+        float y[P];
+        float ylast;
+        {
+            float yy = yin;
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                yy = (lane == 0 && i == 0) ? x[0] : (a * x[i]) + (b * yy);
+                y[i] = yy;
+            }
+            ylast = yy;
+        }
+        for (int iter = 0; iter < 64; iter++) {
+            const float pe = shift_up1(ylast, 0.0f);
+            const bool bad = lane > 0 && (__float_as_uint(pe) != __float_as_uint(yin));
+            if (!__any(bad)) break;
+            if (bad) {
+                yin = pe;
+                float yy = yin;
+#pragma unroll
+                for (int i = 0; i < P; i++) { yy = (a * x[i]) + (b * yy); y[i] = yy; }
+                ylast = yy;
+            }
+        }
+        // window the filtered frame (ref RealTimeAnalyser.h:157) and put it back in the real image.
+        // A lane's P samples lie in one half of the window; the gains w0 + i*wstep are exact dyadic
+        // numbers (so the fma rounds nothing) and equal bartlett_gain<N>(P*lane + i).
+        lane = opaque(lane);
+        const float w0 = bartlett_gain<N>(P * lane);
+        const float wstep = lane < 32 ? (2.0f / N) : -(2.0f / N);
+#pragma unroll
+        for (int i = 0; i < P; i += 4) {
+            f4 v;
+            v.x = y[i]     * __builtin_fmaf(wstep, (float) i, w0);
+            v.y = y[i + 1] * __builtin_fmaf(wstep, (float) (i + 1), w0);
+            v.z = y[i + 2] * __builtin_fmaf(wstep, (float) (i + 2), w0);
+            v.w = y[i + 3] * __builtin_fmaf(wstep, (float) (i + 3), w0);
+            *reinterpret_cast<f4*>(&rbuf[rpad(P * lane + i)]) = v;
+        }
+        wave_fence();
+    }
+
+    // a13 / a14 on the v[] array the inverse transform left in the buffer: the lag estimate (ref PitchAnalyser.h:129-217)
+    __device__ __forceinline__ float lag_search(int lane) const
+    {
+FX_MARK("vcalc");
+        // v[s] = d[s]*d[s]*s, d = planar JUCE inverse output scaled by 1/N (ref :122-123).
+        // Only s in [1, N] is ever read by the lag search; v[N] comes from imag[0].
+        lane = opaque(lane);
+        float* vbuf = rbuf;                                                // [N+1] plain layout
+        float* sums = rbuf + N + 4;                                        // [N+1]; both fit in the buffer
+        wave_fence();
+FX_MARK("scan");
+        // a13 running fp32 sum (ref PitchAnalyser.h:138-150) -- serial by definition, so one lane
+        // adds, 64 samples at a time; after each block all lanes form cnd = v/sum (ref :146-154) for
+        // that block and advance a14's search (ref :161-190), which usually ends long before N:
+        //   first  = first s >= 2 with cnd[s] < 0.01
+        //   stop   = first s' >= first with !(cnd[s'+1] < cnd[s'])   (or N-1)
+        //   lag    = cnd[stop] <= cnd[stop+1] ? stop : stop+1        (ref :192-203)
+        // otherwise the global minimum over [2, N), first occurrence (ref :171-175).
+        float lag = -1.0f;
+        {
+            float run = 0.0f;                 // lane 0: the running sum
+            float carry = 0.0f;               // cnd of the last sample of the previous block
+            int first = 0x7fffffff;
+            bool done = false;
+            float best = 100.0f; int best_i = 0x7fffffff;
+#ifdef FX_EXP_SKIP_SCAN
+            for (int blk = 0; blk < (int) (scale * 0.5f) && !done; blk++) {
+#else
+            for (int blk = 0; blk < P && !done; blk++) {
+#endif
+                if (lane == 0) {
+#pragma unroll
+                    for (int g = 0; g < 64; g += 4) {
+                        const f4 v = *reinterpret_cast<const f4*>(&vbuf[64 * blk + g]);
+                        f4 o;
+                        if (g != 0 || blk != 0) run += v.x;               // the sum starts at sample 1
+                        o.x = run;
+                        run += v.y; o.y = run;
+                        run += v.z; o.z = run;
+                        run += v.w; o.w = run;
+                        *reinterpret_cast<f4*>(&sums[64 * blk + g]) = o;
+                    }
+                }
+                wave_fence();
+                const int s_ = 64 * blk + lane;
+                const float sm = sums[s_];
+                const float v = vbuf[s_];
+                const float c_ = (sm != 0.0f) ? v / sm : 0.0f;
+                const float p_ = shift_up1(c_, carry);                     // cnd of the previous sample
+                carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_), 63));
+                if (s_ >= 2 && c_ < best) { best = c_; best_i = s_; }
+                if (first == 0x7fffffff) {
+                    const unsigned long long hit = __ballot(s_ >= 2 && c_ < 0.01f);
+                    if (hit) first = 64 * blk + (int) __builtin_ctzll(hit);
+                }
+                if (first != 0x7fffffff) {
+                    // sample s-1 ends the walk if it is past `first` and cnd does not keep falling
+                    const unsigned long long st = __ballot(s_ - 1 >= first && !(c_ < p_));
+                    if (st) {
+                        const int src = (int) __builtin_ctzll(st);
+                        const float pc = lane_get(p_, src), cc = lane_get(c_, src);
+                        const int sstar = 64 * blk + src;
+                        lag = (pc <= cc) ? (float) (sstar - 1) : (float) sstar;
+                        done = true;
+                    }
+                }
+            }
+            if (!done) {
+                if (first != 0x7fffffff) {
+                    // the walk ran to N-1 (ref :178: sample + 1 < numSamples); compare with cnd[N]
+                    float cn = 0.0f;
+                    if (lane == 0) { run += vbuf[N]; cn = (run != 0.0f) ? vbuf[N] / run : 0.0f; }
+                    cn = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cn)));
+                    lag = (carry <= cn) ? (float) (N - 1) : (float) N;
+                } else {
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const float ov = __shfl_xor(best, o, 64);
+                        const int oi = __shfl_xor(best_i, o, 64);
+                        if (ov < best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+                    }
+                    lag = best_i == 0x7fffffff ? -1.0f : (float) best_i;
+                }
+            }
+        }
+        return lag;
+    }
+
+    // pitch: low-pass -> window -> FFT -> re^2 -> inverse FFT -> lag; returns f0 = sampleRate / lag (ref PitchAnalyser.h:57)
+    __device__ __forceinline__ double pitch(int lane, const float (&xr)[P]) const
+    {
+        lowpass_window(opaque(lane), xr);
+FX_MARK("pitch_fft");
+        lane = opaque(lane);
+        float xf[P];
+#pragma unroll
+        for (int g = 0; g < G::GA; g++)
+#pragma unroll
+            for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)];
+        wave_fence();
+        fft_from_regs<N, false, OUT_POWER>(xf, cbuf, tw, p.first_tw, lane);            // ref RealTimeAnalyser.h:160
+FX_MARK("power");
+        // a11 getComplexConjugateMultiplication, ref PitchAnalyser.h:83-108: re*re, imag := 0,
+        // picked up directly in the order the inverse transform's first pass wants it
+        lane = opaque(lane);
+#pragma unroll
+        for (int g = 0; g < G::GA; g++)
+#pragma unroll
+            for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)];   // already squared
+        wave_fence();
+FX_MARK("ifft");
+        fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, p.first_tw, lane, scale);        // a12 inverse, ref :110-121
+        const float lag = lag_search(lane);
+        if (lane == 0) fpl->lag = lag;
+        wave_fence();
+        return (nyquist * 2.0) / (double) lag;
     }
 
     __device__ __forceinline__ void harmonic_tail(int lane, HarmonicSpectrum& hs, double f0) const
