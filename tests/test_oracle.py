@@ -92,6 +92,18 @@ def test_impulse_triggers_an_amplitude_onset_one_hop_later():
     assert raw[7, fo.ONSET] == 1.0 and raw[6, fo.ONSET] == 0.0
 
 
+def test_dc_input_has_a_slightly_negative_slope():
+    """a DC 0.5 input run through the real headers gave a slope just below zero, all energy in the
+    low fifth of the spectrum and rms = log10(0.5 * 9 + 1)."""
+    hops = np.full((1, 12, 1024), 0.5, np.float32)
+    raw, _ = fo.push_hops(hops, 2048)
+    last = raw[0, -1]
+    assert -1e-3 < last[fo.SLOPE] < 0.0
+    assert last[fo.LER] == 1.0
+    assert last[fo.RMS] == np.float32(np.log10(np.float32(0.5) * np.float32(9.0) + np.float32(1.0)))
+    assert last[fo.ONSET] == 0.0 and last[fo.FLUX] == 0.0
+
+
 def test_oer_slot_is_a_copy_of_her():
     raw, sm = fo.Channel(1024).push_hops(signals.tone_vibrato_noise(1, 12, 1024)[0])
     assert np.array_equal(raw[:, fo.OER], raw[:, fo.HER])
