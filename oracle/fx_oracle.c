@@ -827,6 +827,7 @@ typedef struct {
     double sr;
     const float* frames;
     float *raw, *smoothed;
+    const fxo_settings* settings;   /* NULL: defaults, `frames` holds pre-assembled windows; else `frames` holds hops */
 } batch_job;
 
 static void* batch_worker(void* arg)
@@ -836,15 +837,40 @@ static void* batch_worker(void* arg)
         fxo_channel* ch = fxo_create(j->window, j->sr, j->order);
         if (!ch) return NULL;
         const size_t o = (size_t) c * j->T;
-        fxo_process_frames(ch, j->frames + o * j->window, j->T,
-                           j->raw ? j->raw + o * FXO_NUM_FEATURES : NULL,
-                           j->smoothed ? j->smoothed + o * FXO_NUM_FEATURES : NULL);
+        float* raw = j->raw ? j->raw + o * FXO_NUM_FEATURES : NULL;
+        float* sm = j->smoothed ? j->smoothed + o * FXO_NUM_FEATURES : NULL;
+        if (j->settings) {
+            fxo_set_gain(ch, j->settings->gain);
+            fxo_set_onset_type(ch, j->settings->onset_type);
+            fxo_set_onset_sensitivity(ch, j->settings->onset_sensitivity);
+            fxo_set_onset_window(ch, j->settings->onset_window);
+            fxo_set_analysers(ch, j->settings->analysers);
+            fxo_push_hops(ch, j->frames + o * (size_t) (j->window / 2), j->T, raw, sm);
+        } else {
+            fxo_process_frames(ch, j->frames + o * j->window, j->T, raw, sm);
+        }
         fxo_destroy(ch);
     }
     return NULL;
 }
 
+static int run_batch(int window_size, double sample_rate, int order_mode, const float* data, const fxo_settings* settings,
+                     int C, int T, float* raw, float* smoothed, int threads);
+
 int fxo_batch_frames(int window_size, double sample_rate, int order_mode, const float* frames,
+                     int C, int T, float* raw, float* smoothed, int threads)
+{
+    return run_batch(window_size, sample_rate, order_mode, frames, NULL, C, T, raw, smoothed, threads);
+}
+
+int fxo_batch_hops(int window_size, double sample_rate, int order_mode, const fxo_settings* settings, const float* hops,
+                   int C, int T, float* raw, float* smoothed, int threads)
+{
+    if (!settings) return -1;
+    return run_batch(window_size, sample_rate, order_mode, hops, settings, C, T, raw, smoothed, threads);
+}
+
+static int run_batch(int window_size, double sample_rate, int order_mode, const float* frames, const fxo_settings* settings,
                      int C, int T, float* raw, float* smoothed, int threads)
 {
     if (threads < 1) threads = 1;
@@ -855,7 +881,7 @@ int fxo_batch_frames(int window_size, double sample_rate, int order_mode, const 
     int started = 0, rc = 0;
     for (int i = 0; i < threads; i++) {
         batch_job j = { window_size, order_mode, (int) ((long long) C * i / threads),
-                        (int) ((long long) C * (i + 1) / threads), T, sample_rate, frames, raw, smoothed };
+                        (int) ((long long) C * (i + 1) / threads), T, sample_rate, frames, raw, smoothed, settings };
         jobs[i] = j;
         if (pthread_create(&th[i], NULL, batch_worker, &jobs[i]) != 0) { rc = -1; break; }
         started++;

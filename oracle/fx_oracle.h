@@ -80,6 +80,10 @@ void fxo_push_hops(fxo_channel*, const float* hops, int T, float* raw, float* sm
  * frames [C][T][N]; raw/smoothed [C][T][12] (either may be NULL).  Returns 0 on success. */
 int fxo_batch_frames(int window_size, double sample_rate, int order_mode, const float* frames,
                      int C, int T, float* raw, float* smoothed, int threads);
+/* The same over hops [C][T][N/2] with the runtime settings applied to every channel before its first hop. */
+typedef struct { float gain; int onset_type; float onset_sensitivity; int onset_window; int analysers; } fxo_settings;
+int fxo_batch_hops(int window_size, double sample_rate, int order_mode, const fxo_settings* settings, const float* hops,
+                   int C, int T, float* raw, float* smoothed, int threads);
 
 /* ---- taps (stateless building blocks, exposed for unit tests) ---- */
 /* JUCE 4.2 FFT restatement; in/out are interleaved complex, size n. */

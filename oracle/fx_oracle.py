@@ -34,6 +34,11 @@ def build(force=False):
 _lib = None
 
 
+class Settings(ctypes.Structure):
+    _fields_ = [("gain", ctypes.c_float), ("onset_type", ctypes.c_int), ("onset_sensitivity", ctypes.c_float),
+                ("onset_window", ctypes.c_int), ("analysers", ctypes.c_int)]
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -55,6 +60,8 @@ def lib():
         L.fxo_push_hops.argtypes = [vp, fp, ctypes.c_int, fp, fp]
         L.fxo_batch_frames.restype = ctypes.c_int
         L.fxo_batch_frames.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int, fp, fp, ctypes.c_int]
+        L.fxo_batch_hops.restype = ctypes.c_int
+        L.fxo_batch_hops.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.POINTER(Settings), fp, ctypes.c_int, ctypes.c_int, fp, fp, ctypes.c_int]
         L.fxo_fft_complex.argtypes = [ctypes.c_int, ctypes.c_int, fp, fp]
         L.fxo_forward_real.argtypes = [ctypes.c_int, fp, fp]
         L.fxo_bartlett.argtypes = [ctypes.c_int, fp]
@@ -166,6 +173,22 @@ def batch_frames(frames, window_size, sample_rate=48000.0, order=ORDER_SPECTRAL_
     rc = lib().fxo_batch_frames(int(window_size), float(sample_rate), int(order), _fp(frames), C, T, _fp(raw), _fp(sm), int(threads))
     if rc != 0:
         raise RuntimeError("fxo_batch_frames failed")
+    return raw, sm
+
+
+def batch_hops(hops, window_size, sample_rate=48000.0, order=ORDER_SPECTRAL_THEN_HARMONIC, threads=1, gain=1.0,
+               onset_type=ONSET_COMBINATION, onset_sensitivity=None, onset_window=5, analysers=3):
+    """hops [C][T][N/2] -> (raw, smoothed) like push_hops(), analysed by `threads` pthreads inside the C library."""
+    hops = _f32(hops)
+    C, T = hops.shape[0], hops.shape[1]
+    raw = np.empty((C, T, NUM_FEATURES), np.float32)
+    sm = np.empty((C, T, NUM_FEATURES), np.float32)
+    if onset_sensitivity is None:
+        raise ValueError("onset_sensitivity must be given (the channel default is set through the same setter)")
+    st = Settings(float(gain), int(onset_type), float(onset_sensitivity), int(onset_window), int(analysers))
+    rc = lib().fxo_batch_hops(int(window_size), float(sample_rate), int(order), ctypes.byref(st), _fp(hops), C, T, _fp(raw), _fp(sm), int(threads))
+    if rc != 0:
+        raise RuntimeError("fxo_batch_hops failed")
     return raw, sm
 
 

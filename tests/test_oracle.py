@@ -200,3 +200,11 @@ def test_oracle_reproduces_committed_fixtures(path):
     T = g["hops"].shape[1]
     if T >= 2:
         assert raw[0, T - 1, fo.F0] == np.float32(f0 / 5000.0)
+
+
+def test_threaded_hop_batch_equals_per_channel_calls():
+    hops = (np.random.default_rng(5).standard_normal((7, 9, 256)) * 0.2).astype(np.float32)
+    kw = dict(order=1, gain=0.5, onset_type=fo.ONSET_AMPLITUDE, onset_sensitivity=0.7, onset_window=4, analysers=3)
+    a = fo.push_hops(hops, 512, **kw)
+    b = fo.batch_hops(hops, 512, threads=3, **kw)
+    assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True)

@@ -11,6 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 fx = importlib.import_module("feature-extractor_amd")
 from oracle import fx_oracle as fo
+from bench import usable_cores
+
+THREADS = usable_cores()
 
 
 def make_signal(rng, C, T, N):
@@ -54,7 +57,7 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
     worst = 0.0
     while time.time() < t_end and (max_cases is None or cases < max_cases):
         N = int(rng.choice([256, 512, 1024, 1024, 2048, 2048, 4096]))
-        C = int(rng.integers(1, 12)) if rng.random() < 0.9 else int(rng.integers(12, 80))
+        C = int(rng.integers(1, 24)) if rng.random() < 0.8 else int(rng.integers(24, 200))
         T = int(rng.integers(1, 40)) if rng.random() < 0.9 else int(rng.integers(40, 130))
         order = int(rng.integers(0, 3))
         otype = int(rng.integers(0, 3))
@@ -70,7 +73,7 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
         split = int(rng.integers(0, T + 1))
         parts = [an.push_hops(hops[:, :split]), an.push_hops(hops[:, split:])]
         raw = np.concatenate([p[0] for p in parts], 1); sm = np.concatenate([p[1] for p in parts], 1)
-        oraw, osm = fo.push_hops(hops, N, order=order, onset_type=otype, onset_window=owin, onset_sensitivity=sens, gain=gain, analysers=mask)
+        oraw, osm = fo.batch_hops(hops, N, order=order, threads=THREADS, onset_type=otype, onset_window=owin, onset_sensitivity=sens, gain=gain, analysers=mask)
         cases += 1; frames += C * T
         for name, g, w in (("raw", raw, oraw), ("smoothed", sm, osm)):
             g64, w64 = g.astype(np.float64), w.astype(np.float64)
