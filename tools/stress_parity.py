@@ -55,6 +55,7 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
     t_end = time.time() + seconds
     cases = frames = bad_cases = 0
     worst = 0.0
+    inexact = np.zeros(12, np.int64)      # values that are within tolerance but not bit-identical, per slot
     while time.time() < t_end and (max_cases is None or cases < max_cases):
         N = int(rng.choice([256, 512, 1024, 1024, 2048, 2048, 4096]))
         C = int(rng.integers(1, 24)) if rng.random() < 0.8 else int(rng.integers(24, 200))
@@ -84,6 +85,8 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
             tol = np.full(12, 1e-5); tol[0] = 0.0
             bad = np.argwhere(err > tol)
             worst = max(worst, float(np.max(np.where(np.isfinite(err), err, 0))))
+            if name == "raw":
+                inexact += np.count_nonzero(~same, axis=(0, 1))
             if len(bad):
                 bad_cases += 1
                 if save_failures and bad_cases <= 6:
@@ -94,6 +97,8 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
                 if verbose:
                     print("MISMATCH %s N=%d C=%d T=%d order=%d otype=%d owin=%d: %d values; first c=%d t=%d %s gpu=%r oracle=%r"
                           % (name, N, C, T, order, otype, owin, len(bad), c, t, fx.FEATURE_NAMES[f], g[c, t, f], w[c, t, f]), flush=True)
+    if verbose and inexact.any():
+        print("raw values not bit-identical (within tolerance), per slot:", dict((fx.FEATURE_NAMES[i], int(n)) for i, n in enumerate(inexact) if n), flush=True)
     return cases, frames, bad_cases, worst
 
 
