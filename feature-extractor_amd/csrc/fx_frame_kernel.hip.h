@@ -191,97 +191,69 @@ FX_MARK("rms");
 
     // The flatness product with the serial-order semantics of `magnitudeProduct *= binMagnitude` (ref
     // SpectralCharacteristics.h:92) over the bins whose magnitude exceeds eps, including IEEE overflow (sticky inf)
-    // and gradual underflow (sticky 0): exponent-extended prefix products locate the first prefix that leaves the
-    // normal range; an overflow decides at once, an underflow is finished serially in IEEE double.
+    // and gradual underflow (precision loss, sticky 0).  Exponent-extended products (mantissa in [0.5,1) + int
+    // exponent) are formed per lane and scanned across lanes; each lane also keeps the range of exponents its own
+    // prefixes pass through.  If no prefix of the serial product can have left the normal range, the product is the
+    // scan's total.  Otherwise the product is continued in plain IEEE double from the start of the first lane where
+    // that may happen, lane to lane in bin order, until it is exactly 0 or inf (both absorbing) or the bins end.
     __device__ __forceinline__ double flatness_product(int lane, const float (&re)[U], double eps) const
     {
 FX_MARK("flatprod");
-        double prod;
 #ifdef FX_EXP_SKIP_FLATPROD
-        prod = 1.0;
-        if (false)
+        return 1.0;
 #endif
-        {
-            FlatProd loc = {0.5, 1};                                       // 1.0
+        FlatProd loc = {0.5, 1};                                           // 1.0
+        int emin = 1, emax = 1;                                            // exponents of the lane's own prefixes (1 = the empty one)
 #pragma unroll
-            for (int j = 0; j < U; j++) {
-                const double v = (double) re[j];
-                const double mag = v * v;
-                if (mag > eps) loc = fp_mul(loc, mag);
-            }
-            // inclusive / exclusive scan of lane totals in lane (= bin) order; identity = 1.0 = (0.5, 1)
-            FlatProd inc = loc;
-#define FX_FP_STEP(CTRL, ROW_MASK) { FlatProd nb; nb.mant = dpp_d<CTRL, ROW_MASK>(0.5, inc.mant); nb.exp = dpp_i<CTRL, ROW_MASK>(1, inc.exp); inc = fp_mul2(nb, inc); }
-            FX_FP_STEP(DPP_ROW_SHR1, 0xF)
-            FX_FP_STEP(DPP_ROW_SHR2, 0xF)
-            FX_FP_STEP(DPP_ROW_SHR4, 0xF)
-            FX_FP_STEP(DPP_ROW_SHR8, 0xF)
-            FX_FP_STEP(DPP_BCAST15, 0xA)
-            FX_FP_STEP(DPP_BCAST31, 0xC)
-#undef FX_FP_STEP
-            FlatProd exc;
-            exc.mant = shift_up1(inc.mant, 0.5);
-            exc.exp = shift_up1(inc.exp, 1);
-            // replay the lane's chain from its true starting value, looking for the first prefix
-            // outside the normal range:  value = mant*2^exp with mant in [0.5,1)
-            //   overflow  : value >= 2^1024  <=> exp >= 1025
-            //   subnormal : value <  2^-1022 <=> exp <= -1022
-            int first_bad = 0x7fffffff;       // bin index of the first abnormal prefix
-            int bad_kind = 0;                 // 1 overflow, 2 subnormal
-            FlatProd run = exc;
-#pragma unroll
-            for (int j = 0; j < U; j++) {
-                const double v = (double) re[j];
-                const double mag = v * v;
-                if (mag > eps) {
-                    run = fp_mul(run, mag);
-                    if (first_bad == 0x7fffffff && run.mant != 0.0) {
-                        if (run.exp >= 1025) { first_bad = U * lane + j; bad_kind = 1; }
-                        else if (run.exp <= -1022) { first_bad = U * lane + j; bad_kind = 2; }
-                    }
-                }
-            }
-            const int fb = wave_min_i(first_bad);
-            const FlatProd total = {bcast63(inc.mant), __builtin_amdgcn_readlane(inc.exp, 63)};
-            if (fb == 0x7fffffff) {
-                prod = ldexp(total.mant, total.exp);
-            } else {
-                // which lane owns bin fb, and what happened there
-                const int owner = fb / U;
-                const int kind = lane_get(bad_kind, owner);
-                if (kind == 1) {
-                    prod = __builtin_huge_val();                           // inf * positive finite stays inf
-                } else {
-                    // value just before bin fb (normal), then IEEE double from fb onwards: the
-                    // owner of bin fb continues through its own bins, hands the product to the next
-                    // lane, and so on until it is exactly 0 (0 * finite stays 0) or the bins end
-                    FlatProd before = exc;
-#pragma unroll
-                    for (int j = 0; j < U; j++) {
-                        const double v = (double) re[j];
-                        const double mag = v * v;
-                        if (mag > eps && (U * lane + j) < fb) before = fp_mul(before, mag);
-                    }
-                    double pr = ldexp(lane_get(before.mant, owner), lane_get(before.exp, owner));
-                    double tailf[U];           // this lane's factors from bin fb on (1.0 = not a factor; x * 1.0 is exact)
-#pragma unroll
-                    for (int j = 0; j < U; j++) {
-                        const double v = (double) re[j];
-                        const double mag = v * v;
-                        tailf[j] = (mag > eps && (U * lane + j) >= fb) ? mag : 1.0;
-                    }
-                    for (int l = owner; l < 64; l++) {
-                        double mine = pr;
-#pragma unroll
-                        for (int j = 0; j < U; j++) mine *= tailf[j];
-                        pr = lane_get(mine, l);
-                        if (pr == 0.0) break;
-                    }
-                    prod = pr;
-                }
+        for (int j = 0; j < U; j++) {
+            const double v = (double) re[j];
+            const double mag = v * v;
+            if (mag > eps) {
+                loc = fp_mul(loc, mag);
+                emin = loc.exp < emin ? loc.exp : emin;
+                emax = loc.exp > emax ? loc.exp : emax;
             }
         }
-        return prod;
+        // inclusive / exclusive scan of lane totals in lane (= bin) order; identity = 1.0 = (0.5, 1)
+        FlatProd inc = loc;
+#define FX_FP_STEP(CTRL, ROW_MASK) { FlatProd nb; nb.mant = dpp_d<CTRL, ROW_MASK>(0.5, inc.mant); nb.exp = dpp_i<CTRL, ROW_MASK>(1, inc.exp); inc = fp_mul2(nb, inc); }
+        FX_FP_STEP(DPP_ROW_SHR1, 0xF)
+        FX_FP_STEP(DPP_ROW_SHR2, 0xF)
+        FX_FP_STEP(DPP_ROW_SHR4, 0xF)
+        FX_FP_STEP(DPP_ROW_SHR8, 0xF)
+        FX_FP_STEP(DPP_BCAST15, 0xA)
+        FX_FP_STEP(DPP_BCAST31, 0xC)
+#undef FX_FP_STEP
+        FlatProd exc;
+        exc.mant = shift_up1(inc.mant, 0.5);
+        exc.exp = shift_up1(inc.exp, 1);
+        // A prefix inside this lane is (exc.mant * m) * 2^(exc.exp + e) with m in [0.5,1) and e in [emin, emax]: the
+        // mantissa product lies in [0.25,1), so its normalised exponent is exc.exp + e - 1 or exc.exp + e.
+        //   overflow  : value >= 2^1024  <=> exponent >= 1025
+        //   subnormal : value <  2^-1022 <=> exponent <= -1022
+        const bool risky = (exc.exp + emax >= 1025) || (exc.exp + emin - 1 <= -1022);
+        const unsigned long long risky_lanes = __ballot(risky);
+        if (risky_lanes == 0)
+            return ldexp(bcast63(inc.mant), __builtin_amdgcn_readlane(inc.exp, 63));
+        // every prefix before the first risky lane is normal, so the serial IEEE product equals the scan there (to
+        // rounding); from that lane on the factors are multiplied one by one in double, as the reference does
+        const int owner = (int) __builtin_ctzll(risky_lanes);
+        double pr = ldexp(lane_get(exc.mant, owner), lane_get(exc.exp, owner));
+        double factor[U];                  // 1.0 = not a factor (x * 1.0 is exact)
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const double v = (double) re[j];
+            const double mag = v * v;
+            factor[j] = mag > eps ? mag : 1.0;
+        }
+        for (int l = owner; l < 64; l++) {
+            double mine = pr;
+#pragma unroll
+            for (int j = 0; j < U; j++) mine *= factor[j];
+            pr = lane_get(mine, l);
+            if (pr == 0.0 || pr == __builtin_huge_val()) break;           // 0 * finite = 0, inf * positive = inf
+        }
+        return pr;
     }
 
     __device__ __forceinline__ void spectral(int lane, const float (&xr)[P], float log_rms) const
