@@ -667,15 +667,16 @@ FX_MARK("harm2");
                 // binIsPeak :127-145: above the mean and none of bins -2,-1,+1 larger (windows are
                 // clipped at the ends, :136-138: no +1 neighbour for the last two bins).
                 // mag = (double) re^2 is exact, so comparing |re| compares magnitudes exactly.
-                const int m = U * lane + j;
                 const float me = fabsf(hre[j]);
                 const float l2 = j >= 2 ? fabsf(hre[j >= 2 ? j - 2 : 0]) : (j == 1 ? h_left1 : h_left2);
                 const float l1 = j >= 1 ? fabsf(hre[j >= 1 ? j - 1 : 0]) : h_left1;
                 const float r1 = j + 1 < U ? fabsf(hre[j + 1 < U ? j + 1 : 0]) : h_right1;
+                // Neighbours that do not exist (below bin 0, above bin M-1) were loaded as 0 and are never greater;
+                // the one clipped neighbour that does exist is bin M-1 seen from bin M-2 (lane 63, j = U-2).
                 bool pk = mag > mean_mag;
-                if (m >= 2 && l2 > me) pk = false;
-                if (m >= 1 && l1 > me) pk = false;
-                if (m < M - 2 && r1 > me) pk = false;
+                if (l2 > me) pk = false;
+                if (l1 > me) pk = false;
+                if (r1 > me && !(j == U - 2 && lane == 63)) pk = false;
                 if (pk) peak_mask |= 1u << j;
             }
             lds_store_block<U>(normed + U * lane, nrm);
