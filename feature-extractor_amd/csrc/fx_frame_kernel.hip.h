@@ -158,12 +158,13 @@ FX_MARK("load");
         }
     }
 
-    // fills xr with the raw frame in first-pass order and returns log10(rms * 9 + 1)
-    __device__ __forceinline__ float rms(int lane, float (&xr)[P]) const
+    // fills xr with the raw frame in first-pass order and returns the sum of its squares: the numerator of
+    // getRMSLevel (a2, ref RealTimeAnalyser.h:207-208).  logRMS itself -- (float) log10(rms * 9 + 1) with
+    // rms = (float) sqrt(sum / N) -- is a ~130-instruction fp64 computation of one number per wave; it is left
+    // to fx_finalise_kernel (one thread per frame), and the spectral section brackets it instead (gate_threshold).
+    __device__ __forceinline__ double sum_squares(int lane, float (&xr)[P]) const
     {
-        float log_rms;
 FX_MARK("rms");
-        // ---------------- a2: RMS on the un-windowed frame (ref RealTimeAnalyser.h:207-208) ---------
         // the frame, in registers, in the order the first FFT pass consumes it; the LDS buffer is
         // free again after this read
 #pragma unroll
@@ -171,22 +172,47 @@ FX_MARK("rms");
 #pragma unroll
             for (int j = 0; j < G::RA; j++) xr[g * G::RA + j] = (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)];
         wave_fence();
-        {
-            double s = 0.0;
+        double s = 0.0;
 #pragma unroll
-            for (int i = 0; i < P; i++) s += (double) (xr[i] * xr[i]);
-            s = wave_sum(s);
-            const float rms = (float) sqrt(s / (double) N);
-            // log10 of a float, correctly rounded: this value gates bins (`mag > 0.01*logRMS`), so it must
-            // equal the CPU oracle's to the last bit (see oracle/fx_oracle.c)
-#ifdef FX_EXP_SKIP_RMSLOG
-            log_rms = __log10f(rms * 9.0f + 1.0f);
+        for (int i = 0; i < P; i++) s += (double) (xr[i] * xr[i]);
+        s = wave_sum(s);
+        if (lane == 0) fpl->sum_sq = s;
+        return s;
+    }
+
+    // log10 of a float, correctly rounded: this value gates bins (`mag > 0.01*logRMS`), so it must
+    // equal the CPU oracle's to the last bit (see oracle/fx_oracle.c)
+    static __device__ __forceinline__ float exact_log_rms(double sum_sq)
+    {
+        const float rms = (float) sqrt(sum_sq / (double) N);
+        return (float) log10((double) (rms * 9.0f + 1.0f));
+    }
+
+    // The flatness gate is `mag > eps`, eps = 0.01 * logRMS (ref SpectralCharacteristics.h:89-94,108).  Only the
+    // comparisons matter here, so logRMS is bracketed from single-precision hardware sqrt / log2 with a margin far
+    // above their error (relative 1e-4, absolute 4e-6 on logRMS, against ~1e-6): if no bin's magnitude falls inside
+    // the bracket -- the usual case -- comparing with its upper end decides every bin exactly as the true value
+    // would; otherwise (rare, wave-uniform) the exact value is computed.
+    __device__ __forceinline__ double gate_threshold(double sum_sq, const float (&re)[U]) const
+    {
+#ifdef FX_EXP_WIDE_BAND
+        const float rel = 0.5f, abs_ = 0.5f;        // test builds: the bracket catches almost every frame
 #else
-            log_rms = (float) log10((double) (rms * 9.0f + 1.0f));
+        const float rel = 1e-4f, abs_ = 4e-6f;
 #endif
-            if (lane == 0) fpl->log_rms = log_rms;
+        const float rms_a = __builtin_amdgcn_sqrtf((float) (sum_sq * (1.0 / (double) N)));
+        const float log_a = __builtin_amdgcn_logf(rms_a * 9.0f + 1.0f) * 0.30103f;      // v_log_f32 is log2
+        const double eps_lo = 0.01 * (double) (log_a * (1.0f - rel) - abs_);
+        const double eps_hi = 0.01 * (double) (log_a * (1.0f + rel) + abs_);
+        bool inside = false;
+#pragma unroll
+        for (int j = 0; j < U; j++) {
+            const double v = (double) re[j];
+            const double mag = v * v;
+            inside |= (mag > eps_lo) && !(mag > eps_hi);
         }
-        return log_rms;
+        if (!__any(inside)) return eps_hi;
+        return 0.01 * (double) exact_log_rms(sum_sq);                      // :108
     }
 
     // The flatness product with the serial-order semantics of `magnitudeProduct *= binMagnitude` (ref
@@ -256,7 +282,7 @@ FX_MARK("flatprod");
         return pr;
     }
 
-    __device__ __forceinline__ void spectral(int lane, const float (&xr)[P], float log_rms) const
+    __device__ __forceinline__ void spectral(int lane, const float (&xr)[P], double sum_sq) const
     {
         float spec_aux = 0.0f;
 FX_MARK("spec_fft");
@@ -289,7 +315,7 @@ FX_MARK("spec_sums");
             // buffer = max |re|, |im| over bins [0, M/2)
             float maxabs = spec_aux;
             lds_load_block<U>(reinterpret_cast<const float*>(cbuf) + U * lane, re);
-            const double eps = 0.01 * (double) log_rms;                        // :108
+            const double eps = gate_threshold(sum_sq, re);
             double mag_sum = 0.0, lhr = 0.0, wsum = 0.0, flat_sum = 0.0;
             float max_re = 0.0f;       // max |re|: (double) re^2 is exact and monotone in |re|, so max mag = max_re^2
             int cnt = 0;               // wave-uniform: bins that pass the flatness gate, counted from the compare masks
@@ -793,13 +819,13 @@ fx_frame_kernel(const FrameParams p)
         // uniform per-frame results go to LDS as soon as they exist instead of occupying ~28 VGPRs
         // in every lane for the whole frame
         FramePart* fpl = parts + wave;
-        if (lane == 0) { fpl->inh = 0.0; fpl->her_score = 0.0; fpl->sum_normed = 1.0; fpl->flags = 0; fpl->pad_ = 0; fpl->spare_ = 0.0; }
+        if (lane == 0) { fpl->inh = 0.0; fpl->her_score = 0.0; fpl->sum_normed = 1.0; fpl->flags = 0; fpl->pad_ = 0; }
         const FrameWave<N> w{p, tw, prev, turn, cbuf, rbuf, fpl, nyquist, rnyq, frpb, scale, c, T, t};
 
         w.load_frame(lane);
         float xr[P];
-        const float log_rms = w.rms(lane, xr);
-        if constexpr (SPEC) w.spectral(lane, xr, log_rms);
+        const double sum_sq = w.sum_squares(lane, xr);
+        if constexpr (SPEC) w.spectral(lane, xr, sum_sq);
         if constexpr (HARM) {
             typename FrameWave<N>::HarmonicSpectrum hs;
             w.harmonic_spectrum(lane, xr, hs);

@@ -29,8 +29,8 @@ struct FramePart {
     double inh;         // inharmonicity before the log                      (ref HarmonicCharacteristics.h:239)
     double her_score;   // sum of the 18 probe maxima                        (ref :157-184)
     double sum_normed;  // sum of mag / max over all bins                    (ref :77); her = score / sum_normed
-    double spare_;
-    float  log_rms;     // ref RealTimeAnalyser.h:208
+    double sum_sq;      // sum of the frame's squared samples: rms = (float) sqrt(sum_sq / N)  (ref RealTimeAnalyser.h:207)
+    float  unused_;
     float  centroid;    // (float)(wsum / mag_sum)                           (ref SpectralCharacteristics.h:127)
     float  cnt;         // numMagnitudesUsedInFlatnessCalculation
     float  lag;         // ref PitchAnalyser.h:188-189

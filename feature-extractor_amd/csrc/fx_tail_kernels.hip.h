@@ -19,8 +19,12 @@ fx_finalise_kernel(const EpilogueParams p)
     float out[FX_NUM_FEATURES];
 #pragma unroll
     for (int i = 0; i < FX_NUM_FEATURES; i++) out[i] = 0.0f;
-    out[FX_RMS] = f.log_rms;
-    const double eps = 0.01 * (double) f.log_rms;                              // :108
+    // a2, ref RealTimeAnalyser.h:207-208: log10 of a float, correctly rounded -- it also gates bins through eps, so it
+    // must equal the CPU oracle's to the last bit (see oracle/fx_oracle.c)
+    const float rms = (float) sqrt(f.sum_sq / (double) p.window);
+    const float log_rms = (float) log10((double) (rms * 9.0f + 1.0f));
+    out[FX_RMS] = log_rms;
+    const double eps = 0.01 * (double) log_rms;                                // :108
 
     const bool spec = p.analysers & 1, harm = p.analysers & 2;
     if (spec && f.mag_sum > 0.05) {                                            // :121-123
