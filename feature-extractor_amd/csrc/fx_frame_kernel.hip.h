@@ -528,11 +528,10 @@ FX_MARK("vcalc");
         // Only s in [1, N] is ever read by the lag search; v[N] comes from imag[0].
         lane = opaque(lane);
         float* vbuf = rbuf;                                                // [N+1] plain layout
-        float* sums = rbuf + N + 4;                                        // [N+1]; both fit in the buffer
         wave_fence();
 FX_MARK("scan");
-        // a13 running fp32 sum (ref PitchAnalyser.h:138-150) -- serial by definition, so one lane
-        // adds, 64 samples at a time; after each block all lanes form cnd = v/sum (ref :146-154) for
+        // a13 running fp32 sum (ref PitchAnalyser.h:138-150) -- serial by definition -- 64 samples at a
+        // time; after each block all lanes form cnd = v/sum (ref :146-154) for
         // that block and advance a14's search (ref :161-190), which usually ends long before N:
         //   first  = first s >= 2 with cnd[s] < 0.01
         //   stop   = first s' >= first with !(cnd[s'+1] < cnd[s'])   (or N-1)
@@ -540,7 +539,7 @@ FX_MARK("scan");
         // otherwise the global minimum over [2, N), first occurrence (ref :171-175).
         float lag = -1.0f;
         {
-            float run = 0.0f;                 // lane 0: the running sum
+            float run = 0.0f;                 // the running sum after the previous block (wave-uniform)
             float carry = 0.0f;               // cnd of the last sample of the previous block
             int first = 0x7fffffff;
             bool done = false;
@@ -550,23 +549,19 @@ FX_MARK("scan");
 #else
             for (int blk = 0; blk < P && !done; blk++) {
 #endif
-                if (lane == 0) {
-#pragma unroll
-                    for (int g = 0; g < 64; g += 4) {
-                        const f4 v = *reinterpret_cast<const f4*>(&vbuf[64 * blk + g]);
-                        f4 o;
-                        if (g != 0 || blk != 0) run += v.x;               // the sum starts at sample 1
-                        o.x = run;
-                        run += v.y; o.y = run;
-                        run += v.z; o.z = run;
-                        run += v.w; o.w = run;
-                        *reinterpret_cast<f4*>(&sums[64 * blk + g]) = o;
-                    }
-                }
-                wave_fence();
+                // The 64 dependent adds of the block run as a chain across the lanes: x[l] = x[l-1] + v[l] with a
+                // wave_shr:1 DPP operand, 63 times.  After pass k lanes 0..k hold their final prefix sums (a lane whose
+                // left neighbour is final recomputes the same value), lane 0 is never written (no source lane), so every
+                // lane ends with the running sum of its own sample -- the same additions in the same order as the
+                // reference's loop, without the single-lane round trip through LDS.
                 const int s_ = 64 * blk + lane;
-                const float sm = sums[s_];
                 const float v = vbuf[s_];
+                const float addend = (s_ == 0) ? 0.0f : v;                 // the sum starts at sample 1
+                float sm = lane == 0 ? run + addend : addend;
+#pragma unroll
+                for (int k = 1; k < 64; k++)                               // (s_nop: a DPP read needs 2 wait states after the write)
+                    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(sm) : "v"(addend));
+                run = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 63));
                 const float c_ = (sm != 0.0f) ? v / sm : 0.0f;
                 const float p_ = shift_up1(c_, carry);                     // cnd of the previous sample
                 carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_), 63));
