@@ -281,14 +281,14 @@ __device__ __forceinline__ void fft_first_pass(const float (&xin)[Geo<N>::P], f2
 enum { OUT_RE_LOW = 1,        // float re[M] (plain layout): all the harmonic analyser reads (ref HarmonicCharacteristics.h:63)
        OUT_RE_LOW_MAXABS = 2, // the same + max(|re|,|im|) over bins [0, M/2) returned per lane (ref SpectralCharacteristics.h:153)
        OUT_POWER = 3,         // float re*re of all N bins in the real image (rpad layout): ref PitchAnalyser.h:97-103
-       OUT_LAG = 4 };         // float v[s] = (re_s/N)^2 * s, s in [0,N), and v[N] from imag[0] (plain layout): ref :119-123
+       OUT_LAG = 4 };         // v[s] = (re_s/N)^2 * s of the lane's own samples s = lane + 64*m in registers (regs_out[m]); returns v[N], from imag[0], in lane 0: ref :119-123
 
 // Last pass -- radix 4 at length N/4 (N <= 1024) or radix 16 at length N/16 -- with all of a lane's items in
 // registers (128 VGPRs of them at N = 4096, which runs one wave per SIMD anyway), fused with the consumer of the spectrum, so the full complex image is never written back and
 // re-read: the spectral / harmonic analysers only read re of bins < N/2, the pitch analyser only re*re, the
 // lag search only the squared, lag-weighted real part.
 template <int N, bool INV, int OUT>
-__device__ __forceinline__ float fft_last_pass_fused(f2* cbuf, const f2* tw, int lane, float scale)
+__device__ __forceinline__ float fft_last_pass_fused(f2* cbuf, const f2* tw, int lane, float scale, float* regs_out)
 {
     typedef Plan<N> PL;
     constexpr int R = PL::R2, L0 = PL::L2, GI = (N / R) / 64, TWOFF = PL::OFF2, M = N / 2;
@@ -334,10 +334,10 @@ __device__ __forceinline__ float fft_last_pass_fused(f2* cbuf, const f2* tw, int
                 fbuf[rpad(bin)] = e[g][i].x * e[g][i].x;
             } else {
                 const float d = e[g][i].x * scale;
-                fbuf[bin] = d * d * (float) bin;
+                regs_out[g + (L0 / 64) * i] = d * d * (float) bin;                // bin = lane + 64 * (g + (L0/64) * i)
             }
         }
-        if (OUT == OUT_LAG && g == 0 && lane == 0) { const float d = e[0][0].y * scale; fbuf[N] = d * d * (float) N; }
+        if (OUT == OUT_LAG && g == 0) { const float d = e[0][0].y * scale; aux = d * d * (float) N; }
     }
     (void) M;
     wave_fence();
@@ -347,10 +347,10 @@ __device__ __forceinline__ float fft_last_pass_fused(f2* cbuf, const f2* tw, int
 // Whole transform of one wavefront: P real inputs per lane (first-pass order) -> OUT (see above).
 template <int N, bool INV, int OUT>
 __device__ __forceinline__ float fft_from_regs(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, const float (&ftw)[18],
-                                               int lane, float scale = 0.0f)
+                                               int lane, float scale = 0.0f, float* regs_out = nullptr)
 {
     typedef Plan<N> PL;
     fft_first_pass<N, INV>(xin, cbuf, ftw, lane);
     fft_pass<N, PL::R1, PL::L1, PL::OFF1, INV>(cbuf, tw, lane);
-    return fft_last_pass_fused<N, INV, OUT>(cbuf, tw, lane, scale);
+    return fft_last_pass_fused<N, INV, OUT>(cbuf, tw, lane, scale, regs_out);
 }

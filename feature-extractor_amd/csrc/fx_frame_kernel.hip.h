@@ -520,84 +520,86 @@ FX_MARK("lpf");
         wave_fence();
     }
 
-    // a13 / a14 on the v[] array the inverse transform left in the buffer: the lag estimate (ref PitchAnalyser.h:129-217)
-    __device__ __forceinline__ float lag_search(int lane) const
+    // a13 / a14 (ref PitchAnalyser.h:129-217) on v[s] = (d[s]/N)^2 * s, which the inverse transform left in
+    // registers: lane l holds v[l + 64*m] in vreg[m], i.e. its own sample of every 64-sample block; v_end = v[N]
+    // (from imag[0]) is valid in lane 0.
+    //   a13: running fp32 sum (:138-150) -- serial by definition -- taken 64 samples at a time; after each block all
+    //        lanes form cnd = v/sum (:146-154) and advance a14's search (:161-190), which usually ends in the first
+    //        block or two:
+    //   first  = first s >= 2 with cnd[s] < 0.01
+    //   stop   = first s' >= first with !(cnd[s'+1] < cnd[s'])   (or N-1)
+    //   lag    = cnd[stop] <= cnd[stop+1] ? stop : stop+1        (ref :192-203)
+    //   otherwise the global minimum over [2, N), first occurrence (ref :171-175).
+    __device__ __forceinline__ float lag_search(int lane, const float (&vreg)[P], float v_end) const
     {
-FX_MARK("vcalc");
-        // v[s] = d[s]*d[s]*s, d = planar JUCE inverse output scaled by 1/N (ref :122-123).
-        // Only s in [1, N] is ever read by the lag search; v[N] comes from imag[0].
-        lane = opaque(lane);
-        float* vbuf = rbuf;                                                // [N+1] plain layout
-        wave_fence();
 FX_MARK("scan");
-        // a13 running fp32 sum (ref PitchAnalyser.h:138-150) -- serial by definition -- 64 samples at a
-        // time; after each block all lanes form cnd = v/sum (ref :146-154) for
-        // that block and advance a14's search (ref :161-190), which usually ends long before N:
-        //   first  = first s >= 2 with cnd[s] < 0.01
-        //   stop   = first s' >= first with !(cnd[s'+1] < cnd[s'])   (or N-1)
-        //   lag    = cnd[stop] <= cnd[stop+1] ? stop : stop+1        (ref :192-203)
-        // otherwise the global minimum over [2, N), first occurrence (ref :171-175).
+        lane = opaque(lane);
         float lag = -1.0f;
-        {
-            float run = 0.0f;                 // the running sum after the previous block (wave-uniform)
-            float carry = 0.0f;               // cnd of the last sample of the previous block
-            int first = 0x7fffffff;
-            bool done = false;
-            float best = 100.0f; int best_i = 0x7fffffff;
-#ifdef FX_EXP_SKIP_SCAN
-            for (int blk = 0; blk < (int) (scale * 0.5f) && !done; blk++) {
-#else
-            for (int blk = 0; blk < P && !done; blk++) {
-#endif
-                // The 64 dependent adds of the block run as a chain across the lanes: x[l] = x[l-1] + v[l] with a
-                // wave_shr:1 DPP operand, 63 times.  After pass k lanes 0..k hold their final prefix sums (a lane whose
-                // left neighbour is final recomputes the same value), lane 0 is never written (no source lane), so every
-                // lane ends with the running sum of its own sample -- the same additions in the same order as the
-                // reference's loop, without the single-lane round trip through LDS.
-                const int s_ = 64 * blk + lane;
-                const float v = vbuf[s_];
-                const float addend = (s_ == 0) ? 0.0f : v;                 // the sum starts at sample 1
-                float sm = lane == 0 ? run + addend : addend;
+        float run = 0.0f;                 // the running sum after the previous block (wave-uniform)
+        float carry = 0.0f;               // cnd of the last sample of the previous block
+        int first = 0x7fffffff;
+        bool done = false;
+        float best = 100.0f; int best_i = 0x7fffffff;
+        auto block = [&](int blk, float v) {
+            // The 64 dependent adds of the block run as a chain across the lanes: x[l] = x[l-1] + v[l] with a
+            // wave_shr:1 DPP operand, 63 times.  After pass k lanes 0..k hold their final prefix sums (a lane whose
+            // left neighbour is final recomputes the same value), lane 0 is never written (no source lane), so every
+            // lane ends with the running sum of its own sample -- the same additions in the same order as the
+            // reference's loop, with no LDS traffic at all.
+            const int s_ = 64 * blk + lane;
+            const float addend = (s_ == 0) ? 0.0f : v;                     // the sum starts at sample 1
+            float sm = lane == 0 ? run + addend : addend;
 #pragma unroll
-                for (int k = 1; k < 64; k++)                               // (s_nop: a DPP read needs 2 wait states after the write)
-                    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(sm) : "v"(addend));
-                run = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 63));
-                const float c_ = (sm != 0.0f) ? v / sm : 0.0f;
-                const float p_ = shift_up1(c_, carry);                     // cnd of the previous sample
-                carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_), 63));
-                if (s_ >= 2 && c_ < best) { best = c_; best_i = s_; }
-                if (first == 0x7fffffff) {
-                    const unsigned long long hit = __ballot(s_ >= 2 && c_ < 0.01f);
-                    if (hit) first = 64 * blk + (int) __builtin_ctzll(hit);
-                }
-                if (first != 0x7fffffff) {
-                    // sample s-1 ends the walk if it is past `first` and cnd does not keep falling
-                    const unsigned long long st = __ballot(s_ - 1 >= first && !(c_ < p_));
-                    if (st) {
-                        const int src = (int) __builtin_ctzll(st);
-                        const float pc = lane_get(p_, src), cc = lane_get(c_, src);
-                        const int sstar = 64 * blk + src;
-                        lag = (pc <= cc) ? (float) (sstar - 1) : (float) sstar;
-                        done = true;
-                    }
+            for (int k = 1; k < 64; k++)                                   // (s_nop: a DPP read needs 2 wait states after the write)
+                asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(sm) : "v"(addend));
+            run = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 63));
+            const float c_ = (sm != 0.0f) ? v / sm : 0.0f;
+            const float p_ = shift_up1(c_, carry);                         // cnd of the previous sample
+            carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_), 63));
+            if (s_ >= 2 && c_ < best) { best = c_; best_i = s_; }
+            if (first == 0x7fffffff) {
+                const unsigned long long hit = __ballot(s_ >= 2 && c_ < 0.01f);
+                if (hit) first = 64 * blk + (int) __builtin_ctzll(hit);
+            }
+            if (first != 0x7fffffff) {
+                // sample s-1 ends the walk if it is past `first` and cnd does not keep falling
+                const unsigned long long st = __ballot(s_ - 1 >= first && !(c_ < p_));
+                if (st) {
+                    const int src = (int) __builtin_ctzll(st);
+                    const float pc = lane_get(p_, src), cc = lane_get(c_, src);
+                    const int sstar = 64 * blk + src;
+                    lag = (pc <= cc) ? (float) (sstar - 1) : (float) sstar;
+                    done = true;
                 }
             }
-            if (!done) {
-                if (first != 0x7fffffff) {
-                    // the walk ran to N-1 (ref :178: sample + 1 < numSamples); compare with cnd[N]
-                    float cn = 0.0f;
-                    if (lane == 0) { run += vbuf[N]; cn = (run != 0.0f) ? vbuf[N] / run : 0.0f; }
-                    cn = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cn)));
-                    lag = (carry <= cn) ? (float) (N - 1) : (float) N;
-                } else {
+        };
+#ifndef FX_EXP_SKIP_SCAN
+        block(0, vreg[0]);
+        if (!done && P > 1) block(1, vreg[1]);
+        if (!done && P > 2) {
+            // rare: the search goes past the second block; the remaining blocks pick their samples from the buffer
+            float* vbuf = rbuf;                                            // [N] plain layout
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const float ov = __shfl_xor(best, o, 64);
-                        const int oi = __shfl_xor(best_i, o, 64);
-                        if (ov < best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
-                    }
-                    lag = best_i == 0x7fffffff ? -1.0f : (float) best_i;
+            for (int m = 2; m < P; m++) vbuf[64 * m + lane] = vreg[m];
+            wave_fence();
+            for (int blk = 2; blk < P && !done; blk++) block(blk, vbuf[64 * blk + lane]);
+        }
+#endif
+        if (!done) {
+            if (first != 0x7fffffff) {
+                // the walk ran to N-1 (ref :178: sample + 1 < numSamples); compare with cnd[N]
+                float cn = 0.0f;
+                if (lane == 0) { run += v_end; cn = (run != 0.0f) ? v_end / run : 0.0f; }
+                cn = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cn)));
+                lag = (carry <= cn) ? (float) (N - 1) : (float) N;
+            } else {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(best, o, 64);
+                    const int oi = __shfl_xor(best_i, o, 64);
+                    if (ov < best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
                 }
+                lag = best_i == 0x7fffffff ? -1.0f : (float) best_i;
             }
         }
         return lag;
@@ -626,8 +628,9 @@ FX_MARK("power");
             for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)];   // already squared
         wave_fence();
 FX_MARK("ifft");
-        fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, p.first_tw, lane, scale);        // a12 inverse, ref :110-121
-        const float lag = lag_search(lane);
+        float vreg[P];
+        const float v_end = fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, p.first_tw, lane, scale, vreg);   // a12 inverse, ref :110-121
+        const float lag = lag_search(lane, vreg, v_end);
         if (lane == 0) fpl->lag = lag;
         wave_fence();
         return (nyquist * 2.0) / (double) lag;
