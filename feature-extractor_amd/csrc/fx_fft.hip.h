@@ -280,7 +280,8 @@ __device__ __forceinline__ void fft_first_pass(const float (&xin)[Geo<N>::P], f2
 // What the last pass leaves in the wave's LDS buffer.
 enum { OUT_RE_LOW = 1,        // float re[M] (plain layout): all the harmonic analyser reads (ref HarmonicCharacteristics.h:63)
        OUT_RE_LOW_MAXABS = 2, // the same + max(|re|,|im|) over bins [0, M/2) returned per lane (ref SpectralCharacteristics.h:153)
-       OUT_POWER = 3,         // float re*re of all N bins in the real image (rpad layout): ref PitchAnalyser.h:97-103
+       OUT_POWER = 3,         // re*re of all N bins (ref PitchAnalyser.h:97-103) as the NEXT transform's first-pass inputs: in registers
+                              // (regs_out, one lane permutation) when a lane owns one first-pass item, else in the real image (rpad layout)
        OUT_LAG = 4 };         // v[s] = (re_s/N)^2 * s of the lane's own samples s = lane + 64*m in registers (regs_out[m]); returns v[N], from imag[0], in lane 0: ref :119-123
 
 // Last pass -- radix 4 at length N/4 (N <= 1024) or radix 16 at length N/16 -- with all of a lane's items in
@@ -331,7 +332,19 @@ __device__ __forceinline__ float fft_last_pass_fused(f2* cbuf, const f2* tw, int
                 if (i < R / 2) fbuf[bin] = e[g][i].x;                          // bins >= N/2 are never read
                 if (OUT == OUT_RE_LOW_MAXABS && i < R / 4) aux = fmaxf(aux, fmaxf(fabsf(e[g][i].x), fabsf(e[g][i].y)));
             } else if (OUT == OUT_POWER) {
-                fbuf[rpad(bin)] = e[g][i].x * e[g][i].x;
+                if constexpr (Geo<N>::GA == 1) {
+                    // Lane l holds the bins congruent to l mod 64: bin = l + 64*m, m = g + (L0/64)*i.  The next
+                    // transform's first pass wants, in lane l', the samples rev4(l') + 64*r(j): the whole set of lane
+                    // rev4(l'), in the order m = r(j).  One ds_bpermute per register instead of a store + gather.
+                    constexpr int RA = Geo<N>::RA;
+                    const int m = g + (L0 / 64) * i;
+                    // j with r(j) == m  (r is its own inverse up to the digit swap used by first_pass_index)
+                    const int j = (RA == 4) ? m : (RA == 8) ? (2 * (m & 3) + (m >> 2)) : (4 * (m & 3) + (m >> 2));
+                    regs_out[j] = __int_as_float(__builtin_amdgcn_ds_bpermute(
+                        rev4<Geo<N>::IDIG>(lane) << 2, __float_as_int(e[g][i].x * e[g][i].x)));
+                } else {
+                    fbuf[rpad(bin)] = e[g][i].x * e[g][i].x;
+                }
             } else {
                 const float d = e[g][i].x * scale;
                 regs_out[g + (L0 / 64) * i] = d * d * (float) bin;                // bin = lane + 64 * (g + (L0/64) * i)

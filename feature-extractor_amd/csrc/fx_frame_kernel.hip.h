@@ -617,16 +617,22 @@ FX_MARK("pitch_fft");
 #pragma unroll
             for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)];
         wave_fence();
-        fft_from_regs<N, false, OUT_POWER>(xf, cbuf, tw, p.first_tw, lane);            // ref RealTimeAnalyser.h:160
+        // a11 getComplexConjugateMultiplication, ref PitchAnalyser.h:83-108: re*re, imag := 0, delivered in the order the
+        // inverse transform's first pass wants it
+        float xp[P];
+        fft_from_regs<N, false, OUT_POWER>(xf, cbuf, tw, p.first_tw, lane, 0.0f, xp);  // ref RealTimeAnalyser.h:160
 FX_MARK("power");
-        // a11 getComplexConjugateMultiplication, ref PitchAnalyser.h:83-108: re*re, imag := 0,
-        // picked up directly in the order the inverse transform's first pass wants it
         lane = opaque(lane);
+        if constexpr (G::GA == 1) {
 #pragma unroll
-        for (int g = 0; g < G::GA; g++)
+            for (int j = 0; j < P; j++) xf[j] = xp[j];
+        } else {
 #pragma unroll
-            for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)];   // already squared
-        wave_fence();
+            for (int g = 0; g < G::GA; g++)
+#pragma unroll
+                for (int j = 0; j < G::RA; j++) xf[g * G::RA + j] = (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)];   // already squared
+            wave_fence();
+        }
 FX_MARK("ifft");
         float vreg[P];
         const float v_end = fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, p.first_tw, lane, scale, vreg);   // a12 inverse, ref :110-121
