@@ -118,7 +118,9 @@ template <int N> struct FrameWave {
     int*   turn;        // index of the frame whose turn it is to read / replace `prev`
     f2*    cbuf;        // this wave's transform buffer ...
     float* rbuf;        // ... and the same memory viewed as the real image
-    FramePart* fpl;     // this wave's result record (LDS), filled as the values appear
+    FramePart* fpl;     // this frame's result record in global memory: lane 0 stores each value as it appears (single-lane LDS
+                        // writes cost a full LDS instruction each, and the LDS pipe is the scarcer resource; the vector-memory
+                        // path is nearly idle)
     double nyquist, rnyq, frpb;   // frpb: ref SpectralCharacteristics.h:64,105
     float  scale;       // JUCE inverse-transform scale 1/N
     int    c, T, t;     // channel, frames in this call, this frame
@@ -767,18 +769,6 @@ FX_MARK("harm2");
         }
         wave_fence();
     }
-
-    __device__ __forceinline__ void store(int lane) const
-    {
-FX_MARK("store");
-        wave_fence();
-        static_assert(sizeof(FramePart) % 16 == 0, "16-byte stores");
-#ifndef FX_EXPERIMENT_NOSTORE
-        if (lane < (int) (sizeof(FramePart) / 16))
-            reinterpret_cast<uint4*>(p.part + ((size_t) c * T + t))[lane] = reinterpret_cast<const uint4*>(fpl)[lane];
-#endif
-        wave_fence();
-    }
 };
 
 // SPEC / HARM: which of the reference's two analysers run (RealTimeSpectralAnalyser,
@@ -794,8 +784,7 @@ fx_frame_kernel(const FrameParams p)
     f2*    tw   = reinterpret_cast<f2*>(smem);                              // [N]
     float* prev = reinterpret_cast<float*>(tw + N);                         // [M]  re of the last accepted frame
     int*   turn = reinterpret_cast<int*>(prev + M);                         // [4]
-    FramePart* parts = reinterpret_cast<FramePart*>(turn + 4);              // [waves] per-frame results, filled as they appear
-    unsigned char* per_wave = reinterpret_cast<unsigned char*>(parts + (blockDim.x >> 6));
+    unsigned char* per_wave = reinterpret_cast<unsigned char*>(turn + 4);
     constexpr size_t WAVE_BYTES = sizeof(f2) * G::CBUF;
 
     const int nwaves = blockDim.x >> 6;
@@ -822,8 +811,8 @@ fx_frame_kernel(const FrameParams p)
         const int lane = opaque(lane0);
         // uniform per-frame results go to LDS as soon as they exist instead of occupying ~28 VGPRs
         // in every lane for the whole frame
-        FramePart* fpl = parts + wave;
-        if (lane == 0) { fpl->inh = 0.0; fpl->her_score = 0.0; fpl->sum_normed = 1.0; fpl->flags = 0; fpl->pad_ = 0; }
+        FramePart* fpl = p.part + ((size_t) c * T + t);
+        if (lane == 0) fpl->flags = 0;            // the harmonic tail sets it; the other fields are read only where written
         const FrameWave<N> w{p, tw, prev, turn, cbuf, rbuf, fpl, nyquist, rnyq, frpb, scale, c, T, t};
 
         w.load_frame(lane);
@@ -836,7 +825,6 @@ fx_frame_kernel(const FrameParams p)
             const double f0 = w.pitch(lane, xr);
             w.harmonic_tail(lane, hs, f0);
         }
-        w.store(lane);
     }
 
     __syncthreads();

@@ -104,7 +104,7 @@ void build_pass_twiddles(int n, const float* canonical, float* out)
 template <int N> static size_t lds_bytes_t(int waves)
 {
     typedef Geo<N> G;
-    return sizeof(f2) * N + sizeof(float) * G::M + 16 + (size_t) waves * (sizeof(FramePart) + sizeof(f2) * G::CBUF);
+    return sizeof(f2) * N + sizeof(float) * G::M + 16 + (size_t) waves * (sizeof(f2) * G::CBUF);
 }
 
 size_t frame_kernel_lds_bytes(int n, int waves)
