@@ -417,7 +417,7 @@ FX_MARK("spec_pass2");
         float h_max_re = 0.0f;
 FX_MARK("harm1");
         // ---------------- harmonic analyser, part 1: raw (un-windowed) spectrum ---------------------
-        // ref RealTimeAnalyser.h:161 -- done before the low-pass overwrites the frame image
+        // ref RealTimeAnalyser.h:161
         lane = opaque(lane);
         fft_from_regs<N, false, OUT_RE_LOW>(xr, cbuf, tw, p.first_tw, lane);
         {
@@ -443,7 +443,7 @@ FX_MARK("harm1");
 
     // returns f0 = sampleRate / lag (ref PitchAnalyser.h:57) and records the lag
     // a10 + ref RealTimeAnalyser.h:157: the one-pole low-pass of the raw frame, windowed, left in the real image
-    __device__ __forceinline__ void lowpass_window(int lane, const float (&xr)[P]) const
+    __device__ __forceinline__ void lowpass_window(int lane) const
     {
 FX_MARK("lpf");
         // a10 AudioFilter::filterAudio, ref RealTimeAudioAnalysis.h:106-125:
@@ -454,11 +454,8 @@ FX_MARK("lpf");
         // neighbour's value until every hand-over matches (exact by induction from lane 0).
         constexpr int KW = 16;
         const float a = p.lpf_a, b = p.lpf_b;
-#pragma unroll
-        for (int g = 0; g < G::GA; g++)
-#pragma unroll
-            for (int j = 0; j < G::RA; j++) (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)] = xr[g * G::RA + j];
-        wave_fence();
+        // (the pitch path runs first, while the real image of the raw frame that load_frame left in the buffer is
+        // still intact)
         float x[P];
 #pragma unroll
         for (int i = 0; i < P; i += 4) {
@@ -608,9 +605,9 @@ FX_MARK("scan");
     }
 
     // pitch: low-pass -> window -> FFT -> re^2 -> inverse FFT -> lag; returns f0 = sampleRate / lag (ref PitchAnalyser.h:57)
-    __device__ __forceinline__ double pitch(int lane, const float (&xr)[P]) const
+    __device__ __forceinline__ double pitch(int lane) const
     {
-        lowpass_window(opaque(lane), xr);
+        lowpass_window(opaque(lane));
 FX_MARK("pitch_fft");
         lane = opaque(lane);
         float xf[P];
@@ -818,11 +815,15 @@ fx_frame_kernel(const FrameParams p)
         w.load_frame(lane);
         float xr[P];
         const double sum_sq = w.sum_squares(lane, xr);
+        // The harmonic analyser's pitch estimate comes first: its low-pass reads the raw frame's real image, which the
+        // transforms below overwrite.  (The order of the two analysers only matters for the smoothed RMS, which
+        // fx_epilogue_kernel derives from the order flag.)
+        double f0 = 0.0;
+        if constexpr (HARM) f0 = w.pitch(lane);
         if constexpr (SPEC) w.spectral(lane, xr, sum_sq);
         if constexpr (HARM) {
             typename FrameWave<N>::HarmonicSpectrum hs;
             w.harmonic_spectrum(lane, xr, hs);
-            const double f0 = w.pitch(lane, xr);
             w.harmonic_tail(lane, hs, f0);
         }
     }
