@@ -4,7 +4,7 @@ N = sys.argv[1] if len(sys.argv) > 1 else "1024"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = tempfile.mkdtemp()
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-mllvm", "-disable-machine-licm",
-                "-c", os.path.join(root, "feature-extractor_amd/csrc/fx_kernels.hip"), "-o", os.path.join(d, "fx.o"), "-save-temps"],
+                "-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-c", os.path.join(root, "feature-extractor_amd/csrc/fx_kernels.hip"), "-o", os.path.join(d, "fx.o"), "-save-temps"],
                cwd=d, stderr=subprocess.DEVNULL)
 src = open(os.path.join(d, "fx_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
 start = src.index("_ZN3fxk15fx_frame_kernelILi%sELb1ELb1EEEvNS_11FrameParamsE:" % N)
