@@ -363,7 +363,7 @@ FX_MARK("flux");
                     const double pv = (double) pvf[j];
                     const double v = (double) re[j];
                     const double diff = v * v - pv * pv;                       // :76
-                    if (diff > 0.0) flux += diff;                              // :77-79
+                    flux += fmax(diff, 0.0);                                   // :77-79 (a NaN difference adds nothing, as `if (diff > 0)`)
                 }
                 if (accepted) lds_store_block<U>(prev + U * lane, re);         // :138 (only on the accepted path)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -655,7 +655,7 @@ FX_MARK("harm2");
 #else
         if (!(h_sum < 0.005)) {                                                // :88-89
 #endif
-            float* normed  = reinterpret_cast<float*>(cbuf);                   // [M] floats
+            float* normed  = reinterpret_cast<float*>(cbuf);                   // [M] floats: re of every bin (normalised on demand)
             int*   peaks   = reinterpret_cast<int*>(cbuf) + M;                 // [<= M] peak bins
             float* peak_re = reinterpret_cast<float*>(cbuf) + 2 * M;           // [<= M] re of those bins
             double mean_mag = h_sum / (double) M;                              // :86
@@ -684,15 +684,12 @@ FX_MARK("harm2");
                 }
             }
             unsigned peak_mask = 0;
-            float nrm[U];
             const double r_hmax = 1.0 / h_max;
             const double sum_normed = h_sum * r_hmax;                          // :77 sum of mag / max over all bins
 #pragma unroll
             for (int j = 0; j < U; j++) {
                 const double v = (double) hre[j];
                 const double mag = v * v;
-                const double nm = mag * r_hmax;                                // :75 (mag / max, via one reciprocal)
-                nrm[j] = (float) nm;
                 // binIsPeak :127-145: above the mean and none of bins -2,-1,+1 larger (windows are
                 // clipped at the ends, :136-138: no +1 neighbour for the last two bins).
                 // mag = (double) re^2 is exact, so comparing |re| compares magnitudes exactly.
@@ -708,7 +705,9 @@ FX_MARK("harm2");
                 if (r1 > me && !(j == U - 2 && lane == 63)) pk = false;
                 if (pk) peak_mask |= 1u << j;
             }
-            lds_store_block<U>(normed + U * lane, nrm);
+            // the probes below need the normalised magnitudes (float)(mag / max) (:75) of a few bins only; the
+            // normalisation is monotone, so the largest of a neighbourhood is the normalised largest |re|
+            lds_store_block<U>(normed + U * lane, hre);
             // compact the peak list
             const int npk_lane = __popc(peak_mask);
             const int pre = wave_scan_incl_i(npk_lane);
@@ -736,9 +735,10 @@ FX_MARK("harm2");
                     // getMaxBinInNeighbourhood :200-210 : [max(0,c-2), min(c+2, M)), start value normed[c]
                     const int s0 = bin - 2 >= 0 ? bin - 2 : 0;
                     const int e0 = bin + 2 < M ? bin + 2 : M;
-                    float mx = normed[bin];
-                    for (int q = s0; q < e0; q++) { const float v = normed[q]; if (v > mx) mx = v; }
-                    probe = (double) mx;
+                    float mx = fabsf(normed[bin]);
+                    for (int q = s0; q < e0; q++) { const float v = fabsf(normed[q]); if (v > mx) mx = v; }
+                    const double pm = (double) mx;
+                    probe = (double) (float) ((pm * pm) * r_hmax);                 // (mag / max, via one reciprocal), as a float (:75)
                 }
             }
             const double score = wave_sum(probe);                              // / sum_normed, clamped: fx_finalise_kernel
