@@ -319,6 +319,8 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
         std::vector<float> ordered(tw.size());
         fxk::build_pass_twiddles(window_size, tw.data(), ordered.data());    // same values, pass access order
         fxk::fill_first_pass_twiddles(window_size, ordered.data(), c->first_tw);
+        if (!fxk::first_pass_twiddles_hermitian(window_size, c->first_tw))
+            return cleanup(fail(FX_ERR_UNSUPPORTED, "this host's cos/sin produce a twiddle table without the mirror symmetry the kernels rely on"));
         TRY_OR_CLEAN(hipMemcpy(c->d_tw, ordered.data(), ordered.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     // ref SpectralCharacteristics.h:180-189: binVar does not depend on the signal

@@ -268,7 +268,13 @@ __device__ __forceinline__ void fft_first_pass(const float (&xin)[Geo<N>::P], f2
             }
             bfly4_core<INV>(e[1], e[5], e[9], e[13], twmul<INV>(e[5], ta[0]), twmul<INV>(e[9], ta[1]), twmul<INV>(e[13], ta[2]));
             bfly4_core<INV>(e[2], e[6], e[10], e[14], twmul_real<INV>(e[6].x, ta[3]), twmul_real<INV>(e[10].x, ta[4]), twmul_real<INV>(e[14].x, ta[5]));
-            bfly4_core<INV>(e[3], e[7], e[11], e[15], twmul<INV>(e[7], ta[6]), twmul<INV>(e[11], ta[7]), twmul<INV>(e[15], ta[8]));
+            // The item is a 16-point transform of real data, and the jin = 3 butterfly is the mirror image of the
+            // jin = 1 butterfly: its operands are the conjugates (bfly4_real: d3 = conj(d1)) and its twiddles W^3, W^6,
+            // W^9 are -i*conj(W^1), -conj(W^2), i*conj(W^3) -- bit for bit, which the host verifies on the float table
+            // before any launch (first_pass_twiddles_hermitian).  Every product and sum then comes out as the exact
+            // conjugate (negation and operand order do not change a rounding): out'[0..3] = conj(out[3], out[2],
+            // out[1], out[0]).  (The jin = 2 butterfly has no such shortcut: the table's cos(pi/2) is 6e-17, not 0.)
+            e[3] = f2{e[13].x, -e[13].y}; e[7] = f2{e[9].x, -e[9].y}; e[11] = f2{e[5].x, -e[5].y}; e[15] = f2{e[1].x, -e[1].y};
         }
         f2* img = cbuf + cpad((lane + 64 * g) * R);
 #pragma unroll

@@ -84,6 +84,7 @@ struct EpilogueParams {
 void build_pass_twiddles(int window_size, const float* canonical, float* out);
 // the first pass's constants, taken from the same pass-ordered table
 void fill_first_pass_twiddles(int window_size, const float* pass_ordered, float* out18);
+bool first_pass_twiddles_hermitian(int window_size, const float* first18);   // must hold before any launch
 
 size_t frame_kernel_lds_bytes(int window_size, int waves);
 // Chooses waves per workgroup and launches; returns hipSuccess or the launch error.

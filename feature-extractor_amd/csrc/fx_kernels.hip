@@ -77,6 +77,17 @@ template <int N> static void fill_first_t(const float* ordered, float* out18)
     for (int i = 0; i < 2 * cnt; i++) out18[i] = ordered[2 * Plan<N>::OFFA + i];
 }
 
+// ta[0..2] = W^1, W^2, W^3; ta[6..8] = W^3, W^6, W^9 with W = e^{-2*pi*i/16} (re, im pairs): the symmetry the
+// 16-input first pass relies on to skip its mirrored butterfly.  Any libm within 1e-9 of the true cosines
+// produces these floats; a table without it is refused rather than silently mis-transformed.
+bool first_pass_twiddles_hermitian(int n, const float* t)
+{
+    if (Geo<1024>::RA != 16 || (n != 1024 && n != 4096)) return true;     // other sizes have no 16-input first pass
+    return t[12] == -t[1] && t[13] == -t[0]             // W^3 = -i * conj(W^1)
+        && t[14] == -t[2] && t[15] == t[3]              // W^6 = -conj(W^2)
+        && t[16] == t[5] && t[17] == t[4];              // W^9 = i * conj(W^3)
+}
+
 void fill_first_pass_twiddles(int n, const float* ordered, float* out18)
 {
     switch (n) {
