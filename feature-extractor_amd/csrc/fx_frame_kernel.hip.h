@@ -339,10 +339,7 @@ FX_MARK("spec_sums");
                 max_re = fmaxf(max_re, fabsf(re[j]));
             }
             lhr = lane < LQ ? mag_sum : (lane == LQ ? lhr : 0.0);
-            mag_sum = wave_sum(mag_sum);
-            lhr = wave_sum(lhr);
-            wsum = wave_sum(wsum);
-            flat_sum = wave_sum(flat_sum);
+            wave_sum4(lane, mag_sum, lhr, wsum, flat_sum);
             max_re = wave_maxf(max_re);
             const double max_mag = (double) max_re * (double) max_re;
             maxabs = wave_maxf(maxabs);

@@ -71,6 +71,38 @@ __device__ __forceinline__ double wave_sum(double v)
     v += dppz_d<DPP_BCAST31>(v);
     return bcast63(v);
 }
+// Four sums at once.  The first two exchange steps fold the four registers into one -- after them lane l holds the
+// partial of sum (l & 3) over its quad -- so the remaining steps move one register instead of four: row_ror:4 / :8
+// add the quads of a row position-wise, v_permlane16_swap / v_permlane32_swap (gfx950) add the rows.  45 VALU
+// instructions against 4 x 20.
+enum { DPP_ROW_ROR4 = 0x124, DPP_ROW_ROR8 = 0x128 };
+__device__ __forceinline__ double swap_add_rows16(double v)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ double swap_add_halves32(double v)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+    return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void wave_sum4(int lane, double& a, double& b, double& c, double& d)
+{
+    const bool odd = lane & 1, upper = lane & 2;
+    const double ab = (odd ? b : a) + dppz_d<DPP_XOR1>(odd ? a : b);      // even lanes: a over the pair, odd lanes: b
+    const double cd = (odd ? d : c) + dppz_d<DPP_XOR1>(odd ? c : d);
+    double q = (upper ? cd : ab) + dppz_d<DPP_XOR2>(upper ? ab : cd);     // lane & 3 = 0, 1, 2, 3: a, b, c, d over the quad
+    q += dppz_d<DPP_ROW_ROR4>(q);
+    q += dppz_d<DPP_ROW_ROR8>(q);                                         // ... over the row
+    q = swap_add_rows16(q);
+    q = swap_add_halves32(q);                                             // ... over the wave, in every lane
+    a = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(q), 0), __builtin_amdgcn_readlane(__double2loint(q), 0));
+    b = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(q), 1), __builtin_amdgcn_readlane(__double2loint(q), 1));
+    c = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(q), 2), __builtin_amdgcn_readlane(__double2loint(q), 2));
+    d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(q), 3), __builtin_amdgcn_readlane(__double2loint(q), 3));
+}
 // (Moving the exchange steps to ds_swizzle -- the LDS crossbar instead of VALU DPP moves -- was measured 3 % slower:
 // the LDS pipe is the kernel's second limiter.)
 // maximum of values that are >= 0 (or NaN, which never wins -- as in `if (x > max) max = x`)
