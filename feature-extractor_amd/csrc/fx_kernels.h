@@ -37,7 +37,7 @@ struct FramePart {
     int    flags;       // bit 0: harmonic analyser ran past the 0.005 gate  (ref HarmonicCharacteristics.h:88)
     int    pad_;
 };
-static_assert(sizeof(FramePart) == 128, "FramePart is written with 16-byte stores");
+static_assert(sizeof(FramePart) == 128, "one 128-byte line per frame");
 
 struct FrameParams {
     const void*  in;            // frames [C][T][N] or hops [C][T][N/2]
