@@ -391,8 +391,7 @@ FX_MARK("spec_pass2");
                     const double dv = mag - mu;
                     vsum += dv * dv;
                 }
-                var = wave_sum(var);
-                vsum = wave_sum(vsum);
+                wave_sum2(lane, var, vsum);
                 if (lane == 0) { fpl->var = var; fpl->vsum = vsum; fpl->centroid = centroid; }
             }
             double max_e = (double) maxabs;                                    // :153
@@ -661,10 +660,11 @@ FX_MARK("harm2");
             // decides for every bin at once.  If any bin sits within rounding distance of the mean,
             // redo the sum in the reference's order, handing the running value from lane to lane.
             {
-                // |re| within ~1e-6 of sqrt(mean) brackets every bin whose magnitude is within 1e-12 of the mean
-                // (a wider band only means the exact recomputation below runs a little more often)
-                const float root_mean = (float) sqrt(mean_mag);
-                const float band = root_mean * 1e-6f;
+                // |re| within ~3e-6 of sqrt(mean) brackets every bin whose magnitude is within 1e-12 of the mean, with
+                // room for the hardware square root's own error (a wider band only means the exact recomputation
+                // below runs a little more often)
+                const float root_mean = __builtin_amdgcn_sqrtf((float) mean_mag);
+                const float band = root_mean * 3e-6f;
                 bool near = false;
 #pragma unroll
                 for (int j = 0; j < U; j++) near |= fabsf(fabsf(hre[j]) - root_mean) <= band;
@@ -738,7 +738,6 @@ FX_MARK("harm2");
                     probe = (double) (float) ((pm * pm) * r_hmax);                 // (mag / max, via one reciprocal), as a float (:75)
                 }
             }
-            const double score = wave_sum(probe);                              // / sum_normed, clamped: fx_finalise_kernel
 
             // calculateInharmonicity :212-244
             double inh = 0.0;
@@ -758,7 +757,8 @@ FX_MARK("harm2");
                     inh += (r - floor(r)) * ((v * v) / h_sum);                 // :236-239
                 }
             }
-            inh = wave_sum(inh);
+            double score = probe;                                              // / sum_normed, clamped: fx_finalise_kernel
+            wave_sum2(lane, score, inh);
             if (lane == 0) { fpl->inh = inh; fpl->her_score = score; fpl->sum_normed = sum_normed; fpl->flags = 1; }
         }
         wave_fence();

@@ -103,6 +103,19 @@ __device__ __forceinline__ void wave_sum4(int lane, double& a, double& b, double
     c = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(q), 2), __builtin_amdgcn_readlane(__double2loint(q), 2));
     d = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(q), 3), __builtin_amdgcn_readlane(__double2loint(q), 3));
 }
+// Two sums at once, the same way (one folding step).
+__device__ __forceinline__ void wave_sum2(int lane, double& a, double& b)
+{
+    const bool odd = lane & 1;
+    double q = (odd ? b : a) + dppz_d<DPP_XOR1>(odd ? a : b);             // even lanes: a over the pair, odd lanes: b
+    q += dppz_d<DPP_XOR2>(q);
+    q += dppz_d<DPP_ROW_ROR4>(q);
+    q += dppz_d<DPP_ROW_ROR8>(q);
+    q = swap_add_rows16(q);
+    q = swap_add_halves32(q);
+    a = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(q), 0), __builtin_amdgcn_readlane(__double2loint(q), 0));
+    b = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(q), 1), __builtin_amdgcn_readlane(__double2loint(q), 1));
+}
 // (Moving the exchange steps to ds_swizzle -- the LDS crossbar instead of VALU DPP moves -- was measured 3 % slower:
 // the LDS pipe is the kernel's second limiter.)
 // maximum of values that are >= 0 (or NaN, which never wins -- as in `if (x > max) max = x`)
