@@ -4,6 +4,8 @@ x[c][n] = 0.4 sin(p) + 0.2 sin(2p) + 0.1 sin(3p) + u,  p = 2*pi*f_c*n/sr,
 f_c = 55 * 2^((c mod 72)/12) Hz,  u uniform(-0.05, 0.05) from splitmix64(0x5EED ^ c<<32 ^ n).
 The same bytes feed the GPU path and the CPU baseline.
 """
+import os
+
 import numpy as np
 
 _MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
@@ -22,14 +24,24 @@ def channel_frequency(c):
     return 55.0 * 2.0 ** ((np.asarray(c) % 72) / 12.0)
 
 
+def _workers():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def samples(channels, num_samples, sample_rate=48000.0, first_channel=0, first_sample=0, dtype=np.float32):
     """[channels][num_samples] synthetic stream, channel ids first_channel .. first_channel+channels-1.
-    Generated in channel blocks so the fp64 temporaries stay small."""
+    Generated in channel blocks so the fp64 temporaries stay small; the blocks are independent and numpy
+    releases the GIL inside its loops, so they are spread over a few threads (same bytes either way)."""
     out = np.empty((channels, num_samples), dtype)
     n = np.arange(first_sample, first_sample + num_samples, dtype=np.uint64)[None, :]
     nf = n.astype(np.float64)
-    block = max(1, min(channels, (1 << 22) // max(1, num_samples)))
-    for c0 in range(0, channels, block):
+    block = max(1, min(channels, (1 << 21) // max(1, num_samples)))
+
+    def fill(c0):
         c1 = min(channels, c0 + block)
         c = np.arange(first_channel + c0, first_channel + c1, dtype=np.uint64)[:, None]
         with np.errstate(over="ignore"):
@@ -37,6 +49,16 @@ def samples(channels, num_samples, sample_rate=48000.0, first_channel=0, first_s
         u = (splitmix64(key) >> np.uint64(11)).astype(np.float64) * (2.0 ** -53) * 0.1 - 0.05
         phase = 2.0 * np.pi * channel_frequency(c.astype(np.float64)) * nf / sample_rate
         out[c0:c1] = (0.4 * np.sin(phase) + 0.2 * np.sin(2 * phase) + 0.1 * np.sin(3 * phase) + u).astype(dtype)
+
+    starts = list(range(0, channels, block))
+    workers = min(_workers(), len(starts))
+    if workers <= 1:
+        for c0 in starts:
+            fill(c0)
+    else:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(workers) as pool:
+            list(pool.map(fill, starts))
     return out
 
 
