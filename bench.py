@@ -49,6 +49,15 @@ def usable_cores():
     return n
 
 
+def _flush_c_stdio():
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def cpu_baseline(fx, window, frames_per_channel, seconds=30.0):
     """The CPU oracle (a port of the reference's algorithm, oracle/fx_oracle.c) on this host's
     cores, on a bounded sample of the same synthetic workload: one pthread per core over disjoint
@@ -274,6 +283,11 @@ def main():
         if not same:
             raise SystemExit(3)
 
+    # RCCL writes its banner through C stdio, which is block-buffered on a pipe and would otherwise surface after
+    # the JSON line (from any rank) when the processes exit: push it out now, on every rank, before rank 0 prints
+    _flush_c_stdio()
+    if collective:
+        dist.barrier()
     if rank == 0:
         frames_total = total_channels * T * args.steps
         value = frames_total / dt
