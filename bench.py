@@ -4,9 +4,15 @@
 Workload at N=1 GPU: BASELINE.json configs[1] -- 1024 synthetic 48 kHz channels x 1024-pt fp32
 frames (50 % overlap, pre-assembled [C][T][1024], resident in HBM), the whole RealTimeAnalyser
 bundle (spectral + pitch + harmonic + RMS + smoothing + onset).  A "step" is one pass of the hot
-path over one batch of T consecutive frames per channel.  With N GPUs every rank analyses its own
-1024-channel shard (weak scaling; channels are independent, so there is no data-path collective)
-and the smoothed feature vectors are gathered to rank 0, the OSC sink, over RCCL.
+path over one batch of T consecutive frames per channel.  With N > 1 GPUs the workload is BASELINE.json
+configs[3]: every rank analyses its own contiguous 8192-channel shard of 8192*N channels (weak scaling;
+channels are independent, so there is no data-path collective) and the smoothed feature vectors are
+gathered to rank 0, the OSC sink, over RCCL (through the C ABI: fx_comm_* / fx_gather_smoothed).
+
+Launch forms (both work):
+    python bench.py --gpus N ...                                   (bench.py starts its N ranks itself)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N ...                    (the driver's form)
 
 Prints ONE JSON line on rank 0.
 """
@@ -67,6 +73,7 @@ def cpu_baseline(fx, window, frames_per_channel, seconds=30.0):
     cores = usable_cores()
     T = min(frames_per_channel, 16)
     probe = fx.synth.frames(4, T, window)
+    fo.batch_frames(probe, window, threads=1)            # first call: page faults, FFT tables
     t0 = time.perf_counter()
     fo.batch_frames(probe, window, threads=1)
     per_frame = (time.perf_counter() - t0) / (4 * T)
@@ -135,27 +142,90 @@ def stream_bench(fx, args, C, T, N, device):
                                  "channels": C, "hops_per_batch": T, "window": N}}), flush=True)
 
 
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a bare shell: this process has made no GPU call; it starts the N ranks
+    as fresh children (torch.distributed.run, one process per GPU), lets rank 0's JSON line through on stdout
+    and exits with their status.  Never an exec of a GPU-initialised process."""
+    import subprocess
+    import torch
+    if args.backend == "nccl" and torch.cuda.device_count() < args.gpus:
+        raise SystemExit("--gpus %d but only %d GPU(s) visible; RCCL needs one GPU per rank "
+                         "(use --backend gloo to let ranks share devices for debugging)" % (args.gpus, torch.cuda.device_count()))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def valu_model(window):
+    """VALU instructions per frame and their mean issue cost, from committed rocprofv3 / microbenchmark records
+    (profiles/valu_model.json, written by tools/valu_model.py); None if there is no record for this window."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "valu_model.json")))
+        return rec.get(str(window))
+    except Exception:
+        return None
+
+
+def time_steps(an, frames, raw, sm, steps, warmup=2):
+    """(frames/s, frame-kernel ms per launch) of `steps` process_frames calls on one analyser."""
+    import torch
+    if raw is None:
+        raw = torch.empty((frames.shape[0], frames.shape[1], 12), dtype=torch.float32, device=frames.device)
+    if sm is None:
+        sm = torch.empty_like(raw)
+    for _ in range(warmup):
+        an.process_frames(frames, out_raw=raw, out_smoothed=sm)
+    an.sync()
+    an.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        an.process_frames(frames, out_raw=raw, out_smoothed=sm)
+    an.sync()
+    dt = time.perf_counter() - t0
+    fms, _, calls = an.profile_end()
+    return frames.shape[0] * frames.shape[1] * steps / dt, fms / max(calls, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--channels-per-gpu", type=int, default=1024)
-    ap.add_argument("--frames", type=int, default=512, help="consecutive frames per channel per step (SURVEY 8d: T >= 64)")
+    ap.add_argument("--channels-per-gpu", type=int, default=None,
+                    help="default: 1024 at --gpus 1 (BASELINE configs[1]), 8192 at --gpus N>1 (configs[3])")
+    ap.add_argument("--frames", type=int, default=None,
+                    help="consecutive frames per channel per step (SURVEY 8d: T >= 64); default 512 at --gpus 1, 64 at --gpus N>1 "
+                         "(the same 524288 frames per GPU per step either way)")
     ap.add_argument("--window", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the spectral-only extra measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements (spectral-only, noise / silence, other windows)")
     ap.add_argument("--signal", default="synth", choices=["synth", "noise", "silence"],
                     help="synth = the BASELINE synthetic mix (default); noise / silence probe data-dependent paths")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo: debugging aid for boxes with fewer GPUs than ranks (ranks share devices, features are gathered through host memory)")
+                    help="nccl: the feature gather runs over RCCL through the C ABI (fx_gather_smoothed), one GPU per rank.  "
+                         "gloo: debugging aid for boxes with fewer GPUs than ranks (ranks share devices, features are gathered through host memory)")
     ap.add_argument("--stream", action="store_true",
                     help="host-resident hops through the pinned ring (fx_stream_*): PCIe-inclusive rate, reported as an extra line")
     ap.add_argument("--fp16", action="store_true", help="--stream only: fp16 samples")
     ap.add_argument("--debug-collective", action="store_true",
-                    help="with --gpus 1: create a one-rank RCCL group and run the N>1 code path (gather included), "
+                    help="with --gpus 1: create a one-rank RCCL communicator and run the N>1 code path (gather included), "
                          "then check the gathered block against the local one")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
 
     import torch
     import torch.distributed as dist
@@ -164,22 +234,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.backend == "gloo":
-        local_rank = local_rank % torch.cuda.device_count()
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     collective = world > 1 or args.debug_collective
     if collective:
+        # control plane (barriers, the communicator id, the max over ranks): a CPU group.  The data-path exchange is
+        # RCCL inside the library.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     fx = importlib.import_module("feature-extractor_amd")
     sharded = importlib.import_module("feature-extractor_amd.sharded")
-    C, T, N = args.channels_per_gpu, args.frames, args.window
+    N = args.window
+    C = args.channels_per_gpu if args.channels_per_gpu is not None else (1024 if world == 1 else 8192)
+    T = args.frames if args.frames is not None else (512 if world == 1 else 64)
     if args.stream:
         return stream_bench(fx, args, C, T, N, local_rank)
     total_channels = C * world
@@ -191,95 +262,83 @@ def main():
     elif args.signal == "silence":
         host_frames = np.zeros_like(host_frames)
     frames = torch.from_numpy(host_frames).cuda(local_rank)
+    del host_frames
     an = fx.BatchAnalyser(count, N, device=local_rank)
     raw = torch.empty((count, T, 12), dtype=torch.float32, device=frames.device)
     sm = torch.empty((count, T, 12), dtype=torch.float32, device=frames.device)
+
     # What travels between GPUs is what the OSC sink samples (ref OSCFeatureAnalysisOutput.h:89-113): the latest
-    # smoothed vector of every channel, [C][12] per rank per step.  Two buffers: the gather of step i
-    # (RCCL, its own stream) reads one while step i+1 fills the other.
-    latest_bufs = [torch.empty((count, 12), dtype=torch.float32, device=frames.device) for _ in range(2)]
+    # smoothed vector of every channel, [C][12] per rank per step, gathered to rank 0.
+    rccl = collective and args.backend == "nccl"
+    gathered = None
+    if rccl:
+        ident = [fx.BatchAnalyser.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        an.comm_create(rank, world, ident[0])
+        total, firsts = an.comm_layout()
+        assert total == total_channels and firsts[rank] == first, (total, firsts, first)
+        if rank == 0:      # two destination buffers: a consumer may read one while the next gather fills the other
+            gathered = [torch.empty((total_channels, 12), dtype=torch.float32, device=frames.device) for _ in range(2)]
+    host_pending = [None]
+    counter = [0]
+
+    def drain():
+        an.sync()
+        if rccl:
+            an.comm_sync()
+        elif host_pending[0] is not None and host_pending[0][1] is not None:
+            host_pending[0][1].wait()
 
     def barrier():
-        an.sync()
+        drain()
         torch.cuda.synchronize()
         if collective:
             dist.barrier()
             torch.cuda.synchronize()
 
-    pending = [None, None]
-    counter = [0]
-    last = [None]
-    # RCCL path: everything is ordered on the device.  `lib_stream` wraps the library's hipStream_t, the gather runs
-    # on `side`; events make the gather wait for the step's kernels and make the kernels that next overwrite a
-    # feature buffer wait for the gather that read it.  The host never blocks inside the timed loop.
-    device_ordered = collective and args.backend == "nccl"
-    if device_ordered:
-        lib_stream = torch.cuda.ExternalStream(an.stream(), device=frames.device)
-        side = torch.cuda.Stream(device=frames.device)
-
-    def drain(slot):
-        if pending[slot] is None:
-            return
-        work = pending[slot][1]
-        if device_ordered:
-            with torch.cuda.stream(side):
-                if work is not None:
-                    work.wait()                          # `side` waits for the collective
-            lib_stream.wait_stream(side)
-        elif work is not None:
-            work.wait()
-        pending[slot] = None
-
     def step():
         slot = counter[0] & 1
         counter[0] += 1
-        if collective:
-            drain(slot)                                  # the gather that last read this buffer is ordered before us
         an.process_frames(frames, out_raw=raw, out_smoothed=sm)
-        if collective:
-            an.get_features(out=latest_bufs[slot])       # async device copy on the library's stream
-        if device_ordered:
-            side.wait_stream(lib_stream)                 # features ready before RCCL reads them
-            with torch.cuda.stream(side):
-                pending[slot] = sharded.gather_features(latest_bufs[slot], total_channels, dst=0, async_op=True, single_rank_collective=True)
-            last[0] = (slot, pending[slot][0])
+        if rccl:
+            # asynchronous, device-ordered: snapshot on the library's stream, RCCL on its side stream
+            an.gather_features(dst=0, out=gathered[slot] if rank == 0 else None)
         elif collective:
-            an.sync()
-            pending[slot] = sharded.gather_features(latest_bufs[slot].cpu(), total_channels, dst=0, async_op=True, single_rank_collective=True)
-            last[0] = (slot, pending[slot][0])
+            if host_pending[0] is not None and host_pending[0][1] is not None:
+                host_pending[0][1].wait()
+            host_pending[0] = sharded.gather_features(torch.from_numpy(an.get_features()), total_channels, dst=0,
+                                                      async_op=True, single_rank_collective=True)
 
     if collective:
-        # one untimed exchange so that the RCCL communicator and the gather buffers exist even with --warmup 0
-        step()
-        drain(0)
-        drain(1)
+        step()                  # one untimed exchange so that the communicator's channels exist even with --warmup 0
     for _ in range(args.warmup):
         step()
-    drain(0)
-    drain(1)
     barrier()
     an.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    drain(0)
-    drain(1)
     barrier()
     dt = time.perf_counter() - t0
     frame_ms, epi_ms, calls = an.profile_end()
 
-    t = torch.tensor([dt], dtype=torch.float64, device=frames.device)
     if collective:
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    if args.debug_collective and rank == 0:
-        slot, gathered = last[0]
-        got = sharded.resolve(gathered)[first:first + count].cpu()
-        want = latest_bufs[slot].cpu()
+        dt = float(t.item())
+    if collective and rank == 0:
+        # the sink's copy of this rank's block must be what the analyser holds
+        want = torch.from_numpy(an.get_features())
+        if rccl:
+            got = gathered[(counter[0] - 1) & 1][first:first + count].cpu()
+        else:
+            got = sharded.resolve(host_pending[0][0])[first:first + count]
         if not torch.equal(torch.nan_to_num(want), torch.nan_to_num(sm[:, -1, :].cpu())):
             raise SystemExit("latest vectors differ from the last frame's smoothed vectors")
         same = bool(torch.equal(torch.nan_to_num(got), torch.nan_to_num(want)))
-        print("debug-collective: gathered block %s the local features" % ("equals" if same else "DIFFERS FROM"), file=sys.stderr, flush=True)
+        print("collective check: gathered block %s the local features (%s, %d rank(s))"
+              % ("equals" if same else "DIFFERS FROM", "RCCL via fx_gather_smoothed" if rccl else "gloo via host", world),
+              file=sys.stderr, flush=True)
         if not same:
             raise SystemExit(3)
 
@@ -295,44 +354,84 @@ def main():
         launch_bytes = bytes_per_frame * count * T
         avg_launch_s = frame_ms / 1e3 / max(calls, 1)
         achieved = launch_bytes / avg_launch_s / 1e9
+        cfg = "configs[1]" if world == 1 else "configs[3]"
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(N, count, T),
+                "kernel": "fx_frame_kernel<%d>" % N, "avg_launch_ms": avg_launch_s * 1e3,
+                "algorithmic_bytes_per_launch": launch_bytes, "launches_timed": calls,
+                "epilogue_ms_per_step": epi_ms / max(calls, 1),
+                "limiter": "valu",
+                "note": "algorithmic bytes = (4*N + 48) B/frame x frames per launch, against the HBM peak as SURVEY 8(d) defines the "
+                        "roofline; the kernel's binding unit is VALU issue (see valu_issue_frac and DESIGN.md 3.3)"}
+        vm = valu_model(N)
+        if vm:
+            # time the kernel's VALU instructions need at the measured per-class issue costs (tools/ubench), as a fraction
+            # of the kernel's duration: the binding unit's utilisation
+            simds = 1024
+            need_s = vm["valu_per_frame"] * vm["mean_issue_ns"] * 1e-9 * count * T / simds
+            roof["valu_issue_frac"] = need_s / avg_launch_s
+            roof["valu_insts_per_frame"] = vm["valu_per_frame"]
+            roof["valu_model_source"] = vm.get("source")
         out = {
             "metric": "frames/sec (1024-pt FFT, 10-feature bundle)" if N == 1024 else "frames/sec (%d-pt FFT, 10-feature bundle)" % N,
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d channels/GPU x %d-pt fp32 frames, %d consecutive frames per channel per step, "
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if args.signal == "synth" else args.signal,
+            "config": {"workload": "%s: %d channels/GPU x %d-pt fp32 frames, %d consecutive frames per channel per step, "
                                    "full 12-feature RealTimeAnalyser bundle (spectral+pitch+harmonic+RMS+smoothing+onset), "
-                                   "frames pre-assembled and resident in HBM" % (C, N, T),
-                       "channels_per_gpu": C, "frames_per_step": T, "window": N, "sample_rate": 48000,
-                       "sharding": "channels, contiguous blocks; per step an RCCL gather of the latest smoothed vectors [C][12] of every rank to rank 0 (the OSC sink)" if world > 1 else "single GPU"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(N, count, T),
-                         "kernel": "fx_frame_kernel<%d>" % N, "avg_launch_ms": avg_launch_s * 1e3,
-                         "algorithmic_bytes_per_launch": launch_bytes, "launches_timed": calls,
-                         "epilogue_ms_per_step": epi_ms / max(calls, 1),
-                         "note": "algorithmic bytes = (4*N + 48) B/frame x frames per launch; this kernel is VALU/LDS-bound, not HBM-bound (see DESIGN.md)"},
+                                   "frames pre-assembled and resident in HBM" % (cfg, C, N, T),
+                       "channels_per_gpu": C, "total_channels": total_channels, "frames_per_step": T, "window": N, "sample_rate": 48000,
+                       "sharding": ("channels, contiguous blocks of %d; per step a gather of the latest smoothed vectors [C][12] of every rank "
+                                    "to rank 0 (the OSC sink) %s" % (C, "over RCCL (fx_gather_smoothed, grouped ncclSend/ncclRecv on a side stream)"
+                                                                     if rccl else "through host memory (gloo debugging backend)"))
+                                   if collective else "single GPU"},
+            "roofline": roof,
         }
-        if world == 1 and not args.no_extra:
+        if world == 1 and not args.no_extra and not args.debug_collective:
+            extra_steps = 10
             # BASELINE configs[1] read literally is the spectral analyser alone ("fused window + FFT +
             # magnitude + SpectralCharacteristics reductions in one kernel"); the same workload with only the
             # RealTimeSpectralAnalyser constructed, as an extra (never `value`)
             an_s = fx.BatchAnalyser(count, N, device=local_rank, analysers="spectral")
-            for _ in range(3):
-                an_s.process_frames(frames, out_raw=raw, out_smoothed=sm)
-            an_s.sync()
-            an_s.profile_begin()
-            t1 = time.perf_counter()
-            for _ in range(10):
-                an_s.process_frames(frames, out_raw=raw, out_smoothed=sm)
-            an_s.sync()
-            dts = time.perf_counter() - t1
-            fms, _, calls_s = an_s.profile_end()
-            ach = launch_bytes / (fms / 1e3 / max(calls_s, 1)) / 1e9
-            out["spectral_only"] = {"value": total_channels * T * 10 / dts, "unit": "frames/s",
-                                    "kernel": "fx_frame_kernel<%d, spectral>" % N, "avg_launch_ms": fms / max(calls_s, 1),
+            fps, fms = time_steps(an_s, frames, raw, sm, extra_steps, warmup=3)
+            an_s.close()
+            ach = launch_bytes / (fms / 1e3) / 1e9
+            out["spectral_only"] = {"value": fps, "unit": "frames/s",
+                                    "kernel": "fx_frame_kernel<%d, spectral>" % N, "avg_launch_ms": fms,
                                     "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS},
                                     "note": "FX_SPECTRAL_ONLY: RMS, centroid, spread, flatness, LER, flux, slope, onset (8 of the 12 slots)"}
-        if not args.no_cpu_baseline and world == 1:
+            # data-dependent paths (ref PitchAnalyser.h:161-190: the lag search ends early on tonal input and runs to the
+            # arg-min fallback on noise; silence takes every early exit): same shape, other contents
+            dd = {}
+            for name in ("noise", "silence"):
+                if name == "noise":
+                    g = torch.Generator(device=frames.device)
+                    g.manual_seed(1234)
+                    other = torch.randn(frames.shape, generator=g, device=frames.device, dtype=torch.float32) * 0.1
+                else:
+                    other = torch.zeros_like(frames)
+                fps, fms = time_steps(an, other, raw, sm, extra_steps)
+                dd[name] = {"value": fps, "unit": "frames/s", "frame_kernel_ms": fms,
+                            "relative_to_synth": (avg_launch_s * 1e3) / fms}
+                del other
+            dd["note"] = "same shape as the headline run; noise = N(0, 0.1^2) white, silence = zeros; relative_to_synth = synth kernel time / this kernel time"
+            out["data_dependence"] = dd
+            an.reset_state()
+            # the reference application's default window (AnalyserTrackController.h:20-21) and the streaming config's window
+            others = {}
+            for (n2, c2, t2, label) in ((2048, 4096, 32, "configs[2] shape: 4096 channels x 2048-pt"), (4096, 1024, 32, "configs[4] window: 1024 channels x 4096-pt")):
+                if n2 == N:
+                    continue
+                fr2 = torch.from_numpy(fx.synth.frames(c2, t2, n2)).cuda(local_rank)
+                an2 = fx.BatchAnalyser(c2, n2, device=local_rank)
+                fps, fms = time_steps(an2, fr2, None, None, extra_steps, warmup=3)
+                an2.close()
+                b2 = (4 * n2 + 48) * c2 * t2
+                others[str(n2)] = {"value": fps, "unit": "frames/s", "frame_kernel_ms": fms, "workload": "%s, %d frames per step" % (label, t2),
+                                   "hbm_frac": b2 / (fms / 1e3) / 1e9 / HBM_PEAK_GBPS}
+                del fr2
+            out["other_windows"] = others
+        if not args.no_cpu_baseline and world == 1 and not args.debug_collective:
             out["cpu_baseline"] = cpu_baseline(fx, N, T)
         else:
             out["cpu_baseline"] = None
@@ -340,6 +439,8 @@ def main():
 
     if collective:
         dist.barrier()
+        if rccl:
+            an.comm_destroy()
         dist.destroy_process_group()
 
 

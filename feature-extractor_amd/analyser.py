@@ -99,13 +99,26 @@ class BatchAnalyser:
             if x.numel() % (C * per_frame):
                 raise ValueError("input size is not a multiple of channels x samples per frame")
             T = x.numel() // (C * per_frame)
+            if x.device.index != self.device:
+                raise ValueError("input lives on %s, the analyser on cuda:%d" % (x.device, self.device))
+            for name, o in (("out_raw", out_raw), ("out_smoothed", out_smoothed)):
+                if o is not None:
+                    self._check_out(o, C * T * 12, name)
             raw = out_raw if out_raw is not None else (torch.empty((C, T, 12), dtype=torch.float32, device=x.device) if want_raw else None)
             sm = out_smoothed if out_smoothed is not None else (torch.empty((C, T, 12), dtype=torch.float32, device=x.device) if want_smoothed else None)
-            # order our stream after the producer of x on torch's current stream
-            torch.cuda.current_stream(x.device).synchronize()
+            # The library enqueues on its own HIP stream.  Order it after the producer of x on torch's current
+            # stream, and torch's current stream after the analysis, both on the device (no host sync).  Because
+            # the current stream waits for the analysis, anything torch later does with these blocks on that
+            # stream -- reading the results, freeing and recycling x -- is ordered after the kernels that use
+            # them.  (Tensor.record_stream is deliberately not used: the allocator would record events on the
+            # library's stream when the tensors die, possibly after fx_destroy has destroyed that stream.)
+            cur = torch.cuda.current_stream(x.device)
+            lib = self._torch_stream(x.device)
+            lib.wait_stream(cur)
             capi.check(fn(self._h, ctypes.c_void_p(x.data_ptr()), T, fmt, capi.MEM_DEVICE,
                           ctypes.c_void_p(raw.data_ptr()) if raw is not None else None,
                           ctypes.c_void_p(sm.data_ptr()) if sm is not None else None))
+            cur.wait_stream(lib)
             return raw, sm
         x = np.ascontiguousarray(x)
         if x.dtype == np.float16:
@@ -123,6 +136,18 @@ class BatchAnalyser:
                       sm.ctypes.data_as(ctypes.c_void_p) if sm is not None else None))
         return raw, sm
 
+    def _torch_stream(self, device):
+        """The library's hipStream_t as a torch stream (for device-side ordering against torch's streams)."""
+        import torch
+        if getattr(self, "_ext_stream", None) is None:
+            self._ext_stream = torch.cuda.ExternalStream(self.stream(), device=device)
+        return self._ext_stream
+
+    def _check_out(self, o, numel, name):
+        if not (_is_torch(o) and o.is_cuda and o.device.index == self.device and o.is_contiguous()
+                and str(o.dtype) == "torch.float32" and o.numel() == numel):
+            raise ValueError("%s must be a contiguous float32 CUDA tensor on cuda:%d with %d elements" % (name, self.device, numel))
+
     def push_hops(self, hops, want_raw=True, want_smoothed=True, out_raw=None, out_smoothed=None):
         """hops [C][T][N/2] -> (raw [C][T][12], smoothed [C][T][12])."""
         return self._run(self._lib.fx_push_hops, hops, self.window_size // 2, want_raw, want_smoothed, out_raw, out_smoothed)
@@ -136,14 +161,58 @@ class BatchAnalyser:
         float32 CUDA tensor of that shape -- an asynchronous device copy on the library's stream (what the OSC
         sink of a sharded run gathers)."""
         if out is not None:
-            if not (_is_torch(out) and out.is_cuda and out.is_contiguous() and out.numel() == self.num_channels * 12
-                    and str(out.dtype) == "torch.float32"):
-                raise ValueError("out must be a contiguous float32 CUDA tensor with num_channels x 12 elements")
+            import torch
+            self._check_out(out, self.num_channels * 12, "out")
+            cur = torch.cuda.current_stream(out.device)
+            lib = self._torch_stream(out.device)
+            lib.wait_stream(cur)
             capi.check(self._lib.fx_get_smoothed(self._h, ctypes.c_void_p(out.data_ptr()), capi.MEM_DEVICE))
+            cur.wait_stream(lib)
             return out
         out = np.empty((self.num_channels, 12), np.float32)
         capi.check(self._lib.fx_get_smoothed(self._h, out.ctypes.data_as(ctypes.c_void_p), capi.MEM_HOST))
         return out
+
+
+    # ---- multi-GPU: gather of the latest smoothed vectors to the OSC sink rank (RCCL, through the C ABI) ----
+    @staticmethod
+    def comm_unique_id():
+        """bytes to hand to every rank's comm_create (rank 0 creates them)."""
+        buf = ctypes.create_string_buffer(capi.COMM_ID_BYTES)
+        capi.check(capi.load_library().fx_comm_unique_id(buf, capi.COMM_ID_BYTES))
+        return buf.raw
+
+    def comm_create(self, rank, world_size, unique_id):
+        capi.check(self._lib.fx_comm_create(self._h, int(rank), int(world_size), ctypes.c_char_p(unique_id), len(unique_id)))
+        self._world = int(world_size)
+
+    def comm_destroy(self):
+        capi.check(self._lib.fx_comm_destroy(self._h))
+
+    def comm_layout(self):
+        """(total channels over all ranks, [first channel of rank r])."""
+        total = ctypes.c_int()
+        first = (ctypes.c_int * self._world)()
+        capi.check(self._lib.fx_comm_layout(self._h, ctypes.byref(total), first))
+        return total.value, list(first)
+
+    def gather_features(self, dst=0, out=None):
+        """Asynchronous gather of every rank's latest smoothed vectors to rank `dst`.  `out`: on dst a host
+        array or contiguous float32 CUDA tensor of [total_channels][12]; valid after comm_sync()."""
+        if out is None:
+            capi.check(self._lib.fx_gather_smoothed(self._h, int(dst), None, capi.MEM_DEVICE))
+        elif _is_torch(out):
+            total, _ = self.comm_layout()
+            self._check_out(out, total * 12, "out")
+            capi.check(self._lib.fx_gather_smoothed(self._h, int(dst), ctypes.c_void_p(out.data_ptr()), capi.MEM_DEVICE))
+        else:
+            if not (out.dtype == np.float32 and out.flags.c_contiguous):
+                raise ValueError("out must be a C-contiguous float32 array")
+            capi.check(self._lib.fx_gather_smoothed(self._h, int(dst), out.ctypes.data_as(ctypes.c_void_p), capi.MEM_HOST))
+        return out
+
+    def comm_sync(self):
+        capi.check(self._lib.fx_comm_sync(self._h))
 
 
 class HopStream:

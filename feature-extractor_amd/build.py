@@ -10,8 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfx_hip.so")
-SOURCES = ["fx_kernels.hip", "fx_capi.cpp"]
-HEADERS = ["fx_kernels.h", "fx_wave.hip.h", "fx_fft.hip.h", "fx_frame_kernel.hip.h", "fx_tail_kernels.hip.h",
+SOURCES = ["fx_kernels.hip", "fx_capi.cpp", "fx_comm.cpp"]
+HEADERS = ["fx_kernels.h", "fx_context.h", "fx_wave.hip.h", "fx_fft.hip.h", "fx_frame_kernel.hip.h", "fx_tail_kernels.hip.h",
            os.path.join("..", "..", "include", "fx.h")]
 
 # -ffp-contract=off : the reference FFT never fuses a*b+c; spectra must be bit-identical.
@@ -54,21 +54,36 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
+    """Compile and link in-tree.  Safe under a multi-rank launch: one process builds at a time (flock on
+    lib/.build.lock), objects and the library are written under temporary names and renamed into place, so
+    a concurrent reader never maps a half-written file."""
     if not force and not needs_build():
         return LIB_PATH
+    import fcntl
     os.makedirs(LIB_DIR, exist_ok=True)
-    objs = []
-    for src in SOURCES:
-        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        _run(cmd)
-        objs.append(obj)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():          # another rank built it while we waited
+                return LIB_PATH
+            tag = ".tmp%d" % os.getpid()
+            objs = []
+            for src in SOURCES:
+                obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
+                cmd = [_hipcc()] + HIPCC_FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj + tag]
+                if verbose:
+                    print(" ".join(cmd))
+                _run(cmd)
+                os.replace(obj + tag, obj)
+                objs.append(obj)
+            # librccl: the feature gather of the multi-GPU path (fx_comm.cpp) calls RCCL directly
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + tag] + objs + ["-L/opt/rocm/lib", "-lrccl"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            os.replace(LIB_PATH + tag, LIB_PATH)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

@@ -22,7 +22,10 @@ EXPORTS = ["fx_create", "fx_destroy", "fx_reset_state", "fx_set_sample_rate", "f
            "fx_set_onset_window", "fx_set_onset_type", "fx_set_gain", "fx_push_hops", "fx_process_frames",
            "fx_get_smoothed", "fx_sync", "fx_get_stream", "fx_last_kernel_ms", "fx_profile_begin", "fx_profile_end",
            "fx_stream_create", "fx_stream_destroy", "fx_stream_acquire", "fx_stream_submit", "fx_stream_collect", "fx_stream_in_flight", "fx_pack_osc12",
-           "fx_pack_osc10", "fx_osc_encode", "fx_last_error", "fx_abi_version"]
+           "fx_pack_osc10", "fx_osc_encode", "fx_last_error", "fx_abi_version",
+           "fx_comm_unique_id", "fx_comm_create", "fx_comm_destroy", "fx_comm_layout", "fx_gather_smoothed", "fx_comm_sync"]
+COMM_ID_BYTES = 128
+ABI_VERSION = 2
 
 
 class FxError(RuntimeError):
@@ -71,6 +74,12 @@ def load_library(build_if_missing=True):
     L.fx_stream_in_flight.argtypes = [vp]
     L.fx_profile_begin.argtypes = [vp]
     L.fx_profile_end.argtypes = [vp, ctypes.POINTER(d), ctypes.POINTER(d), ctypes.POINTER(i)]
+    L.fx_comm_unique_id.argtypes = [vp, i]
+    L.fx_comm_create.argtypes = [vp, i, i, vp, i]
+    L.fx_comm_destroy.argtypes = [vp]
+    L.fx_comm_layout.argtypes = [vp, ctypes.POINTER(i), ctypes.POINTER(i)]
+    L.fx_gather_smoothed.argtypes = [vp, i, vp, i]
+    L.fx_comm_sync.argtypes = [vp]
     L.fx_pack_osc12.argtypes = [fp, fp]
     L.fx_pack_osc12.restype = None
     L.fx_pack_osc10.argtypes = [fp, fp]

@@ -14,72 +14,27 @@
 
 #include "fx_kernels.h"
 
-namespace {
+#include "fx_context.h"
 
-thread_local std::string g_err;
+thread_local std::string g_fx_err;
 
-fx_status fail(fx_status code, const char* fmt, ...)
+fx_status fx_fail(fx_status code, const char* fmt, ...)
 {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    g_err = buf;
+    g_fx_err = buf;
     return code;
 }
 
-#define HIP_TRY(expr)                                                                           \
-    do {                                                                                        \
-        hipError_t e_ = (expr);                                                                 \
-        if (e_ != hipSuccess)                                                                   \
-            return fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP,          \
-                        "%s failed: %s", #expr, hipGetErrorString(e_));                        \
-    } while (0)
+namespace {
 
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 } // namespace
 
-struct fx_context {
-    int      device = 0;
-    int      C = 0, N = 0;
-    double   sample_rate = 48000.0;
-    unsigned flags = 0;
-    // settings (ref RealTimeAnalyser.h:244-258, SpectralCharacteristics.h:237-241,311, AudioDataCollector.h:129)
-    float    gain = 1.0f;
-    int      onset_window = 5;
-    int      onset_type = FX_ONSET_AMPLITUDE;
-    float    onset_multiplier = 1.7f;
-    long long frames_seen = 0;
-    long long onset_reset_frame = 0;
-
-    hipStream_t stream = nullptr;
-    hipEvent_t  ev[3] = {nullptr, nullptr, nullptr};
-    bool        ev_valid = false;
-    bool        profiling = false;
-    std::vector<hipEvent_t> prof_events;     // 3 per recorded call
-    size_t      prof_used = 0;
-
-    float* d_tw = nullptr;        // [N][2]
-    float* d_prev = nullptr;      // [C][N/2]
-    float* d_tail[2] = {nullptr, nullptr};   // [C][N/2], ping-pong
-    float* d_hist[2] = {nullptr, nullptr};   // [C][HLEN][12], ping-pong
-    float* d_latest = nullptr;    // [C][12]
-    int    cur = 0;
-
-    float* d_raw = nullptr;       // [C][T_cap][12]
-    fxk::FramePart* d_part = nullptr;   // [C][T_cap]
-    size_t part_cap = 0;
-    void*  d_in = nullptr;        // staging for host input
-    float* d_out_raw = nullptr;   // staging for host output
-    float* d_out_sm = nullptr;
-    size_t raw_cap = 0, in_cap = 0, out_cap = 0;
-
-    double bin_var = 0.0;
-    float  lpf_a = 0.0f, lpf_b = 0.0f;
-    float  first_tw[18] = {0};
-};
 
 namespace {
 
@@ -113,14 +68,14 @@ template <typename T> fx_status grow(T** ptr, size_t* cap, size_t need)
 fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_kind, int hop_mode,
               float* out_raw, float* out_smoothed)
 {
-    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
-    if (T < 0) return fail(FX_ERR_INVALID_ARGUMENT, "negative frame count");
+    if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (T < 0) return fx_fail(FX_ERR_INVALID_ARGUMENT, "negative frame count");
     if (T == 0) return FX_OK;
-    if (!in) return fail(FX_ERR_INVALID_ARGUMENT, "null input buffer");
+    if (!in) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null input buffer");
     if (sample_format != FX_SAMPLE_F32 && sample_format != FX_SAMPLE_F16)
-        return fail(FX_ERR_INVALID_ARGUMENT, "unknown sample format %d", sample_format);
+        return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown sample format %d", sample_format);
     if (mem_kind != FX_MEM_HOST && mem_kind != FX_MEM_DEVICE)
-        return fail(FX_ERR_INVALID_ARGUMENT, "unknown memory kind %d", mem_kind);
+        return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown memory kind %d", mem_kind);
     HIP_TRY(hipSetDevice(c->device));
 
     const size_t esz = sample_format == FX_SAMPLE_F16 ? 2 : 4;
@@ -156,7 +111,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
         d_os = out_smoothed ? c->d_out_sm : nullptr;
     } else {
         if (reinterpret_cast<uintptr_t>(in) % 16 != 0)
-            return fail(FX_ERR_INVALID_ARGUMENT, "device input must be 16-byte aligned");
+            return fx_fail(FX_ERR_INVALID_ARGUMENT, "device input must be 16-byte aligned");
     }
 
     fxk::FrameParams fp;
@@ -197,7 +152,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
         }
     }
     if (fxk::frame_kernel_lds_bytes(c->N, waves) > lds_cu)
-        return fail(FX_ERR_UNSUPPORTED, "window size %d does not fit the LDS", c->N);
+        return fx_fail(FX_ERR_UNSUPPORTED, "window size %d does not fit the LDS", c->N);
 
     fxk::EpilogueParams ep;
     ep.part = c->d_part;
@@ -255,34 +210,34 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
 extern "C" {
 
 int fx_abi_version(void) { return FX_ABI_VERSION; }
-const char* fx_last_error(void) { return g_err.c_str(); }
+const char* fx_last_error(void) { return g_fx_err.c_str(); }
 
 fx_status fx_create(fx_context** out, int device_id, int num_channels, int window_size, double sample_rate, unsigned flags)
 {
-    if (!out) return fail(FX_ERR_INVALID_ARGUMENT, "null output pointer");
+    if (!out) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null output pointer");
     *out = nullptr;
-    if (num_channels <= 0) return fail(FX_ERR_INVALID_ARGUMENT, "num_channels must be positive");
+    if (num_channels <= 0) return fx_fail(FX_ERR_INVALID_ARGUMENT, "num_channels must be positive");
     if (!is_pow2(window_size) || window_size < 256 || window_size > 4096)
-        return fail(FX_ERR_INVALID_ARGUMENT, "window_size must be a power of two in [256, 4096], got %d", window_size);
-    if (!(sample_rate > 0.0)) return fail(FX_ERR_INVALID_ARGUMENT, "sample_rate must be positive");
+        return fx_fail(FX_ERR_INVALID_ARGUMENT, "window_size must be a power of two in [256, 4096], got %d", window_size);
+    if (!(sample_rate > 0.0)) return fx_fail(FX_ERR_INVALID_ARGUMENT, "sample_rate must be positive");
     if ((flags & FX_ORDER_MASK) == 3u || (flags & ~(FX_ORDER_MASK | FX_SPECTRAL_ONLY | FX_HARMONIC_ONLY)) ||
         ((flags & FX_SPECTRAL_ONLY) && (flags & FX_HARMONIC_ONLY)))
-        return fail(FX_ERR_INVALID_ARGUMENT, "unknown or contradictory flags 0x%x", flags);
+        return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown or contradictory flags 0x%x", flags);
 
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
         (void) hipGetLastError();
-        return fail(FX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+        return fx_fail(FX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
     }
-    if (device_id < 0 || device_id >= count) return fail(FX_ERR_INVALID_ARGUMENT, "device_id %d out of range [0,%d)", device_id, count);
+    if (device_id < 0 || device_id >= count) return fx_fail(FX_ERR_INVALID_ARGUMENT, "device_id %d out of range [0,%d)", device_id, count);
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device_id));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(FX_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device_id, prop.gcnArchName);
+        return fx_fail(FX_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device_id, prop.gcnArchName);
     HIP_TRY(hipSetDevice(device_id));
 
     fx_context* c = new (std::nothrow) fx_context();
-    if (!c) return fail(FX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    if (!c) return fx_fail(FX_ERR_OUT_OF_MEMORY, "host allocation failed");
     c->device = device_id;
     c->C = num_channels;
     c->N = window_size;
@@ -293,9 +248,9 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
     auto cleanup = [&](fx_status s) { fx_destroy(c); return s; };
     {
         hipError_t e = fxk::prepare_kernels(window_size);
-        if (e != hipSuccess) return cleanup(fail(FX_ERR_HIP, "kernel preparation failed: %s", hipGetErrorString(e)));
+        if (e != hipSuccess) return cleanup(fx_fail(FX_ERR_HIP, "kernel preparation failed: %s", hipGetErrorString(e)));
     }
-#define TRY_OR_CLEAN(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return cleanup(fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
+#define TRY_OR_CLEAN(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return cleanup(fx_fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
     TRY_OR_CLEAN(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < 3; i++) TRY_OR_CLEAN(hipEventCreate(&c->ev[i]));
     const size_t half = (size_t) num_channels * (window_size / 2);
@@ -320,7 +275,7 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
         fxk::build_pass_twiddles(window_size, tw.data(), ordered.data());    // same values, pass access order
         fxk::fill_first_pass_twiddles(window_size, ordered.data(), c->first_tw);
         if (!fxk::first_pass_twiddles_hermitian(window_size, c->first_tw))
-            return cleanup(fail(FX_ERR_UNSUPPORTED, "this host's cos/sin produce a twiddle table without the mirror symmetry the kernels rely on"));
+            return cleanup(fx_fail(FX_ERR_UNSUPPORTED, "this host's cos/sin produce a twiddle table without the mirror symmetry the kernels rely on"));
         TRY_OR_CLEAN(hipMemcpy(c->d_tw, ordered.data(), ordered.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     // ref SpectralCharacteristics.h:180-189: binVar does not depend on the signal
@@ -350,6 +305,7 @@ fx_status fx_destroy(fx_context* c)
 {
     if (!c) return FX_OK;
     (void) hipSetDevice(c->device);
+    fx_comm_release(c);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     void* bufs[] = {c->d_tw, c->d_prev, c->d_tail[0], c->d_tail[1], c->d_hist[0], c->d_hist[1], c->d_latest,
                     c->d_raw, c->d_part, c->d_in, c->d_out_raw};
@@ -363,32 +319,32 @@ fx_status fx_destroy(fx_context* c)
 
 fx_status fx_reset_state(fx_context* c)
 {
-    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
     HIP_TRY(hipSetDevice(c->device));
     return zero_state(c);
 }
 
 fx_status fx_set_sample_rate(fx_context* c, double sr)
 {
-    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
-    if (!(sr > 0.0)) return fail(FX_ERR_INVALID_ARGUMENT, "sample_rate must be positive");
+    if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (!(sr > 0.0)) return fx_fail(FX_ERR_INVALID_ARGUMENT, "sample_rate must be positive");
     c->sample_rate = sr;
     return FX_OK;
 }
 
 fx_status fx_set_onset_sensitivity(fx_context* c, float s)
 {
-    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
-    if (!(s >= 0.0f)) return fail(FX_ERR_INVALID_ARGUMENT, "sensitivity must be >= 0");   // jassert, RealTimeAnalyser.h:246
+    if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (!(s >= 0.0f)) return fx_fail(FX_ERR_INVALID_ARGUMENT, "sensitivity must be >= 0");   // jassert, RealTimeAnalyser.h:246
     c->onset_multiplier = 1.0f + s;
     return FX_OK;
 }
 
 fx_status fx_set_onset_window(fx_context* c, int length)
 {
-    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
     if (length < 1 || length > fxk::MAX_ONSET_WINDOW)
-        return fail(FX_ERR_INVALID_ARGUMENT, "onset window must be in [1,%d]", fxk::MAX_ONSET_WINDOW);
+        return fx_fail(FX_ERR_INVALID_ARGUMENT, "onset window must be in [1,%d]", fxk::MAX_ONSET_WINDOW);
     c->onset_window = length;
     c->onset_reset_frame = c->frames_seen;      // both histories emptied, RealTimeAudioAnalysis.h:73-81
     return FX_OK;
@@ -396,15 +352,15 @@ fx_status fx_set_onset_window(fx_context* c, int length)
 
 fx_status fx_set_onset_type(fx_context* c, int type)
 {
-    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
-    if (type < FX_ONSET_SPECTRAL || type > FX_ONSET_COMBINATION) return fail(FX_ERR_INVALID_ARGUMENT, "unknown onset type %d", type);
+    if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (type < FX_ONSET_SPECTRAL || type > FX_ONSET_COMBINATION) return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown onset type %d", type);
     c->onset_type = type;
     return FX_OK;
 }
 
 fx_status fx_set_gain(fx_context* c, float gain)
 {
-    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
     c->gain = gain;
     return FX_OK;
 }
@@ -423,7 +379,7 @@ fx_status fx_process_frames(fx_context* c, const void* frames, int num_frames, i
 
 fx_status fx_get_smoothed(fx_context* c, float* out, int mem_kind)
 {
-    if (!c || !out) return fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    if (!c || !out) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(hipSetDevice(c->device));
     const size_t bytes = (size_t) c->C * FX_NUM_FEATURES * sizeof(float);
     HIP_TRY(hipMemcpyAsync(out, c->d_latest, bytes,
@@ -435,7 +391,7 @@ fx_status fx_get_smoothed(fx_context* c, float* out, int mem_kind)
 
 fx_status fx_sync(fx_context* c)
 {
-    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return FX_OK;
@@ -443,15 +399,15 @@ fx_status fx_sync(fx_context* c)
 
 fx_status fx_get_stream(fx_context* c, void** stream)
 {
-    if (!c || !stream) return fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    if (!c || !stream) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
     *stream = (void*) c->stream;
     return FX_OK;
 }
 
 fx_status fx_last_kernel_ms(fx_context* c, float* frame_ms, float* epi_ms)
 {
-    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
-    if (!c->ev_valid) return fail(FX_ERR_INVALID_ARGUMENT, "no analysis call has been made yet");
+    if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (!c->ev_valid) return fx_fail(FX_ERR_INVALID_ARGUMENT, "no analysis call has been made yet");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(c->ev[2]));
     float a = 0.f, b = 0.f;
@@ -464,7 +420,7 @@ fx_status fx_last_kernel_ms(fx_context* c, float* frame_ms, float* epi_ms)
 
 fx_status fx_profile_begin(fx_context* c)
 {
-    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
     c->profiling = true;
     c->prof_used = 0;
     return FX_OK;
@@ -472,7 +428,7 @@ fx_status fx_profile_begin(fx_context* c)
 
 fx_status fx_profile_end(fx_context* c, double* frame_ms, double* epi_ms, int* calls)
 {
-    if (!c) return fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     double a = 0.0, b = 0.0;
@@ -539,18 +495,18 @@ fx_status fx_stream_destroy(fx_stream* s)
 
 fx_status fx_stream_create(fx_context* c, int hops_per_batch, int slots, int sample_format, fx_stream** out)
 {
-    if (!c || !out) return fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    if (!c || !out) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
-    if (hops_per_batch < 1 || slots < 1 || slots > 64) return fail(FX_ERR_INVALID_ARGUMENT, "hops_per_batch >= 1 and 1 <= slots <= 64 required");
-    if (sample_format != FX_SAMPLE_F32 && sample_format != FX_SAMPLE_F16) return fail(FX_ERR_INVALID_ARGUMENT, "unknown sample format %d", sample_format);
+    if (hops_per_batch < 1 || slots < 1 || slots > 64) return fx_fail(FX_ERR_INVALID_ARGUMENT, "hops_per_batch >= 1 and 1 <= slots <= 64 required");
+    if (sample_format != FX_SAMPLE_F32 && sample_format != FX_SAMPLE_F16) return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown sample format %d", sample_format);
     HIP_TRY(hipSetDevice(c->device));
     fx_stream* s = new (std::nothrow) fx_stream();
-    if (!s) return fail(FX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    if (!s) return fx_fail(FX_ERR_OUT_OF_MEMORY, "host allocation failed");
     s->ctx = c; s->hops = hops_per_batch; s->slots = slots; s->fmt = sample_format;
     s->in_bytes = (size_t) c->C * hops_per_batch * (c->N / 2) * (sample_format == FX_SAMPLE_F16 ? 2 : 4);
     s->out_bytes = (size_t) c->C * hops_per_batch * FX_NUM_FEATURES * sizeof(float);
     s->ring.resize((size_t) slots);
-#define S_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fx_status st_ = fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); fx_stream_destroy(s); return st_; } } while (0)
+#define S_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fx_status st_ = fx_fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); fx_stream_destroy(s); return st_; } } while (0)
     S_TRY(hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
     for (auto& sl : s->ring) {
         S_TRY(hipHostMalloc(&sl.h_in, s->in_bytes, hipHostMallocDefault));
@@ -572,11 +528,11 @@ int fx_stream_in_flight(fx_stream* s) { return s ? s->in_flight : 0; }
 
 fx_status fx_stream_acquire(fx_stream* s, void** host_slot)
 {
-    if (!s || !host_slot) return fail(FX_ERR_INVALID_ARGUMENT, "null argument");
-    if (s->acquired) return fail(FX_ERR_INVALID_ARGUMENT, "a slot is already acquired; submit it first");
+    if (!s || !host_slot) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    if (s->acquired) return fx_fail(FX_ERR_INVALID_ARGUMENT, "a slot is already acquired; submit it first");
     HIP_TRY(hipSetDevice(s->ctx->device));
     if (s->in_flight == s->slots)
-        return fail(FX_ERR_INVALID_ARGUMENT, "all %d slots are in flight; collect a batch first", s->slots);
+        return fx_fail(FX_ERR_INVALID_ARGUMENT, "all %d slots are in flight; collect a batch first", s->slots);
     *host_slot = s->ring[(size_t) s->head].h_in;
     s->acquired = true;
     return FX_OK;
@@ -584,8 +540,8 @@ fx_status fx_stream_acquire(fx_stream* s, void** host_slot)
 
 fx_status fx_stream_submit(fx_stream* s)
 {
-    if (!s) return fail(FX_ERR_INVALID_ARGUMENT, "null stream");
-    if (!s->acquired) return fail(FX_ERR_INVALID_ARGUMENT, "no slot acquired");
+    if (!s) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null stream");
+    if (!s->acquired) return fx_fail(FX_ERR_INVALID_ARGUMENT, "no slot acquired");
     fx_context* c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
     fx_stream::Slot& sl = s->ring[(size_t) s->head];
@@ -593,7 +549,13 @@ fx_status fx_stream_submit(fx_stream* s)
     HIP_TRY(hipEventRecord(sl.copied, s->copy));
     HIP_TRY(hipStreamWaitEvent(c->stream, sl.copied, 0));
     fx_status st = run(c, sl.d_in, s->hops, s->fmt, FX_MEM_DEVICE, 1, sl.d_raw, sl.d_sm);
-    if (st != FX_OK) return st;
+    if (st != FX_OK) {
+        // the copy is already enqueued: let it finish, then hand the slot back so the ring stays usable
+        // (the caller may fill and submit it again)
+        (void) hipStreamSynchronize(s->copy);
+        s->acquired = false;
+        return st;
+    }
     HIP_TRY(hipEventRecord(sl.done, c->stream));
     HIP_TRY(hipStreamWaitEvent(s->copy, sl.done, 0));
     HIP_TRY(hipMemcpyAsync(sl.h_raw, sl.d_raw, s->out_bytes, hipMemcpyDeviceToHost, s->copy));
@@ -607,8 +569,8 @@ fx_status fx_stream_submit(fx_stream* s)
 
 fx_status fx_stream_collect(fx_stream* s, float* out_raw, float* out_smoothed)
 {
-    if (!s) return fail(FX_ERR_INVALID_ARGUMENT, "null stream");
-    if (s->in_flight == 0) return fail(FX_ERR_INVALID_ARGUMENT, "nothing in flight");
+    if (!s) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null stream");
+    if (s->in_flight == 0) return fx_fail(FX_ERR_INVALID_ARGUMENT, "nothing in flight");
     HIP_TRY(hipSetDevice(s->ctx->device));
     fx_stream::Slot& sl = s->ring[(size_t) s->tail];
     HIP_TRY(hipEventSynchronize(sl.out));

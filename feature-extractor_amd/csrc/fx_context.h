@@ -1,0 +1,67 @@
+// fx_context.h -- the context behind the C ABI (include/fx.h), shared by fx_capi.cpp and fx_comm.cpp.  Internal.
+#ifndef FX_CONTEXT_H
+#define FX_CONTEXT_H
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "fx_kernels.h"
+
+fx_status fx_fail(fx_status code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fx_fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP,       \
+                           "%s failed: %s", #expr, hipGetErrorString(e_));                     \
+    } while (0)
+
+struct fx_comm;     // fx_comm.cpp
+void fx_comm_release(fx_context* ctx);   // called by fx_destroy
+
+struct fx_context {
+    int      device = 0;
+    int      C = 0, N = 0;
+    double   sample_rate = 48000.0;
+    unsigned flags = 0;
+    // settings (ref RealTimeAnalyser.h:244-258, SpectralCharacteristics.h:237-241,311, AudioDataCollector.h:129)
+    float    gain = 1.0f;
+    int      onset_window = 5;
+    int      onset_type = FX_ONSET_AMPLITUDE;
+    float    onset_multiplier = 1.7f;
+    long long frames_seen = 0;
+    long long onset_reset_frame = 0;
+
+    hipStream_t stream = nullptr;
+    hipEvent_t  ev[3] = {nullptr, nullptr, nullptr};
+    bool        ev_valid = false;
+    bool        profiling = false;
+    std::vector<hipEvent_t> prof_events;     // 3 per recorded call
+    size_t      prof_used = 0;
+
+    float* d_tw = nullptr;        // [N][2]
+    float* d_prev = nullptr;      // [C][N/2]
+    float* d_tail[2] = {nullptr, nullptr};   // [C][N/2], ping-pong
+    float* d_hist[2] = {nullptr, nullptr};   // [C][HLEN][12], ping-pong
+    float* d_latest = nullptr;    // [C][12]
+    int    cur = 0;
+
+    float* d_raw = nullptr;       // [C][T_cap][12]
+    fxk::FramePart* d_part = nullptr;   // [C][T_cap]
+    size_t part_cap = 0;
+    void*  d_in = nullptr;        // staging for host input
+    float* d_out_raw = nullptr;   // staging for host output
+    float* d_out_sm = nullptr;
+    size_t raw_cap = 0, in_cap = 0, out_cap = 0;
+
+    double bin_var = 0.0;
+    float  lpf_a = 0.0f, lpf_b = 0.0f;
+    float  first_tw[18] = {0};
+
+    fx_comm* comm = nullptr;      // fx_comm_create (fx_comm.cpp); null for a single-GPU context
+};
+
+#endif

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 1
+#define FX_ABI_VERSION 2
 
 typedef int fx_status;
 enum {
@@ -163,6 +163,37 @@ int fx_stream_in_flight(fx_stream* s);
  * smoothing/onset kernels and the number of calls recorded. */
 fx_status fx_profile_begin(fx_context* ctx);
 fx_status fx_profile_end(fx_context* ctx, double* frame_kernel_ms, double* epilogue_kernel_ms, int* calls);
+
+/* ---- multi-GPU: one process per GPU, channels sharded by contiguous blocks ----
+ * Channels are independent (one AnalyserTrackController each, AnalyserTrackController.h:199-210), so
+ * the analysis itself needs no exchange.  The only collective on the path is the gather of every
+ * rank's latest smoothed vectors to the rank that owns the OSC sink -- the two OSCFeatureAnalysisOutput
+ * senders of a track (AnalyserTrackController.h:22-23) sample AudioFeatures::getValue at 60 Hz and
+ * send it (OSCFeatureAnalysisOutput.h:89-136).  It runs over RCCL (xGMI between the GPUs of a node).
+ *
+ *   rank 0:     fx_comm_unique_id(id)  -> hand the FX_COMM_ID_BYTES bytes to every rank (any channel)
+ *   every rank: fx_comm_create(ctx, rank, world, id, FX_COMM_ID_BYTES)       (collective)
+ *   per step:   fx_gather_smoothed(ctx, dst_rank, out, mem_kind)             (collective, asynchronous)
+ *               fx_comm_sync(ctx) before reading `out`
+ */
+#define FX_COMM_ID_BYTES 128
+/* ncclGetUniqueId.  FX_ERR_UNSUPPORTED if RCCL cannot be loaded. */
+fx_status fx_comm_unique_id(void* id_out, int id_bytes);
+/* Join this context to a communicator of `world_size` ranks (ncclCommInitRank on the context's
+ * device; every rank calls it with the same id).  Ranks may own different channel counts; the
+ * counts are exchanged here.  One communicator per context. */
+fx_status fx_comm_create(fx_context* ctx, int rank, int world_size, const void* unique_id, int id_bytes);
+fx_status fx_comm_destroy(fx_context* ctx);
+/* Channels of all ranks (sum of their num_channels) and the channel offset of `rank`'s block. */
+fx_status fx_comm_layout(fx_context* ctx, int* total_channels, int* first_channel_of_rank /*[world_size] or NULL*/);
+/* Snapshot this rank's latest smoothed vectors [num_channels][12] (ordered after the analysis
+ * calls made so far) and gather all ranks' blocks, in rank order, to `dst_rank`:
+ *   out [total_channels][12] floats on dst_rank (FX_MEM_DEVICE or FX_MEM_HOST), ignored elsewhere.
+ * The exchange runs on a side stream behind an event, double-buffered, so it overlaps the kernels of
+ * the next analysis call; nothing blocks the host.  `out` is valid after fx_comm_sync().  */
+fx_status fx_gather_smoothed(fx_context* ctx, int dst_rank, float* out, int mem_kind);
+/* Wait for every gather issued so far on this context. */
+fx_status fx_comm_sync(fx_context* ctx);
 
 /* ---- OSC sink helpers (host side, no GPU) ---- */
 /* Re-order one 12-slot vector into the wire order of

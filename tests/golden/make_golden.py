@@ -1,9 +1,14 @@
-"""Writes tests/golden/*.npz.
+"""Writes tests/golden/*.npz (build container only: needs /root/reference).
 
-PARITY UNPINNED: the reference cannot be built or run in this image (it needs JUCE 4.2.3, which is
-absent), and it ships no golden vectors of its own, so these fixtures are outputs of
-the CPU oracle (oracle/fx_oracle.c), NOT of the reference.  They pin the oracle against drift and
-give the GPU tests committed data to compare with on a box where /root/reference does not exist.
+`raw` and `smoothed` are produced by the REFERENCE'S OWN hot-path headers, compiled unmodified against
+tools/refdiff/juce_standin.h and single-stepped by tools/refdiff/refdiff_driver.cpp (log10(float) correctly
+rounded, the convention DESIGN.md section 5 documents); the `source` field of every file says so, together with
+the order mode.  The oracle must reproduce them bit for bit (tests/test_oracle.py) and the GPU path within
+1e-5 / onset exact (tests/test_gpu_parity.py) on a box where /root/reference does not exist.
+
+PARITY STAYS UNPINNED at the JUCE boundary: the reference cannot be *built* here (JUCE 4.2.3 is absent) and
+ships no vectors of its own; JUCE's FFT / getRMSLevel / applyGainRamp / getMagnitude are restated in the
+stand-in from the same published algorithm as in the oracle.  The `tap_*` arrays are oracle intermediates.
 
 Run from the repo root:  python tests/golden/make_golden.py
 """
@@ -16,8 +21,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "tools", "refdiff"))
+
+import refdiff  # noqa: E402
 import signals  # noqa: E402
 from oracle import fx_oracle as fo  # noqa: E402
+
+ORDER_NAMES = {0: "spectral analyser then harmonic analyser on one shared AudioFeatures",
+               1: "harmonic analyser then spectral analyser on one shared AudioFeatures",
+               2: "one AudioFeatures per analyser (isolated)"}
 
 CASES = [
     # name, signal, N, C, T, order
@@ -40,7 +52,10 @@ CASES = [
 def main():
     for name, sig, N, C, T, order in CASES:
         hops = signals.ALL[sig](C, T, N)
-        raw, sm = fo.push_hops(hops, N, order=order)
+        raw, sm = refdiff.run(hops, N, order=order, mode="cr")
+        oraw, osm = fo.push_hops(hops, N, order=order)
+        for a, b in ((raw, oraw), (sm, osm)):        # the oracle agrees bit for bit (NaN == NaN), or nothing is written
+            assert ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all(), name
         # taps of the first channel's last frame, for debugging a failing port
         frame = np.concatenate([hops[0, T - 2], hops[0, T - 1]])
         spec = fo.forward_real(fo.bartlett(frame))
@@ -51,6 +66,10 @@ def main():
         f0, lag, cnd = fo.estimate_pitch(pitch_spec, 24000.0)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), hops=hops, raw=raw, smoothed=sm,
                             window_size=N, order=order, sample_rate=48000.0,
+                            source="reference headers (/root/reference/Source/{AudioDataCollector,RealTimeAudioAnalysis,PitchAnalyser,"
+                                   "SpectralCharacteristics,HarmonicCharacteristics,RealTimeAnalyser}.h, unmodified) compiled against "
+                                   "tools/refdiff/juce_standin.h, log10(float) correctly rounded; order mode %d: %s; onset: Amplitude, "
+                                   "window 5, sensitivity 0.7 (the reference's defaults)" % (order, ORDER_NAMES[order]),
                             tap_frame=frame, tap_spectrum=spec, tap_lowpass=low, tap_cnd=cnd,
                             tap_lag=np.float32(lag), tap_f0=np.float64(f0))
         print(name, hops.shape, "->", raw.shape)

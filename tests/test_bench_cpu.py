@@ -35,6 +35,41 @@ def test_committed_bench_line_has_the_contract_fields():
         assert key in d, key
     assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["dtype"] == "f32" and "workload" in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and "sample" in c
+
+
+def test_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus 4` from a bare shell must start 4 child ranks through torch.distributed.run (and never
+    exec); with WORLD_SIZE set (the driver's torchrun form) it must not."""
+    import subprocess as sp
+    seen = {}
+
+    class Done:
+        returncode = 0
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return Done()
+
+    import torch
+    monkeypatch.setattr(sp, "run", fake_run)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert "127.0.0.1" in cmd and cmd[-4:] == ["--gpus", "4", "--steps", "7"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # too few GPUs for RCCL: refuse loudly instead of hanging in the communicator
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    try:
+        bench.main()
+        raise AssertionError("expected SystemExit")
+    except SystemExit as e:
+        assert "only 1 GPU" in str(e.code)

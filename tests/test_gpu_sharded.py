@@ -1,0 +1,113 @@
+"""The multi-GPU path on the GPU box: the BASELINE configs[3] shard shape (8192 channels x 1024-pt on one GPU), the
+RCCL gather behind the C ABI (fx_comm_* / fx_gather_smoothed) on a one-rank communicator and -- when the box has
+two GPUs -- between two processes, and bench.py's launch forms."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def test_configs3_shard_8192_channels(gpu_fx, oracle):
+    """One rank's share of BASELINE configs[3]: 8192 channels x 1024-pt.  24 random channels against the oracle;
+    the two 4096-channel halves analysed in their own contexts give the same bits (a channel's result does not
+    depend on the shard it lands in, which is what makes contiguous-block sharding exact)."""
+    import signals
+    N, C, T = 1024, 8192, 16
+    frames = gpu_fx.synth.frames(C, T, N)
+    an = gpu_fx.BatchAnalyser(C, N)
+    raw, sm = an.process_frames(frames)
+    lo = gpu_fx.BatchAnalyser(C // 2, N).process_frames(frames[: C // 2])
+    hi = gpu_fx.BatchAnalyser(C // 2, N).process_frames(frames[C // 2:])
+    assert np.array_equal(np.concatenate([lo[0], hi[0]]), raw, equal_nan=True)
+    assert np.array_equal(np.concatenate([lo[1], hi[1]]), sm, equal_nan=True)
+    assert np.array_equal(an.get_features(), sm[:, -1], equal_nan=True)
+    pick = np.random.default_rng(3).choice(C, 24, replace=False)
+    oraw, osm = oracle.process_frames(frames[pick], N)
+    signals.assert_features_close(raw[pick], oraw, 1e-5, oracle.FEATURE_NAMES, "8192-channel shard raw")
+    signals.assert_features_close(sm[pick], osm, 1e-5, oracle.FEATURE_NAMES, "8192-channel shard smoothed")
+
+
+def test_one_rank_rccl_gather_through_the_c_abi(gpu_fx):
+    """fx_comm_create / fx_gather_smoothed / fx_comm_sync on a one-rank communicator: host and device destinations,
+    several gathers in flight behind analysis calls."""
+    import torch
+    N, C, T = 1024, 37, 11
+    an = gpu_fx.BatchAnalyser(C, N)
+    an.comm_create(0, 1, gpu_fx.BatchAnalyser.comm_unique_id())
+    total, first = an.comm_layout()
+    assert (total, first) == (C, [0])
+    hops = gpu_fx.synth.hops(C, 3 * T, N)
+    host_out = np.full((C, 12), -1.0, np.float32)
+    dev_out = [torch.full((C, 12), -1.0, dtype=torch.float32, device="cuda:0") for _ in range(2)]
+    for i in range(3):
+        _, sm = an.push_hops(hops[:, i * T:(i + 1) * T])
+        an.gather_features(dst=0, out=dev_out[i & 1])
+        an.gather_features(dst=0, out=host_out)
+        an.comm_sync()
+        assert np.array_equal(host_out, sm[:, -1], equal_nan=True)
+        assert np.array_equal(dev_out[i & 1].cpu().numpy(), sm[:, -1], equal_nan=True)
+    with pytest.raises(gpu_fx.FxError):
+        an.comm_create(0, 1, gpu_fx.BatchAnalyser.comm_unique_id())      # one communicator per context
+    an.comm_destroy()
+    with pytest.raises(gpu_fx.FxError):
+        an.gather_features(dst=0, out=host_out)                          # no communicator any more
+
+
+def _build_comm_ranks(fx, tmp_path):
+    exe = str(tmp_path / "comm_ranks")
+    lib_dir = os.path.dirname(fx.library_path())
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "comm_ranks.cpp"), "-o", exe,
+                           "-L", lib_dir, "-lfx_hip", "-Wl,-rpath," + lib_dir])
+    return exe
+
+
+def test_cpp_one_rank_comm(gpu_fx, tmp_path):
+    """The C++ host program (no Python, no torch in the process) on one rank."""
+    out = subprocess.run([_build_comm_ranks(gpu_fx, tmp_path), "1"], capture_output=True, text=True, env=_env(), timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_cpp_two_rank_comm(gpu_fx, tmp_path):
+    """Two processes, two GPUs, ragged shards; skipped on a one-GPU box."""
+    out = subprocess.run([_build_comm_ranks(gpu_fx, tmp_path), "2"], capture_output=True, text=True, env=_env(), timeout=300)
+    if out.returncode == 77:
+        pytest.skip("one GPU visible")
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
+def _bench(args, timeout=600):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=_env(), timeout=timeout)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line), out.stderr
+
+
+def test_bench_debug_collective_runs_the_rccl_path_on_one_rank():
+    d, err = _bench(["--gpus", "1", "--debug-collective", "--steps", "3", "--warmup", "1", "--frames", "32", "--no-cpu-baseline", "--no-extra"])
+    assert d["n_gpus"] == 1 and "RCCL" in d["config"]["sharding"]
+    assert "gathered block equals the local features" in err
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` from a bare shell (no torchrun): rc 0 and n_gpus 2.  On a one-GPU box the two
+    ranks share the device and exchange through host memory (--backend gloo); the shard is configs[3]'s."""
+    import torch
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    d, err = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", backend, "--channels-per-gpu", "2048", "--frames", "16"])
+    assert d["n_gpus"] == 2 and d["config"]["workload"].startswith("configs[3]") and d["config"]["total_channels"] == 4096
+    assert d["cpu_baseline"] is None and d["value"] > 0
+    assert "gathered block equals the local features" in err

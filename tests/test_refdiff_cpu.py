@@ -1,0 +1,84 @@
+"""The reference's own hot-path headers (compiled unmodified against tools/refdiff/juce_standin.h) against the CPU
+oracle.  Build container only: skipped where /root/reference does not exist (the GPU box)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools", "refdiff"))
+
+import refdiff  # noqa: E402
+import signals  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not refdiff.available(), reason="/root/reference is not present on this machine")
+
+CASES = [(sig, N) for sig in sorted(signals.ALL) for N in (256, 1024, 2048)] + [("tone", 4096), ("bursts", 4096), ("levels", 512)]
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _same_bits(a, b):
+    """bit-identical, except that a NaN is a NaN whatever its sign / payload (0.0f / 0 has the sign of its compiler)"""
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return (_bits(a) == _bits(b)) | (np.isnan(a) & np.isnan(b))
+
+
+@pytest.mark.parametrize("sig,N", CASES)
+def test_oracle_is_bit_identical_to_the_reference_headers(oracle, sig, N):
+    """correctly rounded log10(float) on both sides: every raw and smoothed value, every frame"""
+    C, T = 3, 14
+    hops = signals.ALL[sig](C, T, N)
+    raw, sm = refdiff.run(hops, N, mode="cr")
+    oraw, osm = oracle.push_hops(hops, N)
+    assert _same_bits(raw, oraw).all(), "raw differs at %s" % (np.argwhere(~_same_bits(raw, oraw))[:5],)
+    assert _same_bits(sm, osm).all(), "smoothed differs at %s" % (np.argwhere(~_same_bits(sm, osm))[:5],)
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+@pytest.mark.parametrize("otype,window,sens", [(0, 3, 0.3), (1, 5, 0.7), (2, 9, 0.2)])
+def test_order_modes_and_onset_settings(oracle, order, otype, window, sens):
+    N, C, T = 1024, 3, 40
+    hops = signals.bursts(C, T, N, seed=50 + order)
+    raw, sm = refdiff.run(hops, N, order=order, onset_type=otype, onset_window=window, onset_sensitivity=sens, gain=0.75, mode="cr")
+    oraw, osm = oracle.push_hops(hops, N, order=order, onset_type=otype, onset_window=window, onset_sensitivity=sens, gain=0.75)
+    assert _same_bits(raw, oraw).all() and _same_bits(sm, osm).all()
+
+
+def test_sample_rate_other_than_48k(oracle):
+    N, C, T = 2048, 2, 12
+    hops = signals.tone_vibrato_noise(C, T, N, seed=9)
+    raw, sm = refdiff.run(hops, N, sample_rate=44100.0, mode="cr")
+    oraw, osm = oracle.push_hops(hops, N, sample_rate=44100.0)
+    assert _same_bits(raw, oraw).all() and _same_bits(sm, osm).all()
+
+
+def test_platform_log10f_changes_no_decision(oracle):
+    """With this platform's log10f in the reference headers (what a real build would call) the oracle's values stay
+    within 1e-5 and no onset decision flips; the number of values that are not bit-identical is reported."""
+    different = total = 0
+    for sig in sorted(signals.ALL):
+        for N in (1024, 2048):
+            hops = signals.ALL[sig](3, 20, N)
+            raw, sm = refdiff.run(hops, N, mode="libm")
+            oraw, osm = oracle.push_hops(hops, N)
+            signals.assert_features_close(raw, oraw, 1e-5, oracle.FEATURE_NAMES, "%s N=%d raw (libm log10f)" % (sig, N))
+            signals.assert_features_close(sm, osm, 1e-5, oracle.FEATURE_NAMES, "%s N=%d smoothed (libm log10f)" % (sig, N))
+            different += int((~_same_bits(raw, oraw)).sum() + (~_same_bits(sm, osm)).sum())
+            total += raw.size + sm.size
+    print("libm log10f: %d of %d values not bit-identical to the oracle" % (different, total))
+
+
+def test_committed_fixtures_come_from_the_reference_headers():
+    """tests/golden/*.npz were written by tests/golden/make_golden.py from this harness (cr mode): regenerate and compare"""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "*.npz")))
+    assert paths
+    for p in paths:
+        g = np.load(p)
+        assert str(g["source"]).startswith("reference headers"), p
+        raw, sm = refdiff.run(g["hops"], int(g["window_size"]), order=int(g["order"]), sample_rate=float(g["sample_rate"]), mode="cr")
+        assert _same_bits(raw, g["raw"]).all() and _same_bits(sm, g["smoothed"]).all(), p

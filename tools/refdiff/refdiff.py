@@ -1,0 +1,61 @@
+"""Differential harness: the reference's own hot-path headers, compiled unmodified against
+tools/refdiff/juce_standin.h, single-stepped over hop streams -- against oracle/fx_oracle.c.
+
+BUILD CONTAINER ONLY (needs /root/reference and g++).  Not a build of the reference and not a parity pin:
+JUCE's own arithmetic (FFT, getRMSLevel, applyGainRamp, getMagnitude) is a restatement in the stand-in as
+it is in the oracle.  What it checks is the feature arithmetic that IS in the reference's headers.
+
+Two builds of the driver:
+  cr   : log10(float) correctly rounded -- the oracle's documented convention; the oracle must be BIT-IDENTICAL
+  libm : log10(float) = this platform's log10f -- values within 1e-5, and no onset / gate decision may flip
+"""
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFERENCE = "/root/reference/Source"
+BUILD = os.path.join(HERE, "_build")
+HEADERS = ["AudioDataCollector.h", "RealTimeAudioAnalysis.h", "PitchAnalyser.h", "SpectralCharacteristics.h",
+           "HarmonicCharacteristics.h", "RealTimeAnalyser.h"]
+
+
+def available():
+    return all(os.path.exists(os.path.join(REFERENCE, h)) for h in HEADERS)
+
+
+def build(mode):
+    """g++ on the driver; the reference headers are included from where they lie (-I /root/reference/Source)."""
+    assert mode in ("cr", "libm")
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "refdiff_" + mode)
+    srcs = [os.path.join(HERE, "refdiff_driver.cpp"), os.path.join(HERE, "juce_standin.h")]
+    if os.path.exists(exe) and all(os.path.getmtime(s) <= os.path.getmtime(exe) for s in srcs):
+        return exe
+    cmd = ["g++", "-std=c++14", "-O2", "-w", "-ffp-contract=off", "-fno-fast-math", "-I", REFERENCE, "-I", HERE,
+           srcs[0], "-o", exe]
+    if mode == "cr":
+        cmd.insert(1, "-DREFDIFF_LOG10_CR")
+    subprocess.check_call(cmd)
+    return exe
+
+
+def run(hops, window_size, order=0, onset_type=1, onset_window=5, onset_sensitivity=0.7, gain=1.0,
+        sample_rate=48000.0, mode="cr", workdir=None):
+    """hops [C][T][N/2] float32 -> (raw [C][T][12], smoothed [C][T][12]) from the reference's headers."""
+    import tempfile
+    hops = np.ascontiguousarray(hops, np.float32)
+    C, T, half = hops.shape
+    assert half * 2 == window_size
+    exe = build(mode)
+    with tempfile.TemporaryDirectory(dir=workdir) as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<6i2fd", window_size, C, T, order, onset_type, onset_window, onset_sensitivity, gain, sample_rate))
+            f.write(hops.tobytes())
+        subprocess.check_call([exe, fin, fout])
+        out = np.fromfile(fout, np.float32)
+    n = C * T * 12
+    return out[:n].reshape(C, T, 12), out[n:2 * n].reshape(C, T, 12)
