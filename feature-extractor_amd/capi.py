@@ -50,6 +50,14 @@ def load_library(build_if_missing=True):
         _build.build()
     if not os.path.exists(_build.LIB_PATH):
         raise FxError(FX_ERR_UNSUPPORTED, "libfx_hip.so has not been built (run feature-extractor_amd/build.py)")
+    # One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64 / librccl (same SONAMEs as
+    # /opt/rocm's): if libfx_hip.so is loaded first it binds /opt/rocm's copies, a later `import torch` then brings a
+    # second runtime into the process and that one finds no GPU ("No HIP GPUs are available").  Loading torch's first
+    # makes both sides share one runtime, whichever order the caller imports things in.  (C++ hosts link /opt/rocm.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(_build.LIB_PATH)
     vp, fp, i, d, f, u = ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.c_double, ctypes.c_float, ctypes.c_uint
     L.fx_create.argtypes = [ctypes.POINTER(vp), i, i, i, d, u]

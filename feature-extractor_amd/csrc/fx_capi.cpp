@@ -65,6 +65,99 @@ template <typename T> fx_status grow(T** ptr, size_t* cap, size_t need)
     return FX_OK;
 }
 
+// Everything one analysis step launches: kernel arguments and the wavefront count of the frame kernel.
+struct Step {
+    fxk::FrameParams    fp;
+    fxk::EpilogueParams ep;
+    int analysers = 3;
+    int waves = 1;
+};
+
+// Fill the kernel arguments of a step over T frames per channel from the context's current state.  `part` / `raw`
+// default to the context's own (growable) scratch; a captured step passes buffers it owns, because a graph keeps the
+// addresses it was captured with.
+fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format, int hop_mode, float* d_or, float* d_os,
+                       fxk::FramePart* part, float* raw, const fxk::DynParams* dyn, Step* st)
+{
+    fxk::FrameParams& fp = st->fp;
+    fp.in = d_in;
+    fp.sample_format = sample_format;
+    fp.hop_mode = hop_mode;
+    fp.T = T;
+    fp.C = c->C;
+    fp.gain = c->gain;
+    fp.tail_in = c->d_tail[c->cur];
+    fp.tail_out = c->d_tail[c->cur ^ 1];
+    fp.prev_re = c->d_prev;
+    fp.tw = c->d_tw;
+    fp.part = part;
+    fp.nyquist = c->sample_rate / 2.0;          // ref RealTimeAudioAnalysis.h:251, RealTimeAnalyser.h:113
+    fp.bin_var = c->bin_var;
+    fp.lpf_a = c->lpf_a;
+    fp.lpf_b = c->lpf_b;
+    fp.dyn = dyn;
+    for (int i = 0; i < 18; i++) fp.first_tw[i] = c->first_tw[i];
+
+    // waves per workgroup = frames of one channel in flight: the measured-best count for this window size, less when
+    // the call has fewer frames or the LDS holds fewer (one twiddle table + flux state per workgroup, one transform
+    // buffer per wave); FX_WAVES overrides for experiments.
+    const size_t lds_cu = 160 * 1024;
+    int waves = 1;
+    {
+        const int kcap = fxk::frame_kernel_max_waves(c->N);
+        int want = fxk::frame_kernel_preferred_waves(c->N);
+        if (const char* e = getenv("FX_WAVES")) { const int v = atoi(e); if (v >= 1) want = v; }
+        if (want > kcap) want = kcap;
+        if (want > T) want = T;
+        while (want > 1 && fxk::frame_kernel_lds_bytes(c->N, want) > lds_cu) want--;
+        waves = want;
+    }
+    if (fxk::frame_kernel_lds_bytes(c->N, waves) > lds_cu)
+        return fx_fail(FX_ERR_UNSUPPORTED, "window size %d does not fit the LDS", c->N);
+    st->waves = waves;
+
+    fxk::EpilogueParams& ep = st->ep;
+    ep.part = part;
+    ep.raw = raw;
+    ep.nyquist = c->sample_rate / 2.0;
+    ep.bin_var = c->bin_var;
+    ep.window = c->N;
+    ep.hist_in = c->d_hist[c->cur];
+    ep.hist_out = c->d_hist[c->cur ^ 1];
+    ep.out_raw = d_or;
+    ep.out_smoothed = d_os;
+    ep.latest = c->d_latest;
+    ep.C = c->C;
+    ep.T = T;
+    ep.frames_before = c->frames_seen;
+    ep.onset_reset_frame = c->onset_reset_frame;
+    ep.onset_window = c->onset_window;
+    ep.onset_type = c->onset_type;
+    ep.onset_multiplier = c->onset_multiplier;
+    ep.order_mode = (int) (c->flags & FX_ORDER_MASK);
+    st->analysers = (c->flags & FX_SPECTRAL_ONLY) ? 1 : ((c->flags & FX_HARMONIC_ONLY) ? 2 : 3);
+    ep.analysers = st->analysers;
+    ep.dyn = dyn;
+    return FX_OK;
+}
+
+void fill_dyn(const fx_context* c, fxk::DynParams* d)
+{
+    d->nyquist = c->sample_rate / 2.0;
+    d->frames_before = c->frames_seen;
+    d->onset_reset_frame = c->onset_reset_frame;
+    d->gain = c->gain;
+    d->onset_multiplier = c->onset_multiplier;
+    d->onset_window = c->onset_window;
+    d->onset_type = c->onset_type;
+}
+
+void advance(fx_context* c, int T)
+{
+    c->cur ^= 1;
+    c->frames_seen += T;
+}
+
 fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_kind, int hop_mode,
               float* out_raw, float* out_smoothed)
 {
@@ -114,67 +207,8 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
             return fx_fail(FX_ERR_INVALID_ARGUMENT, "device input must be 16-byte aligned");
     }
 
-    fxk::FrameParams fp;
-    fp.in = d_in;
-    fp.sample_format = sample_format;
-    fp.hop_mode = hop_mode;
-    fp.T = T;
-    fp.C = c->C;
-    fp.gain = c->gain;
-    fp.tail_in = c->d_tail[c->cur];
-    fp.tail_out = c->d_tail[c->cur ^ 1];
-    fp.prev_re = c->d_prev;
-    fp.tw = c->d_tw;
-    fp.part = c->d_part;
-    fp.nyquist = c->sample_rate / 2.0;          // ref RealTimeAudioAnalysis.h:251, RealTimeAnalyser.h:113
-    fp.bin_var = c->bin_var;
-    fp.lpf_a = c->lpf_a;
-    fp.lpf_b = c->lpf_b;
-    for (int i = 0; i < 18; i++) fp.first_tw[i] = c->first_tw[i];
-
-    // waves per workgroup = frames of one channel in flight.  Pick the count that keeps the most
-    // wavefronts resident per CU (LDS is the limiter: one twiddle table + flux state per workgroup,
-    // one transform buffer per wave); FX_WAVES overrides for experiments.
-    const size_t lds_cu = 160 * 1024;
-    int waves = 1;
-    {
-        int best_resident = 0;
-        const int kmax = T < 8 ? T : 8;
-        for (int k = 1; k <= kmax; k++) {
-            const size_t need = fxk::frame_kernel_lds_bytes(c->N, k);
-            if (need > lds_cu) break;
-            const int resident = k * (int) (lds_cu / need);
-            if (resident >= best_resident) { best_resident = resident; waves = k; }
-        }
-        if (const char* e = getenv("FX_WAVES")) {
-            const int v = atoi(e);
-            if (v >= 1 && v <= kmax && fxk::frame_kernel_lds_bytes(c->N, v) <= lds_cu) waves = v;
-        }
-    }
-    if (fxk::frame_kernel_lds_bytes(c->N, waves) > lds_cu)
-        return fx_fail(FX_ERR_UNSUPPORTED, "window size %d does not fit the LDS", c->N);
-
-    fxk::EpilogueParams ep;
-    ep.part = c->d_part;
-    ep.raw = c->d_raw;
-    ep.nyquist = c->sample_rate / 2.0;
-    ep.bin_var = c->bin_var;
-    ep.window = c->N;
-    ep.hist_in = c->d_hist[c->cur];
-    ep.hist_out = c->d_hist[c->cur ^ 1];
-    ep.out_raw = d_or;
-    ep.out_smoothed = d_os;
-    ep.latest = c->d_latest;
-    ep.C = c->C;
-    ep.T = T;
-    ep.frames_before = c->frames_seen;
-    ep.onset_reset_frame = c->onset_reset_frame;
-    ep.onset_window = c->onset_window;
-    ep.onset_type = c->onset_type;
-    ep.onset_multiplier = c->onset_multiplier;
-    ep.order_mode = (int) (c->flags & FX_ORDER_MASK);
-    const int analysers = (c->flags & FX_SPECTRAL_ONLY) ? 1 : ((c->flags & FX_HARMONIC_ONLY) ? 2 : 3);
-    ep.analysers = analysers;
+    Step step;
+    if ((st = prepare_step(c, d_in, T, sample_format, hop_mode, d_or, d_os, c->d_part, c->d_raw, nullptr, &step)) != FX_OK) return st;
 
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1], e2 = c->ev[2];
     bool last_valid = true;
@@ -189,13 +223,12 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
         last_valid = false;
     }
     HIP_TRY(hipEventRecord(e0, c->stream));
-    HIP_TRY(fxk::launch_frame_kernel(c->N, fp, analysers, waves, c->stream));
+    HIP_TRY(fxk::launch_frame_kernel(c->N, step.fp, step.analysers, step.waves, c->stream));
     HIP_TRY(hipEventRecord(e1, c->stream));
-    HIP_TRY(fxk::launch_epilogue_kernels(ep, c->stream));
+    HIP_TRY(fxk::launch_epilogue_kernels(step.ep, c->stream));
     HIP_TRY(hipEventRecord(e2, c->stream));
     c->ev_valid = last_valid;
-    c->cur ^= 1;
-    c->frames_seen += T;
+    advance(c, T);
 
     if (mem_kind == FX_MEM_HOST) {
         if (out_raw) HIP_TRY(hipMemcpyAsync(out_raw, c->d_out_raw, raw_bytes, hipMemcpyDeviceToHost, c->stream));
@@ -456,11 +489,20 @@ struct fx_stream {
     int hops = 0, slots = 0, fmt = FX_SAMPLE_F32;
     size_t in_bytes = 0, out_bytes = 0;
     hipStream_t copy = nullptr;
+    // Small batches are launch-bound (one 4096-pt hop: four kernels, three copies and five events cost ~150 us of host
+    // and dispatch time for ~40 us of GPU work): there the whole step -- input copy, per-call scalars, the four
+    // kernels, result copies -- is captured once per ring slot and buffer parity into a hipGraph and replayed.
+    bool use_graph = false;
+    fxk::FramePart* g_part = nullptr;     // scratch the captured kernels own (a graph keeps its addresses)
+    float*          g_raw = nullptr;
     struct Slot {
         void*  h_in = nullptr;  void* d_in = nullptr;
         float* d_raw = nullptr; float* d_sm = nullptr;
         float* h_raw = nullptr; float* h_sm = nullptr;
         hipEvent_t copied = nullptr, done = nullptr, out = nullptr;
+        fxk::DynParams* h_dyn = nullptr;  // pinned: what changes from call to call
+        fxk::DynParams* d_dyn = nullptr;
+        hipGraphExec_t  exec[2] = {nullptr, nullptr};     // per parity of the context's ping-pong buffers
     };
     std::vector<Slot> ring;
     int head = 0;        // next slot to acquire
@@ -484,10 +526,15 @@ fx_status fx_stream_destroy(fx_stream* s)
         if (sl.d_in) (void) hipFree(sl.d_in);
         if (sl.d_raw) (void) hipFree(sl.d_raw);
         if (sl.d_sm) (void) hipFree(sl.d_sm);
+        for (int q = 0; q < 2; q++) if (sl.exec[q]) (void) hipGraphExecDestroy(sl.exec[q]);
+        if (sl.h_dyn) (void) hipHostFree(sl.h_dyn);
+        if (sl.d_dyn) (void) hipFree(sl.d_dyn);
         if (sl.copied) (void) hipEventDestroy(sl.copied);
         if (sl.done) (void) hipEventDestroy(sl.done);
         if (sl.out) (void) hipEventDestroy(sl.out);
     }
+    if (s->g_part) (void) hipFree(s->g_part);
+    if (s->g_raw) (void) hipFree(s->g_raw);
     if (s->copy) (void) hipStreamDestroy(s->copy);
     delete s;
     return FX_OK;
@@ -508,7 +555,19 @@ fx_status fx_stream_create(fx_context* c, int hops_per_batch, int slots, int sam
     s->ring.resize((size_t) slots);
 #define S_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fx_status st_ = fx_fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); fx_stream_destroy(s); return st_; } } while (0)
     S_TRY(hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
+    {
+        const char* e = getenv("FX_STREAM_GRAPH");          // 0 / 1 force the choice (experiments, tests)
+        s->use_graph = e ? atoi(e) != 0 : (size_t) c->C * hops_per_batch <= 4096;
+    }
+    if (s->use_graph) {
+        S_TRY(hipMalloc((void**) &s->g_part, (size_t) c->C * hops_per_batch * sizeof(fxk::FramePart)));
+        S_TRY(hipMalloc((void**) &s->g_raw, s->out_bytes));
+    }
     for (auto& sl : s->ring) {
+        if (s->use_graph) {
+            S_TRY(hipHostMalloc((void**) &sl.h_dyn, sizeof(fxk::DynParams), hipHostMallocDefault));
+            S_TRY(hipMalloc((void**) &sl.d_dyn, sizeof(fxk::DynParams)));
+        }
         S_TRY(hipHostMalloc(&sl.h_in, s->in_bytes, hipHostMallocDefault));
         S_TRY(hipHostMalloc((void**) &sl.h_raw, s->out_bytes, hipHostMallocDefault));
         S_TRY(hipHostMalloc((void**) &sl.h_sm, s->out_bytes, hipHostMallocDefault));
@@ -545,6 +604,41 @@ fx_status fx_stream_submit(fx_stream* s)
     fx_context* c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
     fx_stream::Slot& sl = s->ring[(size_t) s->head];
+    if (s->use_graph) {
+        const int par = c->cur;
+        fill_dyn(c, sl.h_dyn);
+        if (!sl.exec[par]) {
+            // capture the step once for this slot and parity: everything below is recorded, not executed
+            Step step;
+            fx_status st0 = prepare_step(c, sl.d_in, s->hops, s->fmt, 1, sl.d_raw, sl.d_sm, s->g_part, s->g_raw, sl.d_dyn, &step);
+            if (st0 != FX_OK) { s->acquired = false; return st0; }
+            hipGraph_t graph = nullptr;
+            HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            hipError_t e = hipMemcpyAsync(sl.d_in, sl.h_in, s->in_bytes, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(sl.d_dyn, sl.h_dyn, sizeof(fxk::DynParams), hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = fxk::launch_frame_kernel(c->N, step.fp, step.analysers, step.waves, c->stream);
+            if (e == hipSuccess) e = fxk::launch_epilogue_kernels(step.ep, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(sl.h_raw, sl.d_raw, s->out_bytes, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(sl.h_sm, sl.d_sm, s->out_bytes, hipMemcpyDeviceToHost, c->stream);
+            const hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
+            if (e == hipSuccess) e = e2;
+            if (e == hipSuccess) e = hipGraphInstantiate(&sl.exec[par], graph, nullptr, nullptr, 0);
+            if (graph) (void) hipGraphDestroy(graph);
+            if (e != hipSuccess) {
+                sl.exec[par] = nullptr;
+                s->acquired = false;
+                return fx_fail(FX_ERR_HIP, "capturing the streaming step failed: %s", hipGetErrorString(e));
+            }
+        }
+        HIP_TRY(hipGraphLaunch(sl.exec[par], c->stream));
+        HIP_TRY(hipEventRecord(sl.out, c->stream));
+        c->ev_valid = false;
+        advance(c, s->hops);
+        s->head = (s->head + 1) % s->slots;
+        s->in_flight++;
+        s->acquired = false;
+        return FX_OK;
+    }
     HIP_TRY(hipMemcpyAsync(sl.d_in, sl.h_in, s->in_bytes, hipMemcpyHostToDevice, s->copy));
     HIP_TRY(hipEventRecord(sl.copied, s->copy));
     HIP_TRY(hipStreamWaitEvent(c->stream, sl.copied, 0));

@@ -9,15 +9,36 @@
 //                                                          16-byte alignment of 4-sample groups)
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ constexpr int cpad(int p) { return p + (p >> 4); }
-__host__ __device__ constexpr int rpad(int n) { return n + ((n >> 4) << 2); }
 
 template <int N> struct Geo {
     static constexpr int M      = N / 2;            // numMagnitudes (ref SpectralCharacteristics.h:104)
     static constexpr int P      = N / 64;           // samples per lane
     static constexpr int U      = M / 64;           // bins per lane
-    // ONE LDS buffer per wavefront, reused as: real image of the frame (rpad layout), complex image
-    // of each transform (cpad layout), v / running-sum arrays of the lag scan, harmonic scratch.
-    static constexpr int CBUF   = cpad(N) + 2;      // float2 elements (>= rpad(N)+8 floats, >= 2N+8 floats)
+    // Windows >= 2048 exchange the complex image between FFT passes in two halves (every lane owns an even number of
+    // items in the consuming pass, so the first half of its items is read before the producers write the second
+    // half): the per-wave buffer is half a complex image instead of a whole one, which is what bounds how many
+    // wavefronts a CU holds at these sizes.
+    static constexpr bool SPLIT = N >= 2048;
+    // real image: 4 floats of padding per RQ samples; RQ = the lane's own run of samples (>= 16), so that the 16-byte
+    // accesses of lanes P samples apart fall on different banks (lane stride = 4 * odd dwords)
+    static constexpr int RQ     = P > 16 ? P : 16;
+    static constexpr int RIMG   = N + 4 * (N / RQ);                       // floats
+    // bins image (re of bins < M, one run of U bins per lane): the same idea, 4 floats per U bins (U >= 8)
+#ifdef FX_EXP_NO_BPAD
+    static constexpr int BQ     = 0;
+#else
+    static constexpr int BQ     = U >= 8 ? U : 0;
+#endif
+    static constexpr int BIMG   = M + (BQ ? 4 * (M / U) : 0);             // floats
+    // ONE LDS buffer per wavefront, reused as: real image of the frame, complex image of each transform (the whole
+    // image, or one half at a time), v array of the lag scan, harmonic scratch (bins image + 16-bit peak list).
+    static constexpr int QSLOTS = N / 2 + (N == 2048 ? 8 * (N / 128) : 0);                  // second exchange (qpad)
+    static constexpr int CSLOTS = SPLIT ? (cpad(N / 2 - 1) + 1 > QSLOTS ? cpad(N / 2 - 1) + 1 : QSLOTS) : cpad(N) + 2;  // float2 elements
+    static constexpr int CBUF_B = 8 * CSLOTS;
+    static constexpr int RBUF_B = 4 * (SPLIT ? RIMG - 4 : RIMG + 4);      // the last sample sits at RIMG - 5
+    static constexpr int HBUF_B = 4 * BIMG + 2 * M + 16;
+    static constexpr int BUF_B0 = CBUF_B > RBUF_B ? (CBUF_B > HBUF_B ? CBUF_B : HBUF_B) : (RBUF_B > HBUF_B ? RBUF_B : HBUF_B);
+    static constexpr int BUF_BYTES = (BUF_B0 > 4 * N ? BUF_B0 : 4 * N) + 15 & ~15;     // 16-byte multiple, >= N floats (lag-scan spill)
     static constexpr int LOG2N  = (N == 256) ? 8 : (N == 512) ? 9 : (N == 1024) ? 10 : (N == 2048) ? 11 : 12;
     // first FFT pass: R inputs per item, G items per lane, R*G == P
     static constexpr int RA     = (N == 256) ? 4 : ((N == 512 || N == 2048) ? 8 : 16);
@@ -26,6 +47,15 @@ template <int N> struct Geo {
     static constexpr int GA     = ITEMS_A / 64;
     static constexpr int IDIG   = (LOG2N - LOG2RA) / 2;   // base-4 digits of an item index
 };
+
+// position of sample n in the real image / of bin b in the bins image
+template <int N> __host__ __device__ constexpr int rimg(int n) { return n + 4 * (int) ((unsigned) n / (unsigned) Geo<N>::RQ); }
+template <int N> __host__ __device__ constexpr int bimg(int b) { return Geo<N>::BQ ? b + 4 * (int) ((unsigned) b / (unsigned) (Geo<N>::BQ ? Geo<N>::BQ : 1)) : b; }
+// bin (or sample) lane + c with c a compile-time multiple of 64: one per-lane base plus a constant (64 is a multiple of
+// every padding quantum), so the stores of a pass are one address register and immediate offsets
+template <int N> __host__ __device__ constexpr int bimg_step(int c) { return Geo<N>::BQ ? c + 4 * (c / (Geo<N>::BQ ? Geo<N>::BQ : 1)) : c; }
+template <int N> __host__ __device__ constexpr int rimg_step(int c) { return c + 4 * (c / Geo<N>::RQ); }
+static_assert(64 % Geo<1024>::RQ == 0 && 64 % Geo<2048>::RQ == 0 && 64 % Geo<4096>::RQ == 0 && 64 % Geo<4096>::U == 0, "lane + 64*c splits");
 
 // U consecutive floats of a lane, moved with the widest LDS access the alignment allows (a stride-U
 // ds_read_b32 pattern would be an 8-way bank conflict for U = 8)
@@ -217,20 +247,59 @@ template <int N> __device__ __forceinline__ int first_pass_index(int lane, int g
 }
 
 // The same position inside the padded real image, split into a per-lane base and a compile-time step:
-// ITEMS_A is a multiple of 16, so rpad(low + ITEMS_A*r) = rpad(low) + (ITEMS_A + ITEMS_A/4)*r and the
+// ITEMS_A is a multiple of RQ, so rimg(low + ITEMS_A*r) = rimg(low) + (ITEMS_A + 4*ITEMS_A/RQ)*r and the
 // RA accesses of an item are one address register plus immediate offsets.
-template <int N> __device__ __forceinline__ int first_pass_rbase(int lane, int g) { return rpad(rev4<Geo<N>::IDIG>(lane + 64 * g)); }
+template <int N> __device__ __forceinline__ int first_pass_rbase(int lane, int g) { return rimg<N>(rev4<Geo<N>::IDIG>(lane + 64 * g)); }
 template <int N> __host__ __device__ constexpr int first_pass_rstep(int j)
 {
-    return (Geo<N>::ITEMS_A + Geo<N>::ITEMS_A / 4)
+    return (Geo<N>::ITEMS_A + 4 * (Geo<N>::ITEMS_A / Geo<N>::RQ))
          * ((Geo<N>::RA == 4) ? j : (Geo<N>::RA == 8) ? ((j >> 1) + 4 * (j & 1)) : ((j >> 2) + 4 * (j & 3)));
 }
-static_assert(Geo<256>::ITEMS_A % 16 == 0 && Geo<512>::ITEMS_A % 16 == 0 && Geo<1024>::ITEMS_A % 16 == 0, "rpad splits only at multiples of 16");
+static_assert(Geo<256>::ITEMS_A % Geo<256>::RQ == 0 && Geo<512>::ITEMS_A % Geo<512>::RQ == 0 && Geo<1024>::ITEMS_A % Geo<1024>::RQ == 0
+              && Geo<2048>::ITEMS_A % Geo<2048>::RQ == 0 && Geo<4096>::ITEMS_A % Geo<4096>::RQ == 0, "the real image splits only at multiples of RQ");
 
-// First pass: the lane's P REAL inputs are already in registers in first_pass_index order (imag = 0,
-// as in performRealOnlyForwardTransform and in PitchAnalyser's re*re spectrum).  Stages at length 1
-// have unit twiddles and real operands; the stage after them sees real operands in half of its
-// butterflies.  Results go to the complex image.
+// One first-pass item: R REAL inputs (imag = 0, as in performRealOnlyForwardTransform and in PitchAnalyser's re*re
+// spectrum), already in first_pass_index order.  Stages at length 1 have unit twiddles and real operands; the stage
+// after them sees real operands in half of its butterflies.
+template <int N, bool INV>
+__device__ __forceinline__ void first_pass_item(const float* x, const f2 (&ta)[9], f2 (&e)[Geo<N>::RA])
+{
+    constexpr int R = Geo<N>::RA;
+    if constexpr (R == 4) {
+        bfly4_real<INV>(x[0], x[1], x[2], x[3], e[0], e[1], e[2], e[3]);
+    } else if constexpr (R == 8) {
+        // radix-2 at length 1 (unit twiddle, real): pairs (2g', 2g'+1)
+        float r[8];
+#pragma unroll
+        for (int h = 0; h < 4; h++) { r[2 * h] = x[2 * h] + x[2 * h + 1]; r[2 * h + 1] = x[2 * h] - x[2 * h + 1]; }
+        // radix-4 at length 2: legs i = jin + 2*q
+        bfly4_real<INV>(r[0], r[2], r[4], r[6], e[0], e[2], e[4], e[6]);
+        e[1] = f2{r[1], 0.0f};
+        bfly4_core<INV>(e[1], e[3], e[5], e[7], twmul_real<INV>(r[3], ta[0]), twmul_real<INV>(r[5], ta[1]), twmul_real<INV>(r[7], ta[2]));
+    } else {
+        // radix-4 at length 1: groups (4g', .., 4g'+3)
+#pragma unroll
+        for (int h = 0; h < 4; h++)
+            bfly4_real<INV>(x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3], e[4 * h], e[4 * h + 1], e[4 * h + 2], e[4 * h + 3]);
+        // radix-4 at length 4: legs i = jin + 4*q; jin = 0 and 2 have real operands
+        {
+            f2 o0, o1, o2, o3;
+            bfly4_real<INV>(e[0].x, e[4].x, e[8].x, e[12].x, o0, o1, o2, o3);
+            e[0] = o0; e[4] = o1; e[8] = o2; e[12] = o3;
+        }
+        bfly4_core<INV>(e[1], e[5], e[9], e[13], twmul<INV>(e[5], ta[0]), twmul<INV>(e[9], ta[1]), twmul<INV>(e[13], ta[2]));
+        bfly4_core<INV>(e[2], e[6], e[10], e[14], twmul_real<INV>(e[6].x, ta[3]), twmul_real<INV>(e[10].x, ta[4]), twmul_real<INV>(e[14].x, ta[5]));
+        // The item is a 16-point transform of real data, and the jin = 3 butterfly is the mirror image of the
+        // jin = 1 butterfly: its operands are the conjugates (bfly4_real: d3 = conj(d1)) and its twiddles W^3, W^6,
+        // W^9 are -i*conj(W^1), -conj(W^2), i*conj(W^3) -- bit for bit, which the host verifies on the float table
+        // before any launch (first_pass_twiddles_hermitian).  Every product and sum then comes out as the exact
+        // conjugate (negation and operand order do not change a rounding): out'[0..3] = conj(out[3], out[2],
+        // out[1], out[0]).  (The jin = 2 butterfly has no such shortcut: the table's cos(pi/2) is 6e-17, not 0.)
+        e[3] = f2{e[13].x, -e[13].y}; e[7] = f2{e[9].x, -e[9].y}; e[11] = f2{e[5].x, -e[5].y}; e[15] = f2{e[1].x, -e[1].y};
+    }
+}
+
+// First pass of an un-split transform: the lane's P real inputs -> the complex image.
 template <int N, bool INV>
 __device__ __forceinline__ void fft_first_pass(const float (&xin)[Geo<N>::P], f2* cbuf, const float (&ftw)[18], int lane)
 {
@@ -242,46 +311,42 @@ __device__ __forceinline__ void fft_first_pass(const float (&xin)[Geo<N>::P], f2
     for (int i = 0; i < 9; i++) ta[i] = f2{ftw[2 * i], ftw[2 * i + 1]};
 #pragma unroll
     for (int g = 0; g < G::GA; g++) {
-        const float* x = &xin[g * R];
         f2 e[R];
-        if constexpr (R == 4) {
-            bfly4_real<INV>(x[0], x[1], x[2], x[3], e[0], e[1], e[2], e[3]);
-        } else if constexpr (R == 8) {
-            // radix-2 at length 1 (unit twiddle, real): pairs (2g', 2g'+1)
-            float r[8];
-#pragma unroll
-            for (int h = 0; h < 4; h++) { r[2 * h] = x[2 * h] + x[2 * h + 1]; r[2 * h + 1] = x[2 * h] - x[2 * h + 1]; }
-            // radix-4 at length 2: legs i = jin + 2*q
-            bfly4_real<INV>(r[0], r[2], r[4], r[6], e[0], e[2], e[4], e[6]);
-            e[1] = f2{r[1], 0.0f};
-            bfly4_core<INV>(e[1], e[3], e[5], e[7], twmul_real<INV>(r[3], ta[0]), twmul_real<INV>(r[5], ta[1]), twmul_real<INV>(r[7], ta[2]));
-        } else {
-            // radix-4 at length 1: groups (4g', .., 4g'+3)
-#pragma unroll
-            for (int h = 0; h < 4; h++)
-                bfly4_real<INV>(x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3], e[4 * h], e[4 * h + 1], e[4 * h + 2], e[4 * h + 3]);
-            // radix-4 at length 4: legs i = jin + 4*q; jin = 0 and 2 have real operands
-            {
-                f2 o0, o1, o2, o3;
-                bfly4_real<INV>(e[0].x, e[4].x, e[8].x, e[12].x, o0, o1, o2, o3);
-                e[0] = o0; e[4] = o1; e[8] = o2; e[12] = o3;
-            }
-            bfly4_core<INV>(e[1], e[5], e[9], e[13], twmul<INV>(e[5], ta[0]), twmul<INV>(e[9], ta[1]), twmul<INV>(e[13], ta[2]));
-            bfly4_core<INV>(e[2], e[6], e[10], e[14], twmul_real<INV>(e[6].x, ta[3]), twmul_real<INV>(e[10].x, ta[4]), twmul_real<INV>(e[14].x, ta[5]));
-            // The item is a 16-point transform of real data, and the jin = 3 butterfly is the mirror image of the
-            // jin = 1 butterfly: its operands are the conjugates (bfly4_real: d3 = conj(d1)) and its twiddles W^3, W^6,
-            // W^9 are -i*conj(W^1), -conj(W^2), i*conj(W^3) -- bit for bit, which the host verifies on the float table
-            // before any launch (first_pass_twiddles_hermitian).  Every product and sum then comes out as the exact
-            // conjugate (negation and operand order do not change a rounding): out'[0..3] = conj(out[3], out[2],
-            // out[1], out[0]).  (The jin = 2 butterfly has no such shortcut: the table's cos(pi/2) is 6e-17, not 0.)
-            e[3] = f2{e[13].x, -e[13].y}; e[7] = f2{e[9].x, -e[9].y}; e[11] = f2{e[5].x, -e[5].y}; e[15] = f2{e[1].x, -e[1].y};
-        }
+        first_pass_item<N, INV>(&xin[g * R], ta, e);
         f2* img = cbuf + cpad((lane + 64 * g) * R);
 #pragma unroll
         for (int i = 0; i < R; i++) img[i] = e[i];         // R <= 16 contiguous positions: no pad inside
     }
     wave_fence();
 }
+
+// The two radix-4 stages of a 16-element item (stride L0 between elements), in registers.
+template <int L0, bool INV>
+__device__ __forceinline__ void item16_stages(f2 (&e)[16], const f2* t1)
+{
+    {
+        const f2 w1 = t1[0], w2 = t1[L0], w3 = t1[2 * L0];
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            bfly4_core<INV>(e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3],
+                            twmul<INV>(e[4 * g + 1], w1), twmul<INV>(e[4 * g + 2], w2), twmul<INV>(e[4 * g + 3], w3));
+    }
+    const f2* t2 = t1 + 3 * L0;
+#pragma unroll
+    for (int jin = 0; jin < 4; jin++) {
+        const f2 w1 = t2[(jin * 3 + 0) * L0], w2 = t2[(jin * 3 + 1) * L0], w3 = t2[(jin * 3 + 2) * L0];
+        bfly4_core<INV>(e[jin], e[jin + 4], e[jin + 8], e[jin + 12],
+                        twmul<INV>(e[jin + 4], w1), twmul<INV>(e[jin + 8], w2), twmul<INV>(e[jin + 12], w3));
+    }
+}
+
+// Split transforms (N >= 2048): position of a complex element inside the HALF image of the second exchange (second
+// pass -> last pass).  q = k' + (L2/2)*i with k' < L2/2 the last-pass item within its half and i its element: rows of
+// L2/2 consecutive k'.  The last pass reads a row with 64 consecutive lanes (conflict-free for any row offset); the
+// second pass writes runs of L1 consecutive k' that are L2/2 apart, which need the rows 8 slots apart in bank
+// position when L1 = 8 (N = 2048) and nothing when L1 = 16.
+template <int N> __host__ __device__ constexpr int qpad(int q) { return N == 2048 ? q + 8 * (q >> 6) : q; }
+static_assert(qpad<2048>(1023) < Geo<2048>::CSLOTS && qpad<4096>(2047) < Geo<4096>::CSLOTS, "half image fits the wave buffer");
 
 // What the last pass leaves in the wave's LDS buffer.
 enum { OUT_RE_LOW = 1,        // float re[M] (plain layout): all the harmonic analyser reads (ref HarmonicCharacteristics.h:63)
@@ -294,48 +359,34 @@ enum { OUT_RE_LOW = 1,        // float re[M] (plain layout): all the harmonic an
 // registers (128 VGPRs of them at N = 4096, which runs one wave per SIMD anyway), fused with the consumer of the spectrum, so the full complex image is never written back and
 // re-read: the spectral / harmonic analysers only read re of bins < N/2, the pitch analyser only re*re, the
 // lag search only the squared, lag-weighted real part.
+// Last pass, compute half: e[g][*] holds the items of this lane (item k = lane + 64*g).  Radix 4 at length N/4
+// (N <= 1024) or radix 16 at length N/16, fused with the consumer of the spectrum, so the full complex image is never
+// written back and re-read: the spectral / harmonic analysers only read re of bins < N/2, the pitch analyser only
+// re*re, the lag search only the squared, lag-weighted real part.  The wave's buffer must be free (every lane has read
+// its inputs) when this is called.
 template <int N, bool INV, int OUT>
-__device__ __forceinline__ float fft_last_pass_fused(f2* cbuf, const f2* tw, int lane, float scale, float* regs_out)
+__device__ __forceinline__ float fft_last_pass_consume(f2 (&e)[(N / Plan<N>::R2) / 64][Plan<N>::R2], f2* cbuf, const f2* tw, int lane, float scale, float* regs_out)
 {
     typedef Plan<N> PL;
-    constexpr int R = PL::R2, L0 = PL::L2, GI = (N / R) / 64, TWOFF = PL::OFF2, M = N / 2;
-    lane = opaque(lane);
-    f2 e[GI][R];
-#pragma unroll
-    for (int g = 0; g < GI; g++) {
-        const f2* img = cbuf + cpad(lane + 64 * g);
-#pragma unroll
-        for (int i = 0; i < R; i++) e[g][i] = img[item_off(L0, i)];
-    }
-    wave_fence();                 // the wave has read the whole complex image; the buffer may be rewritten
+    constexpr int R = PL::R2, L0 = PL::L2, GI = (N / R) / 64, TWOFF = PL::OFF2;
     float* fbuf = reinterpret_cast<float*>(cbuf);
     float aux = 0.0f;
 #pragma unroll
     for (int g = 0; g < GI; g++) {
         const int k = lane + 64 * g;
         const f2* t1 = tw + TWOFF + k;
-        {
-            const f2 w1 = t1[0], w2 = t1[L0], w3 = t1[2 * L0];
-#pragma unroll
-            for (int h = 0; h < R / 4; h++)
-                bfly4_core<INV>(e[g][4 * h], e[g][4 * h + 1], e[g][4 * h + 2], e[g][4 * h + 3],
-                                twmul<INV>(e[g][4 * h + 1], w1), twmul<INV>(e[g][4 * h + 2], w2), twmul<INV>(e[g][4 * h + 3], w3));
-        }
         if constexpr (R == 16) {
-            const f2* t2 = t1 + 3 * L0;
-#pragma unroll
-            for (int jin = 0; jin < 4; jin++) {
-                const f2 w1 = t2[(jin * 3 + 0) * L0], w2 = t2[(jin * 3 + 1) * L0], w3 = t2[(jin * 3 + 2) * L0];
-                bfly4_core<INV>(e[g][jin], e[g][jin + 4], e[g][jin + 8], e[g][jin + 12],
-                                twmul<INV>(e[g][jin + 4], w1), twmul<INV>(e[g][jin + 8], w2), twmul<INV>(e[g][jin + 12], w3));
-            }
+            item16_stages<L0, INV>(e[g], t1);
+        } else {
+            const f2 w1 = t1[0], w2 = t1[L0], w3 = t1[2 * L0];
+            bfly4_core<INV>(e[g][0], e[g][1], e[g][2], e[g][3], twmul<INV>(e[g][1], w1), twmul<INV>(e[g][2], w2), twmul<INV>(e[g][3], w3));
         }
         // e[g][i] is bin k + L0*i
 #pragma unroll
         for (int i = 0; i < R; i++) {
             const int bin = k + L0 * i;
             if (OUT == OUT_RE_LOW || OUT == OUT_RE_LOW_MAXABS) {
-                if (i < R / 2) fbuf[bin] = e[g][i].x;                          // bins >= N/2 are never read
+                if (i < R / 2) fbuf[bimg<N>(lane) + bimg_step<N>(64 * g + L0 * i)] = e[g][i].x;     // bins >= N/2 are never read
                 if (OUT == OUT_RE_LOW_MAXABS && i < R / 4) aux = fmaxf(aux, fmaxf(fabsf(e[g][i].x), fabsf(e[g][i].y)));
             } else if (OUT == OUT_POWER) {
                 if constexpr (Geo<N>::GA == 1) {
@@ -349,7 +400,7 @@ __device__ __forceinline__ float fft_last_pass_fused(f2* cbuf, const f2* tw, int
                     regs_out[j] = __int_as_float(__builtin_amdgcn_ds_bpermute(
                         rev4<Geo<N>::IDIG>(lane) << 2, __float_as_int(e[g][i].x * e[g][i].x)));
                 } else {
-                    fbuf[rpad(bin)] = e[g][i].x * e[g][i].x;
+                    fbuf[rimg<N>(lane) + rimg_step<N>(64 * g + L0 * i)] = e[g][i].x * e[g][i].x;
                 }
             } else {
                 const float d = e[g][i].x * scale;
@@ -358,7 +409,138 @@ __device__ __forceinline__ float fft_last_pass_fused(f2* cbuf, const f2* tw, int
         }
         if (OUT == OUT_LAG && g == 0) { const float d = e[0][0].y * scale; aux = d * d * (float) N; }
     }
-    (void) M;
+    wave_fence();
+    return aux;
+}
+
+// Last pass of an un-split transform: all of a lane's items are read from the complex image first.
+template <int N, bool INV, int OUT>
+__device__ __forceinline__ float fft_last_pass_fused(f2* cbuf, const f2* tw, int lane, float scale, float* regs_out)
+{
+    typedef Plan<N> PL;
+    constexpr int R = PL::R2, L0 = PL::L2, GI = (N / R) / 64;
+    lane = opaque(lane);
+    f2 e[GI][R];
+#pragma unroll
+    for (int g = 0; g < GI; g++) {
+        const f2* img = cbuf + cpad(lane + 64 * g);
+#pragma unroll
+        for (int i = 0; i < R; i++) e[g][i] = img[item_off(L0, i)];
+    }
+    wave_fence();                 // the wave has read the whole complex image; the buffer may be rewritten
+    return fft_last_pass_consume<N, INV, OUT>(e, cbuf, tw, lane, scale, regs_out);
+}
+
+// What the consumer keeps of a finished 16-element last-pass item (item k: element i is bin k + (N/16)*i).
+template <int N, int OUT>
+__device__ __forceinline__ void last_item_reduce(const f2 (&e)[16], int k, float scale, float (&res)[16], float& aux)
+{
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (OUT == OUT_RE_LOW || OUT == OUT_RE_LOW_MAXABS) {
+            if (i < 8) res[i] = e[i].x;                                        // bins >= N/2 are never read
+            if (OUT == OUT_RE_LOW_MAXABS && i < 4) aux = fmaxf(aux, fmaxf(fabsf(e[i].x), fabsf(e[i].y)));
+        } else if (OUT == OUT_POWER) {
+            res[i] = e[i].x * e[i].x;
+        } else {
+            const float d = e[i].x * scale;
+            res[i] = d * d * (float) (k + (N / 16) * i);
+        }
+    }
+}
+
+// Split transform (N >= 2048): three passes with both exchanges done one half at a time through a half-size image.
+//   first pass  : RA real inputs per item, ITEMS_A/64 = 4 items per lane  (items 0,1 = half 0; items 2,3 = half 1)
+//   second pass : 16-element items at stride L1, GB = N/1024 items per lane: item lane + 64*j reads positions
+//                 (it/L1)*16*L1 + it%L1 + L1*i, which lie in the first-pass half [it >= ITEMS_B/2]
+//   last pass   : 16-element items at stride L2 = N/16, GB items per lane: item k = lane + 64*g reads positions
+//                 k + L2*i, produced as element i' of second-pass items with (k'' + L1*i') mod L2 = k, i.e. by
+//                 elements i' < 8 for the first half of the g's and i' >= 8 for the second half.
+template <int N, bool INV, int OUT>
+__device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, const float (&ftw)[18],
+                                           int lane, float scale, float* regs_out)
+{
+    typedef Geo<N> G;
+    typedef Plan<N> PL;
+    constexpr int RA = G::RA, GA = G::GA, L1 = PL::L1, L2 = PL::L2, GB = (N / 16) / 64, HB = GB / 2;
+    static_assert(PL::R1 == 16 && PL::R2 == 16 && GA == 4 && GB >= 2 && GB % 2 == 0, "split plan: three passes, even item counts");
+    lane = opaque(lane);
+    f2 ta[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) ta[i] = f2{ftw[2 * i], ftw[2 * i + 1]};
+    f2 eb[GB][16];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        // first-pass items of this half -> half image (item lane + 64*g' at local position (lane + 64*g')*RA)
+#pragma unroll
+        for (int gl = 0; gl < GA / 2; gl++) {
+            f2 e[RA];
+            first_pass_item<N, INV>(&xin[(h * (GA / 2) + gl) * RA], ta, e);
+            f2* img = cbuf + cpad((lane + 64 * gl) * RA);
+#pragma unroll
+            for (int i = 0; i < RA; i++) img[i] = e[i];
+        }
+        wave_fence();
+        // second-pass items of this half: local item lane + 64*jl
+#pragma unroll
+        for (int jl = 0; jl < HB; jl++) {
+            const int it = lane + 64 * jl;
+            const f2* img = cbuf + cpad((it / L1) * (16 * L1) + it % L1);
+#pragma unroll
+            for (int i = 0; i < 16; i++) eb[h * HB + jl][i] = img[item_off(L1, i)];
+        }
+        wave_fence();             // every lane has its inputs: the next half may overwrite the image
+#pragma unroll
+        for (int jl = 0; jl < HB; jl++) {
+            const int it = lane + 64 * jl;
+            item16_stages<L1, INV>(eb[h * HB + jl], tw + PL::OFF1 + it % L1);
+        }
+    }
+    // second exchange.  Element i of second-pass item it = lane + 64*j sits at position (it/L1)*L2 + it%L1 + L1*i
+    // (16*L1 == L2): row it/L1 of the last pass's input (its element index), column k = it%L1 + L1*i (its item), and
+    // the half of the last-pass items that column belongs to is k >= L2/2, i.e. i >= 8.  The last-pass items of a half
+    // are finished as soon as they are read (and reduced to what the consumer keeps: <= 16 floats per item), so that the
+    // other half's second-pass results are the only other large live set.
+    static_assert(16 * L1 == L2, "a second-pass item spans exactly one row of the last pass");
+    float res[GB][16];
+    float aux = 0.0f;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+        for (int j = 0; j < GB; j++) {
+            const int it = lane + 64 * j;
+            f2* img = cbuf + qpad<N>((L2 / 2) * (it / L1)) + it % L1;          // row start + column of element 8*h
+#pragma unroll
+            for (int i = 0; i < 8; i++) img[L1 * i] = eb[j][8 * h + i];
+        }
+        wave_fence();
+        f2 ec[HB][16];
+#pragma unroll
+        for (int gl = 0; gl < HB; gl++) {
+            const f2* img = cbuf + (lane + 64 * gl);
+#pragma unroll
+            for (int i = 0; i < 16; i++) ec[gl][i] = img[qpad<N>((L2 / 2) * i)];
+        }
+        wave_fence();
+#pragma unroll
+        for (int gl = 0; gl < HB; gl++) {
+            const int g = h * HB + gl, k = lane + 64 * g;
+            item16_stages<L2, INV>(ec[gl], tw + PL::OFF2 + k);
+            last_item_reduce<N, OUT>(ec[gl], k, scale, res[g], aux);
+            if (OUT == OUT_LAG && g == 0) { const float d = ec[0][0].y * scale; aux = d * d * (float) N; }
+        }
+    }
+    // the buffer is free: hand the results to the consumer
+    float* fbuf = reinterpret_cast<float*>(cbuf);
+#pragma unroll
+    for (int g = 0; g < GB; g++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (OUT == OUT_RE_LOW || OUT == OUT_RE_LOW_MAXABS) { if (i < 8) fbuf[bimg<N>(lane) + bimg_step<N>(64 * g + L2 * i)] = res[g][i]; }
+            else if (OUT == OUT_POWER) fbuf[rimg<N>(lane) + rimg_step<N>(64 * g + L2 * i)] = res[g][i];
+            else regs_out[g + (L2 / 64) * i] = res[g][i];                      // bin = lane + 64 * (g + (L2/64) * i)
+        }
+    }
     wave_fence();
     return aux;
 }
@@ -369,7 +551,11 @@ __device__ __forceinline__ float fft_from_regs(const float (&xin)[Geo<N>::P], f2
                                                int lane, float scale = 0.0f, float* regs_out = nullptr)
 {
     typedef Plan<N> PL;
-    fft_first_pass<N, INV>(xin, cbuf, ftw, lane);
-    fft_pass<N, PL::R1, PL::L1, PL::OFF1, INV>(cbuf, tw, lane);
-    return fft_last_pass_fused<N, INV, OUT>(cbuf, tw, lane, scale, regs_out);
+    if constexpr (Geo<N>::SPLIT) {
+        return fft_split<N, INV, OUT>(xin, cbuf, tw, ftw, lane, scale, regs_out);
+    } else {
+        fft_first_pass<N, INV>(xin, cbuf, ftw, lane);
+        fft_pass<N, PL::R1, PL::L1, PL::OFF1, INV>(cbuf, tw, lane);
+        return fft_last_pass_fused<N, INV, OUT>(cbuf, tw, lane, scale, regs_out);
+    }
 }

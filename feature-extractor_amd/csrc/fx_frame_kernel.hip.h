@@ -5,7 +5,7 @@
 // ---------------------------------------------------------------------------------------------
 // frame load: global -> real LDS image, 16 B per lane, coalesced
 // ---------------------------------------------------------------------------------------------
-template <int HALF>
+template <int N, int HALF>
 __device__ __forceinline__ void load_half(const void* src, int sample_format, float gain, bool apply_gain,
                                           float* rbuf, int dst_off, float* tail_out, int lane)
 {
@@ -22,7 +22,7 @@ __device__ __forceinline__ void load_half(const void* src, int sample_format, fl
             v = *reinterpret_cast<const f4*>(static_cast<const float*>(src) + i);
         }
         if (apply_gain) v *= gain;                       // ref AudioDataCollector.h:88
-        *reinterpret_cast<f4*>(&rbuf[rpad(dst_off + i)]) = v;
+        *reinterpret_cast<f4*>(&rbuf[rimg<N>(dst_off + i)]) = v;
         if (tail_out) *reinterpret_cast<f4*>(tail_out + i) = v;
     }
 }
@@ -31,9 +31,10 @@ __device__ __forceinline__ void load_half(const void* src, int sample_format, fl
 // round trip per frame instead of one per 1 KB piece).  F16_A / F16_B: sample format of the source of
 // the first / second half (the carried-over tail is always fp32).  N >= 512.
 template <int N, bool F16_A, bool F16_B>
-__device__ __forceinline__ void load_window(const void* src_a, const void* src_b, float gain_a, float gain_b,
-                                            float* rbuf, float* tail_out, int lane)
+__device__ __forceinline__ double load_window(const void* src_a, const void* src_b, float gain_a, float gain_b,
+                                              float* rbuf, float* tail_out, int lane)
 {
+    double ssq = 0.0;           // this lane's share of getRMSLevel's sum (ref RealTimeAnalyser.h:207): float squares, double sum
     constexpr int HALF = N / 2, QH = HALF / 256;
     uint4 ra[QH], rb[QH];
 #pragma unroll
@@ -60,14 +61,56 @@ __device__ __forceinline__ void load_window(const void* src_a, const void* src_b
     for (int q = 0; q < QH; q++) {
         const int i = 256 * q + 4 * lane;
         const f4 v = widen(ra[q], F16_A) * gain_a;             // ref AudioDataCollector.h:88 (x * 1.0f is exact)
-        *reinterpret_cast<f4*>(&rbuf[rpad(i)]) = v;
+        *reinterpret_cast<f4*>(&rbuf[rimg<N>(i)]) = v;
+        if (Geo<N>::SPLIT) ssq += (double) (v.x * v.x) + (double) (v.y * v.y) + (double) (v.z * v.z) + (double) (v.w * v.w);
     }
 #pragma unroll
     for (int q = 0; q < QH; q++) {
         const int i = 256 * q + 4 * lane;
         const f4 v = widen(rb[q], F16_B) * gain_b;
-        *reinterpret_cast<f4*>(&rbuf[rpad(HALF + i)]) = v;
+        *reinterpret_cast<f4*>(&rbuf[rimg<N>(HALF + i)]) = v;
         if (tail_out) *reinterpret_cast<f4*>(tail_out + i) = v;
+        if (Geo<N>::SPLIT) ssq += (double) (v.x * v.x) + (double) (v.y * v.y) + (double) (v.z * v.z) + (double) (v.w * v.w);
+    }
+    return ssq;
+}
+
+// The same window straight from global memory into registers in the order the first FFT pass consumes it (split
+// sizes: the raw frame is not kept in registers across the four transforms; it is fetched again -- from L2 -- when
+// the spectral and the harmonic analyser need it).  For a fixed (g, j) the 64 lanes read 64 consecutive samples.
+template <int N, bool F16_A, bool F16_B>
+__device__ __forceinline__ void load_window_first_pass_order(const void* src_a, const void* src_b, float gain_a, float gain_b,
+                                                             int lane, float (&x)[Geo<N>::P])
+{
+    typedef Geo<N> G;
+    // sample index = rev4(lane + 64*g) + ITEMS_A*r(j), and rev4(lane + 64*g) = rev4(lane) + g (lane's three base-4 digits
+    // go to the top of the item index, g's digit to the bottom): ONE per-lane offset, everything else is a compile-time
+    // constant, so each load is a scalar base + that offset + an immediate
+    static_assert(G::IDIG == 4 && G::GA == 4, "split sizes: 256 first-pass items, 4 per lane");
+    // (byte offsets kept in 32 bits: scalar base + 32-bit lane offset + immediate is one addressing mode, a 64-bit
+    // element index is a vector add per load)
+    const unsigned low = (unsigned) rev4<G::IDIG>(lane);
+    const unsigned off_a = low * (F16_A ? 2u : 4u), off_b = low * (F16_B ? 2u : 4u);
+#pragma unroll
+    for (int g = 0; g < G::GA; g++) {
+#pragma unroll
+        for (int j = 0; j < G::RA; j++) {
+            const int r = (G::RA == 4) ? j : (G::RA == 8) ? ((j >> 1) + 4 * (j & 1)) : ((j >> 2) + 4 * (j & 3));
+            const bool second = r >= G::RA / 2;                                // low + g < ITEMS_A <= N/2
+            const int k = g + G::ITEMS_A * (second ? r - G::RA / 2 : r);       // compile-time part of the sample index
+            const bool f16 = second ? F16_B : F16_A;
+            const char* at = static_cast<const char*>(second ? src_b : src_a) + (second ? off_b : off_a) + k * (f16 ? 2 : 4);
+            x[g * G::RA + j] = f16 ? __half2float(*reinterpret_cast<const __half*>(at)) : *reinterpret_cast<const float*>(at);
+        }
+    }
+    if (gain_a != 1.0f || gain_b != 1.0f) {                                   // ref AudioDataCollector.h:88 (wave-uniform)
+#pragma unroll
+        for (int g = 0; g < G::GA; g++)
+#pragma unroll
+            for (int j = 0; j < G::RA; j++) {
+                const int r = (G::RA == 4) ? j : (G::RA == 8) ? ((j >> 1) + 4 * (j & 1)) : ((j >> 2) + 4 * (j & 3));
+                x[g * G::RA + j] *= (r >= G::RA / 2) ? gain_b : gain_a;
+            }
     }
 }
 
@@ -99,10 +142,13 @@ __device__ __forceinline__ FlatProd fp_mul2(FlatProd a, FlatProd b)
 #define FX_OCC_SMALL 4
 #endif
 template <int N> struct Occ {
-    static constexpr int WAVES_PER_SIMD = N <= 1024 ? FX_OCC_SMALL : (N == 2048 ? 2 : 1);
-    // N = 4096 fits at most 3 waves per workgroup in the LDS; a 256-thread bound lets it use the whole
-    // register file at one wave per SIMD instead of spilling
-    static constexpr int MAX_THREADS = N == 4096 ? 256 : 512;
+    // LDS bounds residency: 2 workgroups of 8 waves per CU up to 1024 points (4 waves per SIMD, <= 128 VGPRs),
+    // 2 workgroups of 6 waves at 2048, one workgroup of 6 waves at 4096 (2 per SIMD at most, <= 256 VGPRs: the split
+    // transform keeps a lane's 64 second-pass results in registers).  2048 points is held to 128 VGPRs as well: two
+    // 6-wave workgroups land on the SIMDs as 2+2+1+1 twice, in whatever rotation the dispatcher picks, so 4 waves on
+    // one SIMD must fit -- at 136 registers the second workgroup was not co-resident.
+    static constexpr int WAVES_PER_SIMD = N <= 2048 ? FX_OCC_SMALL : 2;
+    static constexpr int MAX_THREADS = N <= 2048 ? 512 : 448;
 };
 
 // One wavefront's view of the frame it is analysing: where its buffers are and the constants every section
@@ -128,36 +174,60 @@ template <int N> struct FrameWave {
     // |re| of the raw spectrum around and inside the lane's bins, kept from the harmonic FFT to the harmonic tail
     struct HarmonicSpectrum { float hre[U]; float left2, left1, right1; double sum, max; };
 
-    __device__ __forceinline__ void load_frame(int lane) const
+    // where the two halves of this frame's window come from (a1, ref RealTimeAudioAnalysis.h:205-219)
+    struct Sources { const void* a; const void* b; float gain_a, gain_b; bool f16_a, f16_b; };
+    __device__ __forceinline__ Sources sources() const
+    {
+        const size_t esz = p.sample_format == FX_SAMPLE_F16 ? 2 : 4;
+        const unsigned char* in = static_cast<const unsigned char*>(p.in);
+        Sources s;
+        s.f16_a = s.f16_b = p.sample_format == FX_SAMPLE_F16;
+        if (p.hop_mode) {
+            s.gain_a = s.gain_b = p.gain;
+            s.b = in + ((size_t) c * T + t) * HALF * esz;
+            if (t == 0) { s.a = p.tail_in + (size_t) c * HALF; s.f16_a = false; s.gain_a = 1.0f; }   // tail is fp32, already gained
+            else        s.a = in + ((size_t) c * T + (t - 1)) * HALF * esz;
+        } else {
+            s.gain_a = s.gain_b = 1.0f;
+            s.a = in + ((size_t) c * T + t) * N * esz;
+            s.b = static_cast<const unsigned char*>(s.a) + HALF * esz;
+        }
+        return s;
+    }
+
+    // split sizes: the raw window again, from global memory (L2), in first-pass order
+    __device__ __forceinline__ void load_raw(int lane, float (&x)[P]) const
+    {
+        asm volatile("" ::: "memory");        // a fetch of its own each time: the point is not to keep x live in between
+        const Sources s = sources();
+        if (s.f16_a && s.f16_b) load_window_first_pass_order<N, true,  true >(s.a, s.b, s.gain_a, s.gain_b, lane, x);
+        else if (s.f16_b)       load_window_first_pass_order<N, false, true >(s.a, s.b, s.gain_a, s.gain_b, lane, x);
+        else                    load_window_first_pass_order<N, false, false>(s.a, s.b, s.gain_a, s.gain_b, lane, x);
+    }
+
+    // returns the lane's share of the frame's sum of squares (split sizes only; otherwise sum_squares() computes it)
+    __device__ __forceinline__ double load_frame(int lane) const
     {
 FX_MARK("load");
+        double ssq = 0.0;
         // ---------------- a1: window assembly (ref RealTimeAudioAnalysis.h:205-219) ----------------
         {
-            const size_t esz = p.sample_format == FX_SAMPLE_F16 ? 2 : 4;
-            const unsigned char* in = static_cast<const unsigned char*>(p.in);
             float* tail_dst = (t == T - 1) ? p.tail_out + (size_t) c * HALF : nullptr;
-            const bool f16 = p.sample_format == FX_SAMPLE_F16;
-            const void* src_a; const void* src_b; float gain_a, gain_b; bool f16_a = f16;
-            if (p.hop_mode) {
-                gain_a = gain_b = p.gain;
-                src_b = in + ((size_t) c * T + t) * HALF * esz;
-                if (t == 0) { src_a = p.tail_in + (size_t) c * HALF; f16_a = false; gain_a = 1.0f; }   // tail is fp32, already gained
-                else        src_a = in + ((size_t) c * T + (t - 1)) * HALF * esz;
-            } else {
-                gain_a = gain_b = 1.0f;
-                src_a = in + ((size_t) c * T + t) * N * esz;
-                src_b = static_cast<const unsigned char*>(src_a) + HALF * esz;
-            }
+            const Sources sr = sources();
+            const void* src_a = sr.a; const void* src_b = sr.b;
+            const float gain_a = sr.gain_a, gain_b = sr.gain_b;
+            const bool f16_a = sr.f16_a, f16 = sr.f16_b;
             if constexpr (N >= 512) {
-                if (f16_a && f16)       load_window<N, true,  true >(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane);
-                else if (f16)           load_window<N, false, true >(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane);
-                else                    load_window<N, false, false>(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane);
+                if (f16_a && f16)       ssq = load_window<N, true,  true >(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane);
+                else if (f16)           ssq = load_window<N, false, true >(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane);
+                else                    ssq = load_window<N, false, false>(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane);
             } else {
-                load_half<HALF>(src_a, f16_a ? FX_SAMPLE_F16 : FX_SAMPLE_F32, gain_a, gain_a != 1.0f, rbuf, 0, nullptr, lane);
-                load_half<HALF>(src_b, p.sample_format, gain_b, gain_b != 1.0f, rbuf, HALF, tail_dst, lane);
+                load_half<N, HALF>(src_a, f16_a ? FX_SAMPLE_F16 : FX_SAMPLE_F32, gain_a, gain_a != 1.0f, rbuf, 0, nullptr, lane);
+                load_half<N, HALF>(src_b, p.sample_format, gain_b, gain_b != 1.0f, rbuf, HALF, tail_dst, lane);
             }
             wave_fence();
         }
+        return ssq;
     }
 
     // fills xr with the raw frame in first-pass order and returns the sum of its squares: the numerator of
@@ -316,7 +386,7 @@ FX_MARK("spec_sums");
             // ref SpectralCharacteristics.h:153: getMagnitude over the first M floats of the interleaved
             // buffer = max |re|, |im| over bins [0, M/2)
             float maxabs = spec_aux;
-            lds_load_block<U>(reinterpret_cast<const float*>(cbuf) + U * lane, re);
+            lds_load_block<U>(reinterpret_cast<const float*>(cbuf) + bimg<N>(U * lane), re);
             const double eps = gate_threshold(sum_sq, re);
             double mag_sum = 0.0, lhr = 0.0, wsum = 0.0, flat_sum = 0.0;
             float max_re = 0.0f;       // max |re|: (double) re^2 is exact and monotone in |re|, so max mag = max_re^2
@@ -354,7 +424,7 @@ FX_MARK("flux");
                     __builtin_amdgcn_s_sleep(1);
 #endif
                 float pvf[U];
-                lds_load_block<U>(prev + U * lane, pvf);
+                lds_load_block<U>(prev + bimg<N>(U * lane), pvf);
 #pragma unroll
                 for (int j = 0; j < U; j++) {
                     const double pv = (double) pvf[j];
@@ -362,7 +432,7 @@ FX_MARK("flux");
                     const double diff = v * v - pv * pv;                       // :76
                     flux += fmax(diff, 0.0);                                   // :77-79 (a NaN difference adds nothing, as `if (diff > 0)`)
                 }
-                if (accepted) lds_store_block<U>(prev + U * lane, re);         // :138 (only on the accepted path)
+                if (accepted) lds_store_block<U>(prev + bimg<N>(U * lane), re);         // :138 (only on the accepted path)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __hip_atomic_store(turn, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -419,10 +489,10 @@ FX_MARK("harm1");
         {
             const int b0 = U * lane;
             const float* relin = reinterpret_cast<const float*>(cbuf);
-            lds_load_block<U>(relin + b0, hre);
-            h_left2  = b0 >= 2 ? fabsf(relin[b0 - 2]) : 0.0f;
-            h_left1  = b0 >= 1 ? fabsf(relin[b0 - 1]) : 0.0f;
-            h_right1 = b0 + U < M ? fabsf(relin[b0 + U]) : 0.0f;
+            lds_load_block<U>(relin + bimg<N>(b0), hre);
+            h_left2  = b0 >= 2 ? fabsf(relin[bimg<N>(b0 - 2)]) : 0.0f;
+            h_left1  = b0 >= 1 ? fabsf(relin[bimg<N>(b0 - 1)]) : 0.0f;
+            h_right1 = b0 + U < M ? fabsf(relin[bimg<N>(b0 + U)]) : 0.0f;
 #pragma unroll
             for (int j = 0; j < U; j++) {                                      // ref HarmonicCharacteristics.h:61-69
                 const double v = (double) hre[j];
@@ -455,7 +525,7 @@ FX_MARK("lpf");
         float x[P];
 #pragma unroll
         for (int i = 0; i < P; i += 4) {
-            const f4 v = *reinterpret_cast<const f4*>(&rbuf[rpad(P * lane + i)]);
+            const f4 v = *reinterpret_cast<const f4*>(&rbuf[rimg<N>(P * lane + i)]);
             x[i] = v.x; x[i + 1] = v.y; x[i + 2] = v.z; x[i + 3] = v.w;
         }
         float yin = 0.0f;                             // y[P*lane - 1] used as this chunk's input
@@ -465,7 +535,7 @@ FX_MARK("lpf");
             for (int q = 0; q < KW / 4; q++) {
                 const int n0 = first - KW + 4 * q;    // multiple of 4: the whole group is in range or not
                 if (n0 >= 0) {
-                    const f4 v = *reinterpret_cast<const f4*>(&rbuf[rpad(n0)]);
+                    const f4 v = *reinterpret_cast<const f4*>(&rbuf[rimg<N>(n0)]);
                     const float w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int e = 0; e < 4; e++)       // sample 0 starts the filter exactly; the first
@@ -510,7 +580,7 @@ FX_MARK("lpf");
             v.y = y[i + 1] * __builtin_fmaf(wstep, (float) (i + 1), w0);
             v.z = y[i + 2] * __builtin_fmaf(wstep, (float) (i + 2), w0);
             v.w = y[i + 3] * __builtin_fmaf(wstep, (float) (i + 3), w0);
-            *reinterpret_cast<f4*>(&rbuf[rpad(P * lane + i)]) = v;
+            *reinterpret_cast<f4*>(&rbuf[rimg<N>(P * lane + i)]) = v;
         }
         wave_fence();
     }
@@ -651,9 +721,8 @@ FX_MARK("harm2");
 #else
         if (!(h_sum < 0.005)) {                                                // :88-89
 #endif
-            float* normed  = reinterpret_cast<float*>(cbuf);                   // [M] floats: re of every bin (normalised on demand)
-            int*   peaks   = reinterpret_cast<int*>(cbuf) + M;                 // [<= M] peak bins
-            float* peak_re = reinterpret_cast<float*>(cbuf) + 2 * M;           // [<= M] re of those bins
+            float* normed = reinterpret_cast<float*>(cbuf);                    // bins image: re of every bin (normalised on demand)
+            unsigned short* peaks = reinterpret_cast<unsigned short*>(normed + G::BIMG);   // [<= M] peak bins (< 2048: 16 bits)
             double mean_mag = h_sum / (double) M;                              // :86
             // binIsPeak's `mag > mean` (:132) is an exact tie when the spectrum is flat (an impulse at
             // sample 0 or N/2 of the window): then the last bit of the reference's serial sum (:61-66)
@@ -704,7 +773,7 @@ FX_MARK("harm2");
             }
             // the probes below need the normalised magnitudes (float)(mag / max) (:75) of a few bins only; the
             // normalisation is monotone, so the largest of a neighbourhood is the normalised largest |re|
-            lds_store_block<U>(normed + U * lane, hre);
+            lds_store_block<U>(normed + bimg<N>(U * lane), hre);
             // compact the peak list
             const int npk_lane = __popc(peak_mask);
             const int pre = wave_scan_incl_i(npk_lane);
@@ -712,7 +781,7 @@ FX_MARK("harm2");
             int woff = pre - npk_lane;
 #pragma unroll
             for (int j = 0; j < U; j++)
-                if (peak_mask & (1u << j)) { peaks[woff] = U * lane + j; peak_re[woff] = hre[j]; woff++; }
+                if (peak_mask & (1u << j)) { peaks[woff] = (unsigned short) (U * lane + j); woff++; }
             wave_fence();
 
             const double fr = nyquist / (double) M;                            // :93
@@ -732,8 +801,8 @@ FX_MARK("harm2");
                     // getMaxBinInNeighbourhood :200-210 : [max(0,c-2), min(c+2, M)), start value normed[c]
                     const int s0 = bin - 2 >= 0 ? bin - 2 : 0;
                     const int e0 = bin + 2 < M ? bin + 2 : M;
-                    float mx = fabsf(normed[bin]);
-                    for (int q = s0; q < e0; q++) { const float v = fabsf(normed[q]); if (v > mx) mx = v; }
+                    float mx = fabsf(normed[bimg<N>(bin)]);
+                    for (int q = s0; q < e0; q++) { const float v = fabsf(normed[bimg<N>(q)]); if (v > mx) mx = v; }
                     const double pm = (double) mx;
                     probe = (double) (float) ((pm * pm) * r_hmax);                 // (mag / max, via one reciprocal), as a float (:75)
                 }
@@ -743,7 +812,7 @@ FX_MARK("harm2");
             double inh = 0.0;
             if (f0 > 0.0) {                                                    // :98
                 for (int i = lane; i < total_peaks; i += 64) {
-                    const int bin = peaks[i];
+                    const int bin = (int) peaks[i];
                     if (bin == f0_bin) continue;                               // :220-221
                     double fs = (double) bin * fr;
                     if (fs == 0.0) fs = fr * 0.5;                              // :225-226
@@ -753,7 +822,7 @@ FX_MARK("harm2");
                     const double re_ = (fe > f0 ? fe : f0) / (fe > f0 ? f0 : fe);
                     if (floor(rs) != floor(re_)) continue;                     // :232-233
                     const double r = rs < re_ ? rs : re_;
-                    const double v = (double) peak_re[i];
+                    const double v = (double) normed[bimg<N>(bin)];
                     inh += (r - floor(r)) * ((v * v) / h_sum);                 // :236-239
                 }
             }
@@ -769,17 +838,25 @@ FX_MARK("harm2");
 // RealTimeHarmonicAnalyser -- both by default, as AnalyserTrackController constructs them)
 template <int N, bool SPEC, bool HARM>
 __global__ void __launch_bounds__(Occ<N>::MAX_THREADS, Occ<N>::WAVES_PER_SIMD)
-fx_frame_kernel(const FrameParams p)
+fx_frame_kernel(const FrameParams p_arg)
 {
+#ifdef FX_EXP_NO_DYN
+    const FrameParams& p = p_arg;
+#else
+    FrameParams p = p_arg;
+    if (p.dyn) { p.gain = p.dyn->gain; p.nyquist = p.dyn->nyquist; }         // captured step (hipGraph): per-call scalars
+#endif
     typedef Geo<N> G;
     constexpr int M = G::M, P = G::P;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f2*    tw   = reinterpret_cast<f2*>(smem);                              // [N]
-    float* prev = reinterpret_cast<float*>(tw + N);                         // [M]  re of the last accepted frame
-    int*   turn = reinterpret_cast<int*>(prev + M);                         // [4]
-    unsigned char* per_wave = reinterpret_cast<unsigned char*>(turn + 4);
-    constexpr size_t WAVE_BYTES = sizeof(f2) * G::CBUF;
+    float* prev = reinterpret_cast<float*>(tw + N);                         // bins image: re of the last accepted frame
+    // the hand-over counter lives in the first padding gap of the bins image when there is one (4096 points fills the
+    // 160 KB to the byte with 7 waves), else behind it
+    int*   turn = reinterpret_cast<int*>(G::BQ ? prev + G::U : prev + G::BIMG);
+    unsigned char* per_wave = reinterpret_cast<unsigned char*>(prev + G::BIMG + (G::BQ ? 0 : 4));
+    constexpr size_t WAVE_BYTES = G::BUF_BYTES;
 
     const int nwaves = blockDim.x >> 6;
     const int wave = threadIdx.x >> 6;
@@ -792,7 +869,7 @@ fx_frame_kernel(const FrameParams p)
 
     // workgroup prologue: twiddle table + this channel's flux state into LDS
     for (int i = threadIdx.x; i < N; i += blockDim.x) tw[i] = reinterpret_cast<const f2*>(p.tw)[i];
-    for (int i = threadIdx.x; i < M; i += blockDim.x) prev[i] = p.prev_re[(size_t) c * M + i];
+    for (int i = threadIdx.x; i < M; i += blockDim.x) prev[bimg<N>(i)] = p.prev_re[(size_t) c * M + i];
     if (threadIdx.x == 0) turn[0] = 0;
     __syncthreads();
 
@@ -809,22 +886,34 @@ fx_frame_kernel(const FrameParams p)
         if (lane == 0) fpl->flags = 0;            // the harmonic tail sets it; the other fields are read only where written
         const FrameWave<N> w{p, tw, prev, turn, cbuf, rbuf, fpl, nyquist, rnyq, frpb, scale, c, T, t};
 
-        w.load_frame(lane);
+        const double ssq_lane = w.load_frame(lane);
         float xr[P];
-        const double sum_sq = w.sum_squares(lane, xr);
+        double sum_sq;
+        if constexpr (G::SPLIT) {
+            // split sizes do not hold the raw frame in registers across the transforms (a lane's second-pass results
+            // alone are 64 or 128 registers): the sum of squares comes from the load, the frame is fetched again below
+            sum_sq = wave_sum(ssq_lane);
+            if (lane == 0) fpl->sum_sq = sum_sq;
+        } else {
+            sum_sq = w.sum_squares(lane, xr);
+        }
         // The harmonic analyser's pitch estimate comes first: its low-pass reads the raw frame's real image, which the
         // transforms below overwrite.  (The order of the two analysers only matters for the smoothed RMS, which
         // fx_epilogue_kernel derives from the order flag.)
         double f0 = 0.0;
         if constexpr (HARM) f0 = w.pitch(lane);
-        if constexpr (SPEC) w.spectral(lane, xr, sum_sq);
+        if constexpr (SPEC) {
+            if constexpr (G::SPLIT) w.load_raw(lane, xr);
+            w.spectral(lane, xr, sum_sq);
+        }
         if constexpr (HARM) {
             typename FrameWave<N>::HarmonicSpectrum hs;
+            if constexpr (G::SPLIT) w.load_raw(lane, xr);
             w.harmonic_spectrum(lane, xr, hs);
             w.harmonic_tail(lane, hs, f0);
         }
     }
 
     __syncthreads();
-    for (int i = threadIdx.x; i < M; i += blockDim.x) p.prev_re[(size_t) c * M + i] = prev[i];
+    for (int i = threadIdx.x; i < M; i += blockDim.x) p.prev_re[(size_t) c * M + i] = prev[bimg<N>(i)];
 }

@@ -39,6 +39,18 @@ struct FramePart {
 };
 static_assert(sizeof(FramePart) == 128, "one 128-byte line per frame");
 
+// Per-call scalars of a captured (hipGraph) analysis step.  A graph's kernel arguments are frozen at capture, so what
+// changes from call to call lives here, in device memory, refreshed by a copy node at the head of the graph.
+struct DynParams {
+    double    nyquist;
+    long long frames_before;
+    long long onset_reset_frame;
+    float     gain;
+    float     onset_multiplier;
+    int       onset_window;
+    int       onset_type;
+};
+
 struct FrameParams {
     const void*  in;            // frames [C][T][N] or hops [C][T][N/2]
     int          sample_format; // FX_SAMPLE_F32 / FX_SAMPLE_F16
@@ -54,6 +66,7 @@ struct FrameParams {
     double       nyquist;
     double       bin_var;       // sum_i (i/M - 0.5)^2 / M, summed serially on the host (ref SpectralCharacteristics.h:182-189)
     float        lpf_a, lpf_b;  // ref RealTimeAudioAnalysis.h:122
+    const DynParams* dyn;       // non-null in a captured step: overrides gain and nyquist
     float        first_tw[18];  // the <= 9 twiddles of the first FFT pass (re, im pairs): wave-uniform, so they travel as
                                 // kernel arguments (SGPRs) instead of LDS reads; filled by fill_first_pass_twiddles
 };
@@ -77,6 +90,7 @@ struct EpilogueParams {
     float        onset_multiplier;
     int          order_mode;    // FX_ORDER_*
     int          analysers;     // bit 0: spectral analyser runs, bit 1: harmonic analyser runs
+    const DynParams* dyn;       // non-null in a captured step: overrides nyquist, frames_before, onset_*
 };
 
 // Re-order the reference's N-entry twiddle table (canonical[i] = (re, im) of e^{-2*pi*i/N} as floats)
@@ -87,6 +101,8 @@ void fill_first_pass_twiddles(int window_size, const float* pass_ordered, float*
 bool first_pass_twiddles_hermitian(int window_size, const float* first18);   // must hold before any launch
 
 size_t frame_kernel_lds_bytes(int window_size, int waves);
+int frame_kernel_max_waves(int window_size);
+int frame_kernel_preferred_waves(int window_size);     // the frame kernel's launch bound, in wavefronts per workgroup
 // Chooses waves per workgroup and launches; returns hipSuccess or the launch error.
 hipError_t launch_frame_kernel(int window_size, const FrameParams& p, int analysers, int waves, hipStream_t stream);
 hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t stream);

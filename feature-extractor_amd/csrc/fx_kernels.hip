@@ -118,7 +118,29 @@ void build_pass_twiddles(int n, const float* canonical, float* out)
 template <int N> static size_t lds_bytes_t(int waves)
 {
     typedef Geo<N> G;
-    return sizeof(f2) * N + sizeof(float) * G::M + 16 + (size_t) waves * (sizeof(f2) * G::CBUF);
+    return sizeof(f2) * N + sizeof(float) * G::BIMG + (G::BQ ? 0 : 16) + (size_t) waves * G::BUF_BYTES;
+}
+
+template <int N> static int max_waves_t() { return Occ<N>::MAX_THREADS / 64; }
+int frame_kernel_max_waves(int n)
+{
+    switch (n) {
+        case 256:  return max_waves_t<256>();
+        case 512:  return max_waves_t<512>();
+        case 1024: return max_waves_t<1024>();
+        case 2048: return max_waves_t<2048>();
+        case 4096: return max_waves_t<4096>();
+        default:   return 1;
+    }
+}
+
+// Wavefronts per workgroup (= frames of one channel in flight) that measured fastest on MI355X.  Up to 1024 points:
+// 8 (two workgroups per CU, 4 waves per SIMD).  2048: 4 (two workgroups, 2 per SIMD) -- 6 (12 waves per CU) fits but
+// ran 8 % slower: the kernel is VALU-bound from 2 waves per SIMD on and the chip answers denser issue with a lower
+// clock.  4096: as many as the LDS holds (7, the 160 KB to the byte).
+int frame_kernel_preferred_waves(int n)
+{
+    return n <= 1024 ? 8 : (n == 2048 ? 4 : 7);
 }
 
 size_t frame_kernel_lds_bytes(int n, int waves)

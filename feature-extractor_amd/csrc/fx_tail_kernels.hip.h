@@ -2,6 +2,21 @@
 // Included by fx_kernels.hip inside namespace fxk (one translation unit: every kernel sees the same
 // inlined helpers); not a stand-alone header.
 
+// a captured step (hipGraph) reads what changes from call to call from device memory
+__device__ __forceinline__ EpilogueParams with_dyn(const EpilogueParams& in)
+{
+    EpilogueParams p = in;
+    if (p.dyn) {
+        p.nyquist = p.dyn->nyquist;
+        p.frames_before = p.dyn->frames_before;
+        p.onset_reset_frame = p.dyn->onset_reset_frame;
+        p.onset_window = p.dyn->onset_window;
+        p.onset_type = p.dyn->onset_type;
+        p.onset_multiplier = p.dyn->onset_multiplier;
+    }
+    return p;
+}
+
 // ---------------------------------------------------------------------------------------------
 // fx_finalise_kernel: thread = frame.  The scalar tail of calculateSpectralCharacteristicsFrom-
 // Intermediates (ref SpectralCharacteristics.h:116-143), calculateNormalisedSpectralSlope (:189-199),
@@ -9,8 +24,9 @@
 // RealTimeAnalyser.h:165-172,219-224.  Output: raw[C][T][12] with the onset slot still 0.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-fx_finalise_kernel(const EpilogueParams p)
+fx_finalise_kernel(const EpilogueParams p_arg)
 {
+    const EpilogueParams p = with_dyn(p_arg);
     const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long) p.C * p.T) return;
     const FramePart f = p.part[idx];
@@ -126,8 +142,9 @@ __device__ __forceinline__ float rms_value(const RawView& v, int tau, int order_
 }
 
 __global__ void __launch_bounds__(256)
-fx_epilogue_kernel(const EpilogueParams p)
+fx_epilogue_kernel(const EpilogueParams p_arg)
 {
+    const EpilogueParams p = with_dyn(p_arg);
     const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long) p.C * p.T) return;
     const int c = (int) (idx / p.T), t = (int) (idx % p.T);

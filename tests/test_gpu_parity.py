@@ -240,6 +240,49 @@ def test_hop_stream_equals_push_hops_bitwise(gpu_fx):
     st.close()
 
 
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_hop_stream_settings_change_mid_stream(gpu_fx, monkeypatch, graph):
+    """The ring in both of its modes (FX_STREAM_GRAPH=1: every step replayed from a captured hipGraph, whose per-call
+    scalars -- frame counters, gain, onset settings, sample rate -- travel through device memory; =0: plain launches
+    with the copy on a side stream) must equal fx_push_hops with the same setter calls in between, bit for bit."""
+    monkeypatch.setenv("FX_STREAM_GRAPH", graph)
+    N, C, B, nb = 1024, 4, 2, 12
+    hops = signals.bursts(C, B * nb, N, seed=91)
+
+    def settings(an, b):
+        if b == 3:
+            an.set_gain(0.5)
+            an.set_onset_window_length(4)
+        if b == 6:
+            an.set_onset_detection_type(2)
+            an.set_onset_detection_sensitivity(0.2)
+        if b == 8:
+            an.sample_rate_changed(44100.0)
+        if b == 10:
+            an.reset_state()
+
+    ref = gpu_fx.BatchAnalyser(C, N)
+    want = []
+    for b in range(nb):
+        settings(ref, b)
+        want.append(ref.push_hops(hops[:, b * B:(b + 1) * B]))
+    an = gpu_fx.BatchAnalyser(C, N)
+    st = gpu_fx.HopStream(an, B, slots=3)
+    got = []
+    for b in range(nb):
+        # a setter applies to the batches submitted after it, as with fx_push_hops
+        settings(an, b)
+        if st.in_flight() == 3:
+            got.append(st.collect())
+        st.push(hops[:, b * B:(b + 1) * B])
+    while st.in_flight():
+        got.append(st.collect())
+    for k in (0, 1):
+        assert np.array_equal(np.concatenate([g[k] for g in got], 1), np.concatenate([w[k] for w in want], 1), equal_nan=True)
+    assert np.array_equal(an.get_features(), ref.get_features(), equal_nan=True)
+    st.close()
+
+
 def test_hop_stream_fp16_4096(gpu_fx, oracle):
     """BASELINE configs[4] shape: 4096-pt windows, fp16 samples streamed through the pinned ring."""
     N, C, B, nb = 4096, 1, 1, 12
