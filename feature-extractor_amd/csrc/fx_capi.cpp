@@ -609,17 +609,37 @@ fx_status fx_stream_submit(fx_stream* s)
         fill_dyn(c, sl.h_dyn);
         if (!sl.exec[par]) {
             // capture the step once for this slot and parity: everything below is recorded, not executed
+            // A few KB per step: the kernels read the hop and the per-call scalars straight from the pinned host slot and
+            // write the 12-float vectors straight back (zero copy), so the graph is two kernel nodes and no copy nodes;
+            // larger batches keep explicit copies (PCIe is read best in bulk).
+            const char* zc = getenv("FX_STREAM_ZEROCOPY");          // experiments
+            const bool zero_copy = zc ? atoi(zc) != 0 : s->in_bytes <= 64 * 1024;
+            const void* in_dev = sl.d_in;
+            float* raw_dev = sl.d_raw; float* sm_dev = sl.d_sm;
+            const fxk::DynParams* dyn_dev = sl.d_dyn;
+            if (zero_copy) {
+                void* q = nullptr;
+                HIP_TRY(hipHostGetDevicePointer(&q, sl.h_in, 0));  in_dev = q;
+                HIP_TRY(hipHostGetDevicePointer(&q, sl.h_raw, 0)); raw_dev = static_cast<float*>(q);
+                HIP_TRY(hipHostGetDevicePointer(&q, sl.h_sm, 0));  sm_dev = static_cast<float*>(q);
+                HIP_TRY(hipHostGetDevicePointer(&q, sl.h_dyn, 0)); dyn_dev = static_cast<const fxk::DynParams*>(q);
+            }
             Step step;
-            fx_status st0 = prepare_step(c, sl.d_in, s->hops, s->fmt, 1, sl.d_raw, sl.d_sm, s->g_part, s->g_raw, sl.d_dyn, &step);
+            fx_status st0 = prepare_step(c, in_dev, s->hops, s->fmt, 1, raw_dev, sm_dev, s->g_part, s->g_raw, dyn_dev, &step);
             if (st0 != FX_OK) { s->acquired = false; return st0; }
             hipGraph_t graph = nullptr;
             HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-            hipError_t e = hipMemcpyAsync(sl.d_in, sl.h_in, s->in_bytes, hipMemcpyHostToDevice, c->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(sl.d_dyn, sl.h_dyn, sizeof(fxk::DynParams), hipMemcpyHostToDevice, c->stream);
+            hipError_t e = hipSuccess;
+            if (!zero_copy) {
+                e = hipMemcpyAsync(sl.d_in, sl.h_in, s->in_bytes, hipMemcpyHostToDevice, c->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(sl.d_dyn, sl.h_dyn, sizeof(fxk::DynParams), hipMemcpyHostToDevice, c->stream);
+            }
             if (e == hipSuccess) e = fxk::launch_frame_kernel(c->N, step.fp, step.analysers, step.waves, c->stream);
             if (e == hipSuccess) e = fxk::launch_epilogue_kernels(step.ep, c->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(sl.h_raw, sl.d_raw, s->out_bytes, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(sl.h_sm, sl.d_sm, s->out_bytes, hipMemcpyDeviceToHost, c->stream);
+            if (!zero_copy) {
+                if (e == hipSuccess) e = hipMemcpyAsync(sl.h_raw, sl.d_raw, s->out_bytes, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(sl.h_sm, sl.d_sm, s->out_bytes, hipMemcpyDeviceToHost, c->stream);
+            }
             const hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
             if (e == hipSuccess) e = e2;
             if (e == hipSuccess) e = hipGraphInstantiate(&sl.exec[par], graph, nullptr, nullptr, 0);

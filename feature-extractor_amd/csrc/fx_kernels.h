@@ -12,6 +12,8 @@ namespace fxk {
 // evaluated without any sequential state: 32 + 9 rounded up.
 constexpr int HLEN = 48;
 constexpr int MAX_ONSET_WINDOW = 32;
+// calls of at most this many frames per channel run finalise + smoothing/onset + history as one kernel (wavefront = channel)
+constexpr int FUSED_TAIL_MAX_FRAMES = 8;
 
 // What the frame kernel leaves per frame: every reduction over samples / bins / lags is done, the
 // scalar tail (pow, log10, sqrt, a few divisions) is not.  One thread per frame finishes it in

@@ -206,6 +206,10 @@ hipError_t launch_frame_kernel(int n, const FrameParams& p, int analysers, int w
 hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t stream)
 {
     if (p.C <= 0 || p.T <= 0) return hipSuccess;
+    if (p.T <= FUSED_TAIL_MAX_FRAMES) {
+        hipLaunchKernelGGL(fx_tail_fused_kernel, dim3((unsigned) p.C), dim3(64), 0, stream, p);
+        return hipGetLastError();
+    }
     const long long n1 = (long long) p.C * p.T;
     hipLaunchKernelGGL(fx_finalise_kernel, dim3((unsigned) ((n1 + 255) / 256)), dim3(256), 0, stream, p);
     hipError_t e0 = hipGetLastError();

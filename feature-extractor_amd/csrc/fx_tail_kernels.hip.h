@@ -23,12 +23,8 @@ __device__ __forceinline__ EpilogueParams with_dyn(const EpilogueParams& in)
 // the harmonic logs (ref HarmonicCharacteristics.h:101-105) and the slot mapping of
 // RealTimeAnalyser.h:165-172,219-224.  Output: raw[C][T][12] with the onset slot still 0.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-fx_finalise_kernel(const EpilogueParams p_arg)
+__device__ __forceinline__ void finalise_frame(const EpilogueParams& p, long long idx)
 {
-    const EpilogueParams p = with_dyn(p_arg);
-    const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long) p.C * p.T) return;
     const FramePart f = p.part[idx];
     const int M = p.window / 2;
     const double nyquist = p.nyquist;
@@ -91,6 +87,15 @@ fx_finalise_kernel(const EpilogueParams p_arg)
     dst[2] = f4{out[8], out[9], out[10], out[11]};
 }
 
+__global__ void __launch_bounds__(256)
+fx_finalise_kernel(const EpilogueParams p_arg)
+{
+    const EpilogueParams p = with_dyn(p_arg);
+    const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long) p.C * p.T) return;
+    finalise_frame(p, idx);
+}
+
 // ---------------------------------------------------------------------------------------------
 // smoothing (ValueHistory, ref RealTimeAudioAnalysis.h:40-96; AudioFeatures, ref
 // RealTimeAnalyser.h:70-88) and onset detection (ref SpectralCharacteristics.h:249-306,
@@ -141,13 +146,8 @@ __device__ __forceinline__ float rms_value(const RawView& v, int tau, int order_
     return total / (float) recorded;
 }
 
-__global__ void __launch_bounds__(256)
-fx_epilogue_kernel(const EpilogueParams p_arg)
+__device__ __forceinline__ void epilogue_frame(const EpilogueParams& p, int c, int t)
 {
-    const EpilogueParams p = with_dyn(p_arg);
-    const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long) p.C * p.T) return;
-    const int c = (int) (idx / p.T), t = (int) (idx % p.T);
     RawView v;
     v.raw = p.raw + (size_t) c * p.T * FX_NUM_FEATURES;
     v.hist = p.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES;
@@ -236,13 +236,18 @@ fx_epilogue_kernel(const EpilogueParams p_arg)
     }
 }
 
-// carry the newest HLEN frames of raw values over to the next call
 __global__ void __launch_bounds__(256)
-fx_history_kernel(const EpilogueParams p)
+fx_epilogue_kernel(const EpilogueParams p_arg)
 {
+    const EpilogueParams p = with_dyn(p_arg);
     const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long) p.C * HLEN * FX_NUM_FEATURES;
-    if (idx >= total) return;
+    if (idx >= (long long) p.C * p.T) return;
+    epilogue_frame(p, (int) (idx / p.T), (int) (idx % p.T));
+}
+
+// carry the newest HLEN frames of raw values over to the next call
+__device__ __forceinline__ void history_value(const EpilogueParams& p, long long idx)
+{
     const int s = (int) (idx % FX_NUM_FEATURES);
     const int h = (int) ((idx / FX_NUM_FEATURES) % HLEN);
     const int c = (int) (idx / ((long long) FX_NUM_FEATURES * HLEN));
@@ -251,4 +256,40 @@ fx_history_kernel(const EpilogueParams p)
     if (tau >= 0) val = p.raw[((size_t) c * p.T + tau) * FX_NUM_FEATURES + s];
     else          val = p.hist_in[((size_t) c * HLEN + (HLEN + tau)) * FX_NUM_FEATURES + s];
     p.hist_out[idx] = val;
+}
+
+__global__ void __launch_bounds__(256)
+fx_history_kernel(const EpilogueParams p)
+{
+    const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long) p.C * HLEN * FX_NUM_FEATURES) return;
+    history_value(p, idx);
+}
+
+// The three kernels above in one launch for calls of a few frames per channel (the streaming ring at one hop per call),
+// where two kernel boundaries cost more than the work: one wavefront per channel.  Lane t finalises frame t; the raw
+// values of the HLEN frames before the call and of the call's own frames are staged in LDS (one round trip to memory
+// instead of the ~70 dependent ones of the smoothing / onset loops), lane t smooths frame t from there, then all 64
+// lanes carry the history over.
+__global__ void __launch_bounds__(64)
+fx_tail_fused_kernel(const EpilogueParams p_arg)
+{
+    __shared__ float s_hist[HLEN * FX_NUM_FEATURES];
+    __shared__ float s_raw[FUSED_TAIL_MAX_FRAMES * FX_NUM_FEATURES];
+    EpilogueParams p = with_dyn(p_arg);
+    const int c = blockIdx.x, lane = threadIdx.x;
+    for (int i = lane; i < HLEN * FX_NUM_FEATURES; i += 64) s_hist[i] = p.hist_in[(size_t) c * HLEN * FX_NUM_FEATURES + i];
+    if (lane < p.T) finalise_frame(p, (long long) c * p.T + lane);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");           // the wave's raw values are written before any lane reads them back
+    __builtin_amdgcn_s_barrier();
+    for (int i = lane; i < p.T * FX_NUM_FEATURES; i += 64) s_raw[i] = p.raw[(size_t) c * p.T * FX_NUM_FEATURES + i];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    // the smoothing reads channel c's rows through (raw + c*T*12, hist_in + c*HLEN*12): point those at the LDS copies
+    const float* g_raw = p.raw; const float* g_hist = p.hist_in;
+    p.raw = s_raw - (size_t) c * p.T * FX_NUM_FEATURES;
+    p.hist_in = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
+    if (lane < p.T) epilogue_frame(p, c, lane);
+    p.raw = const_cast<float*>(g_raw); p.hist_in = g_hist;
+    for (int i = lane; i < HLEN * FX_NUM_FEATURES; i += 64) history_value(p, (long long) c * HLEN * FX_NUM_FEATURES + i);
 }

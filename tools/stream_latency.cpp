@@ -1,0 +1,48 @@
+// Per-hop cost of the streaming ring (fx_stream_*) from C++, without an interpreter in the loop: BASELINE configs[4] shape
+// (1 channel, 4096-pt windows, fp16 samples, one 2048-sample hop per call).
+//   g++ -O2 -std=c++14 -I include tools/stream_latency.cpp -o stream_latency -L feature-extractor_amd/lib -lfx_hip -Wl,-rpath,$PWD/feature-extractor_amd/lib
+//   ./stream_latency [window] [channels] [hops_per_call] [calls]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "fx.h"
+
+#define CHECK(x) do { fx_status s_ = (x); if (s_ != FX_OK) { fprintf(stderr, "%s: %s\n", #x, fx_last_error()); return 1; } } while (0)
+
+int main(int argc, char** argv)
+{
+    const int N = argc > 1 ? atoi(argv[1]) : 4096, C = argc > 2 ? atoi(argv[2]) : 1, H = argc > 3 ? atoi(argv[3]) : 1, calls = argc > 4 ? atoi(argv[4]) : 4000;
+    fx_context* ctx = nullptr;
+    CHECK(fx_create(&ctx, 0, C, N, 48000.0, 0));
+    fx_stream* st = nullptr;
+    CHECK(fx_stream_create(ctx, H, 3, FX_SAMPLE_F16, &st));
+    const size_t hop_bytes = (size_t) C * H * (N / 2) * 2;
+    std::vector<unsigned short> hop(hop_bytes / 2);
+    for (size_t i = 0; i < hop.size(); i++) hop[i] = (unsigned short) (0x2e00 + (i * 37) % 0x400);     // some fp16 values around 0.1
+    std::vector<float> sm((size_t) C * H * 12);
+    for (int mode = 0; mode < 2; mode++) {
+        // mode 0: one hop in flight (submit, then wait for it: the round trip); mode 1: up to three in flight (throughput)
+        const int depth = mode == 0 ? 1 : 3;
+        for (int warm = 0; warm < 2; warm++) {
+            const int n = warm == 0 ? 200 : calls;
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < n; i++) {
+                if (fx_stream_in_flight(st) == depth) CHECK(fx_stream_collect(st, nullptr, sm.data()));
+                void* slot = nullptr;
+                CHECK(fx_stream_acquire(st, &slot));
+                memcpy(slot, hop.data(), hop_bytes);
+                CHECK(fx_stream_submit(st));
+            }
+            while (fx_stream_in_flight(st)) CHECK(fx_stream_collect(st, nullptr, sm.data()));
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / n;
+            if (warm) printf("%s: %.1f us per call of %d hop(s) x %d channel(s), %d-pt  (%.0f hops/s per channel = %.0fx real time at 48 kHz)\n",
+                             mode == 0 ? "round trip  " : "three in flight", us, H, C, N, 1e6 * H / us, 1e6 * H / us * (N / 2) / 48000.0);
+        }
+    }
+    fx_stream_destroy(st);
+    fx_destroy(ctx);
+    return 0;
+}
