@@ -260,12 +260,13 @@ FX_MARK("rms");
         return (float) log10((double) (rms * 9.0f + 1.0f));
     }
 
-    // The flatness gate is `mag > eps`, eps = 0.01 * logRMS (ref SpectralCharacteristics.h:89-94,108).  Only the
-    // comparisons matter here, so logRMS is bracketed from single-precision hardware sqrt / log2 with a margin far
-    // above their error (relative 1e-4, absolute 4e-6 on logRMS, against ~1e-6): if no bin's magnitude falls inside
-    // the bracket -- the usual case -- comparing with its upper end decides every bin exactly as the true value
-    // would; otherwise (rare, wave-uniform) the exact value is computed.
-    __device__ __forceinline__ double gate_threshold(double sum_sq, const float (&re)[U]) const
+    // The flatness gate is `mag > eps`, eps = 0.01 * logRMS (ref SpectralCharacteristics.h:89-94,108), with mag =
+    // (double) re^2 exact -- so it is a comparison of |re| with a float threshold: the largest float t with t*t <= eps.
+    // Only the comparisons matter here, so logRMS is bracketed from single-precision hardware sqrt / log2 with a margin
+    // far above their error (relative 1e-4, absolute 4e-6 on logRMS, against ~1e-6): if no bin's |re| falls inside the
+    // bracket -- the usual case -- its upper end gates every bin exactly as the true threshold would; otherwise (rare,
+    // wave-uniform) the exact value is computed.  Returns tg: bin j passes the gate iff |re[j]| > tg.
+    __device__ __forceinline__ float gate_threshold(double sum_sq, const float (&re)[U]) const
     {
 #ifdef FX_EXP_WIDE_BAND
         const float rel = 0.5f, abs_ = 0.5f;        // test builds: the bracket catches almost every frame
@@ -274,17 +275,21 @@ FX_MARK("rms");
 #endif
         const float rms_a = __builtin_amdgcn_sqrtf((float) (sum_sq * (1.0 / (double) N)));
         const float log_a = __builtin_amdgcn_logf(rms_a * 9.0f + 1.0f) * 0.30103f;      // v_log_f32 is log2
-        const double eps_lo = 0.01 * (double) (log_a * (1.0f - rel) - abs_);
-        const double eps_hi = 0.01 * (double) (log_a * (1.0f + rel) + abs_);
+        const float eps_lo = 0.01f * (log_a * (1.0f - rel) - abs_);
+        const float eps_hi = 0.01f * (log_a * (1.0f + rel) + abs_);
+        const float t_lo = __builtin_amdgcn_sqrtf(fmaxf(eps_lo, 0.0f)) * (1.0f - 1e-6f);
+        const float t_hi = __builtin_amdgcn_sqrtf(eps_hi) * (1.0f + 1e-6f);
         bool inside = false;
 #pragma unroll
-        for (int j = 0; j < U; j++) {
-            const double v = (double) re[j];
-            const double mag = v * v;
-            inside |= (mag > eps_lo) && !(mag > eps_hi);
-        }
-        if (!__any(inside)) return eps_hi;
-        return 0.01 * (double) exact_log_rms(sum_sq);                      // :108
+        for (int j = 0; j < U; j++) inside |= (fabsf(re[j]) > t_lo) && !(fabsf(re[j]) > t_hi);
+        if (!__any(inside)) return t_hi;              // (a NaN anywhere above lands here too: NaN thresholds gate nothing, as `mag > NaN`)
+        // exact: eps as the reference forms it, then the largest float whose square does not exceed it
+        const double eps = 0.01 * (double) exact_log_rms(sum_sq);          // :108
+        float t = (float) sqrt(eps);
+        const float up = __uint_as_float(__float_as_uint(t) + 1u);
+        if ((double) t * (double) t > eps) t = __uint_as_float(__float_as_uint(t) - 1u);      // t > 0 here: 0*0 > eps is false
+        else if ((double) up * (double) up <= eps) t = up;
+        return t;
     }
 
     // The flatness product with the serial-order semantics of `magnitudeProduct *= binMagnitude` (ref
@@ -294,7 +299,7 @@ FX_MARK("rms");
     // prefixes pass through.  If no prefix of the serial product can have left the normal range, the product is the
     // scan's total.  Otherwise the product is continued in plain IEEE double from the start of the first lane where
     // that may happen, lane to lane in bin order, until it is exactly 0 or inf (both absorbing) or the bins end.
-    __device__ __forceinline__ double flatness_product(int lane, const float (&re)[U], double eps) const
+    __device__ __forceinline__ double flatness_product(int lane, const float (&re)[U], float tg) const
     {
 FX_MARK("flatprod");
 #ifdef FX_EXP_SKIP_FLATPROD
@@ -306,7 +311,7 @@ FX_MARK("flatprod");
         for (int j = 0; j < U; j++) {
             const double v = (double) re[j];
             const double mag = v * v;
-            if (mag > eps) {
+            if (fabsf(re[j]) > tg) {
                 loc = fp_mul(loc, mag);
                 emin = loc.exp < emin ? loc.exp : emin;
                 emax = loc.exp > emax ? loc.exp : emax;
@@ -342,7 +347,7 @@ FX_MARK("flatprod");
         for (int j = 0; j < U; j++) {
             const double v = (double) re[j];
             const double mag = v * v;
-            factor[j] = mag > eps ? mag : 1.0;
+            factor[j] = fabsf(re[j]) > tg ? mag : 1.0;
         }
         for (int l = owner; l < 64; l++) {
             double mine = pr;
@@ -387,29 +392,40 @@ FX_MARK("spec_sums");
             // buffer = max |re|, |im| over bins [0, M/2)
             float maxabs = spec_aux;
             lds_load_block<U>(reinterpret_cast<const float*>(cbuf) + bimg<N>(U * lane), re);
-            const double eps = gate_threshold(sum_sq, re);
-            double mag_sum = 0.0, lhr = 0.0, wsum = 0.0, flat_sum = 0.0;
+            const float tg = gate_threshold(sum_sq, re);
+            // fillIntermediateValues :62-97 over the lane's bins m = U*lane + j.  The sums over bins that the features
+            // need are moments of the magnitudes: B0 = sum mag (magnitudeSum), B1 = sum m*mag, B2 = sum m^2*mag, because
+            // fc[m] = (m + 1/2) * frpb (:70): weightedMagnitudeSum = frpb * (B1 + B0/2) (:95) and the spread's
+            // sum ((fc - centroid)/nyq)^2 * mag (:135-139) = (B2 + B1 + B0/4)/M^2 - 2*cn*(B1 + B0/2)/M + cn^2*B0.  Inside a
+            // lane they come from running suffix sums (T_j = sum_{i>=j} mag_i, V_j = sum_{i>=j} T_i, W = sum_{j>=1} V_j:
+            // sum j*mag_j = V_1, sum j^2*mag_j = 2W - V_1): three adds per bin, no multiplications.  All terms are
+            // positive, so nothing cancels inside the sums; the order differs from the serial loops by ~1e-16.
+            double Ts = 0.0, Vs = 0.0, Ws = 0.0, t_after = 0.0;
+            double flat_sum = 0.0;     // flatnessMagnitudeSum (:91)
             float max_re = 0.0f;       // max |re|: (double) re^2 is exact and monotone in |re|, so max mag = max_re^2
             int cnt = 0;               // wave-uniform: bins that pass the flatness gate, counted from the compare masks
-            // bins m <= M/5 (:86-87, inclusive) are the lanes below LQ entirely and the first LR + 1 bins of lane LQ:
-            // the lane's share of `lhr` is its running magnitude sum at that point
+            // bins m <= M/5 (:86-87, inclusive) are the lanes below LQ entirely and the first LR + 1 bins of lane LQ
             constexpr int LQ = (M / 5) / U, LR = (M / 5) % U;
 #pragma unroll
-            for (int j = 0; j < U; j++) {                                      // fillIntermediateValues :62-97
-                const int m = U * lane + j;
+            for (int j = U - 1; j >= 0; j--) {
                 const double v = (double) re[j];
                 const double mag = v * v;
-                const double fc = (double) m * frpb + (frpb / 2.0);
-                mag_sum += mag;
-                if (j == LR) lhr = mag_sum;
-                const bool gate = mag > eps;
+                Ts += mag;
+                if (j >= 1) { Vs += Ts; Ws += Vs; }
+                if (j == LR + 1) t_after = Ts;                                 // sum of the lane's bins after bin LR
+                const bool gate = fabsf(re[j]) > tg;                           // :89 `binMagnitude > epsilon`
                 cnt += __builtin_popcountll(__ballot(gate));
                 if (gate) flat_sum += mag;
-                wsum += fc * mag;
                 max_re = fmaxf(max_re, fabsf(re[j]));
             }
-            lhr = lane < LQ ? mag_sum : (lane == LQ ? lhr : 0.0);
-            wave_sum4(lane, mag_sum, lhr, wsum, flat_sum);
+            const double ul = (double) (U * lane);
+            double mag_sum = Ts;                                               // B0
+            double b1 = ul * Ts + Vs;
+            double b2 = (ul * ul) * Ts + ((ul + ul) * Vs + ((Ws + Ws) - Vs));
+            double lhr = lane < LQ ? Ts : (lane == LQ ? Ts - t_after : 0.0);
+            wave_sum4(lane, mag_sum, b1, b2, lhr);
+            flat_sum = wave_sum(flat_sum);
+            const double wsum = frpb * (b1 + 0.5 * mag_sum);                   // :95 sum fc * mag
             max_re = wave_maxf(max_re);
             const double max_mag = (double) max_re * (double) max_re;
             maxabs = wave_maxf(maxabs);
@@ -439,29 +455,40 @@ FX_MARK("flux");
             flux = wave_sum(flux);
 
             lane = opaque(lane);
-            const double prod = flatness_product(lane, re, eps);
+            const double prod = flatness_product(lane, re, tg);
 
 FX_MARK("spec_pass2");
-            // second pass over the lane's bins: spread needs the centroid, the slope needs the mean
-            // (ref SpectralCharacteristics.h:135-139 and :182-188); everything after these sums is
-            // scalar and is finished by fx_finalise_kernel
+            // spread needs the centroid (:135-139): from the moments above; the slope needs sum (mag - mean)^2 (:182-188):
+            // a second pass over the lane's bins.  Everything after these sums is scalar and is finished by
+            // fx_finalise_kernel.
             {
                 const float centroid = (float) (wsum / mag_sum);               // :127
                 const double cn = (double) centroid * rnyq;
+                const double rm = 1.0 / (double) M;
+                double var = ((b2 + b1 + 0.25 * mag_sum) * rm - (cn + cn) * (b1 + 0.5 * mag_sum)) * rm + (cn * cn) * mag_sum;
                 const double mu = mag_sum * (1.0 / (double) M);
-                double var = 0.0, vsum = 0.0;
+                double vsum = 0.0;
 #pragma unroll
                 for (int j = 0; j < U; j++) {
-                    const int m = U * lane + j;
                     const double v = (double) re[j];
-                    const double mag = v * v;
-                    const double fc = (double) m * frpb + (frpb / 2.0);
-                    const double d = fc * rnyq - cn;
-                    var += (d * d) * mag;
-                    const double dv = mag - mu;
+                    const double dv = v * v - mu;
                     vsum += dv * dv;
                 }
-                wave_sum2(lane, var, vsum);
+                // The moment form loses (centroid/bandwidth)^2 in relative precision: ~1e-11 for any windowed signal (the
+                // Bartlett main lobe is several bins wide).  Should the weighted variance ever be below 1e-9 of cn^2 * B0
+                // (or not finite), take the sum as the reference writes it.
+                double direct = 0.0;
+                const bool refine = !(var > 1e-9 * (cn * cn) * mag_sum) || !(var < __builtin_huge_val());
+                if (refine) {
+#pragma unroll
+                    for (int j = 0; j < U; j++) {
+                        const double v = (double) re[j];
+                        const double d = ((double) (U * lane + j) * frpb + (frpb / 2.0)) * rnyq - cn;
+                        direct += (d * d) * (v * v);
+                    }
+                }
+                wave_sum2(lane, direct, vsum);
+                if (refine) var = direct;
                 if (lane == 0) { fpl->var = var; fpl->vsum = vsum; fpl->centroid = centroid; }
             }
             double max_e = (double) maxabs;                                    // :153

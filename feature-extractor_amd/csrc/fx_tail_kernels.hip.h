@@ -36,14 +36,15 @@ __device__ __forceinline__ void finalise_frame(const EpilogueParams& p, long lon
     const float rms = (float) sqrt(f.sum_sq / (double) p.window);
     const float log_rms = (float) log10((double) (rms * 9.0f + 1.0f));
     out[FX_RMS] = log_rms;
-    const double eps = 0.01 * (double) log_rms;                                // :108
 
     const bool spec = p.analysers & 1, harm = p.analysers & 2;
     if (spec && f.mag_sum > 0.05) {                                            // :121-123
         const float centroid = f.centroid;
         const double dcnt = (double) f.cnt;
         const double inv_n = 1.0 / (dcnt > 0.0 ? dcnt : 1.0);                  // :129-130
-        const float flatness = f.flat_sum > eps ? (float) (pow(f.prod, inv_n) / (inv_n * f.flat_sum)) : 0.0f;   // :57-60
+        // :57-60 `flatnessMagnitudeSum > epsilon`: every gated bin alone exceeds epsilon (>= 0) and the terms are positive,
+        // so the test is "at least one bin passed the gate"
+        const float flatness = f.cnt > 0.0f ? (float) (pow(f.prod, inv_n) / (inv_n * f.flat_sum)) : 0.0f;
         out[FX_FLATNESS] = (float) log10((double) flatness * 9.0 + 1.0);       // :132
         const float cc = centroid / (float) (nyquist / 2.0);                   // :133
         out[FX_CENTROID] = (float) log10((double) (cc * 9.0f + 1.0f));         // :134

@@ -118,6 +118,17 @@ __device__ __forceinline__ void wave_sum2(int lane, double& a, double& b)
 }
 // (Moving the exchange steps to ds_swizzle -- the LDS crossbar instead of VALU DPP moves -- was measured 3 % slower:
 // the LDS pipe is the kernel's second limiter.)
+// fp32 sum of one value per lane (tree order; for quantities that only need ~1e-6)
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+    v += dppz_f<DPP_XOR1>(v);
+    v += dppz_f<DPP_XOR2>(v);
+    v += dppz_f<DPP_HALF_MIRROR>(v);
+    v += dppz_f<DPP_MIRROR>(v);
+    v += dppz_f<DPP_BCAST15>(v);
+    v += dppz_f<DPP_BCAST31>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 // maximum of values that are >= 0 (or NaN, which never wins -- as in `if (x > max) max = x`)
 __device__ __forceinline__ float wave_maxf(float v)
 {
