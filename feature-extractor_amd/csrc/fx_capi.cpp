@@ -98,23 +98,28 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     fp.dyn = dyn;
     for (int i = 0; i < 18; i++) fp.first_tw[i] = c->first_tw[i];
 
-    // waves per workgroup = frames of one channel in flight: the measured-best count for this window size, less when
-    // the call has fewer frames or the LDS holds fewer (one twiddle table + flux state per workgroup, one transform
-    // buffer per wave); FX_WAVES overrides for experiments.
+    // Workgroup shape: channels per workgroup x wavefronts per channel (= frames of one channel in flight): the
+    // measured-best shape for this window size, fewer waves when the call has fewer frames, fewer channels when the
+    // context has fewer or the LDS holds fewer (one twiddle table per workgroup, one flux state per channel, one
+    // transform buffer per wave).  FX_WAVES / FX_CHANNELS_PER_WG override for experiments.
     const size_t lds_cu = 160 * 1024;
-    int waves = 1;
     {
         const int kcap = fxk::frame_kernel_max_waves(c->N);
-        int want = fxk::frame_kernel_preferred_waves(c->N);
-        if (const char* e = getenv("FX_WAVES")) { const int v = atoi(e); if (v >= 1) want = v; }
-        if (want > kcap) want = kcap;
-        if (want > T) want = T;
-        while (want > 1 && fxk::frame_kernel_lds_bytes(c->N, want) > lds_cu) want--;
-        waves = want;
+        int ch = 1, k = 1;
+        fxk::frame_kernel_preferred_shape(c->N, &ch, &k);
+        if (const char* e = getenv("FX_WAVES")) { const int v = atoi(e); if (v >= 1) k = v; }
+        if (const char* e = getenv("FX_CHANNELS_PER_WG")) { const int v = atoi(e); if (v >= 1) ch = v; }
+        if (k > T) k = T;
+        if (k > kcap) k = kcap;
+        if (ch > c->C) ch = c->C;
+        while (ch > 1 && (ch * k > kcap || fxk::frame_kernel_lds_bytes(c->N, ch, k) > lds_cu)) ch--;
+        while (k > 1 && fxk::frame_kernel_lds_bytes(c->N, ch, k) > lds_cu) k--;
+        if (fxk::frame_kernel_lds_bytes(c->N, ch, k) > lds_cu)
+            return fx_fail(FX_ERR_UNSUPPORTED, "window size %d does not fit the LDS", c->N);
+        fp.ch_per_wg = ch;
+        fp.waves_per_ch = k;
+        st->waves = ch * k;
     }
-    if (fxk::frame_kernel_lds_bytes(c->N, waves) > lds_cu)
-        return fx_fail(FX_ERR_UNSUPPORTED, "window size %d does not fit the LDS", c->N);
-    st->waves = waves;
 
     fxk::EpilogueParams& ep = st->ep;
     ep.part = part;
@@ -223,7 +228,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
         last_valid = false;
     }
     HIP_TRY(hipEventRecord(e0, c->stream));
-    HIP_TRY(fxk::launch_frame_kernel(c->N, step.fp, step.analysers, step.waves, c->stream));
+    HIP_TRY(fxk::launch_frame_kernel(c->N, step.fp, step.analysers, c->stream));
     HIP_TRY(hipEventRecord(e1, c->stream));
     HIP_TRY(fxk::launch_epilogue_kernels(step.ep, c->stream));
     HIP_TRY(hipEventRecord(e2, c->stream));
@@ -634,7 +639,7 @@ fx_status fx_stream_submit(fx_stream* s)
                 e = hipMemcpyAsync(sl.d_in, sl.h_in, s->in_bytes, hipMemcpyHostToDevice, c->stream);
                 if (e == hipSuccess) e = hipMemcpyAsync(sl.d_dyn, sl.h_dyn, sizeof(fxk::DynParams), hipMemcpyHostToDevice, c->stream);
             }
-            if (e == hipSuccess) e = fxk::launch_frame_kernel(c->N, step.fp, step.analysers, step.waves, c->stream);
+            if (e == hipSuccess) e = fxk::launch_frame_kernel(c->N, step.fp, step.analysers, c->stream);
             if (e == hipSuccess) e = fxk::launch_epilogue_kernels(step.ep, c->stream);
             if (!zero_copy) {
                 if (e == hipSuccess) e = hipMemcpyAsync(sl.h_raw, sl.d_raw, s->out_bytes, hipMemcpyDeviceToHost, c->stream);

@@ -142,13 +142,16 @@ __device__ __forceinline__ FlatProd fp_mul2(FlatProd a, FlatProd b)
 #define FX_OCC_SMALL 4
 #endif
 template <int N> struct Occ {
-    // LDS bounds residency: 2 workgroups of 8 waves per CU up to 1024 points (4 waves per SIMD, <= 128 VGPRs),
-    // 2 workgroups of 6 waves at 2048, one workgroup of 6 waves at 4096 (2 per SIMD at most, <= 256 VGPRs: the split
-    // transform keeps a lane's 64 second-pass results in registers).  2048 points is held to 128 VGPRs as well: two
-    // 6-wave workgroups land on the SIMDs as 2+2+1+1 twice, in whatever rotation the dispatcher picks, so 4 waves on
-    // one SIMD must fit -- at 136 registers the second workgroup was not co-resident.
-    static constexpr int WAVES_PER_SIMD = N <= 2048 ? FX_OCC_SMALL : 2;
-    static constexpr int MAX_THREADS = N <= 2048 ? 512 : 448;
+    // Residency is set by the LDS; the waves of a CU should spread evenly over its four SIMDs (a workgroup's waves go
+    // round the SIMDs, so 6 waves are 2+2+1+1 and two such workgroups in the same rotation leave two SIMDs with 4 waves
+    // and two with 2 -- measured no faster than 8 waves per CU).  Hence workgroups of CH channels x K waves with
+    // CH*K a multiple of 4, sharing one twiddle table:
+    //   <= 1024 points: 1 x 8, two workgroups per CU      -> 4 waves per SIMD, <= 128 VGPRs
+    //   2048 points   : 3 x 4 = 12 waves, one workgroup   -> 3 per SIMD, <= 168 VGPRs
+    //   4096 points   : 1 x 7 (the 160 KB to the byte)    -> 2 per SIMD at most, <= 256 VGPRs (the split transform keeps a
+    //                   lane's 64 second-pass results in registers)
+    static constexpr int WAVES_PER_SIMD = N <= 1024 ? FX_OCC_SMALL : (N == 2048 ? 3 : 2);
+    static constexpr int MAX_THREADS = N <= 1024 ? 512 : (N == 2048 ? 768 : 448);
 };
 
 // One wavefront's view of the frame it is analysing: where its buffers are and the constants every section
@@ -159,7 +162,7 @@ template <int N> struct FrameWave {
     static constexpr int M = G::M, P = G::P, U = G::U, HALF = N / 2;
 
     const FrameParams& p;
-    f2*    tw;          // [N] pass-ordered twiddles (workgroup LDS)
+    const f2* tw;       // [N] pass-ordered twiddles (workgroup LDS)
     float* prev;        // [M] re of the channel's last accepted spectral frame (workgroup LDS)
     int*   turn;        // index of the frame whose turn it is to read / replace `prev`
     f2*    cbuf;        // this wave's transform buffer ...
@@ -876,28 +879,44 @@ fx_frame_kernel(const FrameParams p_arg)
     typedef Geo<N> G;
     constexpr int M = G::M, P = G::P;
 
+    // One workgroup = CH channels x K waves (K frames of a channel in flight), sharing one twiddle table.  LDS:
+    //   twiddles [N] | CH x { bins image of the channel's flux state (+ its hand-over counter) } | one buffer per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    f2*    tw   = reinterpret_cast<f2*>(smem);                              // [N]
-    float* prev = reinterpret_cast<float*>(tw + N);                         // bins image: re of the last accepted frame
+    constexpr int PREV_FLOATS = G::BIMG + (G::BQ ? 0 : 4);
+    constexpr size_t WAVE_BYTES = G::BUF_BYTES;
+    const int CH = p.ch_per_wg, K = p.waves_per_ch;
+#ifdef FX_EXP_TW_GLOBAL
+    const f2* tw = reinterpret_cast<const f2*>(p.tw);                     // experiment: twiddles through the vector cache
+    f2*    tw_lds = reinterpret_cast<f2*>(smem);
+#else
+    f2*    tw    = reinterpret_cast<f2*>(smem);                             // [N]
+    f2*    tw_lds = tw;
+#endif
+    float* prev0 = reinterpret_cast<float*>(tw_lds + N);
+    unsigned char* per_wave = reinterpret_cast<unsigned char*>(prev0 + (size_t) CH * PREV_FLOATS);
+
+    const int wave = threadIdx.x >> 6;
+    const int lane0 = threadIdx.x & 63;
+    const int chl = wave / K, slot = wave % K;          // channel within the workgroup, frame slot within the channel
+    const int c = blockIdx.x * CH + chl;
+    const bool live = c < p.C;                          // the last workgroup may hold fewer channels
+    const int T = p.T;
+
+    float* prev = prev0 + (size_t) chl * PREV_FLOATS;   // bins image: re of the channel's last accepted frame
     // the hand-over counter lives in the first padding gap of the bins image when there is one (4096 points fills the
     // 160 KB to the byte with 7 waves), else behind it
     int*   turn = reinterpret_cast<int*>(G::BQ ? prev + G::U : prev + G::BIMG);
-    unsigned char* per_wave = reinterpret_cast<unsigned char*>(prev + G::BIMG + (G::BQ ? 0 : 4));
-    constexpr size_t WAVE_BYTES = G::BUF_BYTES;
-
-    const int nwaves = blockDim.x >> 6;
-    const int wave = threadIdx.x >> 6;
-    const int lane0 = threadIdx.x & 63;
-    const int c = blockIdx.x;
-    const int T = p.T;
-
     f2*    cbuf = reinterpret_cast<f2*>(per_wave + WAVE_BYTES * wave);
     float* rbuf = reinterpret_cast<float*>(cbuf);      // the same memory viewed as the real image
 
-    // workgroup prologue: twiddle table + this channel's flux state into LDS
-    for (int i = threadIdx.x; i < N; i += blockDim.x) tw[i] = reinterpret_cast<const f2*>(p.tw)[i];
-    for (int i = threadIdx.x; i < M; i += blockDim.x) prev[bimg<N>(i)] = p.prev_re[(size_t) c * M + i];
-    if (threadIdx.x == 0) turn[0] = 0;
+    // workgroup prologue: twiddle table + the channels' flux state into LDS
+#ifndef FX_EXP_TW_GLOBAL
+    for (int i = threadIdx.x; i < N; i += blockDim.x) tw_lds[i] = reinterpret_cast<const f2*>(p.tw)[i];
+#endif
+    if (live) {
+        for (int i = lane0 + 64 * slot; i < M; i += 64 * K) prev[bimg<N>(i)] = p.prev_re[(size_t) c * M + i];
+        if (lane0 == 0 && slot == 0) turn[0] = 0;
+    }
     __syncthreads();
 
     const double nyquist = p.nyquist;
@@ -905,7 +924,7 @@ fx_frame_kernel(const FrameParams p_arg)
     const double frpb = nyquist / (double) M;          // ref SpectralCharacteristics.h:64,105
     const float  scale = 1.0f / (float) N;             // JUCE inverse scale
 
-    for (int t = wave; t < T; t += nwaves) {
+    for (int t = live ? slot : T; t < T; t += K) {
         const int lane = opaque(lane0);
         // uniform per-frame results go to LDS as soon as they exist instead of occupying ~28 VGPRs
         // in every lane for the whole frame
@@ -942,5 +961,6 @@ fx_frame_kernel(const FrameParams p_arg)
     }
 
     __syncthreads();
-    for (int i = threadIdx.x; i < M; i += blockDim.x) p.prev_re[(size_t) c * M + i] = prev[bimg<N>(i)];
+    if (live)
+        for (int i = lane0 + 64 * slot; i < M; i += 64 * K) p.prev_re[(size_t) c * M + i] = prev[bimg<N>(i)];
 }

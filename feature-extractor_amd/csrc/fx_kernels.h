@@ -59,6 +59,8 @@ struct FrameParams {
     int          hop_mode;      // 1: `in` holds hops, windows are assembled from tail + hops
     int          T;             // frames (= hops) per channel in this call
     int          C;
+    int          ch_per_wg;     // channels per workgroup (they share the twiddle table in LDS)
+    int          waves_per_ch;  // wavefronts per channel = frames of a channel in flight
     float        gain;          // hop mode only (ref AudioDataCollector.h:88)
     const float* tail_in;       // [C][N/2] second half of the previous window (already gained)
     float*       tail_out;      // [C][N/2]
@@ -102,11 +104,12 @@ void build_pass_twiddles(int window_size, const float* canonical, float* out);
 void fill_first_pass_twiddles(int window_size, const float* pass_ordered, float* out18);
 bool first_pass_twiddles_hermitian(int window_size, const float* first18);   // must hold before any launch
 
-size_t frame_kernel_lds_bytes(int window_size, int waves);
-int frame_kernel_max_waves(int window_size);
-int frame_kernel_preferred_waves(int window_size);     // the frame kernel's launch bound, in wavefronts per workgroup
-// Chooses waves per workgroup and launches; returns hipSuccess or the launch error.
-hipError_t launch_frame_kernel(int window_size, const FrameParams& p, int analysers, int waves, hipStream_t stream);
+size_t frame_kernel_lds_bytes(int window_size, int channels_per_wg, int waves_per_channel);
+int frame_kernel_max_waves(int window_size);     // the frame kernel's launch bound, in wavefronts per workgroup
+// measured-best workgroup shape for a window size: channels per workgroup x wavefronts per channel
+void frame_kernel_preferred_shape(int window_size, int* channels_per_wg, int* waves_per_channel);
+// Launches ceil(C / p.ch_per_wg) workgroups of p.ch_per_wg * p.waves_per_ch wavefronts; returns hipSuccess or the launch error.
+hipError_t launch_frame_kernel(int window_size, const FrameParams& p, int analysers, hipStream_t stream);
 hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t stream);
 hipError_t prepare_kernels(int window_size);   // raises the dynamic-LDS limit once per process
 

@@ -115,10 +115,10 @@ void build_pass_twiddles(int n, const float* canonical, float* out)
     }
 }
 
-template <int N> static size_t lds_bytes_t(int waves)
+template <int N> static size_t lds_bytes_t(int ch, int k)
 {
     typedef Geo<N> G;
-    return sizeof(f2) * N + sizeof(float) * G::BIMG + (G::BQ ? 0 : 16) + (size_t) waves * G::BUF_BYTES;
+    return sizeof(f2) * N + (size_t) ch * sizeof(float) * (G::BIMG + (G::BQ ? 0 : 4)) + (size_t) ch * k * G::BUF_BYTES;
 }
 
 template <int N> static int max_waves_t() { return Occ<N>::MAX_THREADS / 64; }
@@ -134,23 +134,24 @@ int frame_kernel_max_waves(int n)
     }
 }
 
-// Wavefronts per workgroup (= frames of one channel in flight) that measured fastest on MI355X.  Up to 1024 points:
-// 8 (two workgroups per CU, 4 waves per SIMD).  2048: 4 (two workgroups, 2 per SIMD) -- 6 (12 waves per CU) fits but
-// ran 8 % slower: the kernel is VALU-bound from 2 waves per SIMD on and the chip answers denser issue with a lower
-// clock.  4096: as many as the LDS holds (7, the 160 KB to the byte).
-int frame_kernel_preferred_waves(int n)
+// Measured on MI355X (see Occ<N>): up to 1024 points 1 channel x 8 waves (two workgroups per CU); 2048: 1 x 4 (two
+// workgroups, 8 waves per CU: 12 waves as 3 x 4, 2 x 6 or 4 x 3 in one workgroup measured within 4 % of it, the LDS
+// pipe and VALU issue being co-limiting by then); 4096: 1 x 7.
+void frame_kernel_preferred_shape(int n, int* ch, int* k)
 {
-    return n <= 1024 ? 8 : (n == 2048 ? 4 : 7);
+    if (n <= 1024)      { *ch = 1; *k = 8; }
+    else if (n == 2048) { *ch = 1; *k = 4; }
+    else                { *ch = 1; *k = 7; }
 }
 
-size_t frame_kernel_lds_bytes(int n, int waves)
+size_t frame_kernel_lds_bytes(int n, int ch, int k)
 {
     switch (n) {
-        case 256:  return lds_bytes_t<256>(waves);
-        case 512:  return lds_bytes_t<512>(waves);
-        case 1024: return lds_bytes_t<1024>(waves);
-        case 2048: return lds_bytes_t<2048>(waves);
-        case 4096: return lds_bytes_t<4096>(waves);
+        case 256:  return lds_bytes_t<256>(ch, k);
+        case 512:  return lds_bytes_t<512>(ch, k);
+        case 1024: return lds_bytes_t<1024>(ch, k);
+        case 2048: return lds_bytes_t<2048>(ch, k);
+        case 4096: return lds_bytes_t<4096>(ch, k);
         default:   return 0;
     }
 }
@@ -179,10 +180,10 @@ hipError_t prepare_kernels(int n)
     }
 }
 
-template <int N> static hipError_t launch_t(const FrameParams& p, int analysers, int waves, hipStream_t stream)
+template <int N> static hipError_t launch_t(const FrameParams& p, int analysers, hipStream_t stream)
 {
-    const size_t lds = lds_bytes_t<N>(waves);
-    const dim3 grid((unsigned) p.C), block((unsigned) waves * 64);
+    const size_t lds = lds_bytes_t<N>(p.ch_per_wg, p.waves_per_ch);
+    const dim3 grid((unsigned) ((p.C + p.ch_per_wg - 1) / p.ch_per_wg)), block((unsigned) (p.ch_per_wg * p.waves_per_ch) * 64);
     if (analysers == 3)      hipLaunchKernelGGL((fx_frame_kernel<N, true, true>), grid, block, lds, stream, p);
     else if (analysers == 1) hipLaunchKernelGGL((fx_frame_kernel<N, true, false>), grid, block, lds, stream, p);
     else if (analysers == 2) hipLaunchKernelGGL((fx_frame_kernel<N, false, true>), grid, block, lds, stream, p);
@@ -190,15 +191,16 @@ template <int N> static hipError_t launch_t(const FrameParams& p, int analysers,
     return hipGetLastError();
 }
 
-hipError_t launch_frame_kernel(int n, const FrameParams& p, int analysers, int waves, hipStream_t stream)
+hipError_t launch_frame_kernel(int n, const FrameParams& p, int analysers, hipStream_t stream)
 {
     if (p.C <= 0 || p.T <= 0) return hipSuccess;
+    if (p.ch_per_wg < 1 || p.waves_per_ch < 1 || p.ch_per_wg * p.waves_per_ch > frame_kernel_max_waves(n)) return hipErrorInvalidValue;
     switch (n) {
-        case 256:  return launch_t<256>(p, analysers, waves, stream);
-        case 512:  return launch_t<512>(p, analysers, waves, stream);
-        case 1024: return launch_t<1024>(p, analysers, waves, stream);
-        case 2048: return launch_t<2048>(p, analysers, waves, stream);
-        case 4096: return launch_t<4096>(p, analysers, waves, stream);
+        case 256:  return launch_t<256>(p, analysers, stream);
+        case 512:  return launch_t<512>(p, analysers, stream);
+        case 1024: return launch_t<1024>(p, analysers, stream);
+        case 2048: return launch_t<2048>(p, analysers, stream);
+        case 4096: return launch_t<4096>(p, analysers, stream);
         default:   return hipErrorInvalidValue;
     }
 }

@@ -115,6 +115,22 @@ def test_split_calls_equal_one_call_bitwise(gpu_fx, N):
     assert np.array_equal(an.get_features(), one[1][:, -1], equal_nan=True)
 
 
+@pytest.mark.parametrize("N,shape", [(1024, (3, 2)), (1024, (2, 8)), (2048, (3, 4)), (2048, (2, 6)), (512, (4, 2))])
+def test_workgroup_shapes_give_the_same_bits(gpu_fx, monkeypatch, N, shape):
+    """Channels per workgroup x waves per channel is a scheduling choice (several channels can share one workgroup's
+    twiddle table in LDS): every shape must give the results of the default one bit for bit, including a last
+    workgroup that is only partly filled (7 channels in groups of 2, 3 or 4) and calls shorter than the wave count."""
+    C, T = 7, 13
+    hops = signals.bursts(C, T, N, seed=N + shape[0])
+    want = gpu_fx.BatchAnalyser(C, N).push_hops(hops)
+    monkeypatch.setenv("FX_CHANNELS_PER_WG", str(shape[0]))
+    monkeypatch.setenv("FX_WAVES", str(shape[1]))
+    an = gpu_fx.BatchAnalyser(C, N)
+    got = [an.push_hops(hops[:, a:b]) for a, b in ((0, 1), (1, 4), (4, 13))]
+    for k in (0, 1):
+        assert np.array_equal(np.concatenate([g[k] for g in got], 1), want[k], equal_nan=True)
+
+
 def test_streaming_one_hop_per_call_matches_oracle(gpu_fx, oracle):
     N, C, T = 2048, 3, 26
     hops = signals.tone_vibrato_noise(C, T, N, seed=8)
