@@ -28,7 +28,7 @@ def test_usable_cores_is_sane():
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    line = open(os.path.join(ROOT, "profiles", "r01q_bench.json")).read().strip().splitlines()[-1]
+    line = open(os.path.join(ROOT, "profiles", "r02_bench.json")).read().strip().splitlines()[-1]
     d = json.loads(line)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -38,6 +38,15 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and "sample" in c
+    # the extras the round-2 review asked for: unfriendly inputs and the other window sizes
+    assert set(d["data_dependence"]) >= {"noise", "silence"} and set(d["other_windows"]) == {"2048", "4096"}
+
+
+def test_valu_model_record():
+    """profiles/valu_model.json (tools/valu_model.py) is what bench.py's roofline.valu_issue_frac is computed from"""
+    m = bench.valu_model(1024)
+    assert m and 2000 < m["valu_per_frame"] < 3500 and 1.1 <= m["mean_issue_ns"] <= 1.85
+    assert bench.valu_model(2048) and bench.valu_model(4096) and bench.valu_model(512) is None
 
 
 def test_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):

@@ -11,5 +11,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 be
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_sq1 -- python3 bench.py $ARGS > $OUT/pmc_sq1.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq2 -- python3 bench.py $ARGS > $OUT/pmc_sq2.log 2>&1
 python3 tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
-tail -1 $OUT/trace.log > $OUT/bench.json
+grep "^{" $OUT/trace.log | tail -1 > $OUT/bench.json
 cat $OUT/summary.txt
