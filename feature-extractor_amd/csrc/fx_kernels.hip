@@ -216,7 +216,7 @@ hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t stream)
     hipLaunchKernelGGL(fx_finalise_kernel, dim3((unsigned) ((n1 + 255) / 256)), dim3(256), 0, stream, p);
     hipError_t e0 = hipGetLastError();
     if (e0 != hipSuccess) return e0;
-    hipLaunchKernelGGL(fx_epilogue_kernel, dim3((unsigned) ((n1 + 255) / 256)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(fx_epilogue_kernel, dim3((unsigned) (p.C * ((p.T + EPI_TILE - 1) / EPI_TILE))), dim3(EPI_TILE), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const long long n2 = (long long) p.C * HLEN * FX_NUM_FEATURES;

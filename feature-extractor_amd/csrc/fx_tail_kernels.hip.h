@@ -108,13 +108,19 @@ fx_finalise_kernel(const EpilogueParams p_arg)
 // function of the raw values of frames t-HLEN+1 .. t, and all (channel, frame) pairs are evaluated
 // in parallel: thread = (channel, frame).  Frames before this call come from hist_in.
 // ---------------------------------------------------------------------------------------------
+// Rows of raw values around a frame: from global memory (this call's rows in `raw`, the HLEN rows before the call in
+// `hist`), or from an LDS tile holding rows tile_first .. of one channel with TILE_STRIDE floats per row (13: odd, so
+// that threads one row apart fall on different banks).
+constexpr int TILE_STRIDE = 13;
 struct RawView {
     const float* raw; const float* hist; int T; long long frames_before;
+    const float* tile = nullptr; int tile_first = 0;
     // raw value of slot s at frame index tau relative to this call (tau may be negative);
     // frames before the stream began read as "not recorded"
     __device__ __forceinline__ bool valid(int tau) const { return frames_before + (long long) tau >= 0 && tau > -HLEN - 1; }
     __device__ __forceinline__ float get(int tau, int s) const
     {
+        if (tile) return tile[(tau - tile_first) * TILE_STRIDE + s];
         return tau >= 0 ? raw[(size_t) tau * FX_NUM_FEATURES + s] : hist[(size_t) (HLEN + tau) * FX_NUM_FEATURES + s];
     }
 };
@@ -147,13 +153,15 @@ __device__ __forceinline__ float rms_value(const RawView& v, int tau, int order_
     return total / (float) recorded;
 }
 
-__device__ __forceinline__ void epilogue_frame(const EpilogueParams& p, int c, int t)
+__device__ __forceinline__ void epilogue_frame(const EpilogueParams& p, int c, int t, const float* tile = nullptr, int tile_first = 0)
 {
     RawView v;
     v.raw = p.raw + (size_t) c * p.T * FX_NUM_FEATURES;
     v.hist = p.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES;
     v.T = p.T;
     v.frames_before = p.frames_before;
+    v.tile = tile;
+    v.tile_first = tile_first;
 
     float sm[FX_NUM_FEATURES];
     float rw[FX_NUM_FEATURES];
@@ -237,13 +245,29 @@ __device__ __forceinline__ void epilogue_frame(const EpilogueParams& p, int c, i
     }
 }
 
-__global__ void __launch_bounds__(256)
+// thread = (channel, frame); a block is EPI_TILE consecutive frames of ONE channel and first stages the rows it needs
+// (its own and the HLEN - 1 before them) in LDS: each thread's ~70 reads of neighbouring rows then hit LDS instead of L2
+constexpr int EPI_TILE = 256;
+__global__ void __launch_bounds__(EPI_TILE)
 fx_epilogue_kernel(const EpilogueParams p_arg)
 {
+    __shared__ float tile[(EPI_TILE + HLEN) * TILE_STRIDE];
     const EpilogueParams p = with_dyn(p_arg);
-    const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long) p.C * p.T) return;
-    epilogue_frame(p, (int) (idx / p.T), (int) (idx % p.T));
+    const int tiles = (p.T + EPI_TILE - 1) / EPI_TILE;
+    const int c = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * EPI_TILE;
+    const int first = t0 - HLEN;                                     // first row of the tile (may be before the call)
+    const int rows = (p.T - t0 < EPI_TILE ? p.T - t0 : EPI_TILE) + HLEN;
+    const float* raw = p.raw + (size_t) c * p.T * FX_NUM_FEATURES;
+    const float* hist = p.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES;
+    for (int i = threadIdx.x; i < rows * FX_NUM_FEATURES; i += EPI_TILE) {
+        const int r = i / FX_NUM_FEATURES, s = i % FX_NUM_FEATURES, tau = first + r;
+        // rows more than HLEN before the call do not exist (and are never read: RawView::valid)
+        tile[r * TILE_STRIDE + s] = tau >= 0 ? raw[(size_t) tau * FX_NUM_FEATURES + s]
+                                             : (tau >= -HLEN ? hist[(size_t) (HLEN + tau) * FX_NUM_FEATURES + s] : 0.0f);
+    }
+    __syncthreads();
+    const int t = t0 + (int) threadIdx.x;
+    if (t < p.T) epilogue_frame(p, c, t, tile, first);
 }
 
 // carry the newest HLEN frames of raw values over to the next call
