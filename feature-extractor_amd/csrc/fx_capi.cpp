@@ -52,16 +52,24 @@ fx_status zero_state(fx_context* c)
     return FX_OK;
 }
 
+// Scratch that follows the largest call seen.  Growing frees and reallocates (hipFree waits for the device), so a
+// buffer that has grown once grows by at least half again: a caller ramping its batch size up does not pay per call.
 template <typename T> fx_status grow(T** ptr, size_t* cap, size_t need)
 {
     if (need <= *cap) return FX_OK;
-    if (*ptr) HIP_TRY(hipFree(*ptr));
+    size_t want = need;
+    if (*ptr) {
+        if (want < *cap + *cap / 2) want = *cap + *cap / 2;
+        HIP_TRY(hipFree(*ptr));
+    }
     *ptr = nullptr;
     *cap = 0;
     void* p = nullptr;
-    HIP_TRY(hipMalloc(&p, need));
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess && want != need) { (void) hipGetLastError(); want = need; e = hipMalloc(&p, want); }
+    if (e != hipSuccess) return fx_fail(e == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP, "hipMalloc of %zu bytes failed: %s", want, hipGetErrorString(e));
     *ptr = static_cast<T*>(p);
-    *cap = need;
+    *cap = want;
     return FX_OK;
 }
 

@@ -340,6 +340,48 @@ __device__ __forceinline__ void item16_stages(f2 (&e)[16], const f2* t1)
     }
 }
 
+// The same with the item's 15 twiddles already in registers (w[0..2]: first stage; w[3 + 3*jin + q]: second stage).
+template <bool INV>
+__device__ __forceinline__ void item16_stages_r(f2 (&e)[16], const f2 (&w)[15])
+{
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+        bfly4_core<INV>(e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3],
+                        twmul<INV>(e[4 * g + 1], w[0]), twmul<INV>(e[4 * g + 2], w[1]), twmul<INV>(e[4 * g + 3], w[2]));
+#pragma unroll
+    for (int jin = 0; jin < 4; jin++)
+        bfly4_core<INV>(e[jin], e[jin + 4], e[jin + 8], e[jin + 12],
+                        twmul<INV>(e[jin + 4], w[3 + 3 * jin]), twmul<INV>(e[jin + 8], w[4 + 3 * jin]), twmul<INV>(e[jin + 12], w[5 + 3 * jin]));
+}
+
+// Twiddles a lane needs for the second and the last pass of a split transform, held in registers for the wave's whole
+// life (2048 points: the kernel runs at 2 waves per SIMD there, which leaves the registers, and VALU issue and the LDS
+// pipe are co-limiting, so the 180 twiddle reads per frame -- a fifth of its LDS instructions -- are worth removing).
+// The second pass's twiddles depend on it % L1 only, which is the same for all of a lane's items.
+template <int N> struct TwRegs {
+#ifdef FX_EXP_2048_LDS_TW
+    static constexpr bool USE = false;
+#else
+    static constexpr bool USE = N == 2048;
+#endif
+    static constexpr int GB = USE ? (N / 16) / 64 : 1;
+    f2 b[15];
+    f2 c[GB][15];
+    __device__ __forceinline__ void load(const f2* tw, int lane)
+    {
+        typedef Plan<N> PL;
+        const f2* t1 = tw + PL::OFF1 + lane % PL::L1;
+#pragma unroll
+        for (int i = 0; i < 15; i++) b[i] = t1[i * PL::L1];
+#pragma unroll
+        for (int g = 0; g < GB; g++) {
+            const f2* t2 = tw + PL::OFF2 + lane + 64 * g;
+#pragma unroll
+            for (int i = 0; i < 15; i++) c[g][i] = t2[i * PL::L2];
+        }
+    }
+};
+
 // Split transforms (N >= 2048): position of a complex element inside the HALF image of the second exchange (second
 // pass -> last pass).  q = k' + (L2/2)*i with k' < L2/2 the last-pass item within its half and i its element: rows of
 // L2/2 consecutive k'.  The last pass reads a row with 64 consecutive lanes (conflict-free for any row offset); the
@@ -458,7 +500,7 @@ __device__ __forceinline__ void last_item_reduce(const f2 (&e)[16], int k, float
 //                 elements i' < 8 for the first half of the g's and i' >= 8 for the second half.
 template <int N, bool INV, int OUT>
 __device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, const float (&ftw)[18],
-                                           int lane, float scale, float* regs_out)
+                                           int lane, float scale, float* regs_out, const TwRegs<N>* twr)
 {
     typedef Geo<N> G;
     typedef Plan<N> PL;
@@ -493,7 +535,8 @@ __device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cb
 #pragma unroll
         for (int jl = 0; jl < HB; jl++) {
             const int it = lane + 64 * jl;
-            item16_stages<L1, INV>(eb[h * HB + jl], tw + PL::OFF1 + it % L1);
+            if constexpr (TwRegs<N>::USE) item16_stages_r<INV>(eb[h * HB + jl], twr->b);
+            else item16_stages<L1, INV>(eb[h * HB + jl], tw + PL::OFF1 + it % L1);
         }
     }
     // second exchange.  Element i of second-pass item it = lane + 64*j sits at position (it/L1)*L2 + it%L1 + L1*i
@@ -525,7 +568,8 @@ __device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cb
 #pragma unroll
         for (int gl = 0; gl < HB; gl++) {
             const int g = h * HB + gl, k = lane + 64 * g;
-            item16_stages<L2, INV>(ec[gl], tw + PL::OFF2 + k);
+            if constexpr (TwRegs<N>::USE) item16_stages_r<INV>(ec[gl], twr->c[g]);
+            else item16_stages<L2, INV>(ec[gl], tw + PL::OFF2 + k);
             last_item_reduce<N, OUT>(ec[gl], k, scale, res[g], aux);
             if (OUT == OUT_LAG && g == 0) { const float d = ec[0][0].y * scale; aux = d * d * (float) N; }
         }
@@ -548,11 +592,11 @@ __device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cb
 // Whole transform of one wavefront: P real inputs per lane (first-pass order) -> OUT (see above).
 template <int N, bool INV, int OUT>
 __device__ __forceinline__ float fft_from_regs(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, const float (&ftw)[18],
-                                               int lane, float scale = 0.0f, float* regs_out = nullptr)
+                                               int lane, float scale = 0.0f, float* regs_out = nullptr, const TwRegs<N>* twr = nullptr)
 {
     typedef Plan<N> PL;
     if constexpr (Geo<N>::SPLIT) {
-        return fft_split<N, INV, OUT>(xin, cbuf, tw, ftw, lane, scale, regs_out);
+        return fft_split<N, INV, OUT>(xin, cbuf, tw, ftw, lane, scale, regs_out, twr);
     } else {
         fft_first_pass<N, INV>(xin, cbuf, ftw, lane);
         fft_pass<N, PL::R1, PL::L1, PL::OFF1, INV>(cbuf, tw, lane);

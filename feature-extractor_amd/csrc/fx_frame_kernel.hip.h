@@ -150,8 +150,16 @@ template <int N> struct Occ {
     //   2048 points   : 3 x 4 = 12 waves, one workgroup   -> 3 per SIMD, <= 168 VGPRs
     //   4096 points   : 1 x 7 (the 160 KB to the byte)    -> 2 per SIMD at most, <= 256 VGPRs (the split transform keeps a
     //                   lane's 64 second-pass results in registers)
+#ifdef FX_EXP_2048_LDS_TW
     static constexpr int WAVES_PER_SIMD = N <= 1024 ? FX_OCC_SMALL : (N == 2048 ? 3 : 2);
+#else
+    static constexpr int WAVES_PER_SIMD = N <= 1024 ? FX_OCC_SMALL : 2;
+#endif
+#ifdef FX_EXP_2048_LDS_TW
     static constexpr int MAX_THREADS = N <= 1024 ? 512 : (N == 2048 ? 768 : 448);
+#else
+    static constexpr int MAX_THREADS = N <= 2048 ? 512 : 448;
+#endif
 };
 
 // One wavefront's view of the frame it is analysing: where its buffers are and the constants every section
@@ -163,6 +171,7 @@ template <int N> struct FrameWave {
 
     const FrameParams& p;
     const f2* tw;       // [N] pass-ordered twiddles (workgroup LDS)
+    const TwRegs<N>* twr;   // the lane's second- / last-pass twiddles in registers (2048 points), else unused
     float* prev;        // [M] re of the channel's last accepted spectral frame (workgroup LDS)
     int*   turn;        // index of the frame whose turn it is to read / replace `prev`
     f2*    cbuf;        // this wave's transform buffer ...
@@ -385,7 +394,7 @@ FX_MARK("spec_fft");
                     xw[g * G::RA + j] = xr[g * G::RA + j] * gain;
                 }
             }
-            spec_aux = fft_from_regs<N, false, OUT_RE_LOW_MAXABS>(xw, cbuf, tw, p.first_tw, lane);   // a4
+            spec_aux = fft_from_regs<N, false, OUT_RE_LOW_MAXABS>(xw, cbuf, tw, p.first_tw, lane, 0.0f, nullptr, twr);   // a4
         }
 FX_MARK("spec_sums");
         {
@@ -515,7 +524,7 @@ FX_MARK("harm1");
         // ---------------- harmonic analyser, part 1: raw (un-windowed) spectrum ---------------------
         // ref RealTimeAnalyser.h:161
         lane = opaque(lane);
-        fft_from_regs<N, false, OUT_RE_LOW>(xr, cbuf, tw, p.first_tw, lane);
+        fft_from_regs<N, false, OUT_RE_LOW>(xr, cbuf, tw, p.first_tw, lane, 0.0f, nullptr, twr);
         {
             const int b0 = U * lane;
             const float* relin = reinterpret_cast<const float*>(cbuf);
@@ -715,7 +724,7 @@ FX_MARK("pitch_fft");
         // a11 getComplexConjugateMultiplication, ref PitchAnalyser.h:83-108: re*re, imag := 0, delivered in the order the
         // inverse transform's first pass wants it
         float xp[P];
-        fft_from_regs<N, false, OUT_POWER>(xf, cbuf, tw, p.first_tw, lane, 0.0f, xp);  // ref RealTimeAnalyser.h:160
+        fft_from_regs<N, false, OUT_POWER>(xf, cbuf, tw, p.first_tw, lane, 0.0f, xp, twr);  // ref RealTimeAnalyser.h:160
 FX_MARK("power");
         lane = opaque(lane);
         if constexpr (G::GA == 1) {
@@ -730,7 +739,7 @@ FX_MARK("power");
         }
 FX_MARK("ifft");
         float vreg[P];
-        const float v_end = fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, p.first_tw, lane, scale, vreg);   // a12 inverse, ref :110-121
+        const float v_end = fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, p.first_tw, lane, scale, vreg, twr);   // a12 inverse, ref :110-121
         const float lag = lag_search(lane, vreg, v_end);
         if (lane == 0) fpl->lag = lag;
         wave_fence();
@@ -779,9 +788,10 @@ FX_MARK("harm2");
                     mean_mag = h_sum / (double) M;
                 }
             }
-            unsigned peak_mask = 0;
+            bool pk[U];                                                        // lane masks (SGPR pairs), not a per-lane bit field
             const double r_hmax = 1.0 / h_max;
             const double sum_normed = h_sum * r_hmax;                          // :77 sum of mag / max over all bins
+            int npk_lane = 0;
 #pragma unroll
             for (int j = 0; j < U; j++) {
                 const double v = (double) hre[j];
@@ -795,23 +805,24 @@ FX_MARK("harm2");
                 const float r1 = j + 1 < U ? fabsf(hre[j + 1 < U ? j + 1 : 0]) : h_right1;
                 // Neighbours that do not exist (below bin 0, above bin M-1) were loaded as 0 and are never greater;
                 // the one clipped neighbour that does exist is bin M-1 seen from bin M-2 (lane 63, j = U-2).
-                bool pk = mag > mean_mag;
-                if (l2 > me) pk = false;
-                if (l1 > me) pk = false;
-                if (r1 > me && !(j == U - 2 && lane == 63)) pk = false;
-                if (pk) peak_mask |= 1u << j;
+                bool is_peak = (mag > mean_mag) && !(l2 > me) && !(l1 > me);
+                if (j == U - 2) is_peak = is_peak && (!(r1 > me) || lane == 63);
+                else            is_peak = is_peak && !(r1 > me);
+                pk[j] = is_peak;
+                npk_lane += is_peak ? 1 : 0;
             }
             // the probes below need the normalised magnitudes (float)(mag / max) (:75) of a few bins only; the
             // normalisation is monotone, so the largest of a neighbourhood is the normalised largest |re|
             lds_store_block<U>(normed + bimg<N>(U * lane), hre);
             // compact the peak list
-            const int npk_lane = __popc(peak_mask);
             const int pre = wave_scan_incl_i(npk_lane);
             const int total_peaks = __builtin_amdgcn_readlane(pre, 63);
-            int woff = pre - npk_lane;
+            {
+                unsigned short* wp = peaks + (pre - npk_lane);
 #pragma unroll
-            for (int j = 0; j < U; j++)
-                if (peak_mask & (1u << j)) { peaks[woff] = (unsigned short) (U * lane + j); woff++; }
+                for (int j = 0; j < U; j++)
+                    if (pk[j]) { *wp = (unsigned short) (U * lane + j); wp++; }
+            }
             wave_fence();
 
             const double fr = nyquist / (double) M;                            // :93
@@ -828,11 +839,18 @@ FX_MARK("harm2");
                 else if (lane < 18) { if (bin >= M) bin = -1; }                // :174-175 (monotone, so break == skip)
                 else bin = -1;
                 if (bin >= 0 && bin < M) {
-                    // getMaxBinInNeighbourhood :200-210 : [max(0,c-2), min(c+2, M)), start value normed[c]
-                    const int s0 = bin - 2 >= 0 ? bin - 2 : 0;
-                    const int e0 = bin + 2 < M ? bin + 2 : M;
+                    // getMaxBinInNeighbourhood :200-210 : [max(0,c-2), min(c+2, M)) = bins c-2, c-1, c, c+1 where they
+                    // exist, start value normed[c], replaced only by a strictly greater one (`if (v > mx) mx = v`)
                     float mx = fabsf(normed[bimg<N>(bin)]);
-                    for (int q = s0; q < e0; q++) { const float v = fabsf(normed[bimg<N>(q)]); if (v > mx) mx = v; }
+                    const float a2 = bin >= 2 ? fabsf(normed[bimg<N>(bin >= 2 ? bin - 2 : 0)]) : mx;
+                    const float a1 = bin >= 1 ? fabsf(normed[bimg<N>(bin >= 1 ? bin - 1 : 0)]) : mx;
+                    const float b1 = bin + 1 < M ? fabsf(normed[bimg<N>(bin + 1 < M ? bin + 1 : 0)]) : mx;
+                    // in the reference's order: c-2, c-1, (c itself changes nothing), c+1
+                    float run = mx;
+                    if (a2 > run) run = a2;
+                    if (a1 > run) run = a1;
+                    if (b1 > run) run = b1;
+                    mx = run;
                     const double pm = (double) mx;
                     probe = (double) (float) ((pm * pm) * r_hmax);                 // (mag / max, via one reciprocal), as a float (:75)
                 }
@@ -840,6 +858,7 @@ FX_MARK("harm2");
 
             // calculateInharmonicity :212-244
             double inh = 0.0;
+            const double r_hsum = 1.0 / h_sum;
             if (f0 > 0.0) {                                                    // :98
                 for (int i = lane; i < total_peaks; i += 64) {
                     const int bin = (int) peaks[i];
@@ -853,7 +872,7 @@ FX_MARK("harm2");
                     if (floor(rs) != floor(re_)) continue;                     // :232-233
                     const double r = rs < re_ ? rs : re_;
                     const double v = (double) normed[bimg<N>(bin)];
-                    inh += (r - floor(r)) * ((v * v) / h_sum);                 // :236-239
+                    inh += (r - floor(r)) * ((v * v) * r_hsum);                // :236-239 (binMagnitude / magnitudeSum)
                 }
             }
             double score = probe;                                              // / sum_normed, clamped: fx_finalise_kernel
@@ -919,6 +938,9 @@ fx_frame_kernel(const FrameParams p_arg)
     }
     __syncthreads();
 
+    TwRegs<N> twr;
+    if constexpr (TwRegs<N>::USE) twr.load(tw, lane0);
+
     const double nyquist = p.nyquist;
     const double rnyq = 1.0 / nyquist;
     const double frpb = nyquist / (double) M;          // ref SpectralCharacteristics.h:64,105
@@ -930,7 +952,7 @@ fx_frame_kernel(const FrameParams p_arg)
         // in every lane for the whole frame
         FramePart* fpl = p.part + ((size_t) c * T + t);
         if (lane == 0) fpl->flags = 0;            // the harmonic tail sets it; the other fields are read only where written
-        const FrameWave<N> w{p, tw, prev, turn, cbuf, rbuf, fpl, nyquist, rnyq, frpb, scale, c, T, t};
+        const FrameWave<N> w{p, tw, &twr, prev, turn, cbuf, rbuf, fpl, nyquist, rnyq, frpb, scale, c, T, t};
 
         const double ssq_lane = w.load_frame(lane);
         float xr[P];
