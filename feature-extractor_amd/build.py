@@ -11,6 +11,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfx_hip.so")
 SOURCES = ["fx_kernels.hip", "fx_capi.cpp", "fx_comm.cpp"]
+# fx_kernels.hip is compiled twice: frame kernels up to 1024 points (+ tail kernels + host helpers) with the scheduler's
+# alternative register-pressure tracker (+3.5 % at 1024 points), the 2048- / 4096-point frame kernels without (-7 % at 4096)
+UNITS = [("fx_kernels.hip", "fx_kernels_small.o", ["-DFX_PART=1", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"]),
+         ("fx_kernels.hip", "fx_kernels_large.o", ["-DFX_PART=2"]),
+         ("fx_capi.cpp", "fx_capi.o", []),
+         ("fx_comm.cpp", "fx_comm.o", [])]
 HEADERS = ["fx_kernels.h", "fx_context.h", "fx_wave.hip.h", "fx_fft.hip.h", "fx_frame_kernel.hip.h", "fx_tail_kernels.hip.h",
            os.path.join("..", "..", "include", "fx.h")]
 
@@ -25,6 +31,11 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-cont
                "-fno-fast-math", "-mllvm", "-disable-machine-licm", "-Wall", "-Wno-unused-function",
                "-Xclang", "-target-feature", "-Xclang", "-load-store-opt"]
 HIPCC_FLAGS += os.environ.get("FX_EXTRA_HIPCC_FLAGS", "").split()      # experiments only
+
+
+def flags_for_window(window):
+    """hipcc options the frame kernel of this window size is built with (tools that compile fx_kernels.hip as one object)"""
+    return HIPCC_FLAGS + (UNITS[0][2][1:] if window <= 1024 else [])
 
 
 def _hipcc():
@@ -68,9 +79,9 @@ def build(force=False, verbose=False):
                 return LIB_PATH
             tag = ".tmp%d" % os.getpid()
             objs = []
-            for src in SOURCES:
-                obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + ".o")
-                cmd = [_hipcc()] + HIPCC_FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj + tag]
+            for src, objname, extra in UNITS:
+                obj = os.path.join(LIB_DIR, objname)
+                cmd = [_hipcc()] + HIPCC_FLAGS + extra + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj + tag]
                 if verbose:
                     print(" ".join(cmd))
                 _run(cmd)

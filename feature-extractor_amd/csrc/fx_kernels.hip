@@ -40,12 +40,67 @@ namespace fxk {
 #include "fx_wave.hip.h"
 #include "fx_fft.hip.h"
 #include "fx_frame_kernel.hip.h"
+
+// The library builds this file twice (build.py): FX_PART=1 holds the frame kernels up to 1024 points, the tail kernels
+// and every host-side helper; FX_PART=2 holds only the frame kernels for 2048 and 4096 points.  The two halves want
+// different compiler options (the scheduler's alternative register-pressure tracker is worth +3.5 % at 1024 points and
+// costs 7 % at 4096).  Without FX_PART everything is one object (tools/).
+#ifndef FX_PART
+#define FX_PART 0
+#endif
+#if FX_PART != 2
 #include "fx_tail_kernels.hip.h"
+#endif
 
 
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+template <int N> static size_t lds_bytes_t(int ch, int k)
+{
+    typedef Geo<N> G;
+    return sizeof(f2) * N + (size_t) ch * sizeof(float) * (G::BIMG + (G::BQ ? 0 : 4)) + (size_t) ch * k * G::BUF_BYTES;
+}
+
+
+// per window size: the only host functions that name the frame kernels (so that each half of the build instantiates
+// its own sizes and nothing else)
+template <int N> hipError_t prepare_t()
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, true, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, true, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, false, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+template <int N> hipError_t launch_t(const FrameParams& p, int analysers, hipStream_t stream)
+{
+    const size_t lds = lds_bytes_t<N>(p.ch_per_wg, p.waves_per_ch);
+    const dim3 grid((unsigned) ((p.C + p.ch_per_wg - 1) / p.ch_per_wg)), block((unsigned) (p.ch_per_wg * p.waves_per_ch) * 64);
+    if (analysers == 3)      hipLaunchKernelGGL((fx_frame_kernel<N, true, true>), grid, block, lds, stream, p);
+    else if (analysers == 1) hipLaunchKernelGGL((fx_frame_kernel<N, true, false>), grid, block, lds, stream, p);
+    else if (analysers == 2) hipLaunchKernelGGL((fx_frame_kernel<N, false, true>), grid, block, lds, stream, p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+#if FX_PART == 1
+extern template hipError_t prepare_t<2048>();
+extern template hipError_t prepare_t<4096>();
+extern template hipError_t launch_t<2048>(const FrameParams&, int, hipStream_t);
+extern template hipError_t launch_t<4096>(const FrameParams&, int, hipStream_t);
+#elif FX_PART == 2
+template hipError_t prepare_t<2048>();
+template hipError_t prepare_t<4096>();
+template hipError_t launch_t<2048>(const FrameParams&, int, hipStream_t);
+template hipError_t launch_t<4096>(const FrameParams&, int, hipStream_t);
+#endif
+
+#if FX_PART != 2
 template <int N> static void build_tw_t(const float* canon, float* out)
 {
     typedef Plan<N> PL;
@@ -115,12 +170,6 @@ void build_pass_twiddles(int n, const float* canonical, float* out)
     }
 }
 
-template <int N> static size_t lds_bytes_t(int ch, int k)
-{
-    typedef Geo<N> G;
-    return sizeof(f2) * N + (size_t) ch * sizeof(float) * (G::BIMG + (G::BQ ? 0 : 4)) + (size_t) ch * k * G::BUF_BYTES;
-}
-
 template <int N> static int max_waves_t() { return Occ<N>::MAX_THREADS / 64; }
 int frame_kernel_max_waves(int n)
 {
@@ -156,18 +205,6 @@ size_t frame_kernel_lds_bytes(int n, int ch, int k)
     }
 }
 
-template <int N> static hipError_t prepare_t()
-{
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, true, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, true, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, false, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-}
-
 hipError_t prepare_kernels(int n)
 {
     switch (n) {
@@ -178,17 +215,6 @@ hipError_t prepare_kernels(int n)
         case 4096: return prepare_t<4096>();
         default:   return hipErrorInvalidValue;
     }
-}
-
-template <int N> static hipError_t launch_t(const FrameParams& p, int analysers, hipStream_t stream)
-{
-    const size_t lds = lds_bytes_t<N>(p.ch_per_wg, p.waves_per_ch);
-    const dim3 grid((unsigned) ((p.C + p.ch_per_wg - 1) / p.ch_per_wg)), block((unsigned) (p.ch_per_wg * p.waves_per_ch) * 64);
-    if (analysers == 3)      hipLaunchKernelGGL((fx_frame_kernel<N, true, true>), grid, block, lds, stream, p);
-    else if (analysers == 1) hipLaunchKernelGGL((fx_frame_kernel<N, true, false>), grid, block, lds, stream, p);
-    else if (analysers == 2) hipLaunchKernelGGL((fx_frame_kernel<N, false, true>), grid, block, lds, stream, p);
-    else return hipErrorInvalidValue;
-    return hipGetLastError();
 }
 
 hipError_t launch_frame_kernel(int n, const FrameParams& p, int analysers, hipStream_t stream)
@@ -223,6 +249,8 @@ hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t stream)
     hipLaunchKernelGGL(fx_history_kernel, dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
+
+#endif // FX_PART != 2
 
 } // namespace fxk
 

@@ -1,8 +1,9 @@
-tools/profile_window.sh r02_2048 --window 2048 --channels-per-gpu 4096 --frames 32 > /dev/null 2>&1
-grep -A17 "PMC per launch.*fx_frame_kernel" gpurun_out/prof_r02_2048/summary.txt | head -18; grep "trace void fxk::fx_frame" gpurun_out/prof_r02_2048/summary.txt
-timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r02_bench.json 2> gpurun_out/r02_bench.err; echo rc=$?
-python3 -c "
-import json
-d=json.loads(open('gpurun_out/r02_bench.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline'].get('valu_issue_frac'), d['other_windows'], d['data_dependence']['noise']['relative_to_synth'], d['spectral_only']['value'])"
-hipcc --offload-arch=gfx950 -O3 tools/ubench/valu_rates.hip -o /tmp/valu_rates && /tmp/valu_rates > gpurun_out/r02_valu_rates.txt 2>&1; head -40 gpurun_out/r02_valu_rates.txt
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" | tail -4
+b() { timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra $2 2>&1 | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('%-70s kernel ms %.3f  frames/s %.4g  hbm %.4f' % ('$1 $2', r['avg_launch_ms'], d['value'], r['frac']))"; }
+b "" ""
+b "" "--window 2048 --channels-per-gpu 4096 --frames 48"
+b "" "--window 4096 --channels-per-gpu 1024 --frames 42"
+timeout 300 python tools/stress_parity.py 100 4711 2>&1 | tail -3

@@ -3,8 +3,9 @@ import re, subprocess, sys, os, tempfile
 N = sys.argv[1] if len(sys.argv) > 1 else "1024"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = tempfile.mkdtemp()
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-mllvm", "-disable-machine-licm",
-                "-Xclang", "-target-feature", "-Xclang", "-load-store-opt", "-c", os.path.join(root, "feature-extractor_amd/csrc/fx_kernels.hip"), "-o", os.path.join(d, "fx.o"), "-save-temps"],
+sys.path.insert(0, os.path.join(root, "feature-extractor_amd"))
+import build as fxbuild
+subprocess.run(["hipcc"] + fxbuild.flags_for_window(int(N)) + ["-x", "hip", "-c", os.path.join(root, "feature-extractor_amd/csrc/fx_kernels.hip"), "-o", os.path.join(d, "fx.o"), "-save-temps"],
                cwd=d, stderr=subprocess.DEVNULL)
 src = open(os.path.join(d, "fx_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
 start = src.index("_ZN3fxk15fx_frame_kernelILi%sELb1ELb1EEEvNS_11FrameParamsE:" % N)

@@ -24,7 +24,7 @@ def static_mix(window):
     sys.path.insert(0, os.path.join(ROOT, "feature-extractor_amd"))
     import importlib
     build = importlib.import_module("build")
-    subprocess.run([build._hipcc()] + build.HIPCC_FLAGS + ["-x", "hip", "-c", os.path.join(build.CSRC, "fx_kernels.hip"), "-o", os.path.join(d, "fx.o"), "-save-temps"],
+    subprocess.run([build._hipcc()] + build.flags_for_window(window) + ["-x", "hip", "-c", os.path.join(build.CSRC, "fx_kernels.hip"), "-o", os.path.join(d, "fx.o"), "-save-temps"],
                    cwd=d, stderr=subprocess.DEVNULL, check=True)
     src = open(os.path.join(d, "fx_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
     start = src.index("_ZN3fxk15fx_frame_kernelILi%dELb1ELb1EEEvNS_11FrameParamsE:" % window)
