@@ -59,6 +59,15 @@ __global__ void __launch_bounds__(256) NAME(float* out, int iters, float seed) {
 #define T_PKADD(i)   "v_pk_add_f32 %" S(i) ", %" S(i) ", %18"
 #define T_MOV64(i)   "v_mov_b64 %" S(i) ", %18"
 #define T_NOP(i)     "s_nop 0"
+// one compare, then 8 selects on the same mask: through VCC / through an SGPR pair
+#define CMP_8CND   "v_cmp_gt_f32 vcc, %0, %16\n" F8(T_CND)
+#define CMP_8CND64 "v_cmp_gt_f32_e64 s[20:21], %0, %16\n" F8(T_CND64)
+#define SMOV_8CND  "s_mov_b64 vcc, exec\n" F8(T_CND)
+// the same select with VCC named as an explicit VOP3 operand; and a compare / select pair with other work in between
+#define T_CNDV3(i)   "v_cndmask_b32_e64 %" S(i) ", %" S(i) ", %16, vcc"
+#define SMOV_8CNDV3 "s_mov_b64 vcc, exec\n" F8(T_CNDV3)
+#define T_CMP_X_CND(i) "v_cmp_gt_f32 vcc, %" S(i) ", %16\n v_add_f32 %" S(i) ", %" S(i) ", %17\n v_cndmask_b32 %" S(i) ", %" S(i) ", %16, vcc"
+#define T_CMP_XX_CND(i) "v_cmp_gt_f32 vcc, %" S(i) ", %16\n v_add_f32 %" S(i) ", %" S(i) ", %17\n v_mul_f32 %" S(i) ", %" S(i) ", %17\n v_add_f32 %" S(i) ", %" S(i) ", %17\n v_cndmask_b32 %" S(i) ", %" S(i) ", %16, vcc"
 // the two conversions: float register j <-> double register j + 8
 #define CVT_DOWN "v_cvt_f32_f64 %0, %8\n v_cvt_f32_f64 %1, %9\n v_cvt_f32_f64 %2, %10\n v_cvt_f32_f64 %3, %11\n v_cvt_f32_f64 %4, %12\n v_cvt_f32_f64 %5, %13\n v_cvt_f32_f64 %6, %14\n v_cvt_f32_f64 %7, %15"
 #define CVT_UP   "v_cvt_f64_f32 %8, %0\n v_cvt_f64_f32 %9, %1\n v_cvt_f64_f32 %10, %2\n v_cvt_f64_f32 %11, %3\n v_cvt_f64_f32 %12, %4\n v_cvt_f64_f32 %13, %5\n v_cvt_f64_f32 %14, %6\n v_cvt_f64_f32 %15, %7"
@@ -72,6 +81,8 @@ KERNEL(k_cvtdown, CVT_DOWN)     KERNEL(k_cvtup, CVT_UP)         KERNEL(k_rcp, F8
 KERNEL(k_rcp64, D8(T_RCP64))    KERNEL(k_sqrt64, D8(T_SQRT64))  KERNEL(k_ldexp64, D8(T_LDEXP64)) KERNEL(k_frexp64, D8(T_FREXP64))
 KERNEL(k_add64, D8(T_ADD64))    KERNEL(k_fma64, D8(T_FMA64))    KERNEL(k_max64, D8(T_MAX64))    KERNEL(k_pkmul, D8(T_PKMUL))
 KERNEL(k_pkmuls, D8(T_PKMULS))  KERNEL(k_pkadd, D8(T_PKADD))    KERNEL(k_mov64, D8(T_MOV64))    KERNEL(k_nop, F8(T_NOP))
+KERNEL(k_cmp8cnd, CMP_8CND)     KERNEL(k_cmp8cnd64, CMP_8CND64) KERNEL(k_smov8cnd, SMOV_8CND)
+KERNEL(k_smov8cndv3, SMOV_8CNDV3) KERNEL(k_cmpxcnd, F8(T_CMP_X_CND)) KERNEL(k_cmpxxcnd, F8(T_CMP_XX_CND))
 
 typedef void (*kern)(float*, int, float);
 struct E { const char* name; kern k; int per; };
@@ -84,7 +95,10 @@ static E es[] = {{"v_mul_f32", k_mul, 8}, {"v_add_f32", k_add, 8}, {"v_fma_f32 (
                  {"v_cvt_f64_f32", k_cvtup, 8}, {"v_rcp_f32", k_rcp, 8}, {"v_log_f32", k_log, 8}, {"v_rcp_f64", k_rcp64, 8},
                  {"v_sqrt_f64", k_sqrt64, 8}, {"v_ldexp_f64", k_ldexp64, 8}, {"v_frexp_mant_f64", k_frexp64, 8}, {"v_add_f64", k_add64, 8},
                  {"v_fma_f64", k_fma64, 8}, {"v_max_f64", k_max64, 8}, {"v_pk_mul_f32", k_pkmul, 8}, {"v_pk_mul_f32 op_sel", k_pkmuls, 8},
-                 {"v_pk_add_f32", k_pkadd, 8}, {"v_mov_b64", k_mov64, 8}, {"s_nop 0", k_nop, 8}};
+                 {"v_pk_add_f32", k_pkadd, 8}, {"v_mov_b64", k_mov64, 8}, {"s_nop 0", k_nop, 8},
+                 {"1 v_cmp vcc + 8 v_cndmask vcc", k_cmp8cnd, 9}, {"1 v_cmp sgpr + 8 v_cndmask sgpr", k_cmp8cnd64, 9},
+                 {"s_mov vcc + 8 v_cndmask vcc", k_smov8cnd, 9}, {"s_mov vcc + 8 v_cndmask_e64 ..., vcc", k_smov8cndv3, 9},
+                 {"v_cmp vcc, v_add, v_cndmask vcc", k_cmpxcnd, 24}, {"v_cmp vcc, 3 VALU, v_cndmask vcc", k_cmpxxcnd, 40}};
 
 int main()
 {
