@@ -2,6 +2,15 @@
 // Included by fx_kernels.hip inside namespace fxk (one translation unit: every kernel sees the same
 // inlined helpers); not a stand-alone header.
 
+// The un-split transforms (N <= 1024) let the compiler hoist their few lane-derived addresses out of the frame loop
+// (+1 %, 126 VGPRs); everywhere else lane-derived values are re-materialised per frame (opaque(): hoisting them all
+// spills 85 registers at 1024 points).
+#ifdef FX_EXP_FFT_NO_HOIST
+#define FFT_OPAQUE(x) opaque(x)
+#else
+#define FFT_OPAQUE(x) (x)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // LDS images
 //   complex image: position p at p + (p >> 4)            (one float2 of padding per 16)
@@ -186,7 +195,7 @@ __host__ __device__ constexpr int item_off(int L0, int i) { return L0 * i + (L0 
 template <int N, int R, int L0, int TWOFF, bool INV>
 __device__ __forceinline__ void fft_pass(f2* cbuf, const f2* tw, int lane)
 {
-    lane = opaque(lane);
+    lane = FFT_OPAQUE(lane);
     constexpr int ITEMS = N / R;
     for (int it = lane; it < ITEMS; it += 64) {
         f2 e[R];
@@ -305,7 +314,7 @@ __device__ __forceinline__ void fft_first_pass(const float (&xin)[Geo<N>::P], f2
 {
     typedef Geo<N> G;
     constexpr int R = G::RA;
-    lane = opaque(lane);
+    lane = FFT_OPAQUE(lane);
     f2 ta[9];                      // wave-uniform: kernel arguments, not LDS
 #pragma unroll
     for (int i = 0; i < 9; i++) ta[i] = f2{ftw[2 * i], ftw[2 * i + 1]};
@@ -461,7 +470,7 @@ __device__ __forceinline__ float fft_last_pass_fused(f2* cbuf, const f2* tw, int
 {
     typedef Plan<N> PL;
     constexpr int R = PL::R2, L0 = PL::L2, GI = (N / R) / 64;
-    lane = opaque(lane);
+    lane = FFT_OPAQUE(lane);
     f2 e[GI][R];
 #pragma unroll
     for (int g = 0; g < GI; g++) {

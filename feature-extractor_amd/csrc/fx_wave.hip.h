@@ -18,7 +18,11 @@ __device__ __forceinline__ void wave_fence()
 // Re-materialise a lane-derived value so that nothing computed from it is hoisted out of the frame
 // loop (loop-invariant code motion would otherwise keep hundreds of addresses, window gains and
 // shuffle indices live across the whole loop and spill them).
+#ifdef FX_EXP_NO_OPAQUE
+__device__ __forceinline__ int opaque(int v) { return v; }
+#else
 __device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // wavefront reductions (all lanes receive the result, as a wave-uniform value).
