@@ -1,3 +1,9 @@
+// Re-materialisation points of lane-derived values (see opaque()); FX_HOIST_MASK bit n lets the compiler hoist at point n
+// (experiments: tools/variants.sh "-DFX_HOIST_MASK=0x..").
+#ifndef FX_HOIST_MASK
+#define FX_HOIST_MASK 0
+#endif
+#define FX_OPQ(n, x) (((FX_HOIST_MASK) >> (n)) & 1 ? (x) : opaque(x))
 // fx_frame_kernel.hip.h -- frame load and fx_frame_kernel: every reduction over samples, bins and lags of a frame
 // Included by fx_kernels.hip inside namespace fxk (one translation unit: every kernel sees the same
 // inlined helpers); not a stand-alone header.
@@ -376,7 +382,7 @@ FX_MARK("flatprod");
         float spec_aux = 0.0f;
 FX_MARK("spec_fft");
         // ---------------- spectral analyser (ref RealTimeAnalyser.h:212-224) -----------------------
-        lane = opaque(lane);
+        lane = FX_OPQ(0, lane);
         {
             float xw[P];                                                       // a3 Bartlett window
             // sample index of input j of item g is nlow + ITEMS_A*r(j) with nlow < ITEMS_A, so it lies in
@@ -466,7 +472,7 @@ FX_MARK("flux");
             }
             flux = wave_sum(flux);
 
-            lane = opaque(lane);
+            lane = FX_OPQ(1, lane);
             const double prod = flatness_product(lane, re, tg);
 
 FX_MARK("spec_pass2");
@@ -523,7 +529,7 @@ FX_MARK("spec_pass2");
 FX_MARK("harm1");
         // ---------------- harmonic analyser, part 1: raw (un-windowed) spectrum ---------------------
         // ref RealTimeAnalyser.h:161
-        lane = opaque(lane);
+        lane = FX_OPQ(2, lane);
         fft_from_regs<N, false, OUT_RE_LOW>(xr, cbuf, tw, p.first_tw, lane, 0.0f, nullptr, twr);
         {
             const int b0 = U * lane;
@@ -609,7 +615,7 @@ FX_MARK("lpf");
         // window the filtered frame (ref RealTimeAnalyser.h:157) and put it back in the real image.
         // A lane's P samples lie in one half of the window; the gains w0 + i*wstep are exact dyadic
         // numbers (so the fma rounds nothing) and equal bartlett_gain<N>(P*lane + i).
-        lane = opaque(lane);
+        lane = FX_OPQ(3, lane);
         const float w0 = bartlett_gain<N>(P * lane);
         const float wstep = lane < 32 ? (2.0f / N) : -(2.0f / N);
 #pragma unroll
@@ -637,7 +643,7 @@ FX_MARK("lpf");
     __device__ __forceinline__ float lag_search(int lane, const float (&vreg)[P], float v_end) const
     {
 FX_MARK("scan");
-        lane = opaque(lane);
+        lane = FX_OPQ(4, lane);
         float lag = -1.0f;
         float run = 0.0f;                 // the running sum after the previous block (wave-uniform)
         float carry = 0.0f;               // cnd of the last sample of the previous block
@@ -712,9 +718,9 @@ FX_MARK("scan");
     // pitch: low-pass -> window -> FFT -> re^2 -> inverse FFT -> lag; returns f0 = sampleRate / lag (ref PitchAnalyser.h:57)
     __device__ __forceinline__ double pitch(int lane) const
     {
-        lowpass_window(opaque(lane));
+        lowpass_window(FX_OPQ(5, lane));
 FX_MARK("pitch_fft");
-        lane = opaque(lane);
+        lane = FX_OPQ(6, lane);
         float xf[P];
 #pragma unroll
         for (int g = 0; g < G::GA; g++)
@@ -726,7 +732,7 @@ FX_MARK("pitch_fft");
         float xp[P];
         fft_from_regs<N, false, OUT_POWER>(xf, cbuf, tw, p.first_tw, lane, 0.0f, xp, twr);  // ref RealTimeAnalyser.h:160
 FX_MARK("power");
-        lane = opaque(lane);
+        lane = FX_OPQ(7, lane);
         if constexpr (G::GA == 1) {
 #pragma unroll
             for (int j = 0; j < P; j++) xf[j] = xp[j];
@@ -754,7 +760,7 @@ FX_MARK("ifft");
         const double h_max = hs.max;
 FX_MARK("harm2");
         // ---------------- harmonic analyser, part 2 (ref HarmonicCharacteristics.h:71-105) ----------
-        lane = opaque(lane);
+        lane = FX_OPQ(8, lane);
 #ifdef FX_EXP_SKIP_HARM2
         if (h_sum < -1.0) {
 #else
@@ -947,7 +953,7 @@ fx_frame_kernel(const FrameParams p_arg)
     const float  scale = 1.0f / (float) N;             // JUCE inverse scale
 
     for (int t = live ? slot : T; t < T; t += K) {
-        const int lane = opaque(lane0);
+        const int lane = FX_OPQ(15, lane0);
         // uniform per-frame results go to LDS as soon as they exist instead of occupying ~28 VGPRs
         // in every lane for the whole frame
         FramePart* fpl = p.part + ((size_t) c * T + t);
