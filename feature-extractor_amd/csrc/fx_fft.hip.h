@@ -158,6 +158,35 @@ __device__ __forceinline__ void bfly4_core(f2& d0, f2& d1, f2& d2, f2& d3, f2 s0
         d3 = pk_add_rot<false>(s5, s4);
     }
 }
+// The last stage of a transform whose consumer reads real parts only (re of bins < N/2 for the two analysers, re^2 for
+// the pitch path, the squared real part for the lag search): x of outputs 0 and 1 (or of all four when ALL4), and y of
+// output 0 when D0Y (getMagnitude's raw floats, imag[0] of the inverse transform).  Every value that is formed has the
+// operands, the order and the roundings of twmul + bfly4_core; what no consumer reads is not computed: s1 needs its real
+// part only (three plain instructions instead of three packed ones), s3 / s4 one half each (one packed add for both).
+// -DFX_EXP_FULL_LAST restores the full butterfly (A/B).
+template <bool INV, bool ALL4, bool D0Y>
+__device__ __forceinline__ void bfly4_re(f2& d0, f2& d1, f2& d2, f2& d3, f2 w1, f2 w2, f2 w3)
+{
+#ifdef FX_EXP_FULL_LAST
+    bfly4_core<INV>(d0, d1, d2, d3, twmul<INV>(d1, w1), twmul<INV>(d2, w2), twmul<INV>(d3, w3));
+#else
+    const f2 s0 = twmul<INV>(d1, w1);
+    const f2 s2 = twmul<INV>(d3, w3);
+    float s1x, s1y = 0.0f;
+    if (D0Y) { const f2 s1 = twmul<INV>(d2, w2); s1x = s1.x; s1y = s1.y; }
+    else     s1x = INV ? (d2.x * w2.x) + (d2.y * w2.y) : (d2.x * w2.x) - (d2.y * w2.y);
+    f2 t;                                           // (s3.x, s4.y) = (s0.x + s2.x, s0.y - s2.y)
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(t) : "v"(s0), "v"(s2));
+    const float ax = d0.x + s1x, s5x = d0.x - s1x;  // a.x, s5.x
+    const float y0 = D0Y ? (d0.y + s1y) + (s0.y + s2.y) : 0.0f;
+    d0 = f2{ax + t.x, y0};
+    d1 = f2{INV ? s5x - t.y : s5x + t.y, 0.0f};
+    if (ALL4) {
+        d2 = f2{ax - t.x, 0.0f};
+        d3 = f2{INV ? s5x + t.y : s5x - t.y, 0.0f};
+    }
+#endif
+}
 // butterfly4 on four REAL inputs with unit twiddles (first stage of a real-input transform)
 template <bool INV>
 __device__ __forceinline__ void bfly4_real(float a0, float a1, float a2, float a3, f2& d0, f2& d1, f2& d2, f2& d3)
@@ -363,6 +392,35 @@ __device__ __forceinline__ void item16_stages_r(f2 (&e)[16], const f2 (&w)[15])
                         twmul<INV>(e[jin + 4], w[3 + 3 * jin]), twmul<INV>(e[jin + 8], w[4 + 3 * jin]), twmul<INV>(e[jin + 12], w[5 + 3 * jin]));
 }
 
+// What the last pass leaves in the wave's LDS buffer.
+enum { OUT_RE_LOW = 1,        // float re[M] (plain layout): all the harmonic analyser reads (ref HarmonicCharacteristics.h:63)
+       OUT_RE_LOW_MAXABS = 2, // the same + max(|re|,|im|) over bins [0, M/2) returned per lane (ref SpectralCharacteristics.h:153)
+       OUT_POWER = 3,         // re*re of all N bins (ref PitchAnalyser.h:97-103) as the NEXT transform's first-pass inputs: in registers
+                              // (regs_out, one lane permutation) when a lane owns one first-pass item, else in the real image (rpad layout)
+       OUT_LAG = 4 };         // v[s] = (re_s/N)^2 * s of the lane's own samples s = lane + 64*m in registers (regs_out[m]); returns v[N], from imag[0], in lane 0: ref :119-123
+
+// The two stages of a LAST-pass 16-element item: the second stage forms only what the consumer of the spectrum reads
+// (bfly4_re; OUT as in fft_from_regs; `first_item`: the item whose element 0 is bin 0).  w(i): the item's 15 twiddles.
+template <bool INV, int OUT, typename W>
+__device__ __forceinline__ void item16_last(f2 (&e)[16], W w, bool first_item)
+{
+    constexpr bool ALL4 = !(OUT == OUT_RE_LOW || OUT == OUT_RE_LOW_MAXABS);          // those read bins < N/2: elements i < 8
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+        bfly4_core<INV>(e[4 * g], e[4 * g + 1], e[4 * g + 2], e[4 * g + 3],
+                        twmul<INV>(e[4 * g + 1], w(0)), twmul<INV>(e[4 * g + 2], w(1)), twmul<INV>(e[4 * g + 3], w(2)));
+#pragma unroll
+    for (int jin = 0; jin < 4; jin++) {
+        const f2 w1 = w(3 + 3 * jin), w2 = w(4 + 3 * jin), w3 = w(5 + 3 * jin);
+        if (OUT == OUT_RE_LOW_MAXABS)                       // max(|re|, |im|) over elements i < 4: y of every output 0
+            bfly4_re<INV, ALL4, true>(e[jin], e[jin + 4], e[jin + 8], e[jin + 12], w1, w2, w3);
+        else if (OUT == OUT_LAG && jin == 0 && first_item)  // imag[0] of the inverse transform
+            bfly4_re<INV, ALL4, true>(e[jin], e[jin + 4], e[jin + 8], e[jin + 12], w1, w2, w3);
+        else
+            bfly4_re<INV, ALL4, false>(e[jin], e[jin + 4], e[jin + 8], e[jin + 12], w1, w2, w3);
+    }
+}
+
 // Twiddles a lane needs for the second and the last pass of a split transform, held in registers for the wave's whole
 // life (2048 points: the kernel runs at 2 waves per SIMD there, which leaves the registers, and VALU issue and the LDS
 // pipe are co-limiting, so the 180 twiddle reads per frame -- a fifth of its LDS instructions -- are worth removing).
@@ -399,13 +457,6 @@ template <int N> struct TwRegs {
 template <int N> __host__ __device__ constexpr int qpad(int q) { return N == 2048 ? q + 8 * (q >> 6) : q; }
 static_assert(qpad<2048>(1023) < Geo<2048>::CSLOTS && qpad<4096>(2047) < Geo<4096>::CSLOTS, "half image fits the wave buffer");
 
-// What the last pass leaves in the wave's LDS buffer.
-enum { OUT_RE_LOW = 1,        // float re[M] (plain layout): all the harmonic analyser reads (ref HarmonicCharacteristics.h:63)
-       OUT_RE_LOW_MAXABS = 2, // the same + max(|re|,|im|) over bins [0, M/2) returned per lane (ref SpectralCharacteristics.h:153)
-       OUT_POWER = 3,         // re*re of all N bins (ref PitchAnalyser.h:97-103) as the NEXT transform's first-pass inputs: in registers
-                              // (regs_out, one lane permutation) when a lane owns one first-pass item, else in the real image (rpad layout)
-       OUT_LAG = 4 };         // v[s] = (re_s/N)^2 * s of the lane's own samples s = lane + 64*m in registers (regs_out[m]); returns v[N], from imag[0], in lane 0: ref :119-123
-
 // Last pass -- radix 4 at length N/4 (N <= 1024) or radix 16 at length N/16 -- with all of a lane's items in
 // registers (128 VGPRs of them at N = 4096, which runs one wave per SIMD anyway), fused with the consumer of the spectrum, so the full complex image is never written back and
 // re-read: the spectral / harmonic analysers only read re of bins < N/2, the pitch analyser only re*re, the
@@ -430,7 +481,9 @@ __device__ __forceinline__ float fft_last_pass_consume(f2 (&e)[(N / Plan<N>::R2)
             item16_stages<L0, INV>(e[g], t1);
         } else {
             const f2 w1 = t1[0], w2 = t1[L0], w3 = t1[2 * L0];
-            bfly4_core<INV>(e[g][0], e[g][1], e[g][2], e[g][3], twmul<INV>(e[g][1], w1), twmul<INV>(e[g][2], w2), twmul<INV>(e[g][3], w3));
+            constexpr bool ALL4 = !(OUT == OUT_RE_LOW || OUT == OUT_RE_LOW_MAXABS);
+            if (OUT == OUT_RE_LOW_MAXABS || (OUT == OUT_LAG && g == 0)) bfly4_re<INV, ALL4, true>(e[g][0], e[g][1], e[g][2], e[g][3], w1, w2, w3);
+            else bfly4_re<INV, ALL4, false>(e[g][0], e[g][1], e[g][2], e[g][3], w1, w2, w3);
         }
         // e[g][i] is bin k + L0*i
 #pragma unroll
@@ -577,8 +630,8 @@ __device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cb
 #pragma unroll
         for (int gl = 0; gl < HB; gl++) {
             const int g = h * HB + gl, k = lane + 64 * g;
-            if constexpr (TwRegs<N>::USE) item16_stages_r<INV>(ec[gl], twr->c[g]);
-            else item16_stages<L2, INV>(ec[gl], tw + PL::OFF2 + k);
+            if constexpr (TwRegs<N>::USE) { const f2 (&wr)[15] = twr->c[g]; item16_last<INV, OUT>(ec[gl], [&](int i) { return wr[i]; }, g == 0); }
+            else { const f2* t2 = tw + PL::OFF2 + k; item16_last<INV, OUT>(ec[gl], [&](int i) { return t2[i * L2]; }, g == 0); }
             last_item_reduce<N, OUT>(ec[gl], k, scale, res[g], aux);
             if (OUT == OUT_LAG && g == 0) { const float d = ec[0][0].y * scale; aux = d * d * (float) N; }
         }

@@ -121,7 +121,10 @@ __device__ __forceinline__ void wave_sum2(int lane, double& a, double& b)
     b = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(q), 1), __builtin_amdgcn_readlane(__double2loint(q), 1));
 }
 // (Moving the exchange steps to ds_swizzle -- the LDS crossbar instead of VALU DPP moves -- was measured 3 % slower:
-// the LDS pipe is the kernel's second limiter.)
+// the LDS pipe is the kernel's second limiter.  Moving whole sums to the idle matrix pipe -- v_mfma_f64_16x16x4_f64 with
+// B = ones adds lanes l, l+16, l+32, l+48; three adds and a second product give every lane the total: 2 MFMAs + 3 adds
+// instead of 18 DPP / add instructions -- gave the same bits and was 2 % (single sums) to 6 % (all sums) SLOWER at 1024
+// points: each MFMA needs 18 wait states before its result can be read and holds the SIMD's issue port meanwhile.)
 // fp32 sum of one value per lane (tree order; for quantities that only need ~1e-6)
 __device__ __forceinline__ float wave_sum_f32(float v)
 {
