@@ -187,6 +187,16 @@ __device__ __forceinline__ void bfly4_re(f2& d0, f2& d1, f2& d2, f2& d3, f2 w1, 
     }
 #endif
 }
+// Real part of output 0 alone: (d0.x + s1.x) + (s0.x + s2.x), each s a twiddle product's real part (one packed
+// multiply + one add / subtract each) -- what the head of the lag search reads of an inverse transform.
+template <bool INV>
+__device__ __forceinline__ float bfly4_x0(f2 d0, f2 d1, f2 d2, f2 d3, f2 w1, f2 w2, f2 w3)
+{
+    const float s0x = INV ? (d1.x * w1.x) + (d1.y * w1.y) : (d1.x * w1.x) - (d1.y * w1.y);
+    const float s1x = INV ? (d2.x * w2.x) + (d2.y * w2.y) : (d2.x * w2.x) - (d2.y * w2.y);
+    const float s2x = INV ? (d3.x * w3.x) + (d3.y * w3.y) : (d3.x * w3.x) - (d3.y * w3.y);
+    return (d0.x + s1x) + (s0x + s2x);
+}
 // butterfly4 on four REAL inputs with unit twiddles (first stage of a real-input transform)
 template <bool INV>
 __device__ __forceinline__ void bfly4_real(float a0, float a1, float a2, float a3, f2& d0, f2& d1, f2& d2, f2& d3)
@@ -552,6 +562,60 @@ __device__ __forceinline__ void last_item_reduce(const f2 (&e)[16], int k, float
         }
     }
 }
+
+// The inverse transform of the pitch path at 1024 points with its LAST pass left to the lag search, which reads
+// v[s] = (re_s / N)^2 * s from s = 0 upwards and is usually decided within the first 64 or 128 lags: the four last-pass
+// butterflies of a lane are held as operands (e[g], butterfly k = lane + 64*g, output i = sample k + 256*i), and
+//   head(g) : v[lane + 64*g], g = 0..3 -- output 0 of butterfly g alone (bfly4_x0)
+//   rest()  : every other sample, and v[N] from imag[0] (lane 0), when the search goes past sample 255.
+// Each value has the operands and roundings of the whole pass (fft_last_pass_consume, OUT_LAG).
+template <int N> struct LazyLag {
+    static_assert(N == 1024, "four last-pass butterflies per lane, one 64-sample block per butterfly's output 0");
+    typedef Plan<N> PL;
+    static constexpr int L0 = PL::L2;
+    f2 e[4][4];
+    const f2* t1;       // tw + OFF2 + lane
+    float scale;
+    int lane;
+    __device__ __forceinline__ void load(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, const float (&ftw)[18], int lane_, float scale_)
+    {
+        fft_first_pass<N, true>(xin, cbuf, ftw, lane_);
+        fft_pass<N, PL::R1, PL::L1, PL::OFF1, true>(cbuf, tw, lane_);
+        lane = FFT_OPAQUE(lane_);
+        scale = scale_;
+        t1 = tw + PL::OFF2 + lane;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const f2* img = cbuf + cpad(lane + 64 * g);
+#pragma unroll
+            for (int i = 0; i < 4; i++) e[g][i] = img[item_off(L0, i)];
+        }
+        wave_fence();                 // the wave has read the whole complex image; the buffer may be rewritten
+    }
+    __device__ __forceinline__ float head(int g) const          // g: compile-time after unrolling
+    {
+        const f2* t = t1 + 64 * g;
+        const float d = bfly4_x0<true>(e[g][0], e[g][1], e[g][2], e[g][3], t[0], t[L0], t[2 * L0]) * scale;
+        return d * d * (float) (lane + 64 * g);
+    }
+    __device__ __forceinline__ float rest(float (&vreg)[Geo<N>::P])
+    {
+        float v_end = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const f2* t = t1 + 64 * g;
+            if (g == 0) bfly4_re<true, true, true>(e[g][0], e[g][1], e[g][2], e[g][3], t[0], t[L0], t[2 * L0]);
+            else        bfly4_re<true, true, false>(e[g][0], e[g][1], e[g][2], e[g][3], t[0], t[L0], t[2 * L0]);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float d = e[g][i].x * scale;
+                vreg[g + 4 * i] = d * d * (float) (lane + 64 * g + L0 * i);
+            }
+            if (g == 0) { const float d = e[0][0].y * scale; v_end = d * d * (float) N; }
+        }
+        return v_end;
+    }
+};
 
 // Split transform (N >= 2048): three passes with both exchanges done one half at a time through a half-size image.
 //   first pass  : RA real inputs per item, ITEMS_A/64 = 4 items per lane  (items 0,1 = half 0; items 2,3 = half 1)

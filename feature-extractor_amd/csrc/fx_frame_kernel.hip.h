@@ -640,7 +640,10 @@ FX_MARK("lpf");
     //   stop   = first s' >= first with !(cnd[s'+1] < cnd[s'])   (or N-1)
     //   lag    = cnd[stop] <= cnd[stop+1] ? stop : stop+1        (ref :192-203)
     //   otherwise the global minimum over [2, N), first occurrence (ref :171-175).
-    __device__ __forceinline__ float lag_search(int lane, const float (&vreg)[P], float v_end) const
+    // LAZY (1024 points): vreg[0], vreg[1] are filled; blocks 2 and 3 and then all the others are taken from `lz` only if
+    // the search gets there (LazyLag).
+    template <bool LAZY>
+    __device__ __forceinline__ float lag_search(int lane, float (&vreg)[P], float v_end, LazyLag<LAZY ? N : 1024>* lz) const
     {
 FX_MARK("scan");
         lane = FX_OPQ(4, lane);
@@ -689,10 +692,25 @@ FX_MARK("scan");
         if (!done && P > 2) {
             // rare: the search goes past the second block; the remaining blocks pick their samples from the buffer
             float* vbuf = rbuf;                                            // [N] plain layout
+            if constexpr (LAZY) {
+                vbuf[64 * 2 + lane] = lz->head(2);
+                vbuf[64 * 3 + lane] = lz->head(3);
+                wave_fence();
+                for (int blk = 2; blk < P && !done; blk++) {
+                    if (blk == 4) {                                        // past sample 255: the rest of the transform
+                        v_end = lz->rest(vreg);
 #pragma unroll
-            for (int m = 2; m < P; m++) vbuf[64 * m + lane] = vreg[m];
-            wave_fence();
-            for (int blk = 2; blk < P && !done; blk++) block(blk, vbuf[64 * blk + lane]);
+                        for (int m = 4; m < P; m++) vbuf[64 * m + lane] = vreg[m];
+                        wave_fence();
+                    }
+                    block(blk, vbuf[64 * blk + lane]);
+                }
+            } else {
+#pragma unroll
+                for (int m = 2; m < P; m++) vbuf[64 * m + lane] = vreg[m];
+                wave_fence();
+                for (int blk = 2; blk < P && !done; blk++) block(blk, vbuf[64 * blk + lane]);
+            }
         }
 #endif
         if (!done) {
@@ -745,8 +763,20 @@ FX_MARK("power");
         }
 FX_MARK("ifft");
         float vreg[P];
-        const float v_end = fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, p.first_tw, lane, scale, vreg, twr);   // a12 inverse, ref :110-121
-        const float lag = lag_search(lane, vreg, v_end);
+        float lag;
+#ifndef FX_EXP_NO_LAZY_LAG
+        if constexpr (N == 1024) {
+            LazyLag<N> lz;                                                 // a12 inverse, ref :110-121, its last pass on demand
+            lz.load(xf, cbuf, tw, p.first_tw, lane, scale);
+            vreg[0] = lz.head(0);
+            vreg[1] = lz.head(1);
+            lag = lag_search<true>(lane, vreg, 0.0f, &lz);
+        } else
+#endif
+        {
+            const float v_end = fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, p.first_tw, lane, scale, vreg, twr);   // a12 inverse, ref :110-121
+            lag = lag_search<false>(lane, vreg, v_end, nullptr);
+        }
         if (lane == 0) fpl->lag = lag;
         wave_fence();
         return (nyquist * 2.0) / (double) lag;

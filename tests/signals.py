@@ -87,10 +87,26 @@ def flat_edge(C, T, N, seed=6):
     return (x * g).astype(np.float32)
 
 
+def low_tones(C, T, N, seed=7, sr=48000.0):
+    """Fundamentals of 9 .. 70 Hz (a pedal note, mains hum, a rumble), a slow drift and a DC offset under a tone: the
+    lag search (ref PitchAnalyser.h:161-190) is not decided within the first few hundred lags, or never dips below its
+    threshold and falls back to the global minimum -- the frame kernel's second, whole-lag-array pitch pass"""
+    rng = np.random.default_rng(seed)
+    n = np.arange(T * N // 2)
+    out = np.empty((C, n.size), np.float32)
+    for c in range(C):
+        f = 9.0 * (70.0 / 9.0) ** (c / max(1, C - 1))
+        x = 0.6 * np.sin(2 * np.pi * f * n / sr + 0.3 * c)
+        if c % 3 == 1: x = x + 0.4                                   # DC under the tone
+        if c % 3 == 2: x = x + 0.2 * n / n.size                      # slow drift
+        out[c] = x + rng.normal(0, 1e-3, n.size)
+    return out.reshape(C, T, N // 2)
+
+
 ALL = {
     "tone": tone_vibrato_noise, "silence": silence, "loud_noise": loud_noise, "quiet_noise": quiet_noise,
     "impulse": impulse, "sine": sine, "dc": dc, "bursts": bursts, "levels": levels,
-    "flat_edge": flat_edge, "impulse_on_boundary": impulse_on_boundary,
+    "flat_edge": flat_edge, "impulse_on_boundary": impulse_on_boundary, "low_tones": low_tones,
 }
 
 
