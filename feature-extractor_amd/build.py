@@ -15,9 +15,10 @@ SOURCES = ["fx_kernels.hip", "fx_capi.cpp", "fx_comm.cpp"]
 # alternative register-pressure tracker (+3.5 % at 1024 points), the 2048- / 4096-point frame kernels without (-7 % at 4096)
 UNITS = [("fx_kernels.hip", "fx_kernels_small.o", ["-DFX_PART=1", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"]),
          ("fx_kernels.hip", "fx_kernels_large.o", ["-DFX_PART=2"]),
+         ("fx_kernels.hip", "fx_kernels_hop.o", ["-DFX_PART=3"]),
          ("fx_capi.cpp", "fx_capi.o", []),
          ("fx_comm.cpp", "fx_comm.o", [])]
-HEADERS = ["fx_kernels.h", "fx_context.h", "fx_wave.hip.h", "fx_fft.hip.h", "fx_frame_kernel.hip.h", "fx_tail_kernels.hip.h",
+HEADERS = ["fx_kernels.h", "fx_context.h", "fx_wave.hip.h", "fx_fft.hip.h", "fx_frame_kernel.hip.h", "fx_tail_kernels.hip.h", "fx_hop_kernel.hip.h",
            os.path.join("..", "..", "include", "fx.h")]
 
 # -ffp-contract=off : the reference FFT never fuses a*b+c; spectra must be bit-identical.
@@ -78,15 +79,21 @@ def build(force=False, verbose=False):
             if not force and not needs_build():          # another rank built it while we waited
                 return LIB_PATH
             tag = ".tmp%d" % os.getpid()
-            objs = []
-            for src, objname, extra in UNITS:
+            objs = [os.path.join(LIB_DIR, objname) for _, objname, _ in UNITS]
+
+            def compile_unit(unit):
+                src, objname, extra = unit
                 obj = os.path.join(LIB_DIR, objname)
                 cmd = [_hipcc()] + HIPCC_FLAGS + extra + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj + tag]
                 if verbose:
                     print(" ".join(cmd))
                 _run(cmd)
                 os.replace(obj + tag, obj)
-                objs.append(obj)
+
+            # the three kernel objects take ~20-40 s each: compile the units side by side
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:
+                list(pool.map(compile_unit, UNITS))
             # librccl: the feature gather of the multi-GPU path (fx_comm.cpp) calls RCCL directly
             cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + tag] + objs + ["-L/opt/rocm/lib", "-lrccl"]
             if verbose:

@@ -506,6 +506,14 @@ struct fx_stream {
     // and dispatch time for ~40 us of GPU work): there the whole step -- input copy, per-call scalars, the four
     // kernels, result copies -- is captured once per ring slot and buffer parity into a hipGraph and replayed.
     bool use_graph = false;
+    // One hop per call (BASELINE configs[4]) is all latency: there the whole step is ONE launch of fx_hop_kernel
+    // (csrc/fx_hop_kernel.hip.h: three wavefronts per channel + the tail), which reads the hop from the pinned slot,
+    // writes the 12-float vectors back to it and then stores the call's sequence number to the slot's flag; collect
+    // polls that flag.  No graph, no event, no second kernel.
+    bool use_hop_kernel = false;
+    unsigned* d_arrivals = nullptr;       // workgroups of the running hop kernel that have finished (zero between calls)
+    void*     d_stage = nullptr;          // [C][N/2] samples: the hop kernel's device copy of the hop it is analysing
+    unsigned  next_seq = 0;
     fxk::FramePart* g_part = nullptr;     // scratch the captured kernels own (a graph keeps its addresses)
     float*          g_raw = nullptr;
     struct Slot {
@@ -513,6 +521,9 @@ struct fx_stream {
         float* d_raw = nullptr; float* d_sm = nullptr;
         float* h_raw = nullptr; float* h_sm = nullptr;
         hipEvent_t copied = nullptr, done = nullptr, out = nullptr;
+        unsigned* h_flag = nullptr;       // pinned, coherent: sequence number of the last hop-kernel call that completed in this slot
+        const void* dev_in = nullptr; float* dev_raw = nullptr; float* dev_sm = nullptr; unsigned* dev_flag = nullptr;   // device views of the pinned buffers
+        unsigned  seq = 0;                // sequence number of the call in flight in this slot
         fxk::DynParams* h_dyn = nullptr;  // pinned: what changes from call to call
         fxk::DynParams* d_dyn = nullptr;
         hipGraphExec_t  exec[2] = {nullptr, nullptr};     // per parity of the context's ping-pong buffers
@@ -541,11 +552,14 @@ fx_status fx_stream_destroy(fx_stream* s)
         if (sl.d_sm) (void) hipFree(sl.d_sm);
         for (int q = 0; q < 2; q++) if (sl.exec[q]) (void) hipGraphExecDestroy(sl.exec[q]);
         if (sl.h_dyn) (void) hipHostFree(sl.h_dyn);
+        if (sl.h_flag) (void) hipHostFree(sl.h_flag);
         if (sl.d_dyn) (void) hipFree(sl.d_dyn);
         if (sl.copied) (void) hipEventDestroy(sl.copied);
         if (sl.done) (void) hipEventDestroy(sl.done);
         if (sl.out) (void) hipEventDestroy(sl.out);
     }
+    if (s->d_arrivals) (void) hipFree(s->d_arrivals);
+    if (s->d_stage) (void) hipFree(s->d_stage);
     if (s->g_part) (void) hipFree(s->g_part);
     if (s->g_raw) (void) hipFree(s->g_raw);
     if (s->copy) (void) hipStreamDestroy(s->copy);
@@ -572,6 +586,20 @@ fx_status fx_stream_create(fx_context* c, int hops_per_batch, int slots, int sam
         const char* e = getenv("FX_STREAM_GRAPH");          // 0 / 1 force the choice (experiments, tests)
         s->use_graph = e ? atoi(e) != 0 : (size_t) c->C * hops_per_batch <= 4096;
     }
+    {
+        const char* e = getenv("FX_STREAM_HOP_KERNEL");     // 0 forces the captured two-kernel step (experiments, tests)
+        // (up to 1 MiB of hops per call: the kernel reads each hop out of the pinned slot exactly once, 16 bytes per lane)
+        s->use_hop_kernel = hops_per_batch == 1 && s->in_bytes <= 1024 * 1024 && fxk::hop_kernel_available(c->N)
+                            && !(c->flags & (FX_SPECTRAL_ONLY | FX_HARMONIC_ONLY)) && !(e && atoi(e) == 0) && s->use_graph;
+        if (s->use_hop_kernel) s->use_graph = false;
+    }
+    if (s->use_hop_kernel) {
+        S_TRY(hipMalloc((void**) &s->d_arrivals, sizeof(unsigned)));
+        S_TRY(hipMemsetAsync(s->d_arrivals, 0, sizeof(unsigned), c->stream));
+        S_TRY(hipMalloc(&s->d_stage, s->in_bytes));
+    }
+    // the hop kernel's results and flag are read by the host while the kernel may still be running: coherent (fine-grained) memory
+    const unsigned host_flags = s->use_hop_kernel ? hipHostMallocCoherent : hipHostMallocDefault;
     if (s->use_graph) {
         S_TRY(hipMalloc((void**) &s->g_part, (size_t) c->C * hops_per_batch * sizeof(fxk::FramePart)));
         S_TRY(hipMalloc((void**) &s->g_raw, s->out_bytes));
@@ -581,9 +609,13 @@ fx_status fx_stream_create(fx_context* c, int hops_per_batch, int slots, int sam
             S_TRY(hipHostMalloc((void**) &sl.h_dyn, sizeof(fxk::DynParams), hipHostMallocDefault));
             S_TRY(hipMalloc((void**) &sl.d_dyn, sizeof(fxk::DynParams)));
         }
-        S_TRY(hipHostMalloc(&sl.h_in, s->in_bytes, hipHostMallocDefault));
-        S_TRY(hipHostMalloc((void**) &sl.h_raw, s->out_bytes, hipHostMallocDefault));
-        S_TRY(hipHostMalloc((void**) &sl.h_sm, s->out_bytes, hipHostMallocDefault));
+        if (s->use_hop_kernel) {
+            S_TRY(hipHostMalloc((void**) &sl.h_flag, 64, hipHostMallocCoherent));
+            *sl.h_flag = 0;
+        }
+        S_TRY(hipHostMalloc(&sl.h_in, s->in_bytes, host_flags));
+        S_TRY(hipHostMalloc((void**) &sl.h_raw, s->out_bytes, host_flags));
+        S_TRY(hipHostMalloc((void**) &sl.h_sm, s->out_bytes, host_flags));
         S_TRY(hipMalloc(&sl.d_in, s->in_bytes));
         S_TRY(hipMalloc((void**) &sl.d_raw, s->out_bytes));
         S_TRY(hipMalloc((void**) &sl.d_sm, s->out_bytes));
@@ -617,6 +649,30 @@ fx_status fx_stream_submit(fx_stream* s)
     fx_context* c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
     fx_stream::Slot& sl = s->ring[(size_t) s->head];
+    if (s->use_hop_kernel) {
+        if (!sl.dev_flag) {
+            void* q = nullptr;
+            HIP_TRY(hipHostGetDevicePointer(&q, sl.h_in, 0));   sl.dev_in = q;
+            HIP_TRY(hipHostGetDevicePointer(&q, sl.h_raw, 0));  sl.dev_raw = static_cast<float*>(q);
+            HIP_TRY(hipHostGetDevicePointer(&q, sl.h_sm, 0));   sl.dev_sm = static_cast<float*>(q);
+            HIP_TRY(hipHostGetDevicePointer(&q, sl.h_flag, 0)); sl.dev_flag = static_cast<unsigned*>(q);
+        }
+        unsigned* flag_dev = sl.dev_flag;
+        Step step;
+        fx_status st0 = prepare_step(c, sl.dev_in, 1, s->fmt, 1, sl.dev_raw, sl.dev_sm, nullptr, nullptr, nullptr, &step);
+        if (st0 != FX_OK) { s->acquired = false; return st0; }
+        if (++s->next_seq == 0) s->next_seq = 1;            // 0 = "nothing completed yet"
+        sl.seq = s->next_seq;
+        const fxk::HopSignal sig = {s->d_arrivals, flag_dev, sl.seq, 0u, s->d_stage};
+        const hipError_t e = fxk::launch_hop_kernel(c->N, step.fp, step.ep, sig, c->stream);
+        if (e != hipSuccess) { s->acquired = false; return fx_fail(FX_ERR_HIP, "launching the hop kernel failed: %s", hipGetErrorString(e)); }
+        c->ev_valid = false;
+        advance(c, 1);
+        s->head = (s->head + 1) % s->slots;
+        s->in_flight++;
+        s->acquired = false;
+        return FX_OK;
+    }
     if (s->use_graph) {
         const int par = c->cur;
         fill_dyn(c, sl.h_dyn);
@@ -700,7 +756,20 @@ fx_status fx_stream_collect(fx_stream* s, float* out_raw, float* out_smoothed)
     if (s->in_flight == 0) return fx_fail(FX_ERR_INVALID_ARGUMENT, "nothing in flight");
     HIP_TRY(hipSetDevice(s->ctx->device));
     fx_stream::Slot& sl = s->ring[(size_t) s->tail];
-    HIP_TRY(hipEventSynchronize(sl.out));
+    if (s->use_hop_kernel) {
+        // the kernel stores the call's sequence number after its results: poll it (a hop takes tens of microseconds,
+        // an event wait costs as much again); if it does not show up soon -- a large grid, a busy device -- wait for the stream
+        volatile unsigned* flag = sl.h_flag;
+        bool seen = false;
+        for (int spin = 0; spin < 200000; spin++) {
+            if (*flag == sl.seq) { seen = true; break; }
+            __builtin_ia32_pause();
+        }
+        if (!seen) HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    } else {
+        HIP_TRY(hipEventSynchronize(sl.out));
+    }
     if (out_raw) memcpy(out_raw, sl.h_raw, s->out_bytes);
     if (out_smoothed) memcpy(out_smoothed, sl.h_sm, s->out_bytes);
     s->tail = (s->tail + 1) % s->slots;

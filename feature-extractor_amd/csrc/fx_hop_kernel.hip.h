@@ -1,0 +1,162 @@
+// fx_hop_kernel.hip.h -- fx_hop_kernel: ONE hop per channel per call, end to end in one launch (the streaming ring at
+// one hop per call, BASELINE configs[4]).  Included by fx_kernels.hip inside namespace fxk; not a stand-alone header.
+//
+// The batch path (fx_frame_kernel + tail kernels) is built for throughput: a frame lives in one wavefront and a step is
+// two to four launches.  For a single hop that is all latency: ~9.4 k dependent-issue instructions on one SIMD at 4096
+// points, a kernel boundary, a graph replay and an event wait.  Here a workgroup is one channel and THREE wavefronts, one
+// per independent part of the reference's two run() loops (ref RealTimeAnalyser.h:141-177, :201-234):
+//   wave 0  pitch estimate: low-pass, window, transform, re^2, inverse transform, lag search      (a10-a14)
+//   wave 1  spectral analyser: RMS, Bartlett window, transform, spectral sums, flux state         (a2-a7)
+//   wave 2  harmonic analyser: transform of the raw frame, its sums; then -- once wave 0 has the
+//           lag -- peaks, harmonic energy ratio, inharmonicity                                     (a15-a18)
+// each with its own transform buffer, running the very sections of FrameWave the batch kernel runs (same bits).  The
+// frame's record stays in LDS; wave 0 then finishes the hop the way fx_tail_fused_kernel does (scalar tail, smoothing,
+// onset, history) and the last workgroup to arrive stores the call's sequence number where the host is polling -- in
+// pinned host memory, next to the results, which the kernel also writes there directly.  No second launch, no graph,
+// no event: the critical path is the pitch estimate plus the harmonic tail.
+
+template <int N> struct HopGeo {
+    typedef Geo<N> G;
+    static constexpr int    PREV_FLOATS = G::BIMG + (G::BQ ? 0 : 4);
+    static constexpr size_t OFF_PREV = sizeof(f2) * N;
+    static constexpr size_t OFF_WAVES = OFF_PREV + sizeof(float) * PREV_FLOATS;
+    static constexpr size_t OFF_PART = OFF_WAVES + 3 * (size_t) G::BUF_BYTES;
+    static constexpr size_t OFF_HIST = OFF_PART + sizeof(FramePart);
+    static constexpr size_t OFF_RAW = OFF_HIST + sizeof(float) * HLEN * FX_NUM_FEATURES;
+    static constexpr size_t OFF_ONSET = OFF_RAW + sizeof(float) * 16;       // detect_onset_wave's scratch
+    static constexpr size_t BYTES = OFF_ONSET + sizeof(float) * 64;
+    static_assert(OFF_WAVES % 16 == 0 && OFF_PART % 16 == 0, "16-byte aligned sections");
+};
+
+template <int N>
+__global__ void __launch_bounds__(192, 1)
+fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSignal sig)
+{
+    FrameParams p = p_arg;
+    typedef Geo<N> G;
+    typedef HopGeo<N> HG;
+    constexpr int M = G::M, P = G::P;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f2*    tw   = reinterpret_cast<f2*>(smem);
+    float* prev = reinterpret_cast<float*>(smem + HG::OFF_PREV);
+    int*   turn = reinterpret_cast<int*>(G::BQ ? prev + G::U : prev + G::BIMG);
+    FramePart* part = reinterpret_cast<FramePart*>(smem + HG::OFF_PART);
+    float* s_hist = reinterpret_cast<float*>(smem + HG::OFF_HIST);
+    float* s_raw  = reinterpret_cast<float*>(smem + HG::OFF_RAW);
+    float* s_onset = reinterpret_cast<float*>(smem + HG::OFF_ONSET);
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x;
+    f2*    cbuf = reinterpret_cast<f2*>(smem + HG::OFF_WAVES + (size_t) G::BUF_BYTES * wave);
+    float* rbuf = reinterpret_cast<float*>(cbuf);
+
+    // prologue: twiddle table, the channel's flux state, the history of raw values -- 16 bytes per lane per load, all
+    // of them issued before the first is used (this is one trip to memory, not twenty)
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(p.tw);
+        uint4* dst = reinterpret_cast<uint4*>(tw);
+#pragma unroll 4
+        for (int i = threadIdx.x; i < N / 2; i += 192) dst[i] = src[i];
+        const f4* ps = reinterpret_cast<const f4*>(p.prev_re + (size_t) c * M);
+#pragma unroll 2
+        for (int i = threadIdx.x; i < M / 4; i += 192) *reinterpret_cast<f4*>(&prev[bimg<N>(4 * i)]) = ps[i];   // 4 | U: a group stays whole
+        const uint4* hs4 = reinterpret_cast<const uint4*>(ep_arg.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES);
+        for (int i = threadIdx.x; i < HLEN * FX_NUM_FEATURES / 4; i += 192) reinterpret_cast<uint4*>(s_hist)[i] = hs4[i];
+    }
+    if (threadIdx.x == 0) { turn[0] = 0; part->flags = 0; }
+    {
+        // the hop itself: out of the pinned host slot into device memory, 16 bytes per lane, once
+        const size_t hop_bytes = (size_t) (N / 2) * (p.sample_format == FX_SAMPLE_F16 ? 2 : 4);
+        const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(p.in) + (size_t) c * hop_bytes);
+        uint4* dst = reinterpret_cast<uint4*>(static_cast<unsigned char*>(sig.stage) + (size_t) c * hop_bytes);
+        for (int i = threadIdx.x; i < (int) (hop_bytes / 16); i += blockDim.x) dst[i] = src[i];
+        p.in = sig.stage;
+    }
+    __syncthreads();                                            // (waits for the stores above as well)
+
+    TwRegs<N> twr;
+    if constexpr (TwRegs<N>::USE) twr.load(tw, lane);
+    const double nyquist = p.nyquist;
+    const FrameWave<N> w{p, tw, &twr, prev, turn, cbuf, rbuf, part, nyquist, 1.0 / nyquist, nyquist / (double) M,
+                         1.0f / (float) N, c, 1, 0};
+
+    // every wave assembles the window in its own buffer (a1): three reads of the same 2-8 KB, two of them from L2
+    const double ssq_lane = w.load_frame(lane);
+    typename FrameWave<N>::HarmonicSpectrum hs;
+    if (wave == 0) {
+        (void) w.pitch(lane);                                   // leaves the lag in the record
+    } else if (wave == 1) {
+        float xr[P];
+        double sum_sq;
+        if constexpr (G::SPLIT) {
+            sum_sq = wave_sum(ssq_lane);
+            if (lane == 0) part->sum_sq = sum_sq;
+            w.load_raw(lane, xr);
+        } else {
+            sum_sq = w.sum_squares(lane, xr);
+        }
+        w.spectral(lane, xr, sum_sq);
+        // this analyser's slots of the raw vector (ref RealTimeAnalyser.h:209-226), while the pitch estimate is still running
+        if (lane == 0) {
+            EpilogueParams e1 = ep_arg; e1.analysers = 1;
+            float out[FX_NUM_FEATURES];
+            finalise_values(e1, *part, out);
+            s_raw[FX_ONSET] = 0.0f; s_raw[FX_RMS] = out[FX_RMS]; s_raw[FX_CENTROID] = out[FX_CENTROID]; s_raw[FX_SPREAD] = out[FX_SPREAD];
+            s_raw[FX_FLATNESS] = out[FX_FLATNESS]; s_raw[FX_LER] = out[FX_LER]; s_raw[FX_FLUX] = out[FX_FLUX]; s_raw[FX_SLOPE] = out[FX_SLOPE];
+        }
+    } else {
+        float xr[P];
+        if constexpr (G::SPLIT) {
+            w.load_raw(lane, xr);
+        } else {
+#pragma unroll
+            for (int g = 0; g < G::GA; g++)
+#pragma unroll
+                for (int j = 0; j < G::RA; j++) xr[g * G::RA + j] = (rbuf + first_pass_rbase<N>(lane, g))[first_pass_rstep<N>(j)];
+            wave_fence();
+        }
+        w.harmonic_spectrum(lane, xr, hs);
+    }
+    __syncthreads();                                            // the lag is known
+    if (wave == 2) {
+        const double f0 = (nyquist * 2.0) / (double) part->lag; // ref PitchAnalyser.h:57
+        w.harmonic_tail(lane, hs, f0);
+        if (lane == 0) {                                        // the harmonic analyser's slots (ref RealTimeAnalyser.h:150-172)
+            EpilogueParams e2 = ep_arg; e2.analysers = 2;
+            float out[FX_NUM_FEATURES];
+            finalise_values(e2, *part, out);
+            s_raw[FX_F0] = out[FX_F0]; s_raw[FX_HER] = out[FX_HER]; s_raw[FX_OER] = out[FX_OER]; s_raw[FX_INHARM] = out[FX_INHARM];
+        }
+    }
+    __syncthreads();                                            // the record is complete, the flux state is final
+    for (int i = threadIdx.x; i < M; i += blockDim.x) p.prev_re[(size_t) c * M + i] = prev[bimg<N>(i)];
+    if (wave != 0) return;
+
+    // the rest of the hop -- smoothing, onset, history -- as fx_tail_fused_kernel does it for T = 1, from LDS, one slot per lane
+    EpilogueParams ep = ep_arg;
+    ep.raw = s_raw - (size_t) c * FX_NUM_FEATURES;              // epilogue_hop / history_value index by channel
+    ep.hist_in = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
+    epilogue_hop(ep, c, lane, s_onset);
+    for (int i = lane; i < HLEN * FX_NUM_FEATURES; i += 64) history_value(ep, (long long) c * HLEN * FX_NUM_FEATURES + i);
+
+    // completion: this workgroup's results (pinned host memory) are visible system-wide before it counts itself in
+    if (lane == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        const unsigned before = __hip_atomic_fetch_add(sig.arrivals, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (before + 1 == gridDim.x) {
+            __hip_atomic_store(sig.arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sig.host_flag, sig.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+template <int N> hipError_t hop_prepare_t()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_hop_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+template <int N> hipError_t hop_launch_t(const FrameParams& p, const EpilogueParams& ep, const HopSignal& sig, hipStream_t stream)
+{
+    hipLaunchKernelGGL((fx_hop_kernel<N>), dim3((unsigned) p.C), dim3(192), HopGeo<N>::BYTES, stream, p, ep, sig);
+    return hipGetLastError();
+}

@@ -97,6 +97,18 @@ struct EpilogueParams {
     const DynParams* dyn;       // non-null in a captured step: overrides nyquist, frames_before, onset_*
 };
 
+// Completion signal of a one-hop call (fx_hop_kernel): workgroups count themselves in `arrivals` (device memory, zero
+// between calls); the last one resets it and stores `seq` to `host_flag` (pinned host memory, system scope), after the
+// results -- which the kernel writes to pinned host memory as well -- are visible there.
+struct HopSignal {
+    unsigned* arrivals;
+    unsigned* host_flag;
+    unsigned  seq;
+    unsigned  pad_;
+    void*     stage;        // device memory, one hop per channel: the kernel copies the hop out of the pinned slot once
+                            // (coalesced) and its three wavefronts read it from there (the slot is un-cached memory across PCIe)
+};
+
 // Re-order the reference's N-entry twiddle table (canonical[i] = (re, im) of e^{-2*pi*i/N} as floats)
 // into the order the FFT passes read it; `out` has room for window_size complex entries.
 void build_pass_twiddles(int window_size, const float* canonical, float* out);
@@ -112,6 +124,10 @@ void frame_kernel_preferred_shape(int window_size, int* channels_per_wg, int* wa
 hipError_t launch_frame_kernel(int window_size, const FrameParams& p, int analysers, hipStream_t stream);
 hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t stream);
 hipError_t prepare_kernels(int window_size);   // raises the dynamic-LDS limit once per process
+// One hop per channel, whole step in one launch (three wavefronts per channel + the tail), results and completion flag
+// written by the kernel itself; p.T must be 1, p.hop_mode 1, both analysers on.  Window sizes: hop_kernel_available().
+bool hop_kernel_available(int window_size);
+hipError_t launch_hop_kernel(int window_size, const FrameParams& p, const EpilogueParams& ep, const HopSignal& sig, hipStream_t stream);
 
 } // namespace fxk
 #endif

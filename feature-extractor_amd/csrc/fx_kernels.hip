@@ -48,11 +48,41 @@ namespace fxk {
 #ifndef FX_PART
 #define FX_PART 0
 #endif
+// FX_PART=3 holds fx_hop_kernel (one hop per call in one launch: the frame sections and the tail's device functions).
+#if FX_PART == 0 || FX_PART == 1
+#define FX_WITH_TAIL_KERNELS
+#endif
 #if FX_PART != 2
 #include "fx_tail_kernels.hip.h"
 #endif
+#if FX_PART == 0 || FX_PART == 3
+#include "fx_hop_kernel.hip.h"
+#endif
 
 
+#if FX_PART == 0 || FX_PART == 3
+bool hop_kernel_available(int n) { return n == 1024 || n == 2048 || n == 4096; }
+hipError_t launch_hop_kernel(int n, const FrameParams& p, const EpilogueParams& ep, const HopSignal& sig, hipStream_t stream)
+{
+    if (p.C <= 0) return hipSuccess;
+    if (p.T != 1 || !p.hop_mode || ep.T != 1 || ep.analysers != 3) return hipErrorInvalidValue;
+    static bool prepared[3] = {false, false, false};
+    const int slot = n == 1024 ? 0 : (n == 2048 ? 1 : 2);
+    if (!hop_kernel_available(n)) return hipErrorInvalidValue;
+    if (!prepared[slot]) {
+        const hipError_t e = n == 1024 ? hop_prepare_t<1024>() : (n == 2048 ? hop_prepare_t<2048>() : hop_prepare_t<4096>());
+        if (e != hipSuccess) return e;
+        prepared[slot] = true;
+    }
+    switch (n) {
+        case 1024: return hop_launch_t<1024>(p, ep, sig, stream);
+        case 2048: return hop_launch_t<2048>(p, ep, sig, stream);
+        default:   return hop_launch_t<4096>(p, ep, sig, stream);
+    }
+}
+#endif
+
+#if FX_PART != 3
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
@@ -251,6 +281,7 @@ hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t stream)
 }
 
 #endif // FX_PART != 2
+#endif // FX_PART != 3
 
 } // namespace fxk
 

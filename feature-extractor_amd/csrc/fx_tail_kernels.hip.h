@@ -1,6 +1,7 @@
 // fx_tail_kernels.hip.h -- fx_finalise_kernel, fx_epilogue_kernel, fx_history_kernel: scalar tails, smoothing, onset
 // Included by fx_kernels.hip inside namespace fxk (one translation unit: every kernel sees the same
-// inlined helpers); not a stand-alone header.
+// inlined helpers); not a stand-alone header.  The __global__ kernels are compiled only where FX_WITH_TAIL_KERNELS is
+// defined (one object of the library); the device functions are also what fx_hop_kernel finishes a hop with.
 
 // a captured step (hipGraph) reads what changes from call to call from device memory
 __device__ __forceinline__ EpilogueParams with_dyn(const EpilogueParams& in)
@@ -23,12 +24,10 @@ __device__ __forceinline__ EpilogueParams with_dyn(const EpilogueParams& in)
 // the harmonic logs (ref HarmonicCharacteristics.h:101-105) and the slot mapping of
 // RealTimeAnalyser.h:165-172,219-224.  Output: raw[C][T][12] with the onset slot still 0.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void finalise_frame(const EpilogueParams& p, long long idx)
+__device__ __forceinline__ void finalise_values(const EpilogueParams& p, const FramePart& f, float (&out)[FX_NUM_FEATURES])
 {
-    const FramePart f = p.part[idx];
     const int M = p.window / 2;
     const double nyquist = p.nyquist;
-    float out[FX_NUM_FEATURES];
 #pragma unroll
     for (int i = 0; i < FX_NUM_FEATURES; i++) out[i] = 0.0f;
     // a2, ref RealTimeAnalyser.h:207-208: log10 of a float, correctly rounded -- it also gates bins through eps, so it
@@ -82,12 +81,20 @@ __device__ __forceinline__ void finalise_frame(const EpilogueParams& p, long lon
         out[FX_OER] = log_her;                                                 // ref RealTimeAnalyser.h:171 writes HER into the OER slot
         out[FX_INHARM] = (float) log10(f.inh * 9.0 + 1.0);                     // :102
     }
+}
+
+__device__ __forceinline__ void finalise_frame(const EpilogueParams& p, long long idx)
+{
+    const FramePart f = p.part[idx];
+    float out[FX_NUM_FEATURES];
+    finalise_values(p, f, out);
     f4* dst = reinterpret_cast<f4*>(p.raw + idx * FX_NUM_FEATURES);
     dst[0] = f4{out[0], out[1], out[2], out[3]};
     dst[1] = f4{out[4], out[5], out[6], out[7]};
     dst[2] = f4{out[8], out[9], out[10], out[11]};
 }
 
+#ifdef FX_WITH_TAIL_KERNELS
 __global__ void __launch_bounds__(256)
 fx_finalise_kernel(const EpilogueParams p_arg)
 {
@@ -96,6 +103,7 @@ fx_finalise_kernel(const EpilogueParams p_arg)
     if (idx >= (long long) p.C * p.T) return;
     finalise_frame(p, idx);
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // smoothing (ValueHistory, ref RealTimeAudioAnalysis.h:40-96; AudioFeatures, ref
@@ -153,43 +161,11 @@ __device__ __forceinline__ float rms_value(const RawView& v, int tau, int order_
     return total / (float) recorded;
 }
 
-__device__ __forceinline__ void epilogue_frame(const EpilogueParams& p, int c, int t, const float* tile = nullptr, int tile_first = 0)
+// OnsetDetector::detectOnset, ref SpectralCharacteristics.h:249-306, for frame t.  The detector's histories
+// hold (getValue(enFlux), getValue(enRMS)) as seen by detectOnset() of each frame
+// (ref RealTimeAnalyser.h:236-242): flux of that frame, and the RMS mean at that moment.
+__device__ __forceinline__ bool detect_onset(const EpilogueParams& p, const RawView& v, int t, int order_mode, bool spec)
 {
-    RawView v;
-    v.raw = p.raw + (size_t) c * p.T * FX_NUM_FEATURES;
-    v.hist = p.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES;
-    v.T = p.T;
-    v.frames_before = p.frames_before;
-    v.tile = tile;
-    v.tile_first = tile_first;
-
-    float sm[FX_NUM_FEATURES];
-    float rw[FX_NUM_FEATURES];
-#pragma unroll
-    for (int s = 0; s < FX_NUM_FEATURES; s++) rw[s] = v.get(t, s);
-
-    const bool spec = p.analysers & 1, harm = p.analysers & 2;
-    // with a single analyser the RMS slot gets one insert per hop, like an isolated AudioFeatures
-    const int order_mode = (spec && harm) ? p.order_mode : FX_ORDER_ISOLATED;
-    const float never = __int_as_float(0x7fc00000);                  // getValue() of a slot nobody wrote: 0.0f / 0
-    // 10-deep slots (ref RealTimeAnalyser.h:73)
-    long long rec10 = p.frames_before + t + 1; if (rec10 > 10) rec10 = 10;
-#pragma unroll
-    for (int s = 0; s < FX_NUM_FEATURES; s++) {
-        if (s == FX_ONSET || s == FX_FLUX || s == FX_RMS) continue;
-        const bool harm_slot = s == FX_F0 || s == FX_HER || s == FX_OER || s == FX_INHARM;
-        float total = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 10; i++) { const int f = t - 9 + i; total += v.valid(f) ? v.get(f, s) : 0.0f; }
-        sm[s] = (harm_slot ? harm : spec) ? total / (float) rec10 : never;
-    }
-    sm[FX_FLUX] = spec ? (0.0f + rw[FX_FLUX]) / 1.0f : never;        // history length 1
-    // RMS after every analyser of this hop has inserted (what the OSC timer samples)
-    sm[FX_RMS] = rms_value(v, t, order_mode, 2);
-
-    // OnsetDetector::detectOnset, ref SpectralCharacteristics.h:249-306.  The detector's histories
-    // hold (getValue(enFlux), getValue(enRMS)) as seen by detectOnset() of each frame
-    // (ref RealTimeAnalyser.h:236-242): flux of that frame, and the RMS mean at that moment.
     const int L = p.onset_window;
     const int rms_pushes_at_detect = (order_mode == FX_ORDER_HARMONIC_THEN_SPECTRAL) ? 2 : 1;
     const long long g = p.frames_before + t;
@@ -227,6 +203,44 @@ __device__ __forceinline__ void epilogue_frame(const EpilogueParams& p, int c, i
         else if (p.onset_type == FX_ONSET_COMBINATION) res = on_amp && on_sf;
         onset = ok && res;
     }
+    return onset;
+}
+
+__device__ __forceinline__ void epilogue_frame(const EpilogueParams& p, int c, int t, const float* tile = nullptr, int tile_first = 0)
+{
+    RawView v;
+    v.raw = p.raw + (size_t) c * p.T * FX_NUM_FEATURES;
+    v.hist = p.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES;
+    v.T = p.T;
+    v.frames_before = p.frames_before;
+    v.tile = tile;
+    v.tile_first = tile_first;
+
+    float sm[FX_NUM_FEATURES];
+    float rw[FX_NUM_FEATURES];
+#pragma unroll
+    for (int s = 0; s < FX_NUM_FEATURES; s++) rw[s] = v.get(t, s);
+
+    const bool spec = p.analysers & 1, harm = p.analysers & 2;
+    // with a single analyser the RMS slot gets one insert per hop, like an isolated AudioFeatures
+    const int order_mode = (spec && harm) ? p.order_mode : FX_ORDER_ISOLATED;
+    const float never = __int_as_float(0x7fc00000);                  // getValue() of a slot nobody wrote: 0.0f / 0
+    // 10-deep slots (ref RealTimeAnalyser.h:73)
+    long long rec10 = p.frames_before + t + 1; if (rec10 > 10) rec10 = 10;
+#pragma unroll
+    for (int s = 0; s < FX_NUM_FEATURES; s++) {
+        if (s == FX_ONSET || s == FX_FLUX || s == FX_RMS) continue;
+        const bool harm_slot = s == FX_F0 || s == FX_HER || s == FX_OER || s == FX_INHARM;
+        float total = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 10; i++) { const int f = t - 9 + i; total += v.valid(f) ? v.get(f, s) : 0.0f; }
+        sm[s] = (harm_slot ? harm : spec) ? total / (float) rec10 : never;
+    }
+    sm[FX_FLUX] = spec ? (0.0f + rw[FX_FLUX]) / 1.0f : never;        // history length 1
+    // RMS after every analyser of this hop has inserted (what the OSC timer samples)
+    sm[FX_RMS] = rms_value(v, t, order_mode, 2);
+
+    const bool onset = detect_onset(p, v, t, order_mode, spec);
     rw[FX_ONSET] = onset ? 1.0f : 0.0f;
     sm[FX_ONSET] = spec ? (0.0f + rw[FX_ONSET]) / 1.0f : never;      // history length 1
 
@@ -245,9 +259,96 @@ __device__ __forceinline__ void epilogue_frame(const EpilogueParams& p, int c, i
     }
 }
 
+// detect_onset for a whole wavefront: the L <= 32 candidates' (RMS mean, flux) pairs -- each RMS mean is ten history
+// reads and the index arithmetic of the double insert -- are evaluated by L lanes side by side into `scratch` ([64]
+// floats of LDS); the detector's serial loop then only reads them back.  Same values, same order of additions; the
+// result is wave-uniform.
+__device__ __forceinline__ bool detect_onset_wave(const EpilogueParams& p, const RawView& v, int t, int order_mode, bool spec, int lane, float* scratch)
+{
+    const int L = p.onset_window;
+    const int rms_pushes_at_detect = (order_mode == FX_ORDER_HARMONIC_THEN_SPECTRAL) ? 2 : 1;
+    const long long g = p.frames_before + t;
+    long long recorded = g - p.onset_reset_frame + 1;
+    if (recorded > L) recorded = L;
+    if (!(spec && recorded >= L && L > 0)) return false;            // :253-258 both histories full
+    if (lane < L) {
+        const int f = t - L + 1 + lane;
+        scratch[lane] = rms_value(v, f, order_mode, rms_pushes_at_detect);
+        scratch[32 + lane] = (0.0f + v.get(f, FX_FLUX)) / 1.0f;
+    }
+    wave_fence();
+    int cand = L - 1;                                               // :263-266
+    const bool use_amp = p.onset_type == FX_ONSET_AMPLITUDE || p.onset_type == FX_ONSET_COMBINATION;
+    const bool use_flux = p.onset_type == FX_ONSET_SPECTRAL || p.onset_type == FX_ONSET_COMBINATION;
+    if (use_flux) cand = L / 2;
+    const float cand_amp = scratch[cand];
+    const float cand_sf = scratch[32 + cand];
+    bool ok = !(cand_amp < 0.01f);                                  // :271-274
+    float tot_amp = 0.0f, tot_flux = 0.0f;
+#pragma unroll 1
+    for (int i = 0; i < L; i++) {                                   // :260-261 totals, :276-289 neighbours
+        const float amp_i = scratch[i];
+        const float flx_i = scratch[32 + i];
+        tot_amp += amp_i;
+        tot_flux += flx_i;
+        if (i != cand) {
+            if (amp_i >= cand_amp && use_amp) ok = false;
+            if (flx_i >= cand_sf && use_flux) ok = false;
+        }
+    }
+    const float mean_flux = tot_flux / (float) recorded;
+    const float mean_amp = tot_amp / (float) recorded;
+    const bool on_sf = cand_sf > mean_flux * p.onset_multiplier;    // :291-292
+    const bool on_amp = cand_amp > mean_amp * p.onset_multiplier;
+    bool res = false;
+    if (p.onset_type == FX_ONSET_AMPLITUDE) res = on_amp;
+    else if (p.onset_type == FX_ONSET_SPECTRAL) res = on_sf;
+    else if (p.onset_type == FX_ONSET_COMBINATION) res = on_amp && on_sf;
+    return ok && res;
+}
+
+// The same for the single frame of a one-hop call (T == 1) with the twelve slots spread over twelve lanes: lane s
+// evaluates slot s (the onset lane the detector, the RMS lane the double-insert mean), so the hop's tail takes the time
+// of its longest slot instead of the sum of all.  Same expressions, same order of the fp32 additions as epilogue_frame.
+__device__ __forceinline__ void epilogue_hop(const EpilogueParams& p, int c, int lane, float* scratch)
+{
+    RawView v;
+    v.raw = p.raw + (size_t) c * p.T * FX_NUM_FEATURES;
+    v.hist = p.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES;
+    v.T = p.T;
+    v.frames_before = p.frames_before;
+    const int t = 0, s = lane;
+    const bool spec = p.analysers & 1, harm = p.analysers & 2;
+    const int order_mode = (spec && harm) ? p.order_mode : FX_ORDER_ISOLATED;
+    const float never = __int_as_float(0x7fc00000);
+    const bool onset = detect_onset_wave(p, v, t, order_mode, spec, lane, scratch);       // all 64 lanes
+    if (lane >= FX_NUM_FEATURES) return;
+    float rw = v.get(t, s), sm;
+    if (s == FX_ONSET) {
+        rw = onset ? 1.0f : 0.0f;
+        sm = spec ? (0.0f + rw) / 1.0f : never;
+    } else if (s == FX_FLUX) {
+        sm = spec ? (0.0f + rw) / 1.0f : never;
+    } else if (s == FX_RMS) {
+        sm = rms_value(v, t, order_mode, 2);
+    } else {
+        long long rec10 = p.frames_before + t + 1; if (rec10 > 10) rec10 = 10;
+        const bool harm_slot = s == FX_F0 || s == FX_HER || s == FX_OER || s == FX_INHARM;
+        float total = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 10; i++) { const int f = t - 9 + i; total += v.valid(f) ? v.get(f, s) : 0.0f; }
+        sm = (harm_slot ? harm : spec) ? total / (float) rec10 : never;
+    }
+    const size_t o = ((size_t) c * p.T + t) * FX_NUM_FEATURES + s;
+    if (p.out_raw) p.out_raw[o] = rw;
+    if (p.out_smoothed) p.out_smoothed[o] = sm;
+    p.latest[(size_t) c * FX_NUM_FEATURES + s] = sm;
+}
+
 // thread = (channel, frame); a block is EPI_TILE consecutive frames of ONE channel and first stages the rows it needs
 // (its own and the HLEN - 1 before them) in LDS: each thread's ~70 reads of neighbouring rows then hit LDS instead of L2
 constexpr int EPI_TILE = 256;
+#ifdef FX_WITH_TAIL_KERNELS
 __global__ void __launch_bounds__(EPI_TILE)
 fx_epilogue_kernel(const EpilogueParams p_arg)
 {
@@ -269,6 +370,7 @@ fx_epilogue_kernel(const EpilogueParams p_arg)
     const int t = t0 + (int) threadIdx.x;
     if (t < p.T) epilogue_frame(p, c, t, tile, first);
 }
+#endif
 
 // carry the newest HLEN frames of raw values over to the next call
 __device__ __forceinline__ void history_value(const EpilogueParams& p, long long idx)
@@ -283,6 +385,7 @@ __device__ __forceinline__ void history_value(const EpilogueParams& p, long long
     p.hist_out[idx] = val;
 }
 
+#ifdef FX_WITH_TAIL_KERNELS
 __global__ void __launch_bounds__(256)
 fx_history_kernel(const EpilogueParams p)
 {
@@ -290,12 +393,14 @@ fx_history_kernel(const EpilogueParams p)
     if (idx >= (long long) p.C * HLEN * FX_NUM_FEATURES) return;
     history_value(p, idx);
 }
+#endif
 
 // The three kernels above in one launch for calls of a few frames per channel (the streaming ring at one hop per call),
 // where two kernel boundaries cost more than the work: one wavefront per channel.  Lane t finalises frame t; the raw
 // values of the HLEN frames before the call and of the call's own frames are staged in LDS (one round trip to memory
 // instead of the ~70 dependent ones of the smoothing / onset loops), lane t smooths frame t from there, then all 64
 // lanes carry the history over.
+#ifdef FX_WITH_TAIL_KERNELS
 __global__ void __launch_bounds__(64)
 fx_tail_fused_kernel(const EpilogueParams p_arg)
 {
@@ -318,3 +423,4 @@ fx_tail_fused_kernel(const EpilogueParams p_arg)
     p.raw = const_cast<float*>(g_raw); p.hist_in = g_hist;
     for (int i = lane; i < HLEN * FX_NUM_FEATURES; i += 64) history_value(p, (long long) c * HLEN * FX_NUM_FEATURES + i);
 }
+#endif

@@ -299,6 +299,59 @@ def test_hop_stream_settings_change_mid_stream(gpu_fx, monkeypatch, graph):
     st.close()
 
 
+@pytest.mark.parametrize("N,C", [(1024, 5), (2048, 3), (4096, 1), (4096, 4)])
+def test_one_hop_per_call_kernel_equals_push_hops_bitwise(gpu_fx, monkeypatch, N, C):
+    """One hop per call through the ring runs as ONE launch of fx_hop_kernel (three wavefronts per channel, results and
+    completion flag written by the kernel, the host polling the flag).  It must equal fx_push_hops bit for bit -- the
+    same sections of the frame code, the same tail -- with setter calls in between, with up to three calls in flight,
+    and it must equal the captured two-kernel step it replaces (FX_STREAM_HOP_KERNEL=0)."""
+    nb = 40
+    hops = np.concatenate([signals.bursts(C, nb // 2, N, seed=5), signals.low_tones(C, nb - nb // 2, N)], axis=1)
+
+    def settings(an, b):
+        if b == 7:
+            an.set_gain(0.5)
+            an.set_onset_window_length(4)
+        if b == 15:
+            an.set_onset_detection_type(2)
+            an.set_onset_detection_sensitivity(0.2)
+        if b == 22:
+            an.sample_rate_changed(44100.0)
+        if b == 31:
+            an.reset_state()
+
+    ref = gpu_fx.BatchAnalyser(C, N)
+    want = []
+    for b in range(nb):
+        settings(ref, b)
+        want.append(ref.push_hops(hops[:, b:b + 1]))
+
+    def through_ring(depth):
+        an = gpu_fx.BatchAnalyser(C, N)
+        st = gpu_fx.HopStream(an, 1, slots=3)
+        got = []
+        for b in range(nb):
+            settings(an, b)
+            if st.in_flight() == depth:
+                got.append(st.collect())
+            st.push(hops[:, b:b + 1])
+        while st.in_flight():
+            got.append(st.collect())
+        feats = an.get_features()
+        st.close()
+        return got, feats
+
+    for depth in (1, 3):
+        got, feats = through_ring(depth)
+        for k in (0, 1):
+            assert np.array_equal(np.concatenate([g[k] for g in got], 1), np.concatenate([w[k] for w in want], 1), equal_nan=True), (depth, k)
+        assert np.array_equal(feats, ref.get_features(), equal_nan=True)
+    monkeypatch.setenv("FX_STREAM_HOP_KERNEL", "0")
+    got, feats = through_ring(2)
+    for k in (0, 1):
+        assert np.array_equal(np.concatenate([g[k] for g in got], 1), np.concatenate([w[k] for w in want], 1), equal_nan=True)
+
+
 def test_hop_stream_fp16_4096(gpu_fx, oracle):
     """BASELINE configs[4] shape: 4096-pt windows, fp16 samples streamed through the pinned ring."""
     N, C, B, nb = 4096, 1, 1, 12

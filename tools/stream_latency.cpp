@@ -1,8 +1,9 @@
 // Per-hop cost of the streaming ring (fx_stream_*) from C++, without an interpreter in the loop: BASELINE configs[4] shape
 // (1 channel, 4096-pt windows, fp16 samples, one 2048-sample hop per call).
 //   g++ -O2 -std=c++14 -I include tools/stream_latency.cpp -o stream_latency -L feature-extractor_amd/lib -lfx_hip -Wl,-rpath,$PWD/feature-extractor_amd/lib
-//   ./stream_latency [window] [channels] [hops_per_call] [calls]
+//   ./stream_latency [window] [channels] [hops_per_call] [calls] [ramp]
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,8 +21,34 @@ int main(int argc, char** argv)
     fx_stream* st = nullptr;
     CHECK(fx_stream_create(ctx, H, 3, FX_SAMPLE_F16, &st));
     const size_t hop_bytes = (size_t) C * H * (N / 2) * 2;
-    std::vector<unsigned short> hop(hop_bytes / 2);
-    for (size_t i = 0; i < hop.size(); i++) hop[i] = (unsigned short) (0x2e00 + (i * 37) % 0x400);     // some fp16 values around 0.1
+    // the bench's synthetic signal (a tone with two harmonics and a little noise, 55 * 2^(c/12) Hz per channel
+    // starting at A3 here), `calls` hops of it, as fp16; argv[5] = "ramp" gives the round-1 test pattern instead
+    // (positive values around 0.1: a DC-like input, the lag search's longest path)
+    const bool ramp = argc > 5 && !strcmp(argv[5], "ramp");
+    const int H2 = N / 2, nhops = 64;
+    std::vector<std::vector<unsigned short>> hops(nhops, std::vector<unsigned short>(hop_bytes / 2));
+    {
+        auto to_half = [](float f) -> unsigned short {          // round to nearest even, normal range only
+            unsigned u; memcpy(&u, &f, 4);
+            const unsigned sign = (u >> 16) & 0x8000u; const int e = (int) ((u >> 23) & 0xff) - 127 + 15; unsigned m = u & 0x7fffffu;
+            if (e <= 0) return (unsigned short) sign;
+            unsigned h = sign | ((unsigned) e << 10) | (m >> 13);
+            if ((m & 0x1fffu) > 0x1000u || ((m & 0x1fffu) == 0x1000u && (h & 1u))) h++;
+            return (unsigned short) h;
+        };
+        unsigned long long rng = 0x5EEDull;
+        for (int k = 0; k < nhops; k++)
+            for (int c = 0; c < C; c++)
+                for (int h = 0; h < H; h++)
+                    for (int i = 0; i < H2; i++) {
+                        const size_t at = ((size_t) c * H + h) * H2 + i;
+                        if (ramp) { hops[k][at] = (unsigned short) (0x2e00 + (at * 37) % 0x400); continue; }
+                        const double f = 220.0 * pow(2.0, (c % 36) / 12.0), ph = 2.0 * 3.14159265358979323846 * f * ((double) (k * H + h) * H2 + i) / 48000.0;
+                        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+                        const double u = ((double) (rng >> 40) / 16777216.0 - 0.5) * 0.1;
+                        hops[k][at] = to_half((float) (0.4 * sin(ph) + 0.2 * sin(2 * ph) + 0.1 * sin(3 * ph) + u));
+                    }
+    }
     std::vector<float> sm((size_t) C * H * 12);
     for (int mode = 0; mode < 2; mode++) {
         // mode 0: one hop in flight (submit, then wait for it: the round trip); mode 1: up to three in flight (throughput)
@@ -33,7 +60,7 @@ int main(int argc, char** argv)
                 if (fx_stream_in_flight(st) == depth) CHECK(fx_stream_collect(st, nullptr, sm.data()));
                 void* slot = nullptr;
                 CHECK(fx_stream_acquire(st, &slot));
-                memcpy(slot, hop.data(), hop_bytes);
+                memcpy(slot, hops[i % nhops].data(), hop_bytes);
                 CHECK(fx_stream_submit(st));
             }
             while (fx_stream_in_flight(st)) CHECK(fx_stream_collect(st, nullptr, sm.data()));
