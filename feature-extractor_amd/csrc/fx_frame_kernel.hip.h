@@ -457,8 +457,12 @@ FX_MARK("flux");
                 while (__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t)
                     __builtin_amdgcn_s_sleep(1);
 #endif
+                // the turn is held for two LDS reads and two writes only: the next frame's wave is usually waiting for it
                 float pvf[U];
                 lds_load_block<U>(prev + bimg<N>(U * lane), pvf);
+                if (accepted) lds_store_block<U>(prev + bimg<N>(U * lane), re);         // :138 (only on the accepted path)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(turn, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
                 for (int j = 0; j < U; j++) {
                     const double pv = (double) pvf[j];
@@ -466,9 +470,6 @@ FX_MARK("flux");
                     const double diff = v * v - pv * pv;                       // :76
                     flux += fmax(diff, 0.0);                                   // :77-79 (a NaN difference adds nothing, as `if (diff > 0)`)
                 }
-                if (accepted) lds_store_block<U>(prev + bimg<N>(U * lane), re);         // :138 (only on the accepted path)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) __hip_atomic_store(turn, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             flux = wave_sum(flux);
 
