@@ -431,6 +431,27 @@ def main():
                                    "hbm_frac": b2 / (fms / 1e3) / 1e9 / HBM_PEAK_GBPS}
                 del fr2
             out["other_windows"] = others
+            # BASELINE configs[4]: 1 channel, 4096-pt windows, fp16 samples, ONE hop per call through the pinned ring
+            # (fx_hop_kernel: the whole step in one launch, the host polls a flag) -- per-hop round trip as this
+            # interpreter sees it (tools/stream_latency.cpp measures the same from C++, a few microseconds less)
+            try:
+                an4 = fx.BatchAnalyser(1, 4096, device=local_rank)
+                st4 = fx.HopStream(an4, 1, slots=3, dtype=np.float16)
+                h4 = fx.synth.hops(1, 64, 4096, first_channel=24).astype(np.float16)
+                n_calls = 2000
+                for k in range(n_calls + 200):
+                    if k == 200:
+                        t_s = time.perf_counter()
+                    st4.slot()[...] = h4[:, k % 64:k % 64 + 1]
+                    st4.submit()
+                    st4.collect(want_raw=False)
+                us = (time.perf_counter() - t_s) / n_calls * 1e6
+                st4.close()
+                an4.close()
+                out["streaming_hop"] = {"round_trip_us": us, "unit": "us per 2048-sample hop", "calls": n_calls,
+                                        "workload": "configs[4]: 1 channel x 4096-pt windows, fp16 samples, one hop per call, submit + collect from Python"}
+            except Exception as e:          # never let an extra take the headline line down
+                out["streaming_hop"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1 and not args.debug_collective:
             out["cpu_baseline"] = cpu_baseline(fx, N, T)
         else:

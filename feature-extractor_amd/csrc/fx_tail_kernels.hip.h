@@ -164,7 +164,10 @@ __device__ __forceinline__ float rms_value(const RawView& v, int tau, int order_
 // OnsetDetector::detectOnset, ref SpectralCharacteristics.h:249-306, for frame t.  The detector's histories
 // hold (getValue(enFlux), getValue(enRMS)) as seen by detectOnset() of each frame
 // (ref RealTimeAnalyser.h:236-242): flux of that frame, and the RMS mean at that moment.
-__device__ __forceinline__ bool detect_onset(const EpilogueParams& p, const RawView& v, int t, int order_mode, bool spec)
+// `amp` (optional): amp[f - amp_first] = rms_value(v, f, order_mode, pushes at detection) for the frames around t,
+// evaluated once per frame by the caller's workgroup instead of once per (frame, candidate) here.
+__device__ __forceinline__ bool detect_onset(const EpilogueParams& p, const RawView& v, int t, int order_mode, bool spec,
+                                             const float* amp = nullptr, int amp_first = 0)
 {
     const int L = p.onset_window;
     const int rms_pushes_at_detect = (order_mode == FX_ORDER_HARMONIC_THEN_SPECTRAL) ? 2 : 1;
@@ -177,14 +180,14 @@ __device__ __forceinline__ bool detect_onset(const EpilogueParams& p, const RawV
         const bool use_amp = p.onset_type == FX_ONSET_AMPLITUDE || p.onset_type == FX_ONSET_COMBINATION;
         const bool use_flux = p.onset_type == FX_ONSET_SPECTRAL || p.onset_type == FX_ONSET_COMBINATION;
         if (use_flux) cand = L / 2;
-        const float cand_amp = rms_value(v, t - L + 1 + cand, order_mode, rms_pushes_at_detect);
+        const float cand_amp = amp ? amp[t - L + 1 + cand - amp_first] : rms_value(v, t - L + 1 + cand, order_mode, rms_pushes_at_detect);
         const float cand_sf = (0.0f + v.get(t - L + 1 + cand, FX_FLUX)) / 1.0f;
         bool ok = !(cand_amp < 0.01f);                              // :271-274
         float tot_amp = 0.0f, tot_flux = 0.0f;
 #pragma unroll 1
         for (int i = 0; i < L; i++) {                               // :260-261 totals, :276-289 neighbours
             const int f = t - L + 1 + i;
-            const float amp_i = rms_value(v, f, order_mode, rms_pushes_at_detect);
+            const float amp_i = amp ? amp[f - amp_first] : rms_value(v, f, order_mode, rms_pushes_at_detect);
             const float flx_i = (0.0f + v.get(f, FX_FLUX)) / 1.0f;
             tot_amp += amp_i;
             tot_flux += flx_i;
@@ -206,7 +209,8 @@ __device__ __forceinline__ bool detect_onset(const EpilogueParams& p, const RawV
     return onset;
 }
 
-__device__ __forceinline__ void epilogue_frame(const EpilogueParams& p, int c, int t, const float* tile = nullptr, int tile_first = 0)
+__device__ __forceinline__ void epilogue_frame(const EpilogueParams& p, int c, int t, const float* tile = nullptr, int tile_first = 0,
+                                               const float* amp = nullptr, int amp_first = 0)
 {
     RawView v;
     v.raw = p.raw + (size_t) c * p.T * FX_NUM_FEATURES;
@@ -240,7 +244,7 @@ __device__ __forceinline__ void epilogue_frame(const EpilogueParams& p, int c, i
     // RMS after every analyser of this hop has inserted (what the OSC timer samples)
     sm[FX_RMS] = rms_value(v, t, order_mode, 2);
 
-    const bool onset = detect_onset(p, v, t, order_mode, spec);
+    const bool onset = detect_onset(p, v, t, order_mode, spec, amp, amp_first);
     rw[FX_ONSET] = onset ? 1.0f : 0.0f;
     sm[FX_ONSET] = spec ? (0.0f + rw[FX_ONSET]) / 1.0f : never;      // history length 1
 
@@ -353,6 +357,7 @@ __global__ void __launch_bounds__(EPI_TILE)
 fx_epilogue_kernel(const EpilogueParams p_arg)
 {
     __shared__ float tile[(EPI_TILE + HLEN) * TILE_STRIDE];
+    __shared__ float amp[EPI_TILE + MAX_ONSET_WINDOW];
     const EpilogueParams p = with_dyn(p_arg);
     const int tiles = (p.T + EPI_TILE - 1) / EPI_TILE;
     const int c = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * EPI_TILE;
@@ -367,8 +372,24 @@ fx_epilogue_kernel(const EpilogueParams p_arg)
                                              : (tau >= -HLEN ? hist[(size_t) (HLEN + tau) * FX_NUM_FEATURES + s] : 0.0f);
     }
     __syncthreads();
+    // The detector of frame t compares the RMS means of frames t - L + 1 .. t as they stood at each frame's own
+    // detection (ref RealTimeAnalyser.h:236-242): one value per FRAME, wanted by up to L frames -- evaluated once here
+    // (ten history reads and the double-insert index arithmetic each) for this tile's frames and the MAX_ONSET_WINDOW
+    // before them.
+    {
+        RawView v;
+        v.raw = raw; v.hist = hist; v.T = p.T; v.frames_before = p.frames_before; v.tile = tile; v.tile_first = first;
+        const bool both = (p.analysers & 1) && (p.analysers & 2);
+        const int order_mode = both ? p.order_mode : FX_ORDER_ISOLATED;
+        const int pushes = (order_mode == FX_ORDER_HARMONIC_THEN_SPECTRAL) ? 2 : 1;
+        for (int j = threadIdx.x; j < EPI_TILE + MAX_ONSET_WINDOW; j += EPI_TILE) {
+            const int f = t0 - MAX_ONSET_WINDOW + j;
+            amp[j] = (f < p.T) ? rms_value(v, f, order_mode, pushes) : 0.0f;
+        }
+    }
+    __syncthreads();
     const int t = t0 + (int) threadIdx.x;
-    if (t < p.T) epilogue_frame(p, c, t, tile, first);
+    if (t < p.T) epilogue_frame(p, c, t, tile, first, amp, t0 - MAX_ONSET_WINDOW);
 }
 #endif
 
