@@ -763,7 +763,9 @@ fx_status fx_stream_collect(fx_stream* s, float* out_raw, float* out_smoothed)
         bool seen = false;
         for (int spin = 0; spin < 200000; spin++) {
             if (*flag == sl.seq) { seen = true; break; }
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#endif
         }
         if (!seen) HIP_TRY(hipStreamSynchronize(s->ctx->stream));
         __atomic_thread_fence(__ATOMIC_ACQUIRE);

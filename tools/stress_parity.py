@@ -56,6 +56,8 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
     cases = frames = bad_cases = 0
     worst = 0.0
     inexact = np.zeros(12, np.int64)      # values that are within tolerance but not bit-identical, per slot
+    ring_cases = [0]
+    last_note = time.time()
     while time.time() < t_end and (max_cases is None or cases < max_cases):
         N = int(rng.choice([256, 512, 1024, 1024, 2048, 2048, 4096]))
         C = int(rng.integers(1, 24)) if rng.random() < 0.8 else int(rng.integers(24, 200))
@@ -72,10 +74,27 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
         an.set_onset_detection_type(otype); an.set_onset_window_length(owin)
         an.set_onset_detection_sensitivity(sens); an.set_gain(gain)
         split = int(rng.integers(0, T + 1))
-        parts = [an.push_hops(hops[:, :split]), an.push_hops(hops[:, split:])]
+        ring = which == "both" and N >= 1024 and T <= 24 and rng.random() < 0.25
+        if ring:
+            # one hop per call through the pinned ring: fx_hop_kernel (three wavefronts per channel, one launch per hop)
+            st = fx.HopStream(an, 1, slots=3)
+            parts = []
+            for t in range(T):
+                if st.in_flight() == 3:
+                    parts.append(st.collect())
+                st.push(hops[:, t:t + 1])
+            while st.in_flight():
+                parts.append(st.collect())
+            st.close()
+            ring_cases[0] += 1
+        else:
+            parts = [an.push_hops(hops[:, :split]), an.push_hops(hops[:, split:])]
         raw = np.concatenate([p[0] for p in parts], 1); sm = np.concatenate([p[1] for p in parts], 1)
         oraw, osm = fo.batch_hops(hops, N, order=order, threads=THREADS, onset_type=otype, onset_window=owin, onset_sensitivity=sens, gain=gain, analysers=mask)
         cases += 1; frames += C * T
+        if verbose and time.time() - last_note > 60.0:          # (a run that prints nothing for minutes looks hung to the GPU box's watchdog)
+            last_note = time.time()
+            print("... %d cases, %d frames, %d mismatching so far" % (cases, frames, bad_cases), flush=True)
         for name, g, w in (("raw", raw, oraw), ("smoothed", sm, osm)):
             g64, w64 = g.astype(np.float64), w.astype(np.float64)
             same = (g64 == w64) | (np.isnan(g64) & np.isnan(w64))
@@ -97,6 +116,8 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
                 if verbose:
                     print("MISMATCH %s N=%d C=%d T=%d order=%d otype=%d owin=%d: %d values; first c=%d t=%d %s gpu=%r oracle=%r"
                           % (name, N, C, T, order, otype, owin, len(bad), c, t, fx.FEATURE_NAMES[f], g[c, t, f], w[c, t, f]), flush=True)
+    if verbose:
+        print("cases run one hop per call through the ring (fx_hop_kernel): %d" % ring_cases[0], flush=True)
     if verbose and inexact.any():
         print("raw values not bit-identical (within tolerance), per slot:", dict((fx.FEATURE_NAMES[i], int(n)) for i, n in enumerate(inexact) if n), flush=True)
     return cases, frames, bad_cases, worst
