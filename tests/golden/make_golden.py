@@ -46,11 +46,17 @@ CASES = [
     ("loud_noise_2048", "loud_noise", 2048, 2, 8, 0),
     ("sine_512", "sine", 512, 2, 12, 0),
     ("dc_256", "dc", 256, 1, 12, 0),
+    # the lag search runs past the first few hundred lags (fundamentals of 9 .. 70 Hz, DC under a tone, drift)
+    ("low_tones_1024", "low_tones", 1024, 6, 10, 0),
+    ("low_tones_4096", "low_tones", 4096, 3, 8, 0),
 ]
 
 
 def main():
+    only = sys.argv[1:]                      # optional: names of the cases to (re)write
     for name, sig, N, C, T, order in CASES:
+        if only and name not in only:
+            continue
         hops = signals.ALL[sig](C, T, N)
         raw, sm = refdiff.run(hops, N, order=order, mode="cr")
         oraw, osm = fo.push_hops(hops, N, order=order)
