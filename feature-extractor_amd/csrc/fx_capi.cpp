@@ -127,6 +127,19 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
         fp.ch_per_wg = ch;
         fp.waves_per_ch = k;
         st->waves = ch * k;
+        // Long calls are cut in time as well (FrameParams::num_chunks): units of 64 frames -- 8 per wavefront -- once there
+        // are at least two of them.  A captured step (dyn) is a few frames and never is.  FX_FRAMES_PER_CHUNK overrides
+        // (0 = never).
+        int per_chunk = 64;
+        if (const char* e = getenv("FX_FRAMES_PER_CHUNK")) per_chunk = atoi(e);
+        fp.frames_per_chunk = 0;
+        fp.num_chunks = 1;
+        fp.queue = nullptr;
+        if (!dyn && c->d_queue && per_chunk >= k && T >= 2 * per_chunk) {
+            fp.frames_per_chunk = per_chunk;
+            fp.num_chunks = (T + per_chunk - 1) / per_chunk;
+            fp.queue = c->d_queue;
+        }
     }
 
     fxk::EpilogueParams& ep = st->ep;
@@ -235,6 +248,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
         c->prof_used += 3;
         last_valid = false;
     }
+    if (step.fp.num_chunks > 1) HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned) * (1 + (size_t) c->C), c->stream));
     HIP_TRY(hipEventRecord(e0, c->stream));
     HIP_TRY(fxk::launch_frame_kernel(c->N, step.fp, step.analysers, c->stream));
     HIP_TRY(hipEventRecord(e1, c->stream));
@@ -307,6 +321,7 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
         TRY_OR_CLEAN(hipMalloc((void**) &c->d_hist[i], sizeof(float) * (size_t) num_channels * fxk::HLEN * FX_NUM_FEATURES));
     }
     TRY_OR_CLEAN(hipMalloc((void**) &c->d_latest, sizeof(float) * (size_t) num_channels * FX_NUM_FEATURES));
+    TRY_OR_CLEAN(hipMalloc((void**) &c->d_queue, sizeof(unsigned) * (1 + (size_t) num_channels)));
 
     // Twiddle table exactly as the reference's FFT builds it (JUCE 4.2 FFT::FFTConfig, SURVEY.md
     // App. A.1): phase in double, entries rounded to float.  The inverse table is its conjugate.
@@ -354,7 +369,7 @@ fx_status fx_destroy(fx_context* c)
     fx_comm_release(c);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     void* bufs[] = {c->d_tw, c->d_prev, c->d_tail[0], c->d_tail[1], c->d_hist[0], c->d_hist[1], c->d_latest,
-                    c->d_raw, c->d_part, c->d_in, c->d_out_raw};
+                    c->d_raw, c->d_part, c->d_in, c->d_out_raw, c->d_queue};
     for (void* b : bufs) if (b) (void) hipFree(b);
     for (int i = 0; i < 3; i++) if (c->ev[i]) (void) hipEventDestroy(c->ev[i]);
     for (hipEvent_t e : c->prof_events) (void) hipEventDestroy(e);

@@ -48,6 +48,7 @@ struct fx_context {
     float* d_hist[2] = {nullptr, nullptr};   // [C][HLEN][12], ping-pong
     float* d_latest = nullptr;    // [C][12]
     int    cur = 0;
+    unsigned* d_queue = nullptr;  // [1 + C]: ticket counter and per-channel chunk counts of a frame-kernel launch cut in time (FrameParams::queue)
 
     float* d_raw = nullptr;       // [C][T_cap][12]
     fxk::FramePart* d_part = nullptr;   // [C][T_cap]

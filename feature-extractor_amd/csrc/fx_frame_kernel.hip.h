@@ -954,9 +954,23 @@ fx_frame_kernel(const FrameParams p_arg)
     const int wave = threadIdx.x >> 6;
     const int lane0 = threadIdx.x & 63;
     const int chl = wave / K, slot = wave % K;          // channel within the workgroup, frame slot within the channel
-    const int c = blockIdx.x * CH + chl;
-    const bool live = c < p.C;                          // the last workgroup may hold fewer channels
     const int T = p.T;
+    // which channels, which frames: the whole call for channel group blockIdx.x, or -- a call cut in time (FrameParams::
+    // num_chunks) -- the unit a ticket names, chunk-major: every earlier chunk of these channels has a lower ticket
+    int group = (int) blockIdx.x, chunk = 0;
+    if (p.num_chunks > 1) {
+        unsigned* ticket_s = reinterpret_cast<unsigned*>(per_wave);           // (wave 0's buffer is not in use yet)
+        if (threadIdx.x == 0) *ticket_s = __hip_atomic_fetch_add(p.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned ticket = *ticket_s, groups = gridDim.x / (unsigned) p.num_chunks;
+        __syncthreads();                                                       // (before anyone writes that buffer)
+        chunk = (int) (ticket / groups);
+        group = (int) (ticket % groups);
+    }
+    const int c = group * CH + chl;
+    const bool live = c < p.C;                          // the last workgroup may hold fewer channels
+    const int t_begin = p.num_chunks > 1 ? chunk * p.frames_per_chunk : 0;
+    const int t_end = p.num_chunks > 1 ? (t_begin + p.frames_per_chunk < T ? t_begin + p.frames_per_chunk : T) : T;
 
     float* prev = prev0 + (size_t) chl * PREV_FLOATS;   // bins image: re of the channel's last accepted frame
     // the hand-over counter lives in the first padding gap of the bins image when there is one (4096 points fills the
@@ -969,9 +983,23 @@ fx_frame_kernel(const FrameParams p_arg)
 #ifndef FX_EXP_TW_GLOBAL
     for (int i = threadIdx.x; i < N; i += blockDim.x) tw_lds[i] = reinterpret_cast<const f2*>(p.tw)[i];
 #endif
+    if (chunk > 0) {
+        // the flux state comes from the chunk before, written by another workgroup (another CU): its count, then an
+        // agent-scope acquire, then the barrier (MI355X guide: one relaxed poll -> one acquire -> vmcnt(0) -> barrier ->
+        // plain loads).  The predecessor holds a lower ticket, so it is running or done; it was dispatched a whole round
+        // of channels earlier and is normally long finished.  The spin is bounded all the same (~2 s).
+        if (live && slot == 0 && lane0 == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(p.queue + 1 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned) chunk && ++spins < (1u << 22))
+                __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+    }
     if (live) {
         for (int i = lane0 + 64 * slot; i < M; i += 64 * K) prev[bimg<N>(i)] = p.prev_re[(size_t) c * M + i];
-        if (lane0 == 0 && slot == 0) turn[0] = 0;
+        if (lane0 == 0 && slot == 0) turn[0] = t_begin;
     }
     __syncthreads();
 
@@ -983,7 +1011,7 @@ fx_frame_kernel(const FrameParams p_arg)
     const double frpb = nyquist / (double) M;          // ref SpectralCharacteristics.h:64,105
     const float  scale = 1.0f / (float) N;             // JUCE inverse scale
 
-    for (int t = live ? slot : T; t < T; t += K) {
+    for (int t = live ? t_begin + slot : t_end; t < t_end; t += K) {
         const int lane = FX_OPQ(15, lane0);
         // uniform per-frame results go to LDS as soon as they exist instead of occupying ~28 VGPRs
         // in every lane for the whole frame
@@ -1022,4 +1050,15 @@ fx_frame_kernel(const FrameParams p_arg)
     __syncthreads();
     if (live)
         for (int i = lane0 + 64 * slot; i < M; i += 64 * K) p.prev_re[(size_t) c * M + i] = prev[bimg<N>(i)];
+    if (chunk + 1 < p.num_chunks) {
+        // hand the flux state to the next chunk's workgroup: every storing wave's stores done, the barrier, one lane's
+        // agent-scope release, then the count (MI355X guide, producer form)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (live && slot == 0 && lane0 == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(p.queue + 1 + c, (unsigned) (chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }

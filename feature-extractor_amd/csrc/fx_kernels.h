@@ -61,6 +61,16 @@ struct FrameParams {
     int          C;
     int          ch_per_wg;     // channels per workgroup (they share the twiddle table in LDS)
     int          waves_per_ch;  // wavefronts per channel = frames of a channel in flight
+    // A long call over few channels is cut in time as well: num_chunks workgroups per channel group, each analysing
+    // frames_per_chunk consecutive frames (many small work units keep every CU busy to the end of the launch; one
+    // workgroup per channel is two rounds of 512 at the bench shape, and 8 % slower).  The one thing a chunk needs from
+    // the one before it is the channel's flux state: workgroups take their (chunk, channel group) from a ticket counter,
+    // chunk-major, so the predecessor's ticket is always lower -- held by a workgroup that is running or done -- and wait
+    // for that channel's count of finished chunks.  queue: [0] the ticket counter, [1 + c] finished chunks of channel c;
+    // zeroed before the launch.  num_chunks == 1: one workgroup per channel group, no queue.
+    int          frames_per_chunk;
+    int          num_chunks;
+    unsigned*    queue;
     float        gain;          // hop mode only (ref AudioDataCollector.h:88)
     const float* tail_in;       // [C][N/2] second half of the previous window (already gained)
     float*       tail_out;      // [C][N/2]

@@ -110,7 +110,8 @@ template <int N> hipError_t prepare_t()
 template <int N> hipError_t launch_t(const FrameParams& p, int analysers, hipStream_t stream)
 {
     const size_t lds = lds_bytes_t<N>(p.ch_per_wg, p.waves_per_ch);
-    const dim3 grid((unsigned) ((p.C + p.ch_per_wg - 1) / p.ch_per_wg)), block((unsigned) (p.ch_per_wg * p.waves_per_ch) * 64);
+    const dim3 grid((unsigned) ((p.C + p.ch_per_wg - 1) / p.ch_per_wg) * (unsigned) (p.num_chunks > 1 ? p.num_chunks : 1)),
+               block((unsigned) (p.ch_per_wg * p.waves_per_ch) * 64);
     if (analysers == 3)      hipLaunchKernelGGL((fx_frame_kernel<N, true, true>), grid, block, lds, stream, p);
     else if (analysers == 1) hipLaunchKernelGGL((fx_frame_kernel<N, true, false>), grid, block, lds, stream, p);
     else if (analysers == 2) hipLaunchKernelGGL((fx_frame_kernel<N, false, true>), grid, block, lds, stream, p);
@@ -251,6 +252,7 @@ hipError_t launch_frame_kernel(int n, const FrameParams& p, int analysers, hipSt
 {
     if (p.C <= 0 || p.T <= 0) return hipSuccess;
     if (p.ch_per_wg < 1 || p.waves_per_ch < 1 || p.ch_per_wg * p.waves_per_ch > frame_kernel_max_waves(n)) return hipErrorInvalidValue;
+    if (p.num_chunks > 1 && (!p.queue || p.frames_per_chunk < 1 || (long long) p.num_chunks * p.frames_per_chunk < p.T)) return hipErrorInvalidValue;
     switch (n) {
         case 256:  return launch_t<256>(p, analysers, stream);
         case 512:  return launch_t<512>(p, analysers, stream);

@@ -115,6 +115,43 @@ def test_split_calls_equal_one_call_bitwise(gpu_fx, N):
     assert np.array_equal(an.get_features(), one[1][:, -1], equal_nan=True)
 
 
+@pytest.mark.parametrize("N,C,T", [(1024, 3, 300), (2048, 2, 130), (256, 5, 200), (4096, 2, 129)])
+def test_long_calls_cut_in_time_match_oracle_and_the_uncut_launch(gpu_fx, oracle, monkeypatch, N, C, T):
+    """Calls of >= 128 frames per channel are cut in time (FrameParams::num_chunks): several workgroups per channel, each
+    taking 64 consecutive frames, the flux state handed from one to the next through global memory behind a ticket
+    order.  Bursts with digital silence in between put the reference's skip rule (no update of the previous magnitudes,
+    SpectralCharacteristics.h:121-123) across chunk boundaries; the last chunk is ragged."""
+    hops = signals.bursts(C, T, N, seed=12)
+    raw, sm = gpu_fx.BatchAnalyser(C, N).push_hops(hops)
+    oraw, osm = oracle.push_hops(hops, N)
+    close(raw, oraw, "chunked raw")
+    close(sm, osm, "chunked smoothed")
+    frames = gpu_fx.synth.frames(C, T, N, first_channel=7)
+    fraw, fsm = gpu_fx.BatchAnalyser(C, N).process_frames(frames)
+    for per_chunk in ("0", "16", "100"):
+        monkeypatch.setenv("FX_FRAMES_PER_CHUNK", per_chunk)
+        r0, s0 = gpu_fx.BatchAnalyser(C, N).push_hops(hops)
+        assert np.array_equal(r0, raw, equal_nan=True) and np.array_equal(s0, sm, equal_nan=True), per_chunk
+        r1, s1 = gpu_fx.BatchAnalyser(C, N).process_frames(frames)
+        assert np.array_equal(r1, fraw, equal_nan=True) and np.array_equal(s1, fsm, equal_nan=True), per_chunk
+
+
+def test_cut_launch_with_many_channels_equals_the_uncut_one_bitwise(gpu_fx, monkeypatch):
+    """Enough work units (2400 channels x 3 chunks of 256-pt frames) that chunks of one channel run on different CUs
+    while others wait for their predecessor: every value must equal the one-workgroup-per-channel launch."""
+    C, T, N = 2400, 192, 256
+    hops = np.tile(signals.bursts(48, T, N, seed=3), (C // 48, 1, 1))
+    hops = (hops * np.linspace(0.2, 1.0, C, dtype=np.float32)[:, None, None]).astype(np.float32)
+    an = gpu_fx.BatchAnalyser(C, N)
+    raw, sm = an.push_hops(hops)
+    raw2, sm2 = an.push_hops(hops)                       # a second call continues from the first's state
+    monkeypatch.setenv("FX_FRAMES_PER_CHUNK", "0")
+    an0 = gpu_fx.BatchAnalyser(C, N)
+    want = an0.push_hops(hops), an0.push_hops(hops)
+    assert np.array_equal(raw, want[0][0], equal_nan=True) and np.array_equal(sm, want[0][1], equal_nan=True)
+    assert np.array_equal(raw2, want[1][0], equal_nan=True) and np.array_equal(sm2, want[1][1], equal_nan=True)
+
+
 @pytest.mark.parametrize("N,shape", [(1024, (3, 2)), (1024, (2, 8)), (2048, (3, 4)), (2048, (2, 6)), (512, (4, 2))])
 def test_workgroup_shapes_give_the_same_bits(gpu_fx, monkeypatch, N, shape):
     """Channels per workgroup x waves per channel is a scheduling choice (several channels can share one workgroup's
