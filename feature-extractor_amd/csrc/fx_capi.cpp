@@ -135,24 +135,47 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
         // workgroups carry a 16-32 KB twiddle table each and already run in 4-8 rounds at their usual shapes: those
         // are never cut.  The call is cut into equal units of about that size.  A captured step (dyn) is a few frames
         // and never cut.  FX_FRAMES_PER_CHUNK overrides the unit (0 = never cut).
-        fp.frames_per_chunk = 0;
         fp.num_chunks = 1;
         fp.queue = nullptr;
+        for (int i = 0; i <= fxk::FX_MAX_CHUNKS; i++) fp.chunk_begin[i] = 0;
         if (!dyn && c->d_queue) {
             int per_wave = c->N <= 256 ? 32 : (c->N == 512 ? 16 : 8);
             if (c->flags & FX_HARMONIC_ONLY) per_wave *= 2;
             int unit = (c->N > 1024 || (c->flags & FX_SPECTRAL_ONLY)) ? 0 : k * per_wave;
             if (const char* e = getenv("FX_FRAMES_PER_CHUNK")) unit = atoi(e);
-            if (unit >= k && unit > 0) {
-                const int n = (2 * T + unit) / (2 * unit);                 // T / unit, rounded
-                if (n >= 2) {
-                    int per_chunk = (T + n - 1) / n;
-                    per_chunk = (per_chunk + k - 1) / k * k;               // whole rounds of the k wavefronts
-                    fp.frames_per_chunk = per_chunk;
-                    fp.num_chunks = (T + per_chunk - 1) / per_chunk;
-                    fp.queue = fp.num_chunks > 1 ? c->d_queue : nullptr;
-                    if (fp.num_chunks < 2) { fp.frames_per_chunk = 0; fp.num_chunks = 1; }
+            std::vector<int> sizes;
+            if (const char* plan = getenv("FX_CHUNK_PLAN")) {          // experiments: "192,128,96,64,32" (must add up to T)
+                int sum = 0;
+                for (const char* q = plan; *q; ) { const int v = atoi(q); if (v > 0) { sizes.push_back(v); sum += v; } while (*q && *q != ',') q++; if (*q == ',') q++; }
+                if (sum != T || (int) sizes.size() > fxk::FX_MAX_CHUNKS) sizes.clear();
+            }
+            if (sizes.empty() && unit >= k && unit > 0) {
+                if (T >= 8 * unit) {
+                    // very long calls: long units first (less overhead), short ones last (the launch's tail is one short unit
+                    // deep) -- a third of what is left each time, down to a quarter unit: 512 frames = 168, 112, 80, 48,
+                    // 32, 24, 16, 16, 16 (2.74 against 2.80 ms for eight units of 64 at the bench shape)
+                    const int least = unit / 4 > k ? unit / 4 / k * k : k;
+                    for (int rem = T; rem > 0 && (int) sizes.size() < fxk::FX_MAX_CHUNKS; ) {
+                        int sz = (rem / 3 + k / 2) / k * k;
+                        if (sz < least) sz = least;
+                        if (sz > 4 * unit && T <= 4 * unit * (fxk::FX_MAX_CHUNKS - 10)) sz = 4 * unit;   // (no unit longer than ~1 ms)
+                        if (rem - sz < least || (int) sizes.size() == fxk::FX_MAX_CHUNKS - 1) sz = rem;
+                        sizes.push_back(sz);
+                        rem -= sz;
+                    }
+                } else {
+                    const int n = (2 * T + unit) / (2 * unit);                 // T / unit, rounded
+                    if (n >= 2 && n <= fxk::FX_MAX_CHUNKS) {
+                        int per_chunk = (T + n - 1) / n;
+                        per_chunk = (per_chunk + k - 1) / k * k;               // whole rounds of the k wavefronts
+                        for (int at = 0; at < T; at += per_chunk) sizes.push_back(at + per_chunk < T ? per_chunk : T - at);
+                    }
                 }
+            }
+            if (sizes.size() >= 2) {
+                fp.num_chunks = (int) sizes.size();
+                fp.queue = c->d_queue;
+                for (int i = 0; i < fp.num_chunks; i++) fp.chunk_begin[i + 1] = fp.chunk_begin[i] + sizes[(size_t) i];
             }
         }
     }

@@ -969,8 +969,8 @@ fx_frame_kernel(const FrameParams p_arg)
     }
     const int c = group * CH + chl;
     const bool live = c < p.C;                          // the last workgroup may hold fewer channels
-    const int t_begin = p.num_chunks > 1 ? chunk * p.frames_per_chunk : 0;
-    const int t_end = p.num_chunks > 1 ? (t_begin + p.frames_per_chunk < T ? t_begin + p.frames_per_chunk : T) : T;
+    const int t_begin = p.num_chunks > 1 ? p_arg.chunk_begin[chunk] : 0;
+    const int t_end = p.num_chunks > 1 ? p_arg.chunk_begin[chunk + 1] : T;
 
     float* prev = prev0 + (size_t) chl * PREV_FLOATS;   // bins image: re of the channel's last accepted frame
     // the hand-over counter lives in the first padding gap of the bins image when there is one (4096 points fills the

@@ -53,6 +53,8 @@ struct DynParams {
     int       onset_type;
 };
 
+constexpr int FX_MAX_CHUNKS = 24;
+
 struct FrameParams {
     const void*  in;            // frames [C][T][N] or hops [C][T][N/2]
     int          sample_format; // FX_SAMPLE_F32 / FX_SAMPLE_F16
@@ -67,10 +69,11 @@ struct FrameParams {
     // the one before it is the channel's flux state: workgroups take their (chunk, channel group) from a ticket counter,
     // chunk-major, so the predecessor's ticket is always lower -- held by a workgroup that is running or done -- and wait
     // for that channel's count of finished chunks.  queue: [0] the ticket counter, [1 + c] finished chunks of channel c;
-    // zeroed before the launch.  num_chunks == 1: one workgroup per channel group, no queue.
-    int          frames_per_chunk;
+    // zeroed before the launch.  num_chunks == 1: one workgroup per channel group, no queue.  Chunks need not be equal: long
+    // ones first (little overhead), short ones last (the launch's tail is one short unit deep).
     int          num_chunks;
     unsigned*    queue;
+    int          chunk_begin[FX_MAX_CHUNKS + 1];   // chunk k analyses frames [chunk_begin[k], chunk_begin[k + 1]); the last entry used is T
     float        gain;          // hop mode only (ref AudioDataCollector.h:88)
     const float* tail_in;       // [C][N/2] second half of the previous window (already gained)
     float*       tail_out;      // [C][N/2]

@@ -252,7 +252,10 @@ hipError_t launch_frame_kernel(int n, const FrameParams& p, int analysers, hipSt
 {
     if (p.C <= 0 || p.T <= 0) return hipSuccess;
     if (p.ch_per_wg < 1 || p.waves_per_ch < 1 || p.ch_per_wg * p.waves_per_ch > frame_kernel_max_waves(n)) return hipErrorInvalidValue;
-    if (p.num_chunks > 1 && (!p.queue || p.frames_per_chunk < 1 || (long long) p.num_chunks * p.frames_per_chunk < p.T)) return hipErrorInvalidValue;
+    if (p.num_chunks > 1) {
+        if (!p.queue || p.num_chunks > FX_MAX_CHUNKS || p.chunk_begin[0] != 0 || p.chunk_begin[p.num_chunks] != p.T) return hipErrorInvalidValue;
+        for (int k = 0; k < p.num_chunks; k++) if (p.chunk_begin[k + 1] <= p.chunk_begin[k]) return hipErrorInvalidValue;
+    }
     switch (n) {
         case 256:  return launch_t<256>(p, analysers, stream);
         case 512:  return launch_t<512>(p, analysers, stream);

@@ -115,7 +115,7 @@ def test_split_calls_equal_one_call_bitwise(gpu_fx, N):
     assert np.array_equal(an.get_features(), one[1][:, -1], equal_nan=True)
 
 
-@pytest.mark.parametrize("N,C,T", [(1024, 3, 300), (2048, 2, 130), (256, 5, 200), (4096, 2, 129)])
+@pytest.mark.parametrize("N,C,T", [(1024, 3, 300), (1024, 2, 700), (2048, 2, 130), (256, 5, 200), (4096, 2, 129)])
 def test_long_calls_cut_in_time_match_oracle_and_the_uncut_launch(gpu_fx, oracle, monkeypatch, N, C, T):
     """Calls of >= 128 frames per channel are cut in time (FrameParams::num_chunks): several workgroups per channel, each
     taking 64 consecutive frames, the flux state handed from one to the next through global memory behind a ticket
