@@ -23,7 +23,8 @@ EXPORTS = ["fx_create", "fx_destroy", "fx_reset_state", "fx_set_sample_rate", "f
            "fx_get_smoothed", "fx_sync", "fx_get_stream", "fx_last_kernel_ms", "fx_profile_begin", "fx_profile_end",
            "fx_stream_create", "fx_stream_destroy", "fx_stream_acquire", "fx_stream_submit", "fx_stream_collect", "fx_stream_in_flight", "fx_pack_osc12",
            "fx_pack_osc10", "fx_osc_encode", "fx_last_error", "fx_abi_version",
-           "fx_comm_unique_id", "fx_comm_create", "fx_comm_destroy", "fx_comm_layout", "fx_gather_smoothed", "fx_comm_sync"]
+           "fx_comm_unique_id", "fx_comm_create", "fx_comm_destroy", "fx_comm_layout", "fx_gather_smoothed", "fx_comm_sync",
+           "fx_plan_units"]
 COMM_ID_BYTES = 128
 ABI_VERSION = 2
 

@@ -73,6 +73,60 @@ template <typename T> fx_status grow(T** ptr, size_t* cap, size_t need)
     return FX_OK;
 }
 
+} // namespace
+
+// Long calls are cut in time as well (FrameParams::num_chunks): work units of ~200 us -- long enough to carry a
+// workgroup's prologue and the hand-over, short enough for many rounds of them.  Measured (1024 ch x 512 frames, best
+// of three interleaved runs): 8 frames per wavefront for the full bundle at 1024 points (2.80 against 3.01 ms uncut),
+// twice that with the harmonic analyser alone (1.93 / 2.04), more for the small windows (512 points +3 %, 256 points
+// +2 %); nothing for the spectral analyser alone, and a LOSS of 3-8 % at 2048 and 4096 points, whose workgroups carry
+// a 16-32 KB twiddle table each and already run in 4-8 rounds at their usual shapes: those are never cut.  Calls of up
+// to 8 units are cut into equal units; longer ones into units of decreasing length -- a third of what is left each
+// time (at most four units' worth), down to a quarter unit -- long units first (little overhead), short ones last (the
+// launch's tail is one short unit deep): 512 frames = 168, 112, 80, 48, 32, 24, 16, 16, 16 (2.74 against 2.80 ms for
+// eight units of 64 at the bench shape).  FX_FRAMES_PER_CHUNK overrides the unit (0 = never cut), FX_CHUNK_PLAN=a,b,...
+// gives the lengths outright (experiments).  Host-only arithmetic: declared in include/fx.h so that the CPU tests can
+// hold it to its invariants.
+extern "C" int fx_plan_units(int window_size, unsigned flags, int waves_per_channel, int num_frames, int* sizes, int cap)
+{
+    const int k = waves_per_channel, T = num_frames;
+    if (!sizes || cap < 1 || k < 1 || T < 1) return 0;
+    int per_wave = window_size <= 256 ? 32 : (window_size == 512 ? 16 : 8);
+    if (flags & FX_HARMONIC_ONLY) per_wave *= 2;
+    int unit = (window_size > 1024 || (flags & FX_SPECTRAL_ONLY)) ? 0 : k * per_wave;
+    if (const char* e = getenv("FX_FRAMES_PER_CHUNK")) unit = atoi(e);
+    int n = 0;
+    if (const char* plan = getenv("FX_CHUNK_PLAN")) {
+        int sum = 0;
+        for (const char* q = plan; *q && n < cap; ) { const int v = atoi(q); if (v > 0) { sizes[n++] = v; sum += v; } while (*q && *q != ',') q++; if (*q == ',') q++; }
+        if (sum != T) n = 0;
+    }
+    if (n == 0 && unit >= k && unit > 0) {
+        if (T >= 8 * unit) {
+            const int least = unit / 4 > k ? unit / 4 / k * k : k;
+            for (int rem = T; rem > 0 && n < cap; ) {
+                int sz = (rem / 3 + k / 2) / k * k;
+                if (sz < least) sz = least;
+                if (sz > 4 * unit && T <= 4 * unit * (cap - 10)) sz = 4 * unit;       // (no unit longer than ~1 ms)
+                if (rem - sz < least || n == cap - 1) sz = rem;
+                sizes[n++] = sz;
+                rem -= sz;
+            }
+        } else {
+            const int cnt = (2 * T + unit) / (2 * unit);                  // T / unit, rounded
+            if (cnt >= 2 && cnt <= cap) {
+                int per = (T + cnt - 1) / cnt;
+                per = (per + k - 1) / k * k;                               // whole rounds of the k wavefronts
+                for (int at = 0; at < T; at += per) sizes[n++] = at + per < T ? per : T - at;
+            }
+        }
+    }
+    if (n < 2) { sizes[0] = T; n = 1; }
+    return n;
+}
+
+namespace {
+
 // Everything one analysis step launches: kernel arguments and the wavefront count of the frame kernel.
 struct Step {
     fxk::FrameParams    fp;
@@ -127,55 +181,16 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
         fp.ch_per_wg = ch;
         fp.waves_per_ch = k;
         st->waves = ch * k;
-        // Long calls are cut in time as well (FrameParams::num_chunks): work units of ~200 us -- long enough to carry a
-        // workgroup's prologue and the hand-over, short enough for many rounds of them.  Measured (1024 ch x 512 frames,
-        // best of three interleaved runs): 8 frames per wavefront for the full bundle at 1024 points (2.80 against 3.01 ms
-        // uncut), twice that with the harmonic analyser alone (1.93 / 2.04), more for the small windows (512 points +3 %,
-        // 256 points +2 %); nothing for the spectral analyser alone, and a LOSS of 3-8 % at 2048 and 4096 points, whose
-        // workgroups carry a 16-32 KB twiddle table each and already run in 4-8 rounds at their usual shapes: those
-        // are never cut.  The call is cut into equal units of about that size.  A captured step (dyn) is a few frames
-        // and never cut.  FX_FRAMES_PER_CHUNK overrides the unit (0 = never cut).
         fp.num_chunks = 1;
         fp.queue = nullptr;
         for (int i = 0; i <= fxk::FX_MAX_CHUNKS; i++) fp.chunk_begin[i] = 0;
         if (!dyn && c->d_queue) {
-            int per_wave = c->N <= 256 ? 32 : (c->N == 512 ? 16 : 8);
-            if (c->flags & FX_HARMONIC_ONLY) per_wave *= 2;
-            int unit = (c->N > 1024 || (c->flags & FX_SPECTRAL_ONLY)) ? 0 : k * per_wave;
-            if (const char* e = getenv("FX_FRAMES_PER_CHUNK")) unit = atoi(e);
-            std::vector<int> sizes;
-            if (const char* plan = getenv("FX_CHUNK_PLAN")) {          // experiments: "192,128,96,64,32" (must add up to T)
-                int sum = 0;
-                for (const char* q = plan; *q; ) { const int v = atoi(q); if (v > 0) { sizes.push_back(v); sum += v; } while (*q && *q != ',') q++; if (*q == ',') q++; }
-                if (sum != T || (int) sizes.size() > fxk::FX_MAX_CHUNKS) sizes.clear();
-            }
-            if (sizes.empty() && unit >= k && unit > 0) {
-                if (T >= 8 * unit) {
-                    // very long calls: long units first (less overhead), short ones last (the launch's tail is one short unit
-                    // deep) -- a third of what is left each time, down to a quarter unit: 512 frames = 168, 112, 80, 48,
-                    // 32, 24, 16, 16, 16 (2.74 against 2.80 ms for eight units of 64 at the bench shape)
-                    const int least = unit / 4 > k ? unit / 4 / k * k : k;
-                    for (int rem = T; rem > 0 && (int) sizes.size() < fxk::FX_MAX_CHUNKS; ) {
-                        int sz = (rem / 3 + k / 2) / k * k;
-                        if (sz < least) sz = least;
-                        if (sz > 4 * unit && T <= 4 * unit * (fxk::FX_MAX_CHUNKS - 10)) sz = 4 * unit;   // (no unit longer than ~1 ms)
-                        if (rem - sz < least || (int) sizes.size() == fxk::FX_MAX_CHUNKS - 1) sz = rem;
-                        sizes.push_back(sz);
-                        rem -= sz;
-                    }
-                } else {
-                    const int n = (2 * T + unit) / (2 * unit);                 // T / unit, rounded
-                    if (n >= 2 && n <= fxk::FX_MAX_CHUNKS) {
-                        int per_chunk = (T + n - 1) / n;
-                        per_chunk = (per_chunk + k - 1) / k * k;               // whole rounds of the k wavefronts
-                        for (int at = 0; at < T; at += per_chunk) sizes.push_back(at + per_chunk < T ? per_chunk : T - at);
-                    }
-                }
-            }
-            if (sizes.size() >= 2) {
-                fp.num_chunks = (int) sizes.size();
+            int sizes[fxk::FX_MAX_CHUNKS];
+            const int n = fx_plan_units(c->N, c->flags, k, T, sizes, fxk::FX_MAX_CHUNKS);
+            if (n >= 2) {
+                fp.num_chunks = n;
                 fp.queue = c->d_queue;
-                for (int i = 0; i < fp.num_chunks; i++) fp.chunk_begin[i + 1] = fp.chunk_begin[i] + sizes[(size_t) i];
+                for (int i = 0; i < n; i++) fp.chunk_begin[i + 1] = fp.chunk_begin[i] + sizes[i];
             }
         }
     }

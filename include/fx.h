@@ -160,6 +160,13 @@ fx_status fx_stream_collect(fx_stream* s, float* out_raw, float* out_smoothed);
 /* Number of submitted batches not yet collected. */
 int fx_stream_in_flight(fx_stream* s);
 
+/* Host-only arithmetic, exposed for testing: how a call of `num_frames` frames per channel is cut into
+ * work units for the frame kernel (several workgroups per channel, each analysing a run of consecutive
+ * frames and handing the channel's flux state -- previousBinMagnitudes, SpectralCharacteristics.h:203 --
+ * to the next through device memory).  Writes the unit lengths to sizes[0..n) and returns n (1 = one
+ * workgroup per channel); the lengths are positive and add up to num_frames.  No GPU needed. */
+int fx_plan_units(int window_size, unsigned flags, int waves_per_channel, int num_frames, int* sizes, int cap);
+
 /* Kernel-time accounting over a region of calls: fx_profile_begin() starts recording a HIP event
  * triple per analysis call on the context's stream (no synchronisation, at most 4096 calls);
  * fx_profile_end() synchronises and returns the summed device time of the frame kernel and of the

@@ -83,3 +83,41 @@ def test_synth_is_deterministic_and_frames_match_hops(fx):
     fr = fx.synth.frames(3, 5, 1024, first_channel=7)
     assert np.array_equal(fr[:, 0, :512], np.zeros((3, 512), np.float32))
     assert np.array_equal(fr[:, 2, :512], a[:, 1]) and np.array_equal(fr[:, 2, 512:], a[:, 2])
+
+
+def test_work_unit_plans_cover_every_frame_once(fx, monkeypatch):
+    """fx_plan_units (host arithmetic, no GPU): however a call is cut into work units for the frame kernel, the unit
+    lengths are positive, add up to the call's frames per channel, fit the kernel's table, and only the last unit may be a
+    partial round of wavefronts; windows of 2048 / 4096 points and the spectral analyser alone are never cut."""
+    import ctypes
+    lib = fx.load_library(build_if_missing=True)
+    lib.fx_plan_units.restype = ctypes.c_int
+    lib.fx_plan_units.argtypes = [ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+    for var in ("FX_FRAMES_PER_CHUNK", "FX_CHUNK_PLAN"):
+        monkeypatch.delenv(var, raising=False)
+    cap = 24
+    buf = (ctypes.c_int * cap)()
+
+    def plan(N, flags, k, T):
+        n = lib.fx_plan_units(N, flags, k, T, buf, cap)
+        return list(buf[:n])
+
+    for N, k in ((256, 8), (512, 8), (1024, 8), (1024, 3), (2048, 4), (4096, 7)):
+        for flags in (0, 4, 8):                       # both analysers, FX_SPECTRAL_ONLY, FX_HARMONIC_ONLY
+            for T in list(range(1, 700)) + [1000, 4096, 5000, 65536, 1000000]:
+                sizes = plan(N, flags, k, T)
+                assert 1 <= len(sizes) <= cap and sum(sizes) == T and min(sizes) >= 1, (N, flags, k, T, sizes)
+                assert all(s % k == 0 for s in sizes[:-1]), (N, flags, k, T, sizes)
+                if N > 1024 or flags == 4:
+                    assert sizes == [T]
+    assert plan(1024, 0, 8, 512) == [168, 112, 80, 48, 32, 24, 16, 16, 16]      # the bench shape (DESIGN.md 3.1)
+    assert plan(1024, 0, 8, 128) == [64, 64] and plan(1024, 0, 8, 100) == [56, 44] and plan(1024, 0, 8, 90) == [90]
+    monkeypatch.setenv("FX_FRAMES_PER_CHUNK", "0")
+    assert plan(1024, 0, 8, 512) == [512]
+    monkeypatch.setenv("FX_FRAMES_PER_CHUNK", "16")
+    forced = plan(4096, 0, 7, 129)            # the override applies to every window size (tests force cut launches with it)
+    assert len(forced) >= 4 and sum(forced) == 129 and all(v % 7 == 0 for v in forced[:-1])
+    assert plan(4096, 0, 7, 100) == [21, 21, 21, 21, 16]
+    monkeypatch.delenv("FX_FRAMES_PER_CHUNK")
+    monkeypatch.setenv("FX_CHUNK_PLAN", "300,200,12")
+    assert plan(1024, 0, 8, 512) == [300, 200, 12] and plan(1024, 0, 8, 511) != [300, 200, 12]
