@@ -91,6 +91,7 @@ extern "C" int fx_plan_units(int window_size, unsigned flags, int waves_per_chan
 {
     const int k = waves_per_channel, T = num_frames;
     if (!sizes || cap < 1 || k < 1 || T < 1) return 0;
+    if (T < 2 * k) { sizes[0] = T; return 1; }          // (a few hops: nothing to cut, and the one-hop path is latency-critical)
     int per_wave = window_size <= 256 ? 32 : (window_size == 512 ? 16 : 8);
     if (flags & FX_HARMONIC_ONLY) per_wave *= 2;
     int unit = (window_size > 1024 || (flags & FX_SPECTRAL_ONLY)) ? 0 : k * per_wave;
