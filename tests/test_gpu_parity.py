@@ -336,8 +336,8 @@ def test_hop_stream_settings_change_mid_stream(gpu_fx, monkeypatch, graph):
     st.close()
 
 
-@pytest.mark.parametrize("N,C", [(1024, 5), (2048, 3), (4096, 1), (4096, 4)])
-def test_one_hop_per_call_kernel_equals_push_hops_bitwise(gpu_fx, monkeypatch, N, C):
+@pytest.mark.parametrize("N,C,order", [(1024, 5, 0), (2048, 3, 0), (4096, 1, 0), (4096, 4, 0), (1024, 70, 1), (2048, 2, 2)])
+def test_one_hop_per_call_kernel_equals_push_hops_bitwise(gpu_fx, monkeypatch, N, C, order):
     """One hop per call through the ring runs as ONE launch of fx_hop_kernel (three wavefronts per channel, results and
     completion flag written by the kernel, the host polling the flag).  It must equal fx_push_hops bit for bit -- the
     same sections of the frame code, the same tail -- with setter calls in between, with up to three calls in flight,
@@ -357,14 +357,14 @@ def test_one_hop_per_call_kernel_equals_push_hops_bitwise(gpu_fx, monkeypatch, N
         if b == 31:
             an.reset_state()
 
-    ref = gpu_fx.BatchAnalyser(C, N)
+    ref = gpu_fx.BatchAnalyser(C, N, order=order)
     want = []
     for b in range(nb):
         settings(ref, b)
         want.append(ref.push_hops(hops[:, b:b + 1]))
 
     def through_ring(depth):
-        an = gpu_fx.BatchAnalyser(C, N)
+        an = gpu_fx.BatchAnalyser(C, N, order=order)
         st = gpu_fx.HopStream(an, 1, slots=3)
         got = []
         for b in range(nb):
