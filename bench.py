@@ -206,8 +206,8 @@ def main():
     ap.add_argument("--channels-per-gpu", type=int, default=None,
                     help="default: 1024 at --gpus 1 (BASELINE configs[1]), 8192 at --gpus N>1 (configs[3])")
     ap.add_argument("--frames", type=int, default=None,
-                    help="consecutive frames per channel per step (SURVEY 8d: T >= 64); default 512 at --gpus 1, 64 at --gpus N>1 "
-                         "(the same 524288 frames per GPU per step either way)")
+                    help="consecutive frames per channel per step (SURVEY 8d: T >= 64); default 512 at --gpus 1, 128 at --gpus N>1 "
+                         "(8192 channels x 128 frames = 4.3 GB of input per GPU; 1.81e8 frames/s per GPU, as the single-GPU line)")
     ap.add_argument("--window", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements (spectral-only, noise / silence, other windows)")
@@ -250,7 +250,7 @@ def main():
     sharded = importlib.import_module("feature-extractor_amd.sharded")
     N = args.window
     C = args.channels_per_gpu if args.channels_per_gpu is not None else (1024 if world == 1 else 8192)
-    T = args.frames if args.frames is not None else (512 if world == 1 else 64)
+    T = args.frames if args.frames is not None else (512 if world == 1 else 128)
     if args.stream:
         return stream_bench(fx, args, C, T, N, local_rank)
     total_channels = C * world
