@@ -43,6 +43,23 @@ def test_committed_fixtures(gpu_fx, path):
     close(sm, g["smoothed"], "golden smoothed")
 
 
+def test_random_reference_cases(gpu_fx):
+    """The HIP path against outputs of the reference's own headers on forty random cases (tests/golden/random/cases.npz,
+    made in the build container by tests/golden/make_random_cases.py; hops regenerated from seeds and CRC-checked): no
+    oracle in between.  Some of the cases are long calls, which the frame kernel cuts in time."""
+    from test_oracle import _random_reference_cases
+    for k, p, hops, raw, sm in _random_reference_cases():
+        an = gpu_fx.BatchAnalyser(p["C"], p["N"], p["sample_rate"], order=p["order"])
+        an.set_onset_detection_type(p["onset_type"])
+        an.set_onset_window_length(p["onset_window"])
+        an.set_onset_detection_sensitivity(p["sensitivity"])
+        an.set_gain(p["gain"])
+        graw, gsm = an.push_hops(hops)
+        close(graw, raw, "random case %d %r raw" % (k, p))
+        close(gsm, sm, "random case %d %r smoothed" % (k, p))
+        an.close()
+
+
 @pytest.mark.parametrize("N", [1024, 2048])
 def test_preassembled_frames_match_oracle(gpu_fx, oracle, N):
     frames = gpu_fx.synth.frames(5, 12, N, first_channel=3)

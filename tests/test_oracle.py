@@ -208,3 +208,29 @@ def test_threaded_hop_batch_equals_per_channel_calls():
     a = fo.push_hops(hops, 512, **kw)
     b = fo.batch_hops(hops, 512, threads=3, **kw)
     assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True)
+
+
+def _random_reference_cases():
+    import sys
+    import zlib
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from random_cases import NUM_CASES, draw_case
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "random", "cases.npz"))
+    assert int(fx["num_cases"]) == NUM_CASES
+    at = 0
+    for k in range(NUM_CASES):
+        p, hops = draw_case(k)
+        n = p["C"] * p["T"] * 12
+        if zlib.crc32(hops.tobytes()) != int(fx["hop_crc32"][k]):
+            pytest.fail("case %d: this platform regenerates other samples than the fixture was made from (numpy / libm)" % k)
+        yield k, p, hops, fx["raw"][at:at + n].reshape(p["C"], p["T"], 12), fx["smoothed"][at:at + n].reshape(p["C"], p["T"], 12)
+        at += n
+
+
+def test_oracle_reproduces_random_reference_cases():
+    """Forty random cases (signal mix, level, window size, order mode, onset settings, gain, sample rate) whose expected
+    outputs come from the reference's own headers (tests/golden/make_random_cases.py): bit for bit."""
+    for k, p, hops, raw, sm in _random_reference_cases():
+        oraw, osm = fo.batch_hops(hops, p["N"], sample_rate=p["sample_rate"], order=p["order"], gain=p["gain"], onset_type=p["onset_type"],
+                                  onset_sensitivity=p["sensitivity"], onset_window=p["onset_window"])
+        assert np.array_equal(oraw, raw, equal_nan=True) and np.array_equal(osm, sm, equal_nan=True), (k, p)
