@@ -53,41 +53,6 @@ struct DynParams {
     int       onset_type;
 };
 
-constexpr int FX_MAX_CHUNKS = 24;
-
-struct FrameParams {
-    const void*  in;            // frames [C][T][N] or hops [C][T][N/2]
-    int          sample_format; // FX_SAMPLE_F32 / FX_SAMPLE_F16
-    int          hop_mode;      // 1: `in` holds hops, windows are assembled from tail + hops
-    int          T;             // frames (= hops) per channel in this call
-    int          C;
-    int          ch_per_wg;     // channels per workgroup (they share the twiddle table in LDS)
-    int          waves_per_ch;  // wavefronts per channel = frames of a channel in flight
-    // A long call over few channels is cut in time as well: num_chunks workgroups per channel group, each analysing
-    // frames_per_chunk consecutive frames (many small work units keep every CU busy to the end of the launch; one
-    // workgroup per channel is two rounds of 512 at the bench shape, and 8 % slower).  The one thing a chunk needs from
-    // the one before it is the channel's flux state: workgroups take their (chunk, channel group) from a ticket counter,
-    // chunk-major, so the predecessor's ticket is always lower -- held by a workgroup that is running or done -- and wait
-    // for that channel's count of finished chunks.  queue: [0] the ticket counter, [1 + c] finished chunks of channel c;
-    // zeroed before the launch.  num_chunks == 1: one workgroup per channel group, no queue.  Chunks need not be equal: long
-    // ones first (little overhead), short ones last (the launch's tail is one short unit deep).
-    int          num_chunks;
-    unsigned*    queue;
-    int          chunk_begin[FX_MAX_CHUNKS + 1];   // chunk k analyses frames [chunk_begin[k], chunk_begin[k + 1]); the last entry used is T
-    float        gain;          // hop mode only (ref AudioDataCollector.h:88)
-    const float* tail_in;       // [C][N/2] second half of the previous window (already gained)
-    float*       tail_out;      // [C][N/2]
-    float*       prev_re;       // [C][N/2] real parts of the last accepted spectral frame (flux state)
-    const float* tw;            // [N][2] forward twiddles, (float)cos/sin of a double phase, in pass order (build_pass_twiddles)
-    FramePart*   part;          // [C][T] per-frame partial results
-    double       nyquist;
-    double       bin_var;       // sum_i (i/M - 0.5)^2 / M, summed serially on the host (ref SpectralCharacteristics.h:182-189)
-    float        lpf_a, lpf_b;  // ref RealTimeAudioAnalysis.h:122
-    const DynParams* dyn;       // non-null in a captured step: overrides gain and nyquist
-    float        first_tw[18];  // the <= 9 twiddles of the first FFT pass (re, im pairs): wave-uniform, so they travel as
-                                // kernel arguments (SGPRs) instead of LDS reads; filled by fill_first_pass_twiddles
-};
-
 struct EpilogueParams {
     const FramePart* part;      // [C][T] from the frame kernel
     float*       raw;           // [C][T][12] raw values: written by fx_finalise_kernel, read by the smoothing kernel
@@ -109,6 +74,47 @@ struct EpilogueParams {
     int          analysers;     // bit 0: spectral analyser runs, bit 1: harmonic analyser runs
     const DynParams* dyn;       // non-null in a captured step: overrides nyquist, frames_before, onset_*
 };
+
+constexpr int FX_MAX_CHUNKS = 24;
+
+struct FrameParams {
+    const void*  in;            // frames [C][T][N] or hops [C][T][N/2]
+    int          sample_format; // FX_SAMPLE_F32 / FX_SAMPLE_F16
+    int          hop_mode;      // 1: `in` holds hops, windows are assembled from tail + hops
+    int          T;             // frames (= hops) per channel in this call
+    int          C;
+    int          ch_per_wg;     // channels per workgroup (they share the twiddle table in LDS)
+    int          waves_per_ch;  // wavefronts per channel = frames of a channel in flight
+    // A long call over few channels is cut in time as well: num_chunks workgroups per channel group, each analysing
+    // frames_per_chunk consecutive frames (many small work units keep every CU busy to the end of the launch; one
+    // workgroup per channel is two rounds of 512 at the bench shape, and 8 % slower).  The one thing a chunk needs from
+    // the one before it is the channel's flux state: workgroups take their (chunk, channel group) from a ticket counter,
+    // chunk-major, so the predecessor's ticket is always lower -- held by a workgroup that is running or done -- and wait
+    // for that channel's count of finished chunks.  queue: [0] the ticket counter, [1 + c] finished chunks of channel c;
+    // zeroed before the launch.  num_chunks == 1: one workgroup per channel group, no queue.  Chunks need not be equal: long
+    // ones first (little overhead), short ones last (the launch's tail is one short unit deep).
+    int          num_chunks;
+    unsigned*    queue;
+    int          chunk_begin[FX_MAX_CHUNKS + 1];   // chunk k analyses frames [chunk_begin[k], chunk_begin[k + 1]); the last entry used is T
+    // A cut launch can carry the step's tail as well: after the last chunk's tickets come one ticket per channel for that
+    // channel's scalar tail, smoothing / onset and history (what fx_finalise_kernel, fx_epilogue_kernel and
+    // fx_history_kernel do as three more launches) -- they start as channels finish and fill the launch's tail.
+    int          tail_in_queue;
+    EpilogueParams tail;
+    float        gain;          // hop mode only (ref AudioDataCollector.h:88)
+    const float* tail_in;       // [C][N/2] second half of the previous window (already gained)
+    float*       tail_out;      // [C][N/2]
+    float*       prev_re;       // [C][N/2] real parts of the last accepted spectral frame (flux state)
+    const float* tw;            // [N][2] forward twiddles, (float)cos/sin of a double phase, in pass order (build_pass_twiddles)
+    FramePart*   part;          // [C][T] per-frame partial results
+    double       nyquist;
+    double       bin_var;       // sum_i (i/M - 0.5)^2 / M, summed serially on the host (ref SpectralCharacteristics.h:182-189)
+    float        lpf_a, lpf_b;  // ref RealTimeAudioAnalysis.h:122
+    const DynParams* dyn;       // non-null in a captured step: overrides gain and nyquist
+    float        first_tw[18];  // the <= 9 twiddles of the first FFT pass (re, im pairs): wave-uniform, so they travel as
+                                // kernel arguments (SGPRs) instead of LDS reads; filled by fill_first_pass_twiddles
+};
+
 
 // Completion signal of a one-hop call (fx_hop_kernel): workgroups count themselves in `arrivals` (device memory, zero
 // between calls); the last one resets it and stores `seq` to `host_flag` (pinned host memory, system scope), after the
