@@ -222,7 +222,7 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     // A cut launch carries the step's tail in its own work queue (FrameParams::tail_in_queue) where the tail units fit:
     // one channel per workgroup, >= 256 threads, room for their tiles in the wave buffers.  FX_TAIL_IN_QUEUE=0: three
     // more launches instead, as for every uncut step.
-    if (fp.num_chunks > 1 && fp.ch_per_wg == 1 && st->waves * 64 >= 256 && c->N <= 1024) {
+    if (fp.num_chunks > 1 && fp.ch_per_wg == 1 && st->waves * 64 >= 256 && c->N <= 1024 && st->analysers != 1) {   // (the kernel variants that exist)
         const char* e = getenv("FX_TAIL_IN_QUEUE");
         const size_t need = (size_t) (st->waves * 64 / 256) * sizeof(float) * ((256 + fxk::HLEN) * 13 + 256 + fxk::MAX_ONSET_WINDOW);
         const size_t have = fxk::frame_kernel_lds_bytes(c->N, 1, st->waves) - fxk::frame_kernel_lds_bytes(c->N, 1, 0);

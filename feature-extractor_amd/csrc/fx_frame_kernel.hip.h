@@ -922,7 +922,10 @@ FX_MARK("harm2");
 
 // SPEC / HARM: which of the reference's two analysers run (RealTimeSpectralAnalyser,
 // RealTimeHarmonicAnalyser -- both by default, as AnalyserTrackController constructs them)
-template <int N, bool SPEC, bool HARM>
+// TAILQ: the variant whose cut launches carry the step's tail as their last work units (FrameParams::tail_in_queue).  A
+// kernel of its own, because the tail code under this kernel's register budget costs a few spills -- a scratch segment,
+// which every launch then pays ~7 us of host time for, whether it has tail units or not.
+template <int N, bool SPEC, bool HARM, bool TAILQ = false>
 __global__ void __launch_bounds__(Occ<N>::MAX_THREADS, Occ<N>::WAVES_PER_SIMD)
 fx_frame_kernel(const FrameParams p_arg)
 {
@@ -967,7 +970,7 @@ fx_frame_kernel(const FrameParams p_arg)
         chunk = (int) (ticket / groups);
         group = (int) (ticket % groups);
 #ifdef FX_HAVE_CHANNEL_TAIL
-        if (chunk >= p.num_chunks) {
+        if (TAILQ && chunk >= p.num_chunks) {
             // a tail unit (FrameParams::tail_in_queue; one channel per workgroup): the channel's scalar tail, smoothing /
             // onset and history, once its last chunk has counted itself in -- every chunk holds a lower ticket
             const int ct = group;

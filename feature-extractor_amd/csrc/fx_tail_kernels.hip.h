@@ -423,11 +423,15 @@ __device__ __forceinline__ void channel_tail(const EpilogueParams& p, int c, flo
     for (int t = tid; t < p.T; t += nthreads) finalise_frame(p, (long long) c * p.T + t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this workgroup's raw rows are written ...
     __syncthreads();                                                 // ... before any of its threads reads them back
-    const int groups = nthreads / EPI_TILE, g = tid / EPI_TILE, tiles = (p.T + EPI_TILE - 1) / EPI_TILE;
-    float* tile = lds + (size_t) (g < groups ? g : 0) * (EPI_TILE_FLOATS + EPI_AMP_FLOATS);
+    const int groups = nthreads / EPI_TILE, tiles = (p.T + EPI_TILE - 1) / EPI_TILE;
+#pragma unroll 1
     for (int tp = 0; tp < tiles; tp += groups) {
+        // (the thread's group and tile address are formed again in every round rather than kept in registers across the
+        // loop: inside fx_frame_kernel this code runs under that kernel's register budget)
+        const int tq = opaque(tid), g = tq / EPI_TILE;
+        float* tile = lds + (size_t) (g < groups ? g : 0) * (EPI_TILE_FLOATS + EPI_AMP_FLOATS);
         const bool live = g < groups && tp + g < tiles;
-        epilogue_tile(p, c, (tp + g) * EPI_TILE, live, tile, tile + EPI_TILE_FLOATS, tid % EPI_TILE);
+        epilogue_tile(p, c, (tp + g) * EPI_TILE, live, tile, tile + EPI_TILE_FLOATS, tq % EPI_TILE);
         __syncthreads();                                             // (the tiles are reused by the next round)
     }
     for (int i = tid; i < HLEN * FX_NUM_FEATURES; i += nthreads) history_value(p, (long long) c * HLEN * FX_NUM_FEATURES + i);
