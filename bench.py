@@ -421,7 +421,7 @@ def main():
             an.reset_state()
             # the reference application's default window (AnalyserTrackController.h:20-21) and the streaming config's window
             others = {}
-            for (n2, c2, t2, label) in ((2048, 4096, 32, "configs[2] shape: 4096 channels x 2048-pt"), (4096, 1024, 32, "configs[4] window: 1024 channels x 4096-pt")):
+            for (n2, c2, t2, label) in ((2048, 4096, 64, "configs[2] shape: 4096 channels x 2048-pt"), (4096, 1024, 64, "configs[4] window: 1024 channels x 4096-pt")):
                 if n2 == N:
                     continue
                 fr2 = torch.from_numpy(fx.synth.frames(c2, t2, n2)).cuda(local_rank)
