@@ -8,7 +8,7 @@ import build as fxbuild
 subprocess.run(["hipcc"] + fxbuild.flags_for_window(int(N)) + ["-x", "hip", "-c", os.path.join(root, "feature-extractor_amd/csrc/fx_kernels.hip"), "-o", os.path.join(d, "fx.o"), "-save-temps"],
                cwd=d, stderr=subprocess.DEVNULL)
 src = open(os.path.join(d, "fx_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
-start = src.index("_ZN3fxk15fx_frame_kernelILi%sELb1ELb1ELb0EEEvNS_11FrameParamsE:" % N)
+start = src.index("_ZN3fxk15fx_frame_kernelILi%sELb1ELb1EEEvNS_11FrameParamsE:" % N)
 body = src[start:src.index("s_endpgm", start)]
 sec = "pre"; counts = {}; order = []
 for line in body.splitlines():

@@ -27,7 +27,7 @@ def static_mix(window):
     subprocess.run([build._hipcc()] + build.flags_for_window(window) + ["-x", "hip", "-c", os.path.join(build.CSRC, "fx_kernels.hip"), "-o", os.path.join(d, "fx.o"), "-save-temps"],
                    cwd=d, stderr=subprocess.DEVNULL, check=True)
     src = open(os.path.join(d, "fx_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
-    start = src.index("_ZN3fxk15fx_frame_kernelILi%dELb1ELb1ELb0EEEvNS_11FrameParamsE:" % window)
+    start = src.index("_ZN3fxk15fx_frame_kernelILi%dELb1ELb1EEEvNS_11FrameParamsE:" % window)
     body = src[start:src.index("s_endpgm", start)]
     fast = slow = 0
     for line in body.splitlines():
