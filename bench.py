@@ -362,9 +362,7 @@ def main():
                 "epilogue_ms_per_step": epi_ms / max(calls, 1),
                 "limiter": "valu",
                 "note": "algorithmic bytes = (4*N + 48) B/frame x frames per launch, against the HBM peak as SURVEY 8(d) defines the "
-                        "roofline; the kernel's binding unit is VALU issue (see valu_issue_frac and DESIGN.md 3.3).  A launch cut in "
-                        "time (long calls at <= 1024 points) also carries the step's scalar tail, smoothing / onset and history as "
-                        "its last work units: avg_launch_ms then is the whole step's device time and epilogue_ms_per_step ~0"}
+                        "roofline; the kernel's binding unit is VALU issue (see valu_issue_frac and DESIGN.md 3.3)"}
         vm = valu_model(N)
         if vm:
             # time the kernel's VALU instructions need at the measured per-class issue costs (tools/ubench), as a fraction

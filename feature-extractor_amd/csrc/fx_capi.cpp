@@ -184,7 +184,6 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
         st->waves = ch * k;
         fp.num_chunks = 1;
         fp.queue = nullptr;
-        fp.tail_in_queue = 0;
         for (int i = 0; i <= fxk::FX_MAX_CHUNKS; i++) fp.chunk_begin[i] = 0;
         if (!dyn && c->d_queue) {
             int sizes[fxk::FX_MAX_CHUNKS];
@@ -219,18 +218,6 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     st->analysers = (c->flags & FX_SPECTRAL_ONLY) ? 1 : ((c->flags & FX_HARMONIC_ONLY) ? 2 : 3);
     ep.analysers = st->analysers;
     ep.dyn = dyn;
-    // A cut launch carries the step's tail in its own work queue (FrameParams::tail_in_queue) where the tail units fit:
-    // one channel per workgroup, >= 256 threads, room for their tiles in the wave buffers.  FX_TAIL_IN_QUEUE=0: three
-    // more launches instead, as for every uncut step.
-    if (fp.num_chunks > 1 && fp.ch_per_wg == 1 && st->waves * 64 >= 256 && c->N <= 1024 && st->analysers != 1) {   // (the kernel variants that exist)
-        const char* e = getenv("FX_TAIL_IN_QUEUE");
-        const size_t need = (size_t) (st->waves * 64 / 256) * sizeof(float) * ((256 + fxk::HLEN) * 13 + 256 + fxk::MAX_ONSET_WINDOW);
-        const size_t have = fxk::frame_kernel_lds_bytes(c->N, 1, st->waves) - fxk::frame_kernel_lds_bytes(c->N, 1, 0);
-        if (!(e && atoi(e) == 0) && need <= have) {
-            fp.tail_in_queue = 1;
-            fp.tail = ep;
-        }
-    }
     return FX_OK;
 }
 
@@ -319,7 +306,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     HIP_TRY(hipEventRecord(e0, c->stream));
     HIP_TRY(fxk::launch_frame_kernel(c->N, step.fp, step.analysers, c->stream));
     HIP_TRY(hipEventRecord(e1, c->stream));
-    if (!step.fp.tail_in_queue) HIP_TRY(fxk::launch_epilogue_kernels(step.ep, c->stream));
+    HIP_TRY(fxk::launch_epilogue_kernels(step.ep, c->stream));
     HIP_TRY(hipEventRecord(e2, c->stream));
     c->ev_valid = last_valid;
     advance(c, T);

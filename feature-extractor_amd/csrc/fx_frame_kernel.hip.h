@@ -922,10 +922,7 @@ FX_MARK("harm2");
 
 // SPEC / HARM: which of the reference's two analysers run (RealTimeSpectralAnalyser,
 // RealTimeHarmonicAnalyser -- both by default, as AnalyserTrackController constructs them)
-// TAILQ: the variant whose cut launches carry the step's tail as their last work units (FrameParams::tail_in_queue).  A
-// kernel of its own, because the tail code under this kernel's register budget costs a few spills -- a scratch segment,
-// which every launch then pays ~7 us of host time for, whether it has tail units or not.
-template <int N, bool SPEC, bool HARM, bool TAILQ = false>
+template <int N, bool SPEC, bool HARM>
 __global__ void __launch_bounds__(Occ<N>::MAX_THREADS, Occ<N>::WAVES_PER_SIMD)
 fx_frame_kernel(const FrameParams p_arg)
 {
@@ -965,27 +962,10 @@ fx_frame_kernel(const FrameParams p_arg)
         unsigned* ticket_s = reinterpret_cast<unsigned*>(per_wave);           // (wave 0's buffer is not in use yet)
         if (threadIdx.x == 0) *ticket_s = __hip_atomic_fetch_add(p.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
-        const unsigned ticket = *ticket_s, groups = gridDim.x / (unsigned) (p.num_chunks + (p.tail_in_queue ? 1 : 0));
+        const unsigned ticket = *ticket_s, groups = gridDim.x / (unsigned) p.num_chunks;
         __syncthreads();                                                       // (before anyone writes that buffer)
         chunk = (int) (ticket / groups);
         group = (int) (ticket % groups);
-#ifdef FX_HAVE_CHANNEL_TAIL
-        if (TAILQ && chunk >= p.num_chunks) {
-            // a tail unit (FrameParams::tail_in_queue; one channel per workgroup): the channel's scalar tail, smoothing /
-            // onset and history, once its last chunk has counted itself in -- every chunk holds a lower ticket
-            const int ct = group;
-            if (threadIdx.x == 0) {
-                unsigned spins = 0;
-                while (__hip_atomic_load(p.queue + 1 + ct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned) p.num_chunks && ++spins < (1u << 22))
-                    __builtin_amdgcn_s_sleep(8);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __syncthreads();
-            channel_tail(p_arg.tail, ct, reinterpret_cast<float*>(per_wave), (int) threadIdx.x, (int) blockDim.x);
-            return;
-        }
-#endif
     }
     const int c = group * CH + chl;
     const bool live = c < p.C;                          // the last workgroup may hold fewer channels
@@ -1070,7 +1050,7 @@ fx_frame_kernel(const FrameParams p_arg)
     __syncthreads();
     if (live)
         for (int i = lane0 + 64 * slot; i < M; i += 64 * K) p.prev_re[(size_t) c * M + i] = prev[bimg<N>(i)];
-    if (chunk + 1 < p.num_chunks || (p.num_chunks > 1 && p.tail_in_queue)) {
+    if (chunk + 1 < p.num_chunks) {
         // hand the flux state to the next chunk's workgroup: every storing wave's stores done, the barrier, one lane's
         // agent-scope release, then the count (MI355X guide, producer form)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

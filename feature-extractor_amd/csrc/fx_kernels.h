@@ -53,28 +53,6 @@ struct DynParams {
     int       onset_type;
 };
 
-struct EpilogueParams {
-    const FramePart* part;      // [C][T] from the frame kernel
-    float*       raw;           // [C][T][12] raw values: written by fx_finalise_kernel, read by the smoothing kernel
-    double       nyquist;
-    double       bin_var;
-    int          window;
-    const float* hist_in;       // [C][HLEN][12] raw values of the HLEN frames before this call
-    float*       hist_out;      // [C][HLEN][12]
-    float*       out_raw;       // [C][T][12] or nullptr
-    float*       out_smoothed;  // [C][T][12] or nullptr
-    float*       latest;        // [C][12] smoothed values after the last frame
-    int          C, T;
-    long long    frames_before; // frames analysed since the last state reset, before this call
-    long long    onset_reset_frame; // global index of the first frame after the last onset-window reset
-    int          onset_window;  // history length of the OnsetDetector (default 5)
-    int          onset_type;
-    float        onset_multiplier;
-    int          order_mode;    // FX_ORDER_*
-    int          analysers;     // bit 0: spectral analyser runs, bit 1: harmonic analyser runs
-    const DynParams* dyn;       // non-null in a captured step: overrides nyquist, frames_before, onset_*
-};
-
 constexpr int FX_MAX_CHUNKS = 24;
 
 struct FrameParams {
@@ -96,11 +74,6 @@ struct FrameParams {
     int          num_chunks;
     unsigned*    queue;
     int          chunk_begin[FX_MAX_CHUNKS + 1];   // chunk k analyses frames [chunk_begin[k], chunk_begin[k + 1]); the last entry used is T
-    // A cut launch can carry the step's tail as well: after the last chunk's tickets come one ticket per channel for that
-    // channel's scalar tail, smoothing / onset and history (what fx_finalise_kernel, fx_epilogue_kernel and
-    // fx_history_kernel do as three more launches) -- they start as channels finish and fill the launch's tail.
-    int          tail_in_queue;
-    EpilogueParams tail;
     float        gain;          // hop mode only (ref AudioDataCollector.h:88)
     const float* tail_in;       // [C][N/2] second half of the previous window (already gained)
     float*       tail_out;      // [C][N/2]
@@ -115,6 +88,27 @@ struct FrameParams {
                                 // kernel arguments (SGPRs) instead of LDS reads; filled by fill_first_pass_twiddles
 };
 
+struct EpilogueParams {
+    const FramePart* part;      // [C][T] from the frame kernel
+    float*       raw;           // [C][T][12] raw values: written by fx_finalise_kernel, read by the smoothing kernel
+    double       nyquist;
+    double       bin_var;
+    int          window;
+    const float* hist_in;       // [C][HLEN][12] raw values of the HLEN frames before this call
+    float*       hist_out;      // [C][HLEN][12]
+    float*       out_raw;       // [C][T][12] or nullptr
+    float*       out_smoothed;  // [C][T][12] or nullptr
+    float*       latest;        // [C][12] smoothed values after the last frame
+    int          C, T;
+    long long    frames_before; // frames analysed since the last state reset, before this call
+    long long    onset_reset_frame; // global index of the first frame after the last onset-window reset
+    int          onset_window;  // history length of the OnsetDetector (default 5)
+    int          onset_type;
+    float        onset_multiplier;
+    int          order_mode;    // FX_ORDER_*
+    int          analysers;     // bit 0: spectral analyser runs, bit 1: harmonic analyser runs
+    const DynParams* dyn;       // non-null in a captured step: overrides nyquist, frames_before, onset_*
+};
 
 // Completion signal of a one-hop call (fx_hop_kernel): workgroups count themselves in `arrivals` (device memory, zero
 // between calls); the last one resets it and stores `seq` to `host_flag` (pinned host memory, system scope), after the

@@ -39,6 +39,7 @@ namespace fxk {
 
 #include "fx_wave.hip.h"
 #include "fx_fft.hip.h"
+#include "fx_frame_kernel.hip.h"
 
 // The library builds this file twice (build.py): FX_PART=1 holds the frame kernels up to 1024 points, the tail kernels
 // and every host-side helper; FX_PART=2 holds only the frame kernels for 2048 and 4096 points.  The two halves want
@@ -54,7 +55,6 @@ namespace fxk {
 #if FX_PART != 2
 #include "fx_tail_kernels.hip.h"
 #endif
-#include "fx_frame_kernel.hip.h"
 #if FX_PART == 0 || FX_PART == 3
 #include "fx_hop_kernel.hip.h"
 #endif
@@ -103,29 +103,15 @@ template <int N> hipError_t prepare_t()
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, true, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, false, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    if constexpr (N <= 1024) {                           // the variants with tail units (cut launches only exist at these sizes)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, true, true, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, false, true, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    }
-    return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, false, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 template <int N> hipError_t launch_t(const FrameParams& p, int analysers, hipStream_t stream)
 {
     const size_t lds = lds_bytes_t<N>(p.ch_per_wg, p.waves_per_ch);
-    const dim3 grid((unsigned) ((p.C + p.ch_per_wg - 1) / p.ch_per_wg) * (unsigned) (p.num_chunks > 1 ? p.num_chunks + (p.tail_in_queue ? 1 : 0) : 1)),
+    const dim3 grid((unsigned) ((p.C + p.ch_per_wg - 1) / p.ch_per_wg) * (unsigned) (p.num_chunks > 1 ? p.num_chunks : 1)),
                block((unsigned) (p.ch_per_wg * p.waves_per_ch) * 64);
-    if constexpr (N <= 1024) {
-        if (p.tail_in_queue && analysers == 3) { hipLaunchKernelGGL((fx_frame_kernel<N, true, true, true>), grid, block, lds, stream, p); return hipGetLastError(); }
-        if (p.tail_in_queue && analysers == 2) { hipLaunchKernelGGL((fx_frame_kernel<N, false, true, true>), grid, block, lds, stream, p); return hipGetLastError(); }
-    }
-    if (p.tail_in_queue) return hipErrorInvalidValue;
     if (analysers == 3)      hipLaunchKernelGGL((fx_frame_kernel<N, true, true>), grid, block, lds, stream, p);
     else if (analysers == 1) hipLaunchKernelGGL((fx_frame_kernel<N, true, false>), grid, block, lds, stream, p);
     else if (analysers == 2) hipLaunchKernelGGL((fx_frame_kernel<N, false, true>), grid, block, lds, stream, p);

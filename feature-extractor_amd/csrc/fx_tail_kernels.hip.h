@@ -352,53 +352,44 @@ __device__ __forceinline__ void epilogue_hop(const EpilogueParams& p, int c, int
 // thread = (channel, frame); a block is EPI_TILE consecutive frames of ONE channel and first stages the rows it needs
 // (its own and the HLEN - 1 before them) in LDS: each thread's ~70 reads of neighbouring rows then hit LDS instead of L2
 constexpr int EPI_TILE = 256;
-// One tile: frames t0 .. t0 + EPI_TILE - 1 of channel c by EPI_TILE threads (tid = 0 .. EPI_TILE - 1); tile / amp: this
-// group's LDS.  Contains workgroup barriers: every thread of the workgroup calls it, `live` or not.
-__device__ __forceinline__ void epilogue_tile(const EpilogueParams& p, int c, int t0, bool live, float* tile, float* amp, int tid)
+#ifdef FX_WITH_TAIL_KERNELS
+__global__ void __launch_bounds__(EPI_TILE)
+fx_epilogue_kernel(const EpilogueParams p_arg)
 {
+    __shared__ float tile[(EPI_TILE + HLEN) * TILE_STRIDE];
+    __shared__ float amp[EPI_TILE + MAX_ONSET_WINDOW];
+    const EpilogueParams p = with_dyn(p_arg);
+    const int tiles = (p.T + EPI_TILE - 1) / EPI_TILE;
+    const int c = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * EPI_TILE;
     const int first = t0 - HLEN;                                     // first row of the tile (may be before the call)
     const int rows = (p.T - t0 < EPI_TILE ? p.T - t0 : EPI_TILE) + HLEN;
     const float* raw = p.raw + (size_t) c * p.T * FX_NUM_FEATURES;
     const float* hist = p.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES;
-    if (live) {
-        for (int i = tid; i < rows * FX_NUM_FEATURES; i += EPI_TILE) {
-            const int r = i / FX_NUM_FEATURES, s = i % FX_NUM_FEATURES, tau = first + r;
-            // rows more than HLEN before the call do not exist (and are never read: RawView::valid)
-            tile[r * TILE_STRIDE + s] = tau >= 0 ? raw[(size_t) tau * FX_NUM_FEATURES + s]
-                                                 : (tau >= -HLEN ? hist[(size_t) (HLEN + tau) * FX_NUM_FEATURES + s] : 0.0f);
-        }
+    for (int i = threadIdx.x; i < rows * FX_NUM_FEATURES; i += EPI_TILE) {
+        const int r = i / FX_NUM_FEATURES, s = i % FX_NUM_FEATURES, tau = first + r;
+        // rows more than HLEN before the call do not exist (and are never read: RawView::valid)
+        tile[r * TILE_STRIDE + s] = tau >= 0 ? raw[(size_t) tau * FX_NUM_FEATURES + s]
+                                             : (tau >= -HLEN ? hist[(size_t) (HLEN + tau) * FX_NUM_FEATURES + s] : 0.0f);
     }
     __syncthreads();
     // The detector of frame t compares the RMS means of frames t - L + 1 .. t as they stood at each frame's own
     // detection (ref RealTimeAnalyser.h:236-242): one value per FRAME, wanted by up to L frames -- evaluated once here
     // (ten history reads and the double-insert index arithmetic each) for this tile's frames and the MAX_ONSET_WINDOW
     // before them.
-    if (live) {
+    {
         RawView v;
         v.raw = raw; v.hist = hist; v.T = p.T; v.frames_before = p.frames_before; v.tile = tile; v.tile_first = first;
         const bool both = (p.analysers & 1) && (p.analysers & 2);
         const int order_mode = both ? p.order_mode : FX_ORDER_ISOLATED;
         const int pushes = (order_mode == FX_ORDER_HARMONIC_THEN_SPECTRAL) ? 2 : 1;
-        for (int j = tid; j < EPI_TILE + MAX_ONSET_WINDOW; j += EPI_TILE) {
+        for (int j = threadIdx.x; j < EPI_TILE + MAX_ONSET_WINDOW; j += EPI_TILE) {
             const int f = t0 - MAX_ONSET_WINDOW + j;
             amp[j] = (f < p.T) ? rms_value(v, f, order_mode, pushes) : 0.0f;
         }
     }
     __syncthreads();
-    const int t = t0 + tid;
-    if (live && t < p.T) epilogue_frame(p, c, t, tile, first, amp, t0 - MAX_ONSET_WINDOW);
-}
-constexpr int EPI_TILE_FLOATS = (EPI_TILE + HLEN) * TILE_STRIDE, EPI_AMP_FLOATS = EPI_TILE + MAX_ONSET_WINDOW;
-
-#ifdef FX_WITH_TAIL_KERNELS
-__global__ void __launch_bounds__(EPI_TILE)
-fx_epilogue_kernel(const EpilogueParams p_arg)
-{
-    __shared__ float tile[EPI_TILE_FLOATS];
-    __shared__ float amp[EPI_AMP_FLOATS];
-    const EpilogueParams p = with_dyn(p_arg);
-    const int tiles = (p.T + EPI_TILE - 1) / EPI_TILE;
-    epilogue_tile(p, (int) (blockIdx.x / tiles), (int) (blockIdx.x % tiles) * EPI_TILE, true, tile, amp, (int) threadIdx.x);
+    const int t = t0 + (int) threadIdx.x;
+    if (t < p.T) epilogue_frame(p, c, t, tile, first, amp, t0 - MAX_ONSET_WINDOW);
 }
 #endif
 
@@ -414,29 +405,6 @@ __device__ __forceinline__ void history_value(const EpilogueParams& p, long long
     else          val = p.hist_in[((size_t) c * HLEN + (HLEN + tau)) * FX_NUM_FEATURES + s];
     p.hist_out[idx] = val;
 }
-
-// The whole tail of one channel of a call -- scalar tail of every frame, smoothing / onset, history -- by one workgroup
-// of `nthreads` >= EPI_TILE threads (fx_frame_kernel's tail units; `lds`: (nthreads / EPI_TILE) x (EPI_TILE_FLOATS +
-// EPI_AMP_FLOATS) floats).  What the three tail kernels do, in their order, for channel c.
-__device__ __forceinline__ void channel_tail(const EpilogueParams& p, int c, float* lds, int tid, int nthreads)
-{
-    for (int t = tid; t < p.T; t += nthreads) finalise_frame(p, (long long) c * p.T + t);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this workgroup's raw rows are written ...
-    __syncthreads();                                                 // ... before any of its threads reads them back
-    const int groups = nthreads / EPI_TILE, tiles = (p.T + EPI_TILE - 1) / EPI_TILE;
-#pragma unroll 1
-    for (int tp = 0; tp < tiles; tp += groups) {
-        // (the thread's group and tile address are formed again in every round rather than kept in registers across the
-        // loop: inside fx_frame_kernel this code runs under that kernel's register budget)
-        const int tq = opaque(tid), g = tq / EPI_TILE;
-        float* tile = lds + (size_t) (g < groups ? g : 0) * (EPI_TILE_FLOATS + EPI_AMP_FLOATS);
-        const bool live = g < groups && tp + g < tiles;
-        epilogue_tile(p, c, (tp + g) * EPI_TILE, live, tile, tile + EPI_TILE_FLOATS, tq % EPI_TILE);
-        __syncthreads();                                             // (the tiles are reused by the next round)
-    }
-    for (int i = tid; i < HLEN * FX_NUM_FEATURES; i += nthreads) history_value(p, (long long) c * HLEN * FX_NUM_FEATURES + i);
-}
-#define FX_HAVE_CHANNEL_TAIL 1
 
 #ifdef FX_WITH_TAIL_KERNELS
 __global__ void __launch_bounds__(256)

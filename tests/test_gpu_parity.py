@@ -136,7 +136,7 @@ def test_split_calls_equal_one_call_bitwise(gpu_fx, N):
 def test_long_calls_cut_in_time_match_oracle_and_the_uncut_launch(gpu_fx, oracle, monkeypatch, N, C, T):
     """Calls of >= 128 frames per channel are cut in time (FrameParams::num_chunks): several workgroups per channel, each
     taking 64 consecutive frames, the flux state handed from one to the next through global memory behind a ticket
-    order, and one more per channel doing the step's tail (scalar tail, smoothing / onset, history) inside the same launch.  Bursts with digital silence in between put the reference's skip rule (no update of the previous magnitudes,
+    order.  Bursts with digital silence in between put the reference's skip rule (no update of the previous magnitudes,
     SpectralCharacteristics.h:121-123) across chunk boundaries; the last chunk is ragged."""
     hops = signals.bursts(C, T, N, seed=12)
     raw, sm = gpu_fx.BatchAnalyser(C, N).push_hops(hops)
@@ -145,10 +145,6 @@ def test_long_calls_cut_in_time_match_oracle_and_the_uncut_launch(gpu_fx, oracle
     close(sm, osm, "chunked smoothed")
     frames = gpu_fx.synth.frames(C, T, N, first_channel=7)
     fraw, fsm = gpu_fx.BatchAnalyser(C, N).process_frames(frames)
-    monkeypatch.setenv("FX_TAIL_IN_QUEUE", "0")          # the same cut launch followed by the three tail kernels
-    r0, s0 = gpu_fx.BatchAnalyser(C, N).push_hops(hops)
-    assert np.array_equal(r0, raw, equal_nan=True) and np.array_equal(s0, sm, equal_nan=True)
-    monkeypatch.delenv("FX_TAIL_IN_QUEUE")
     for per_chunk in ("0", "16", "100"):
         monkeypatch.setenv("FX_FRAMES_PER_CHUNK", per_chunk)
         r0, s0 = gpu_fx.BatchAnalyser(C, N).push_hops(hops)
