@@ -59,6 +59,23 @@ class BatchAnalyser:
     def reset_state(self):
         capi.check(self._lib.fx_reset_state(self._h))
 
+    # ---- launch-shape knobs (never change a result bit) ----
+    def get_tuning(self):
+        t = capi.Tuning()
+        capi.check(self._lib.fx_get_tuning(self._h, ctypes.byref(t)))
+        return t
+
+    def set_tuning(self, tuning=None, **knobs):
+        """Replace the context's knobs (struct fx_tuning); keyword arguments change single fields of the current ones."""
+        t = tuning if tuning is not None else self.get_tuning()
+        for k, v in knobs.items():
+            if k == "unit_plan":
+                t.set_plan(v)
+            else:
+                setattr(t, k, int(v))
+        capi.check(self._lib.fx_set_tuning(self._h, ctypes.byref(t)))
+        return t
+
     def sync(self):
         capi.check(self._lib.fx_sync(self._h))
 

@@ -94,8 +94,8 @@ def build(force=False, verbose=False):
             from concurrent.futures import ThreadPoolExecutor
             with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:
                 list(pool.map(compile_unit, UNITS))
-            # librccl: the feature gather of the multi-GPU path (fx_comm.cpp) calls RCCL directly
-            cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + tag] + objs + ["-L/opt/rocm/lib", "-lrccl"]
+            # (librccl is NOT linked: fx_comm.cpp loads it on the first fx_comm_* call, so single-GPU users never map it)
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + tag] + objs + ["-ldl"]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

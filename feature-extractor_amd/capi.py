@@ -24,9 +24,36 @@ EXPORTS = ["fx_create", "fx_destroy", "fx_reset_state", "fx_set_sample_rate", "f
            "fx_stream_create", "fx_stream_destroy", "fx_stream_acquire", "fx_stream_submit", "fx_stream_collect", "fx_stream_in_flight", "fx_pack_osc12",
            "fx_pack_osc10", "fx_osc_encode", "fx_last_error", "fx_abi_version",
            "fx_comm_unique_id", "fx_comm_create", "fx_comm_destroy", "fx_comm_layout", "fx_gather_smoothed", "fx_comm_sync",
-           "fx_plan_units"]
+           "fx_plan_units", "fx_tuning_defaults", "fx_tuning_from_env", "fx_get_tuning", "fx_set_tuning"]
 COMM_ID_BYTES = 128
-ABI_VERSION = 2
+ABI_VERSION = 3
+MAX_UNITS = 24
+
+
+class Tuning(ctypes.Structure):
+    """struct fx_tuning of include/fx.h: launch-shape knobs, none of which changes a result bit."""
+    _fields_ = [("waves_per_channel", ctypes.c_int), ("channels_per_workgroup", ctypes.c_int), ("waves_per_frame", ctypes.c_int),
+                ("frames_per_unit", ctypes.c_int), ("unit_plan_len", ctypes.c_int), ("unit_plan", ctypes.c_int * MAX_UNITS),
+                ("stream_graph", ctypes.c_int), ("stream_hop_kernel", ctypes.c_int), ("stream_zero_copy", ctypes.c_int),
+                ("one_hop_kernel", ctypes.c_int), ("handover_spin_limit", ctypes.c_int), ("debug_flags", ctypes.c_int)]
+
+    @classmethod
+    def defaults(cls):
+        t = cls()
+        load_library().fx_tuning_defaults(ctypes.byref(t))
+        return t
+
+    @classmethod
+    def from_env(cls):
+        t = cls()
+        load_library().fx_tuning_from_env(ctypes.byref(t))
+        return t
+
+    def set_plan(self, sizes):
+        self.unit_plan_len = len(sizes)
+        for k, v in enumerate(sizes):
+            self.unit_plan[k] = int(v)
+        return self
 
 
 class FxError(RuntimeError):
@@ -89,6 +116,13 @@ def load_library(build_if_missing=True):
     L.fx_comm_layout.argtypes = [vp, ctypes.POINTER(i), ctypes.POINTER(i)]
     L.fx_gather_smoothed.argtypes = [vp, i, vp, i]
     L.fx_comm_sync.argtypes = [vp]
+    L.fx_plan_units.argtypes = [i, u, i, i, ctypes.POINTER(Tuning), ctypes.POINTER(i), i]
+    L.fx_tuning_defaults.argtypes = [ctypes.POINTER(Tuning)]
+    L.fx_tuning_defaults.restype = None
+    L.fx_tuning_from_env.argtypes = [ctypes.POINTER(Tuning)]
+    L.fx_tuning_from_env.restype = None
+    L.fx_get_tuning.argtypes = [vp, ctypes.POINTER(Tuning)]
+    L.fx_set_tuning.argtypes = [vp, ctypes.POINTER(Tuning)]
     L.fx_pack_osc12.argtypes = [fp, fp]
     L.fx_pack_osc12.restype = None
     L.fx_pack_osc10.argtypes = [fp, fp]
@@ -102,6 +136,14 @@ def load_library(build_if_missing=True):
 def check(status):
     if status != FX_OK:
         raise FxError(status, load_library().fx_last_error().decode(errors="replace"))
+
+
+def plan_units(window_size, flags, waves_per_channel, num_frames, tuning=None):
+    """fx_plan_units: the work-unit lengths a call of `num_frames` frames per channel is cut into (host arithmetic)."""
+    buf = (ctypes.c_int * MAX_UNITS)()
+    n = load_library().fx_plan_units(int(window_size), int(flags), int(waves_per_channel), int(num_frames),
+                                     ctypes.byref(tuning) if tuning is not None else None, buf, MAX_UNITS)
+    return list(buf[:n])
 
 
 def _fp(a):

@@ -84,10 +84,10 @@ template <typename T> fx_status grow(T** ptr, size_t* cap, size_t need)
 // to 8 units are cut into equal units; longer ones into units of decreasing length -- a third of what is left each
 // time (at most four units' worth), down to a quarter unit -- long units first (little overhead), short ones last (the
 // launch's tail is one short unit deep): 512 frames = 168, 112, 80, 48, 32, 24, 16, 16, 16 (2.74 against 2.80 ms for
-// eight units of 64 at the bench shape).  FX_FRAMES_PER_CHUNK overrides the unit (0 = never cut), FX_CHUNK_PLAN=a,b,...
-// gives the lengths outright (experiments).  Host-only arithmetic: declared in include/fx.h so that the CPU tests can
-// hold it to its invariants.
-extern "C" int fx_plan_units(int window_size, unsigned flags, int waves_per_channel, int num_frames, int* sizes, int cap)
+// eight units of 64 at the bench shape).  fx_tuning::frames_per_unit overrides the unit (0 = never cut), fx_tuning::unit_plan
+// gives the lengths outright (experiments).  Host-only arithmetic, pure (no environment, no device): declared in
+// include/fx.h so that the CPU tests can hold it to its invariants.
+extern "C" int fx_plan_units(int window_size, unsigned flags, int waves_per_channel, int num_frames, const fx_tuning* tuning, int* sizes, int cap)
 {
     const int k = waves_per_channel, T = num_frames;
     if (!sizes || cap < 1 || k < 1 || T < 1) return 0;
@@ -95,11 +95,11 @@ extern "C" int fx_plan_units(int window_size, unsigned flags, int waves_per_chan
     int per_wave = window_size <= 256 ? 32 : (window_size == 512 ? 16 : 8);
     if (flags & FX_HARMONIC_ONLY) per_wave *= 2;
     int unit = (window_size > 1024 || (flags & FX_SPECTRAL_ONLY)) ? 0 : k * per_wave;
-    if (const char* e = getenv("FX_FRAMES_PER_CHUNK")) unit = atoi(e);
+    if (tuning && tuning->frames_per_unit >= 0) unit = tuning->frames_per_unit;
     int n = 0;
-    if (const char* plan = getenv("FX_CHUNK_PLAN")) {
+    if (tuning && tuning->unit_plan_len > 0 && tuning->unit_plan_len <= cap && tuning->unit_plan_len <= FX_MAX_UNITS) {
         int sum = 0;
-        for (const char* q = plan; *q && n < cap; ) { const int v = atoi(q); if (v > 0) { sizes[n++] = v; sum += v; } while (*q && *q != ',') q++; if (*q == ',') q++; }
+        for (int i = 0; i < tuning->unit_plan_len; i++) { const int v = tuning->unit_plan[i]; if (v <= 0) { sum = -1; break; } sizes[n++] = v; sum += v; }
         if (sum != T) n = 0;
     }
     if (n == 0 && unit >= k && unit > 0) {
@@ -124,6 +124,64 @@ extern "C" int fx_plan_units(int window_size, unsigned flags, int waves_per_chan
     }
     if (n < 2) { sizes[0] = T; n = 1; }
     return n;
+}
+
+extern "C" void fx_tuning_defaults(fx_tuning* t)
+{
+    if (!t) return;
+    memset(t, 0, sizeof *t);
+    t->frames_per_unit = -1;
+    t->stream_graph = t->stream_hop_kernel = t->stream_zero_copy = t->one_hop_kernel = -1;
+}
+
+// The ONLY place the library reads the environment: called once per context, by fx_create.
+extern "C" void fx_tuning_from_env(fx_tuning* t)
+{
+    if (!t) return;
+    fx_tuning_defaults(t);
+    auto geti = [](const char* name, int* out, int lo) { if (const char* e = getenv(name)) { const int v = atoi(e); if (v >= lo) *out = v; } };
+    geti("FX_WAVES", &t->waves_per_channel, 1);
+    geti("FX_CHANNELS_PER_WG", &t->channels_per_workgroup, 1);
+    geti("FX_WAVES_PER_FRAME", &t->waves_per_frame, 1);
+    geti("FX_FRAMES_PER_CHUNK", &t->frames_per_unit, 0);
+    if (const char* plan = getenv("FX_CHUNK_PLAN")) {
+        int n = 0;
+        for (const char* q = plan; *q && n < FX_MAX_UNITS; ) { const int v = atoi(q); if (v > 0) t->unit_plan[n++] = v; while (*q && *q != ',') q++; if (*q == ',') q++; }
+        t->unit_plan_len = n;
+    }
+    geti("FX_STREAM_GRAPH", &t->stream_graph, 0);
+    geti("FX_STREAM_HOP_KERNEL", &t->stream_hop_kernel, 0);
+    geti("FX_STREAM_ZEROCOPY", &t->stream_zero_copy, 0);
+    geti("FX_ONE_HOP_KERNEL", &t->one_hop_kernel, 0);
+    geti("FX_HANDOVER_SPINS", &t->handover_spin_limit, 1);
+    geti("FX_DEBUG_FLAGS", &t->debug_flags, 0);
+}
+
+extern "C" fx_status fx_get_tuning(fx_context* c, fx_tuning* out)
+{
+    if (!c || !out) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    *out = c->tuning;
+    return FX_OK;
+}
+
+extern "C" fx_status fx_set_tuning(fx_context* c, const fx_tuning* t)
+{
+    if (!c || !t) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    if (t->waves_per_channel < 0 || t->channels_per_workgroup < 0 || t->waves_per_frame < 0 || t->waves_per_frame > 2 ||
+        t->unit_plan_len < 0 || t->unit_plan_len > FX_MAX_UNITS || t->handover_spin_limit < 0)
+        return fx_fail(FX_ERR_INVALID_ARGUMENT, "tuning value out of range");
+    c->tuning = *t;
+    return FX_OK;
+}
+
+// A frame-kernel work unit that gave up waiting for its predecessor's flux state stores 1 to c->h_err (pinned host
+// memory).  Sticky: every synchronising entry point reports it until fx_reset_state.
+fx_status fx_check_device_error(fx_context* c)
+{
+    if (c && c->h_err && *(volatile unsigned*) c->h_err != 0)
+        return fx_fail(FX_ERR_HIP, "a frame-kernel work unit timed out waiting for the flux state of the unit before it; "
+                                   "the results of that call and of every call since are not valid (fx_reset_state clears this)");
+    return FX_OK;
 }
 
 namespace {
@@ -164,14 +222,14 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     // Workgroup shape: channels per workgroup x wavefronts per channel (= frames of one channel in flight): the
     // measured-best shape for this window size, fewer waves when the call has fewer frames, fewer channels when the
     // context has fewer or the LDS holds fewer (one twiddle table per workgroup, one flux state per channel, one
-    // transform buffer per wave).  FX_WAVES / FX_CHANNELS_PER_WG override for experiments.
+    // transform buffer per wave).  fx_tuning overrides for experiments.
     const size_t lds_cu = 160 * 1024;
     {
         const int kcap = fxk::frame_kernel_max_waves(c->N);
         int ch = 1, k = 1;
         fxk::frame_kernel_preferred_shape(c->N, &ch, &k);
-        if (const char* e = getenv("FX_WAVES")) { const int v = atoi(e); if (v >= 1) k = v; }
-        if (const char* e = getenv("FX_CHANNELS_PER_WG")) { const int v = atoi(e); if (v >= 1) ch = v; }
+        if (c->tuning.waves_per_channel >= 1) k = c->tuning.waves_per_channel;
+        if (c->tuning.channels_per_workgroup >= 1) ch = c->tuning.channels_per_workgroup;
         if (k > T) k = T;
         if (k > kcap) k = kcap;
         if (ch > c->C) ch = c->C;
@@ -184,10 +242,13 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
         st->waves = ch * k;
         fp.num_chunks = 1;
         fp.queue = nullptr;
+        fp.err = c->d_err;
+        fp.spin_limit = c->tuning.handover_spin_limit > 0 ? (unsigned) c->tuning.handover_spin_limit : (1u << 22);
+        fp.debug_flags = (unsigned) c->tuning.debug_flags;
         for (int i = 0; i <= fxk::FX_MAX_CHUNKS; i++) fp.chunk_begin[i] = 0;
         if (!dyn && c->d_queue) {
             int sizes[fxk::FX_MAX_CHUNKS];
-            const int n = fx_plan_units(c->N, c->flags, k, T, sizes, fxk::FX_MAX_CHUNKS);
+            const int n = fx_plan_units(c->N, c->flags, k, T, &c->tuning, sizes, fxk::FX_MAX_CHUNKS);
             if (n >= 2) {
                 fp.num_chunks = n;
                 fp.queue = c->d_queue;
@@ -250,6 +311,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     if (mem_kind != FX_MEM_HOST && mem_kind != FX_MEM_DEVICE)
         return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown memory kind %d", mem_kind);
     HIP_TRY(hipSetDevice(c->device));
+    { const fx_status es = fx_check_device_error(c); if (es != FX_OK) return es; }     // sticky: an earlier call's hand-over failed
 
     const size_t esz = sample_format == FX_SAMPLE_F16 ? 2 : 4;
     const size_t per_frame = hop_mode ? (size_t) c->N / 2 : (size_t) c->N;
@@ -302,12 +364,24 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
         c->prof_used += 3;
         last_valid = false;
     }
-    if (step.fp.num_chunks > 1) HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned) * (1 + (size_t) c->C), c->stream));
-    HIP_TRY(hipEventRecord(e0, c->stream));
-    HIP_TRY(fxk::launch_frame_kernel(c->N, step.fp, step.analysers, c->stream));
-    HIP_TRY(hipEventRecord(e1, c->stream));
-    HIP_TRY(fxk::launch_epilogue_kernels(step.ep, c->stream));
-    HIP_TRY(hipEventRecord(e2, c->stream));
+    // ONE frame per channel -- the reference's own cadence, an analysis per hop as it arrives (AudioDataCollector.h:66-94,
+    // RealTimeAnalyser.h:201-234) -- is one launch of fx_hop_kernel: three wavefronts per channel (pitch / spectral /
+    // harmonic) and the hop's tail, instead of one wavefront per channel and a second launch.
+    const bool one_hop = T == 1 && step.analysers == 3 && c->tuning.one_hop_kernel != 0 && fxk::hop_kernel_available(c->N);
+    if (one_hop) {
+        const fxk::HopSignal none = {nullptr, nullptr, 0u, 0u, nullptr};
+        HIP_TRY(hipEventRecord(e0, c->stream));
+        HIP_TRY(fxk::launch_hop_kernel(c->N, step.fp, step.ep, none, c->stream));
+        HIP_TRY(hipEventRecord(e1, c->stream));
+        HIP_TRY(hipEventRecord(e2, c->stream));
+    } else {
+        if (step.fp.num_chunks > 1) HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned) * (1 + (size_t) c->C), c->stream));
+        HIP_TRY(hipEventRecord(e0, c->stream));
+        HIP_TRY(fxk::launch_frame_kernel(c->N, step.fp, step.analysers, c->stream));
+        HIP_TRY(hipEventRecord(e1, c->stream));
+        HIP_TRY(fxk::launch_epilogue_kernels(step.ep, c->stream));
+        HIP_TRY(hipEventRecord(e2, c->stream));
+    }
     c->ev_valid = last_valid;
     advance(c, T);
 
@@ -315,6 +389,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
         if (out_raw) HIP_TRY(hipMemcpyAsync(out_raw, c->d_out_raw, raw_bytes, hipMemcpyDeviceToHost, c->stream));
         if (out_smoothed) HIP_TRY(hipMemcpyAsync(out_smoothed, c->d_out_sm, raw_bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        return fx_check_device_error(c);
     }
     return FX_OK;
 }
@@ -357,11 +432,13 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
     c->N = window_size;
     c->sample_rate = sample_rate;
     c->flags = flags;
+    fx_tuning_from_env(&c->tuning);          // once; nothing on the analysis path reads the environment
 
     fx_status st = FX_OK;
     auto cleanup = [&](fx_status s) { fx_destroy(c); return s; };
     {
         hipError_t e = fxk::prepare_kernels(window_size);
+        if (e == hipSuccess) e = fxk::prepare_hop_kernel(window_size);
         if (e != hipSuccess) return cleanup(fx_fail(FX_ERR_HIP, "kernel preparation failed: %s", hipGetErrorString(e)));
     }
 #define TRY_OR_CLEAN(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return cleanup(fx_fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
@@ -376,6 +453,9 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
     }
     TRY_OR_CLEAN(hipMalloc((void**) &c->d_latest, sizeof(float) * (size_t) num_channels * FX_NUM_FEATURES));
     TRY_OR_CLEAN(hipMalloc((void**) &c->d_queue, sizeof(unsigned) * (1 + (size_t) num_channels)));
+    TRY_OR_CLEAN(hipHostMalloc((void**) &c->h_err, 64, hipHostMallocCoherent));
+    *c->h_err = 0;
+    { void* q = nullptr; TRY_OR_CLEAN(hipHostGetDevicePointer(&q, c->h_err, 0)); c->d_err = static_cast<unsigned*>(q); }
 
     // Twiddle table exactly as the reference's FFT builds it (JUCE 4.2 FFT::FFTConfig, SURVEY.md
     // App. A.1): phase in double, entries rounded to float.  The inverse table is its conjugate.
@@ -425,6 +505,7 @@ fx_status fx_destroy(fx_context* c)
     void* bufs[] = {c->d_tw, c->d_prev, c->d_tail[0], c->d_tail[1], c->d_hist[0], c->d_hist[1], c->d_latest,
                     c->d_raw, c->d_part, c->d_in, c->d_out_raw, c->d_queue};
     for (void* b : bufs) if (b) (void) hipFree(b);
+    if (c->h_err) (void) hipHostFree(c->h_err);
     for (int i = 0; i < 3; i++) if (c->ev[i]) (void) hipEventDestroy(c->ev[i]);
     for (hipEvent_t e : c->prof_events) (void) hipEventDestroy(e);
     if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -436,6 +517,8 @@ fx_status fx_reset_state(fx_context* c)
 {
     if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->h_err) *c->h_err = 0;
     return zero_state(c);
 }
 
@@ -499,7 +582,7 @@ fx_status fx_get_smoothed(fx_context* c, float* out, int mem_kind)
     const size_t bytes = (size_t) c->C * FX_NUM_FEATURES * sizeof(float);
     HIP_TRY(hipMemcpyAsync(out, c->d_latest, bytes,
                            mem_kind == FX_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
-    if (mem_kind != FX_MEM_DEVICE) HIP_TRY(hipStreamSynchronize(c->stream));
+    if (mem_kind != FX_MEM_DEVICE) { HIP_TRY(hipStreamSynchronize(c->stream)); return fx_check_device_error(c); }
     return FX_OK;
 }
 
@@ -509,7 +592,7 @@ fx_status fx_sync(fx_context* c)
     if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return FX_OK;
+    return fx_check_device_error(c);
 }
 
 fx_status fx_get_stream(fx_context* c, void** stream)
@@ -530,7 +613,7 @@ fx_status fx_last_kernel_ms(fx_context* c, float* frame_ms, float* epi_ms)
     HIP_TRY(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
     if (frame_ms) *frame_ms = a;
     if (epi_ms) *epi_ms = b;
-    return FX_OK;
+    return fx_check_device_error(c);
 }
 
 fx_status fx_profile_begin(fx_context* c)
@@ -558,7 +641,7 @@ fx_status fx_profile_end(fx_context* c, double* frame_ms, double* epi_ms, int* c
     if (calls) *calls = (int) (c->prof_used / 3);
     c->profiling = false;
     c->prof_used = 0;
-    return FX_OK;
+    return fx_check_device_error(c);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -580,6 +663,7 @@ struct fx_stream {
     // writes the 12-float vectors back to it and then stores the call's sequence number to the slot's flag; collect
     // polls that flag.  No graph, no event, no second kernel.
     bool use_hop_kernel = false;
+    bool zero_copy = false;               // captured step: kernels read / write the pinned slot directly (a few KB per step)
     unsigned* d_arrivals = nullptr;       // workgroups of the running hop kernel that have finished (zero between calls)
     void*     d_stage = nullptr;          // [C][N/2] samples: the hop kernel's device copy of the hop it is analysing
     unsigned  next_seq = 0;
@@ -651,17 +735,13 @@ fx_status fx_stream_create(fx_context* c, int hops_per_batch, int slots, int sam
     s->ring.resize((size_t) slots);
 #define S_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fx_status st_ = fx_fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); fx_stream_destroy(s); return st_; } } while (0)
     S_TRY(hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
-    {
-        const char* e = getenv("FX_STREAM_GRAPH");          // 0 / 1 force the choice (experiments, tests)
-        s->use_graph = e ? atoi(e) != 0 : (size_t) c->C * hops_per_batch <= 4096;
-    }
-    {
-        const char* e = getenv("FX_STREAM_HOP_KERNEL");     // 0 forces the captured two-kernel step (experiments, tests)
-        // (up to 1 MiB of hops per call: the kernel reads each hop out of the pinned slot exactly once, 16 bytes per lane)
-        s->use_hop_kernel = hops_per_batch == 1 && s->in_bytes <= 1024 * 1024 && fxk::hop_kernel_available(c->N)
-                            && !(c->flags & (FX_SPECTRAL_ONLY | FX_HARMONIC_ONLY)) && !(e && atoi(e) == 0) && s->use_graph;
-        if (s->use_hop_kernel) s->use_graph = false;
-    }
+    // which of the equivalent paths runs: by batch size, unless the context's tuning forces one (experiments, tests)
+    s->use_graph = c->tuning.stream_graph >= 0 ? c->tuning.stream_graph != 0 : (size_t) c->C * hops_per_batch <= 4096;
+    // (up to 1 MiB of hops per call: the kernel reads each hop out of the pinned slot exactly once, 16 bytes per lane)
+    s->use_hop_kernel = hops_per_batch == 1 && s->in_bytes <= 1024 * 1024 && fxk::hop_kernel_available(c->N)
+                        && !(c->flags & (FX_SPECTRAL_ONLY | FX_HARMONIC_ONLY)) && c->tuning.stream_hop_kernel != 0 && s->use_graph;
+    if (s->use_hop_kernel) s->use_graph = false;
+    s->zero_copy = c->tuning.stream_zero_copy >= 0 ? c->tuning.stream_zero_copy != 0 : s->in_bytes <= 64 * 1024;
     if (s->use_hop_kernel) {
         S_TRY(hipMalloc((void**) &s->d_arrivals, sizeof(unsigned)));
         S_TRY(hipMemsetAsync(s->d_arrivals, 0, sizeof(unsigned), c->stream));
@@ -718,13 +798,18 @@ fx_status fx_stream_submit(fx_stream* s)
     fx_context* c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
     fx_stream::Slot& sl = s->ring[(size_t) s->head];
+    { const fx_status es = fx_check_device_error(c); if (es != FX_OK) { s->acquired = false; return es; } }
+    // Any failure below hands the slot back (the caller may fill and submit it again): the ring never wedges on
+    // "a slot is already acquired".
+#define SUB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { s->acquired = false; \
+        return fx_fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
     if (s->use_hop_kernel) {
         if (!sl.dev_flag) {
             void* q = nullptr;
-            HIP_TRY(hipHostGetDevicePointer(&q, sl.h_in, 0));   sl.dev_in = q;
-            HIP_TRY(hipHostGetDevicePointer(&q, sl.h_raw, 0));  sl.dev_raw = static_cast<float*>(q);
-            HIP_TRY(hipHostGetDevicePointer(&q, sl.h_sm, 0));   sl.dev_sm = static_cast<float*>(q);
-            HIP_TRY(hipHostGetDevicePointer(&q, sl.h_flag, 0)); sl.dev_flag = static_cast<unsigned*>(q);
+            SUB_TRY(hipHostGetDevicePointer(&q, sl.h_in, 0));   sl.dev_in = q;
+            SUB_TRY(hipHostGetDevicePointer(&q, sl.h_raw, 0));  sl.dev_raw = static_cast<float*>(q);
+            SUB_TRY(hipHostGetDevicePointer(&q, sl.h_sm, 0));   sl.dev_sm = static_cast<float*>(q);
+            SUB_TRY(hipHostGetDevicePointer(&q, sl.h_flag, 0)); sl.dev_flag = static_cast<unsigned*>(q);
         }
         unsigned* flag_dev = sl.dev_flag;
         Step step;
@@ -750,23 +835,22 @@ fx_status fx_stream_submit(fx_stream* s)
             // A few KB per step: the kernels read the hop and the per-call scalars straight from the pinned host slot and
             // write the 12-float vectors straight back (zero copy), so the graph is two kernel nodes and no copy nodes;
             // larger batches keep explicit copies (PCIe is read best in bulk).
-            const char* zc = getenv("FX_STREAM_ZEROCOPY");          // experiments
-            const bool zero_copy = zc ? atoi(zc) != 0 : s->in_bytes <= 64 * 1024;
+            const bool zero_copy = s->zero_copy;
             const void* in_dev = sl.d_in;
             float* raw_dev = sl.d_raw; float* sm_dev = sl.d_sm;
             const fxk::DynParams* dyn_dev = sl.d_dyn;
             if (zero_copy) {
                 void* q = nullptr;
-                HIP_TRY(hipHostGetDevicePointer(&q, sl.h_in, 0));  in_dev = q;
-                HIP_TRY(hipHostGetDevicePointer(&q, sl.h_raw, 0)); raw_dev = static_cast<float*>(q);
-                HIP_TRY(hipHostGetDevicePointer(&q, sl.h_sm, 0));  sm_dev = static_cast<float*>(q);
-                HIP_TRY(hipHostGetDevicePointer(&q, sl.h_dyn, 0)); dyn_dev = static_cast<const fxk::DynParams*>(q);
+                SUB_TRY(hipHostGetDevicePointer(&q, sl.h_in, 0));  in_dev = q;
+                SUB_TRY(hipHostGetDevicePointer(&q, sl.h_raw, 0)); raw_dev = static_cast<float*>(q);
+                SUB_TRY(hipHostGetDevicePointer(&q, sl.h_sm, 0));  sm_dev = static_cast<float*>(q);
+                SUB_TRY(hipHostGetDevicePointer(&q, sl.h_dyn, 0)); dyn_dev = static_cast<const fxk::DynParams*>(q);
             }
             Step step;
             fx_status st0 = prepare_step(c, in_dev, s->hops, s->fmt, 1, raw_dev, sm_dev, s->g_part, s->g_raw, dyn_dev, &step);
             if (st0 != FX_OK) { s->acquired = false; return st0; }
             hipGraph_t graph = nullptr;
-            HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            SUB_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             hipError_t e = hipSuccess;
             if (!zero_copy) {
                 e = hipMemcpyAsync(sl.d_in, sl.h_in, s->in_bytes, hipMemcpyHostToDevice, c->stream);
@@ -778,7 +862,7 @@ fx_status fx_stream_submit(fx_stream* s)
                 if (e == hipSuccess) e = hipMemcpyAsync(sl.h_raw, sl.d_raw, s->out_bytes, hipMemcpyDeviceToHost, c->stream);
                 if (e == hipSuccess) e = hipMemcpyAsync(sl.h_sm, sl.d_sm, s->out_bytes, hipMemcpyDeviceToHost, c->stream);
             }
-            const hipError_t e2 = hipStreamEndCapture(c->stream, &graph);
+            const hipError_t e2 = hipStreamEndCapture(c->stream, &graph);       // (always: a failed step must not leave the capture open)
             if (e == hipSuccess) e = e2;
             if (e == hipSuccess) e = hipGraphInstantiate(&sl.exec[par], graph, nullptr, nullptr, 0);
             if (graph) (void) hipGraphDestroy(graph);
@@ -788,15 +872,18 @@ fx_status fx_stream_submit(fx_stream* s)
                 return fx_fail(FX_ERR_HIP, "capturing the streaming step failed: %s", hipGetErrorString(e));
             }
         }
-        HIP_TRY(hipGraphLaunch(sl.exec[par], c->stream));
-        HIP_TRY(hipEventRecord(sl.out, c->stream));
+        SUB_TRY(hipGraphLaunch(sl.exec[par], c->stream));
+        // the step is enqueued: the context has moved on whatever happens to the bookkeeping event below
         c->ev_valid = false;
         advance(c, s->hops);
+        const hipError_t er = hipEventRecord(sl.out, c->stream);
         s->head = (s->head + 1) % s->slots;
         s->in_flight++;
         s->acquired = false;
+        if (er != hipSuccess) return fx_fail(FX_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(er));
         return FX_OK;
     }
+#undef SUB_TRY
     HIP_TRY(hipMemcpyAsync(sl.d_in, sl.h_in, s->in_bytes, hipMemcpyHostToDevice, s->copy));
     HIP_TRY(hipEventRecord(sl.copied, s->copy));
     HIP_TRY(hipStreamWaitEvent(c->stream, sl.copied, 0));
@@ -845,7 +932,7 @@ fx_status fx_stream_collect(fx_stream* s, float* out_raw, float* out_smoothed)
     if (out_smoothed) memcpy(out_smoothed, sl.h_sm, s->out_bytes);
     s->tail = (s->tail + 1) % s->slots;
     s->in_flight--;
-    return FX_OK;
+    return fx_check_device_error(s->ctx);
 }
 
 // ---- OSC sink helpers (ref OSCFeatureAnalysisOutput.h:107, README.md:57) ----

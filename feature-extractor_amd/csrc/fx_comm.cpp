@@ -11,13 +11,65 @@
 // waits for the gather that read it -- the host never blocks and the exchange overlaps the next
 // analysis call's kernels.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>          // types and prototypes only: the library itself is loaded on first use (below)
 
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "fx_context.h"
+
+// librccl is half a gigabyte and only the multi-GPU gather needs it: libfx_hip.so does not link it.  The first
+// fx_comm_* call loads it (the copy already in the process if the host -- PyTorch, say -- has mapped one: same SONAME,
+// one RCCL per process), and a host without it gets FX_ERR_UNSUPPORTED from these entries while every single-GPU entry
+// works.
+namespace {
+struct Rccl {
+    decltype(&::ncclGetUniqueId)    GetUniqueId = nullptr;
+    decltype(&::ncclCommInitRank)   CommInitRank = nullptr;
+    decltype(&::ncclCommDestroy)    CommDestroy = nullptr;
+    decltype(&::ncclCommCount)      CommCount = nullptr;
+    decltype(&::ncclAllGather)      AllGather = nullptr;
+    decltype(&::ncclGroupStart)     GroupStart = nullptr;
+    decltype(&::ncclGroupEnd)       GroupEnd = nullptr;
+    decltype(&::ncclSend)           Send = nullptr;
+    decltype(&::ncclRecv)           Recv = nullptr;
+    decltype(&::ncclGetErrorString) GetErrorString = nullptr;
+    std::string why;                 // empty = loaded
+};
+
+const Rccl* rccl()
+{
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::vector<std::string> names = {"librccl.so.1", "librccl.so"};
+        for (const char* var : {"ROCM_PATH", "ROCM_HOME"})
+            if (const char* root = getenv(var)) names.push_back(std::string(root) + "/lib/librccl.so.1");
+        names.push_back("/opt/rocm/lib/librccl.so.1");
+        void* h = nullptr;
+        for (const std::string& n : names) if ((h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) { const char* e = dlerror(); r.why = std::string("librccl could not be loaded: ") + (e ? e : "not found"); return; }
+        bool ok = true;
+        auto sym = [&](const char* name) { void* p = dlsym(h, name); if (!p) { ok = false; r.why = std::string("librccl lacks ") + name; } return p; };
+#define FX_RCCL_SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(sym(name))
+        FX_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");   FX_RCCL_SYM(CommInitRank, "ncclCommInitRank"); FX_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+        FX_RCCL_SYM(CommCount, "ncclCommCount");       FX_RCCL_SYM(AllGather, "ncclAllGather");       FX_RCCL_SYM(GroupStart, "ncclGroupStart");
+        FX_RCCL_SYM(GroupEnd, "ncclGroupEnd");         FX_RCCL_SYM(Send, "ncclSend");                 FX_RCCL_SYM(Recv, "ncclRecv");
+        FX_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef FX_RCCL_SYM
+        if (ok) r.why.clear();
+    });
+    return &r;
+}
+} // namespace
+#define RCCL_OR_UNSUPPORTED() do { if (!rccl()->why.empty()) return fx_fail(FX_ERR_UNSUPPORTED, "%s", rccl()->why.c_str()); } while (0)
 
 struct fx_comm {
     ncclComm_t  comm = nullptr;
@@ -40,7 +92,7 @@ struct fx_comm {
     do {                                                                                        \
         ncclResult_t r_ = (expr);                                                               \
         if (r_ != ncclSuccess)                                                                  \
-            return fx_fail(FX_ERR_HIP, "%s failed: %s", #expr, ncclGetErrorString(r_));        \
+            return fx_fail(FX_ERR_HIP, "%s failed: %s", #expr, rccl()->GetErrorString(r_));  \
     } while (0)
 
 void fx_comm_release(fx_context* c)
@@ -49,7 +101,7 @@ void fx_comm_release(fx_context* c)
     fx_comm* m = c->comm;
     (void) hipSetDevice(c->device);
     if (m->side) (void) hipStreamSynchronize(m->side);
-    if (m->comm) (void) ncclCommDestroy(m->comm);
+    if (m->comm) (void) rccl()->CommDestroy(m->comm);
     for (int i = 0; i < 2; i++) {
         if (m->stage[i]) (void) hipFree(m->stage[i]);
         if (m->snap[i]) (void) hipEventDestroy(m->snap[i]);
@@ -69,8 +121,9 @@ fx_status fx_comm_unique_id(void* id_out, int id_bytes)
     if (!id_out || id_bytes < (int) sizeof(ncclUniqueId))
         return fx_fail(FX_ERR_INVALID_ARGUMENT, "id buffer must hold FX_COMM_ID_BYTES (%d) bytes", (int) sizeof(ncclUniqueId));
     static_assert(sizeof(ncclUniqueId) == FX_COMM_ID_BYTES, "FX_COMM_ID_BYTES must equal NCCL_UNIQUE_ID_BYTES");
+    RCCL_OR_UNSUPPORTED();
     ncclUniqueId id;
-    NCCL_TRY(ncclGetUniqueId(&id));
+    NCCL_TRY(rccl()->GetUniqueId(&id));
     memcpy(id_out, &id, sizeof id);
     return FX_OK;
 }
@@ -81,6 +134,7 @@ fx_status fx_comm_create(fx_context* c, int rank, int world, const void* unique_
     if (c->comm) return fx_fail(FX_ERR_INVALID_ARGUMENT, "this context already belongs to a communicator");
     if (world < 1 || rank < 0 || rank >= world) return fx_fail(FX_ERR_INVALID_ARGUMENT, "rank %d outside world of %d", rank, world);
     if (id_bytes != (int) sizeof(ncclUniqueId)) return fx_fail(FX_ERR_INVALID_ARGUMENT, "unique id must be %d bytes", (int) sizeof(ncclUniqueId));
+    RCCL_OR_UNSUPPORTED();
     HIP_TRY(hipSetDevice(c->device));
     fx_comm* m = new (std::nothrow) fx_comm();
     if (!m) return fx_fail(FX_ERR_OUT_OF_MEMORY, "host allocation failed");
@@ -89,10 +143,17 @@ fx_status fx_comm_create(fx_context* c, int rank, int world, const void* unique_
     m->world = world;
     auto bail = [&](fx_status s) { fx_comm_release(c); return s; };
 #define M_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return bail(fx_fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
-#define M_NCCL(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) return bail(fx_fail(FX_ERR_HIP, "%s failed: %s", #expr, ncclGetErrorString(r_))); } while (0)
+#define M_NCCL(expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) return bail(fx_fail(FX_ERR_HIP, "%s failed: %s", #expr, rccl()->GetErrorString(r_))); } while (0)
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof id);
-    M_NCCL(ncclCommInitRank(&m->comm, world, id, rank));
+    M_NCCL(rccl()->CommInitRank(&m->comm, world, id, rank));
+    {
+        // what RCCL itself thinks the communicator is (a launch that started fewer ranks than it claims shows up here)
+        int count = -1;
+        M_NCCL(rccl()->CommCount(m->comm, &count));
+        fprintf(stderr, "[fx_comm] rank %d of %d: RCCL communicator of %d rank(s) on device %d\n", rank, world, count, c->device);
+        if (count != world) return bail(fx_fail(FX_ERR_HIP, "RCCL reports %d ranks in the communicator, expected %d", count, world));
+    }
     M_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
     const size_t bytes = (size_t) c->C * FX_NUM_FEATURES * sizeof(float);
     for (int i = 0; i < 2; i++) {
@@ -106,12 +167,12 @@ fx_status fx_comm_create(fx_context* c, int rank, int world, const void* unique_
         M_HIP(hipMalloc((void**) &d_counts, sizeof(int) * (size_t) world));
         hipError_t e = hipMemcpyAsync(d_counts + rank, &c->C, sizeof(int), hipMemcpyHostToDevice, m->side);
         ncclResult_t r = ncclSuccess;
-        if (e == hipSuccess) r = ncclAllGather(d_counts + rank, d_counts, 1, ncclInt32, m->comm, m->side);
+        if (e == hipSuccess) r = rccl()->AllGather(d_counts + rank, d_counts, 1, ncclInt32, m->comm, m->side);
         m->channels.assign((size_t) world, 0);
         if (e == hipSuccess && r == ncclSuccess) e = hipMemcpyAsync(m->channels.data(), d_counts, sizeof(int) * (size_t) world, hipMemcpyDeviceToHost, m->side);
         if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(m->side);
         (void) hipFree(d_counts);
-        if (r != ncclSuccess) return bail(fx_fail(FX_ERR_HIP, "ncclAllGather of the channel counts failed: %s", ncclGetErrorString(r)));
+        if (r != ncclSuccess) return bail(fx_fail(FX_ERR_HIP, "ncclAllGather of the channel counts failed: %s", rccl()->GetErrorString(r)));
         if (e != hipSuccess) return bail(fx_fail(FX_ERR_HIP, "exchange of the channel counts failed: %s", hipGetErrorString(e)));
     }
     m->first.assign((size_t) world, 0);
@@ -167,16 +228,16 @@ fx_status fx_gather_smoothed(fx_context* c, int dst, float* out, int mem_kind)
     HIP_TRY(hipMemcpyAsync(m->stage[s], c->d_latest, bytes, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipEventRecord(m->snap[s], c->stream));
     HIP_TRY(hipStreamWaitEvent(m->side, m->snap[s], 0));
-    NCCL_TRY(ncclGroupStart());
-    ncclResult_t r = ncclSend(m->stage[s], (size_t) c->C * FX_NUM_FEATURES, ncclFloat32, dst, m->comm, m->side);
+    NCCL_TRY(rccl()->GroupStart());
+    ncclResult_t r = rccl()->Send(m->stage[s], (size_t) c->C * FX_NUM_FEATURES, ncclFloat32, dst, m->comm, m->side);
     if (r == ncclSuccess && sink) {
         for (int src = 0; src < m->world && r == ncclSuccess; src++)
-            r = ncclRecv(d_dst + (size_t) m->first[(size_t) src] * FX_NUM_FEATURES, (size_t) m->channels[(size_t) src] * FX_NUM_FEATURES,
+            r = rccl()->Recv(d_dst + (size_t) m->first[(size_t) src] * FX_NUM_FEATURES, (size_t) m->channels[(size_t) src] * FX_NUM_FEATURES,
                          ncclFloat32, src, m->comm, m->side);
     }
-    const ncclResult_t re = ncclGroupEnd();
-    if (r != ncclSuccess) return fx_fail(FX_ERR_HIP, "ncclSend / ncclRecv failed: %s", ncclGetErrorString(r));
-    if (re != ncclSuccess) return fx_fail(FX_ERR_HIP, "ncclGroupEnd failed: %s", ncclGetErrorString(re));
+    const ncclResult_t re = rccl()->GroupEnd();
+    if (r != ncclSuccess) return fx_fail(FX_ERR_HIP, "ncclSend / ncclRecv failed: %s", rccl()->GetErrorString(r));
+    if (re != ncclSuccess) return fx_fail(FX_ERR_HIP, "ncclGroupEnd failed: %s", rccl()->GetErrorString(re));
     HIP_TRY(hipEventRecord(m->sent[s], m->side));
     m->sent_valid[s] = true;
     if (sink && mem_kind == FX_MEM_HOST) {

@@ -21,6 +21,7 @@ fx_status fx_fail(fx_status code, const char* fmt, ...) __attribute__((format(pr
 
 struct fx_comm;     // fx_comm.cpp
 void fx_comm_release(fx_context* ctx);   // called by fx_destroy
+fx_status fx_check_device_error(fx_context* ctx);   // after a synchronisation: FX_ERR_HIP if a kernel reported a failed hand-over
 
 struct fx_context {
     int      device = 0;
@@ -48,6 +49,9 @@ struct fx_context {
     float* d_hist[2] = {nullptr, nullptr};   // [C][HLEN][12], ping-pong
     float* d_latest = nullptr;    // [C][12]
     int    cur = 0;
+    fx_tuning tuning;             // launch-shape knobs: taken from the environment ONCE, in fx_create (fx_set_tuning replaces them)
+    unsigned* h_err = nullptr;    // pinned, coherent: a kernel stores 1 here when a work unit gave up waiting for its predecessor (sticky)
+    unsigned* d_err = nullptr;    // device view of h_err
     unsigned* d_queue = nullptr;  // [1 + C]: ticket counter and per-channel chunk counts of a frame-kernel launch cut in time (FrameParams::queue)
 
     float* d_raw = nullptr;       // [C][T_cap][12]

@@ -987,11 +987,15 @@ fx_frame_kernel(const FrameParams p_arg)
         // the flux state comes from the chunk before, written by another workgroup (another CU): its count, then an
         // agent-scope acquire, then the barrier (MI355X guide: one relaxed poll -> one acquire -> vmcnt(0) -> barrier ->
         // plain loads).  The predecessor holds a lower ticket, so it is running or done; it was dispatched a whole round
-        // of channels earlier and is normally long finished.  The spin is bounded all the same (~2 s).
+        // of channels earlier and is normally long finished.  The spin is bounded all the same (FrameParams::spin_limit polls), and a
+        // unit that runs into the bound reports it (FrameParams::err) instead of carrying on silently.
         if (live && slot == 0 && lane0 == 0) {
             unsigned spins = 0;
-            while (__hip_atomic_load(p.queue + 1 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned) chunk && ++spins < (1u << 22))
+            bool there;
+            while (!(there = __hip_atomic_load(p.queue + 1 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned) chunk) && ++spins < p.spin_limit)
                 __builtin_amdgcn_s_sleep(8);
+            // gave up: the state loaded below is stale.  Say so where the host looks at its next synchronisation.
+            if (!there) __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1055,7 +1059,7 @@ fx_frame_kernel(const FrameParams p_arg)
         // agent-scope release, then the count (MI355X guide, producer form)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (live && slot == 0 && lane0 == 0) {
+        if (live && slot == 0 && lane0 == 0 && !(p.debug_flags & 1u)) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(p.queue + 1 + c, (unsigned) (chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -65,7 +65,7 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
         for (int i = threadIdx.x; i < HLEN * FX_NUM_FEATURES / 4; i += 192) reinterpret_cast<uint4*>(s_hist)[i] = hs4[i];
     }
     if (threadIdx.x == 0) { turn[0] = 0; part->flags = 0; }
-    {
+    if (sig.stage) {
         // the hop itself: out of the pinned host slot into device memory, 16 bytes per lane, once
         const size_t hop_bytes = (size_t) (N / 2) * (p.sample_format == FX_SAMPLE_F16 ? 2 : 4);
         const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(p.in) + (size_t) c * hop_bytes);
@@ -141,7 +141,7 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
     for (int i = lane; i < HLEN * FX_NUM_FEATURES; i += 64) history_value(ep, (long long) c * HLEN * FX_NUM_FEATURES + i);
 
     // completion: this workgroup's results (pinned host memory) are visible system-wide before it counts itself in
-    if (lane == 0) {
+    if (lane == 0 && sig.host_flag) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         const unsigned before = __hip_atomic_fetch_add(sig.arrivals, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         if (before + 1 == gridDim.x) {

@@ -53,7 +53,7 @@ struct DynParams {
     int       onset_type;
 };
 
-constexpr int FX_MAX_CHUNKS = 24;
+constexpr int FX_MAX_CHUNKS = FX_MAX_UNITS;
 
 struct FrameParams {
     const void*  in;            // frames [C][T][N] or hops [C][T][N/2]
@@ -73,6 +73,12 @@ struct FrameParams {
     // ones first (little overhead), short ones last (the launch's tail is one short unit deep).
     int          num_chunks;
     unsigned*    queue;
+    // A work unit that gives up waiting for its predecessor (after spin_limit polls) stores 1 here -- pinned host memory,
+    // system scope -- and the host turns that into FX_ERR_HIP at the next synchronisation: a stale flux state is never
+    // handed on silently.  debug_flags bit 0 (tests): units do not publish their hand-over, which forces the time-out.
+    unsigned*    err;
+    unsigned     spin_limit;
+    unsigned     debug_flags;
     int          chunk_begin[FX_MAX_CHUNKS + 1];   // chunk k analyses frames [chunk_begin[k], chunk_begin[k + 1]); the last entry used is T
     float        gain;          // hop mode only (ref AudioDataCollector.h:88)
     const float* tail_in;       // [C][N/2] second half of the previous window (already gained)
@@ -113,6 +119,7 @@ struct EpilogueParams {
 // Completion signal of a one-hop call (fx_hop_kernel): workgroups count themselves in `arrivals` (device memory, zero
 // between calls); the last one resets it and stores `seq` to `host_flag` (pinned host memory, system scope), after the
 // results -- which the kernel writes to pinned host memory as well -- are visible there.
+// (All pointers null: a one-hop call on device-resident input through fx_push_hops -- the stream orders it, nothing to signal.)
 struct HopSignal {
     unsigned* arrivals;
     unsigned* host_flag;
@@ -136,7 +143,8 @@ void frame_kernel_preferred_shape(int window_size, int* channels_per_wg, int* wa
 // Launches ceil(C / p.ch_per_wg) workgroups of p.ch_per_wg * p.waves_per_ch wavefronts; returns hipSuccess or the launch error.
 hipError_t launch_frame_kernel(int window_size, const FrameParams& p, int analysers, hipStream_t stream);
 hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t stream);
-hipError_t prepare_kernels(int window_size);   // raises the dynamic-LDS limit once per process
+hipError_t prepare_kernels(int window_size);   // raises the kernels' dynamic-LDS limit on the CURRENT device (every fx_create: the attribute is per device)
+hipError_t prepare_hop_kernel(int window_size);   // the same for fx_hop_kernel; hipSuccess where there is none for this size
 // One hop per channel, whole step in one launch (three wavefronts per channel + the tail), results and completion flag
 // written by the kernel itself; p.T must be 1, p.hop_mode 1, both analysers on.  Window sizes: hop_kernel_available().
 bool hop_kernel_available(int window_size);

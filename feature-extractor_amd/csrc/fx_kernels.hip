@@ -62,18 +62,22 @@ namespace fxk {
 
 #if FX_PART == 0 || FX_PART == 3
 bool hop_kernel_available(int n) { return n == 1024 || n == 2048 || n == 4096; }
+// hipFuncSetAttribute is per device: every context prepares the kernels it will launch on its own device (fx_create),
+// so there is no process-wide "already prepared" state to go stale when a second device or thread comes along.
+hipError_t prepare_hop_kernel(int n)
+{
+    switch (n) {
+        case 1024: return hop_prepare_t<1024>();
+        case 2048: return hop_prepare_t<2048>();
+        case 4096: return hop_prepare_t<4096>();
+        default:   return hipSuccess;
+    }
+}
 hipError_t launch_hop_kernel(int n, const FrameParams& p, const EpilogueParams& ep, const HopSignal& sig, hipStream_t stream)
 {
     if (p.C <= 0) return hipSuccess;
-    if (p.T != 1 || !p.hop_mode || ep.T != 1 || ep.analysers != 3) return hipErrorInvalidValue;
-    static bool prepared[3] = {false, false, false};
-    const int slot = n == 1024 ? 0 : (n == 2048 ? 1 : 2);
+    if (p.T != 1 || ep.T != 1 || ep.analysers != 3) return hipErrorInvalidValue;
     if (!hop_kernel_available(n)) return hipErrorInvalidValue;
-    if (!prepared[slot]) {
-        const hipError_t e = n == 1024 ? hop_prepare_t<1024>() : (n == 2048 ? hop_prepare_t<2048>() : hop_prepare_t<4096>());
-        if (e != hipSuccess) return e;
-        prepared[slot] = true;
-    }
     switch (n) {
         case 1024: return hop_launch_t<1024>(p, ep, sig, stream);
         case 2048: return hop_launch_t<2048>(p, ep, sig, stream);

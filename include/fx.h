@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 2
+#define FX_ABI_VERSION 3
 
 typedef int fx_status;
 enum {
@@ -126,7 +126,9 @@ fx_status fx_process_frames(fx_context* ctx, const void* frames, int num_frames,
  * OSCFeatureAnalysisOutput.h:91-104). */
 fx_status fx_get_smoothed(fx_context* ctx, float* out, int mem_kind);
 
-/* Wait for all enqueued work of this context. */
+/* Wait for all enqueued work of this context.  FX_ERR_HIP if a kernel of this context reported a failed
+ * hand-over between work units (the results of that call and of the calls after it are not valid;
+ * fx_reset_state clears the condition). */
 fx_status fx_sync(fx_context* ctx);
 
 /* The context's hipStream_t (as void*), so callers can order their own copies. */
@@ -160,12 +162,43 @@ fx_status fx_stream_collect(fx_stream* s, float* out_raw, float* out_smoothed);
 /* Number of submitted batches not yet collected. */
 int fx_stream_in_flight(fx_stream* s);
 
+/* ---- launch-shape knobs (experiments, tests) ----
+ * None of these changes a result bit (tests/test_gpu_parity.py pins that); they choose workgroup shapes,
+ * how long calls are cut into work units, and which of the equivalent streaming paths runs.  A context
+ * takes its knobs ONCE, in fx_create, from the FX_* environment variables named below (later changes of
+ * the environment have no effect: no entry point on the analysis path reads the environment);
+ * fx_set_tuning replaces them explicitly.  A stream takes the stream_* knobs in fx_stream_create. */
+#define FX_MAX_UNITS 24
+typedef struct fx_tuning {
+    int waves_per_channel;       /* FX_WAVES: frames of one channel in flight in a workgroup; 0 = measured best */
+    int channels_per_workgroup;  /* FX_CHANNELS_PER_WG; 0 = measured best */
+    int waves_per_frame;         /* FX_WAVES_PER_FRAME: 1 = a frame lives in one wavefront, 2 = in a pair of wavefronts
+                                    (windows >= 2048 only); 0 = measured best */
+    int frames_per_unit;         /* FX_FRAMES_PER_CHUNK: work-unit length of a call cut in time; 0 = never cut; -1 = measured best */
+    int unit_plan_len;           /* FX_CHUNK_PLAN=a,b,...: explicit unit lengths (used when they add up to the call's frames) */
+    int unit_plan[FX_MAX_UNITS];
+    int stream_graph;            /* FX_STREAM_GRAPH: 1 / 0 force / forbid the captured hipGraph step; -1 = by batch size */
+    int stream_hop_kernel;       /* FX_STREAM_HOP_KERNEL: 0 forbids the one-launch hop kernel in the ring; -1 = when it applies */
+    int stream_zero_copy;        /* FX_STREAM_ZEROCOPY: 1 / 0 force / forbid zero-copy slots in the captured step; -1 = by size */
+    int one_hop_kernel;          /* FX_ONE_HOP_KERNEL: 0 = fx_push_hops / fx_process_frames of ONE frame per channel run the
+                                    batch kernels instead of the one-launch hop kernel; -1 = hop kernel when it applies */
+    int handover_spin_limit;     /* FX_HANDOVER_SPINS: polls a work unit spends waiting for its predecessor's flux state
+                                    before it gives up and the call is reported failed (FX_ERR_HIP); 0 = default (1 << 22) */
+    int debug_flags;             /* FX_DEBUG_FLAGS: bit 0 = work units do not publish their hand-over (forces the time-out; tests) */
+} fx_tuning;
+void fx_tuning_defaults(fx_tuning* t);     /* every knob "measured best" */
+void fx_tuning_from_env(fx_tuning* t);     /* defaults overridden by the FX_* variables set right now */
+fx_status fx_get_tuning(fx_context* ctx, fx_tuning* out);
+fx_status fx_set_tuning(fx_context* ctx, const fx_tuning* t);
+
 /* Host-only arithmetic, exposed for testing: how a call of `num_frames` frames per channel is cut into
  * work units for the frame kernel (several workgroups per channel, each analysing a run of consecutive
  * frames and handing the channel's flux state -- previousBinMagnitudes, SpectralCharacteristics.h:203 --
  * to the next through device memory).  Writes the unit lengths to sizes[0..n) and returns n (1 = one
- * workgroup per channel); the lengths are positive and add up to num_frames.  No GPU needed. */
-int fx_plan_units(int window_size, unsigned flags, int waves_per_channel, int num_frames, int* sizes, int cap);
+ * workgroup per channel); the lengths are positive and add up to num_frames.  `tuning` may be NULL
+ * (defaults).  Pure: reads neither the environment nor a device. */
+int fx_plan_units(int window_size, unsigned flags, int waves_per_channel, int num_frames,
+                  const fx_tuning* tuning, int* sizes, int cap);
 
 /* Kernel-time accounting over a region of calls: fx_profile_begin() starts recording a HIP event
  * triple per analysis call on the context's stream (no synchronisation, at most 4096 calls);
@@ -187,7 +220,8 @@ fx_status fx_profile_end(fx_context* ctx, double* frame_kernel_ms, double* epilo
  *               fx_comm_sync(ctx) before reading `out`
  */
 #define FX_COMM_ID_BYTES 128
-/* ncclGetUniqueId.  FX_ERR_UNSUPPORTED if RCCL cannot be loaded. */
+/* ncclGetUniqueId.  librccl is loaded on first use of an fx_comm_* entry (single-GPU users never map it);
+ * FX_ERR_UNSUPPORTED if it cannot be loaded. */
 fx_status fx_comm_unique_id(void* id_out, int id_bytes);
 /* Join this context to a communicator of `world_size` ranks (ncclCommInitRank on the context's
  * device; every rank calls it with the same id).  Ranks may own different channel counts; the

@@ -28,7 +28,7 @@ def test_library_builds_loads_and_exports_every_symbol(fx):
     assert os.path.exists(fx.library_path())
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.fx_abi_version() == 2
+    assert lib.fx_abi_version() == 3
 
 
 def test_library_contains_gfx950_code(fx):
@@ -86,21 +86,19 @@ def test_synth_is_deterministic_and_frames_match_hops(fx):
 
 
 def test_work_unit_plans_cover_every_frame_once(fx, monkeypatch):
-    """fx_plan_units (host arithmetic, no GPU): however a call is cut into work units for the frame kernel, the unit
-    lengths are positive, add up to the call's frames per channel, fit the kernel's table, and only the last unit may be a
-    partial round of wavefronts; windows of 2048 / 4096 points and the spectral analyser alone are never cut."""
-    import ctypes
-    lib = fx.load_library(build_if_missing=True)
-    lib.fx_plan_units.restype = ctypes.c_int
-    lib.fx_plan_units.argtypes = [ctypes.c_int, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int]
-    for var in ("FX_FRAMES_PER_CHUNK", "FX_CHUNK_PLAN"):
-        monkeypatch.delenv(var, raising=False)
-    cap = 24
-    buf = (ctypes.c_int * cap)()
+    """fx_plan_units (host arithmetic, no GPU, no environment): however a call is cut into work units for the frame kernel,
+    the unit lengths are positive, add up to the call's frames per channel, fit the kernel's table, and only the last unit
+    may be a partial round of wavefronts; windows of 2048 / 4096 points and the spectral analyser alone are never cut."""
+    from importlib import import_module
+    capi = import_module("feature-extractor_amd.capi")
+    fx.load_library(build_if_missing=True)
+    cap = capi.MAX_UNITS
+    # the planner is pure: variables in the environment must not reach it (only fx_create reads them, once)
+    monkeypatch.setenv("FX_FRAMES_PER_CHUNK", "0")
+    monkeypatch.setenv("FX_CHUNK_PLAN", "1,2,3")
 
-    def plan(N, flags, k, T):
-        n = lib.fx_plan_units(N, flags, k, T, buf, cap)
-        return list(buf[:n])
+    def plan(N, flags, k, T, tuning=None):
+        return capi.plan_units(N, flags, k, T, tuning)
 
     for N, k in ((256, 8), (512, 8), (1024, 8), (1024, 3), (2048, 4), (4096, 7)):
         for flags in (0, 4, 8):                       # both analysers, FX_SPECTRAL_ONLY, FX_HARMONIC_ONLY
@@ -112,12 +110,36 @@ def test_work_unit_plans_cover_every_frame_once(fx, monkeypatch):
                     assert sizes == [T]
     assert plan(1024, 0, 8, 512) == [168, 112, 80, 48, 32, 24, 16, 16, 16]      # the bench shape
     assert plan(1024, 0, 8, 128) == [64, 64] and plan(1024, 0, 8, 100) == [56, 44] and plan(1024, 0, 8, 90) == [90]
-    monkeypatch.setenv("FX_FRAMES_PER_CHUNK", "0")
-    assert plan(1024, 0, 8, 512) == [512]
-    monkeypatch.setenv("FX_FRAMES_PER_CHUNK", "16")
-    forced = plan(4096, 0, 7, 129)            # the override applies to every window size (tests force cut launches with it)
+    # the knobs arrive in a struct fx_tuning (a context takes its own from the environment once, in fx_create)
+    t = capi.Tuning.defaults()
+    assert plan(1024, 0, 8, 512, t) == plan(1024, 0, 8, 512)
+    t.frames_per_unit = 0
+    assert plan(1024, 0, 8, 512, t) == [512]
+    t.frames_per_unit = 16
+    forced = plan(4096, 0, 7, 129, t)         # the override applies to every window size (tests force cut launches with it)
     assert len(forced) >= 4 and sum(forced) == 129 and all(v % 7 == 0 for v in forced[:-1])
-    assert plan(4096, 0, 7, 100) == [21, 21, 21, 21, 16]
-    monkeypatch.delenv("FX_FRAMES_PER_CHUNK")
+    assert plan(4096, 0, 7, 100, t) == [21, 21, 21, 21, 16]
+    t = capi.Tuning.defaults().set_plan([300, 200, 12])
+    assert plan(1024, 0, 8, 512, t) == [300, 200, 12] and plan(1024, 0, 8, 511, t) != [300, 200, 12]
+
+
+def test_tuning_comes_from_the_environment_once(fx, monkeypatch):
+    """fx_tuning_from_env is the one reader of the FX_* variables (fx_create calls it once per context); unset variables
+    leave every knob at "measured best"."""
+    from importlib import import_module
+    capi = import_module("feature-extractor_amd.capi")
+    fx.load_library(build_if_missing=True)
+    for var in ("FX_WAVES", "FX_CHANNELS_PER_WG", "FX_WAVES_PER_FRAME", "FX_FRAMES_PER_CHUNK", "FX_CHUNK_PLAN", "FX_STREAM_GRAPH",
+                "FX_STREAM_HOP_KERNEL", "FX_STREAM_ZEROCOPY", "FX_ONE_HOP_KERNEL", "FX_HANDOVER_SPINS", "FX_DEBUG_FLAGS"):
+        monkeypatch.delenv(var, raising=False)
+    d, e = capi.Tuning.defaults(), capi.Tuning.from_env()
+    assert bytes(d) == bytes(e)
+    assert (d.waves_per_channel, d.frames_per_unit, d.stream_graph, d.one_hop_kernel, d.handover_spin_limit, d.debug_flags) == (0, -1, -1, -1, 0, 0)
+    monkeypatch.setenv("FX_WAVES", "3")
+    monkeypatch.setenv("FX_FRAMES_PER_CHUNK", "0")
     monkeypatch.setenv("FX_CHUNK_PLAN", "300,200,12")
-    assert plan(1024, 0, 8, 512) == [300, 200, 12] and plan(1024, 0, 8, 511) != [300, 200, 12]
+    monkeypatch.setenv("FX_STREAM_HOP_KERNEL", "0")
+    monkeypatch.setenv("FX_HANDOVER_SPINS", "64")
+    e = capi.Tuning.from_env()
+    assert (e.waves_per_channel, e.frames_per_unit, e.stream_hop_kernel, e.handover_spin_limit) == (3, 0, 0, 64)
+    assert list(e.unit_plan[:e.unit_plan_len]) == [300, 200, 12]

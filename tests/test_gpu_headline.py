@@ -1,0 +1,151 @@
+"""The launches bench.py times, held to the oracle and to the uncut launch; the hand-over between work units failing
+loudly; one-frame calls through the one-launch hop kernel; contexts used from two threads.  All through the C ABI."""
+import threading
+
+import numpy as np
+import pytest
+
+import signals
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def close(got, want, what):
+    from oracle import fx_oracle as fo
+    return signals.assert_features_close(got, want, RTOL, fo.FEATURE_NAMES, what)
+
+
+@pytest.mark.parametrize("C,T", [(1024, 512), (8192, 128)], ids=["bench_1gpu_1024x512", "bench_per_rank_8192x128"])
+def test_bench_launch_matches_oracle_and_the_uncut_launch(gpu_fx, oracle, C, T):
+    """Exactly the shapes bench.py times (configs[1]: 1024 channels x 512 frames x 1024-pt, nine work units of decreasing
+    length per channel; configs[3] per rank: 8192 x 128, two units), through fx_process_frames on device-resident input:
+    24 random channels against the oracle, every value against the launch that is not cut in time (one workgroup per
+    channel), and a second call that continues from the first one's state (flux state, window tail, histories:
+    ref SpectralCharacteristics.h:76-79,121-123,138,203)."""
+    import torch
+    N = 1024
+    rng = np.random.default_rng(C + T)
+    sel = np.sort(rng.choice(C, 24, replace=False))
+    host = gpu_fx.synth.frames(C, T, N)
+    dev = torch.from_numpy(host).cuda()
+    # second call: other contents without a second trip through the generator -- every channel gets half of the frames
+    # of the channel 37 below it (x 0.5 is exact), with a stretch of digital silence across unit boundaries in six of the
+    # checked channels: the skip rule (:121-123) at a hand-over
+    second_host = 0.5 * host[(sel - 37) % C]
+    second_host[:6, 40:90] = 0.0
+    dev2 = dev.roll(37, dims=0) * 0.5
+    dev2[torch.from_numpy(sel[:6]).cuda(), 40:90] = 0.0
+    calls = [(dev, host[sel].copy()), (dev2, second_host)]
+    del host
+    an = gpu_fx.BatchAnalyser(C, N)
+    plan = gpu_fx.capi.plan_units(N, 0, 8, T, an.get_tuning())
+    assert len(plan) >= 2, plan                         # the launch under test really is cut in time
+    an0 = gpu_fx.BatchAnalyser(C, N)
+    an0.set_tuning(frames_per_unit=0)
+    want_frames = np.concatenate([c[1] for c in calls], axis=1)
+    oraw, osm = oracle.process_frames(want_frames, N)
+    for k, (dev, _) in enumerate(calls):
+        raw, sm = an.process_frames(dev)
+        raw0, sm0 = an0.process_frames(dev)
+        an.sync(); an0.sync()
+        assert torch.equal(torch.nan_to_num(raw), torch.nan_to_num(raw0)) and torch.equal(raw.isnan(), raw0.isnan()), "call %d raw: cut != uncut" % k
+        assert torch.equal(torch.nan_to_num(sm), torch.nan_to_num(sm0)) and torch.equal(sm.isnan(), sm0.isnan()), "call %d smoothed: cut != uncut" % k
+        close(raw[sel].cpu().numpy(), oraw[:, k * T:(k + 1) * T], "bench launch call %d raw" % k)
+        close(sm[sel].cpu().numpy(), osm[:, k * T:(k + 1) * T], "bench launch call %d smoothed" % k)
+    assert np.array_equal(an.get_features(), an0.get_features(), equal_nan=True)
+
+
+def test_failed_handover_between_work_units_is_reported(gpu_fx):
+    """A work unit that gives up waiting for its predecessor's flux state must not carry on silently (it would hand a
+    stale previousBinMagnitudes down the channel, ref SpectralCharacteristics.h:76-79,203): the kernel raises an error
+    word and every synchronising entry point returns FX_ERR_HIP until fx_reset_state.  Forced here by units that do
+    not publish (fx_tuning::debug_flags bit 0) and a poll bound of 8."""
+    C, T, N = 64, 256, 1024
+    hops = signals.bursts(C, T, N, seed=77)
+    good = gpu_fx.BatchAnalyser(C, N).push_hops(hops)
+    an = gpu_fx.BatchAnalyser(C, N)
+    an.set_tuning(handover_spin_limit=8, debug_flags=1)
+    with pytest.raises(gpu_fx.FxError) as e:
+        an.push_hops(hops)                              # host buffers: the call synchronises and must report
+    assert e.value.code == 3 and "timed out" in str(e.value)
+    with pytest.raises(gpu_fx.FxError):
+        an.sync()                                       # sticky
+    with pytest.raises(gpu_fx.FxError):
+        an.push_hops(hops[:, :4])
+    an.reset_state()                                    # a fresh analyser again
+    an.set_tuning(handover_spin_limit=0, debug_flags=0)
+    got = an.push_hops(hops)
+    an.sync()
+    for k in (0, 1):
+        assert np.array_equal(got[k], good[k], equal_nan=True)
+
+
+@pytest.mark.parametrize("N,C", [(1024, 300), (2048, 130), (4096, 40)])
+def test_one_frame_calls_run_the_hop_kernel_and_equal_the_batch_kernels(gpu_fx, oracle, N, C):
+    """One frame per channel per call -- the reference's own cadence (ref AudioDataCollector.h:66-94, RealTimeAnalyser.h:
+    201-234) -- runs as ONE launch of fx_hop_kernel from fx_push_hops / fx_process_frames too (host or device buffers, any
+    channel count): bit for bit what the batch kernels give, and the oracle's values."""
+    import torch
+    T = 14
+    hops = np.concatenate([signals.bursts(C, T // 2, N, seed=N), signals.low_tones(C, T - T // 2, N)], axis=1)
+    hop_k, batch_k = gpu_fx.BatchAnalyser(C, N), gpu_fx.BatchAnalyser(C, N)
+    batch_k.set_tuning(one_hop_kernel=0)
+    dev = torch.from_numpy(hops).cuda()
+    got, want = [], []
+    for t in range(T):
+        if t % 2:
+            r, s = hop_k.push_hops(dev[:, t:t + 1].contiguous())
+            got.append((r.cpu().numpy(), s.cpu().numpy()))
+        else:
+            got.append(hop_k.push_hops(hops[:, t:t + 1]))
+        want.append(batch_k.push_hops(hops[:, t:t + 1]))
+    for k in (0, 1):
+        assert np.array_equal(np.concatenate([g[k] for g in got], 1), np.concatenate([w[k] for w in want], 1), equal_nan=True), k
+    assert np.array_equal(hop_k.get_features(), batch_k.get_features(), equal_nan=True)
+    sel = np.arange(0, C, max(1, C // 12))
+    oraw, osm = oracle.push_hops(hops[sel], N)
+    close(np.concatenate([g[0] for g in got], 1)[sel], oraw, "one-frame calls raw")
+    close(np.concatenate([g[1] for g in got], 1)[sel], osm, "one-frame calls smoothed")
+    # pre-assembled windows, one per call
+    frames = gpu_fx.synth.frames(C, 5, N, first_channel=3)
+    a, b = gpu_fx.BatchAnalyser(C, N), gpu_fx.BatchAnalyser(C, N)
+    b.set_tuning(one_hop_kernel=0)
+    for t in range(5):
+        ga, gb = a.process_frames(frames[:, t:t + 1]), b.process_frames(frames[:, t:t + 1])
+        assert np.array_equal(ga[0], gb[0], equal_nan=True) and np.array_equal(ga[1], gb[1], equal_nan=True), t
+
+
+def test_contexts_created_and_streamed_from_two_threads(gpu_fx):
+    """Two contexts on device 0, each created and driven by its own thread, streaming one hop per call (fx_hop_kernel
+    through the pinned ring): kernel preparation is per context / device, with no process-wide "already prepared" state
+    to race on.  Both must give what a single-threaded run gives."""
+    N, C, T = 2048, 6, 30
+    hops = [signals.tone_vibrato_noise(C, T, N, seed=s) for s in (41, 42)]
+    want = [gpu_fx.BatchAnalyser(C, N).push_hops(h) for h in hops]
+    out, errs = [None, None], []
+
+    def worker(k):
+        try:
+            an = gpu_fx.BatchAnalyser(C, N)
+            st = gpu_fx.HopStream(an, 1, slots=2)
+            got = []
+            for t in range(T):
+                if st.in_flight() == 2:
+                    got.append(st.collect())
+                st.push(hops[k][:, t:t + 1])
+            while st.in_flight():
+                got.append(st.collect())
+            st.close()
+            an.close()
+            out[k] = (np.concatenate([g[0] for g in got], 1), np.concatenate([g[1] for g in got], 1))
+        except Exception as e:          # noqa: BLE001 -- reported below, in the main thread
+            errs.append(e)
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errs, errs
+    for k in (0, 1):
+        assert np.array_equal(out[k][0], want[k][0], equal_nan=True) and np.array_equal(out[k][1], want[k][1], equal_nan=True), k

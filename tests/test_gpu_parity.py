@@ -375,6 +375,7 @@ def test_one_hop_per_call_kernel_equals_push_hops_bitwise(gpu_fx, monkeypatch, N
             an.reset_state()
 
     ref = gpu_fx.BatchAnalyser(C, N, order=order)
+    ref.set_tuning(one_hop_kernel=0)                    # the batch kernels (frame kernel + fused tail), not the hop kernel
     want = []
     for b in range(nb):
         settings(ref, b)
