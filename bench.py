@@ -9,7 +9,7 @@ configs[3]: every rank analyses its own contiguous 8192-channel shard of 8192*N 
 channels are independent, so there is no data-path collective) and the smoothed feature vectors are
 gathered to rank 0, the OSC sink, over RCCL (through the C ABI: fx_comm_* / fx_gather_smoothed).
 
-Launch forms (both work):
+Launch forms (both work, and both run the ranks in the same environment -- rank_environment()):
     python bench.py --gpus N ...                                   (bench.py starts its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N ...                    (the driver's form)
@@ -17,10 +17,17 @@ Launch forms (both work):
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import csv
+import glob
 import importlib
 import json
+import math
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 import numpy as np
@@ -29,6 +36,48 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X fp32 vector peak (MI355X_MICROARCH.md), counted with FMA = 2 flop
+FP32_NO_FMA_PEAK_TFLOPS = FP32_VECTOR_PEAK_TFLOPS / 2.0   # the bit-exact FFT DAG may not fuse a*b+c: one flop per lane per issue
+
+
+def flops_per_frame(window):
+    """the as-written bundle is four complex N-point FFTs (5 N log2 N each) + ~30 N of reductions."""
+    return 4 * 5.0 * window * math.log2(window) + 30.0 * window
+
+
+def rank_environment(env=None):
+    """What a rank process needs in its environment BEFORE the HIP runtime starts, whichever way it was launched
+    (self_launch passes it to its children; main() applies it to os.environ first thing, so the driver's own
+    `python -m torch.distributed.run ... bench.py` form runs the ranks under the same settings)."""
+    env = os.environ if env is None else env
+    # the host driver supports dmabuf IPC only: without this RCCL's peer buffers fail with hipIpcGetMemHandle: invalid argument
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return env
+
+
+class Watchdog:
+    """A phase that must finish in `seconds` or the process exits non-zero with a message (a wedged rank -- one peer never
+    reaching ncclCommInitRank or a barrier -- otherwise hangs the whole multi-GPU run).  The process EXITS; nothing is
+    re-executed."""
+
+    def __init__(self, seconds, what):
+        self.what, self.seconds = what, seconds
+        self.timer = threading.Timer(seconds, self._fire)
+        self.timer.daemon = True
+
+    def _fire(self):
+        print("bench.py: rank %s: '%s' did not finish within %d s -- giving up (exit 124)"
+              % (os.environ.get("RANK", "0"), self.what, self.seconds), file=sys.stderr, flush=True)
+        os._exit(124)
+
+    def __enter__(self):
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
 
 
 def usable_cores():
@@ -95,17 +144,121 @@ def cpu_baseline(fx, window, frames_per_channel, seconds=30.0):
                       % (chans, T, window, cores, os.cpu_count() or 1, dt, dt * cores)}
 
 
-def load_traffic(window, channels, frames):
-    """HBM bytes per frame-kernel launch from committed PMC passes (profiles/pmc_traffic.json,
-    written by tools/pmc_traffic.py from rocprofv3 --pmc runs of this same command)."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+# ---------------------------------------------------------------------------------------------------------------
+# counters: measured IN THIS RUN by rocprofv3 children of this process; committed records only as a labelled fallback
+# ---------------------------------------------------------------------------------------------------------------
+def kernel_sources_sha():
+    """sha256 over the kernel sources (csrc/*.h, *.hip, *.cpp): what a committed counter record must have been taken
+    from to describe the library that is running."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(ROOT, "feature-extractor_amd", "csrc", "*"))):
+        if path.endswith((".h", ".hip", ".cpp")):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_counters(window, channels, frames, path=None, sources_sha=None):
+    """profiles/counters.json (written by `bench.py --write-counters` on a GPU box): counters of earlier runs, keyed by
+    shape.  Used only when the counters cannot be read in this run, and only if the record was taken from exactly the
+    kernel sources that are running -- a stale record is reported as absent, never as a number."""
+    path = path or os.path.join(ROOT, "profiles", "counters.json")
+    sha = sources_sha or kernel_sources_sha()
     try:
-        rec = json.load(open(path))
-        if rec.get("window") == window and rec.get("channels") == channels and rec.get("frames") == frames:
-            return rec.get("hbm_bytes_per_launch")
+        rec = json.load(open(path)).get("%d:%d:%d" % (window, channels, frames))
     except Exception:
-        pass
-    return None
+        return None, "no committed record"
+    if not rec:
+        return None, "no committed record for this shape"
+    if rec.get("kernel_sources_sha") != sha:
+        return None, "committed record is stale (taken from kernel sources %s, running %s)" % (rec.get("kernel_sources_sha"), sha)
+    return rec, "committed record (profiles/counters.json, same kernel sources)"
+
+
+PMC_PASSES = [
+    # one rocprofv3 run each (MI355X guide: SQ has 8 slots; FETCH_SIZE and WRITE_SIZE do not fit one TCC pass)
+    ("sq", ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT"]),
+    ("fetch", ["FETCH_SIZE"]),
+    ("write", ["WRITE_SIZE"]),
+]
+
+
+def _parse_counter_csv(out_dir, kernel_substr):
+    sums, counts = {}, {}
+    for f in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if kernel_substr in row.get("Kernel_Name", ""):
+                c = row["Counter_Name"]
+                sums[c] = sums.get(c, 0.0) + float(row["Counter_Value"])
+                counts[c] = counts.get(c, 0) + 1
+    return {c: sums[c] / counts[c] for c in sums}, (max(counts.values()) if counts else 0)
+
+
+def measure_counters(window, channels, frames, input_file, timeout_s=150):
+    """Per-launch counters of the frame kernel at this shape, read now: each pass is a child `rocprofv3 --pmc ... --
+    python3 bench.py --pmc-child ...` (a fresh process; this one is never re-executed).  Returns (dict or None, note)."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="fx_pmc_", dir="/tmp")
+    env = dict(os.environ)
+    env["TMPDIR"] = "/tmp"
+    got, launches = {}, 0
+    try:
+        for name, counters in PMC_PASSES:
+            out = os.path.join(tmp, name)
+            cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                                               "--pmc-child", "--window", str(window), "--channels-per-gpu", str(channels),
+                                               "--frames", str(frames), "--input-file", input_file, "--steps", "3", "--warmup", "1"]
+            try:
+                p = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 pass '%s' exceeded %d s" % (name, timeout_s)
+            if p.returncode != 0:
+                return None, "rocprofv3 pass '%s' failed (rc %d): %s" % (name, p.returncode, (p.stderr or "").strip().splitlines()[-1:] or "")
+            vals, n = _parse_counter_csv(out, "fx_frame_kernel<%d" % window)
+            if not vals:
+                return None, "rocprofv3 pass '%s' recorded no fx_frame_kernel dispatch" % name
+            got.update(vals)
+            launches = max(launches, n)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    got["launches"] = launches
+    return got, "rocprofv3 --pmc children of this run (%d passes, %d launches each)" % (len(PMC_PASSES), launches)
+
+
+def counters_to_fields(pmc, n_frames):
+    """The bench line's counter-derived fields from per-launch counter means (MI355X guide, HBM section: read bytes =
+    2 x FETCH_SIZE on gfx950 for wide coalesced streaming reads, WRITE_SIZE exact; both in KB)."""
+    out = {}
+    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        out["traffic"] = (2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+    if "SQ_INSTS_VALU" in pmc:
+        out["valu_insts_per_frame"] = pmc["SQ_INSTS_VALU"] / n_frames
+    if "SQ_INSTS_LDS" in pmc:
+        out["lds_insts_per_frame"] = pmc["SQ_INSTS_LDS"] / n_frames
+    if pmc.get("SQ_WAVE_CYCLES"):
+        # share of a resident wavefront's lifetime in which it is issuing a VALU instruction / stalled on the LDS pipe
+        out["valu_active_per_wave"] = pmc.get("SQ_ACTIVE_INST_VALU", 0.0) / pmc["SQ_WAVE_CYCLES"]
+        out["lds_issue_stall_per_wave"] = pmc.get("SQ_WAIT_INST_LDS", 0.0) / pmc["SQ_WAVE_CYCLES"]
+    return out
+
+
+def pmc_child(args):
+    """The process rocprofv3 wraps: the same launches as the timed region, on the same input bytes, nothing else."""
+    import torch
+    fx = importlib.import_module("feature-extractor_amd")
+    torch.cuda.set_device(0)
+    frames = torch.from_numpy(np.load(args.input_file)).cuda(0)
+    C, T = frames.shape[0], frames.shape[1]
+    an = fx.BatchAnalyser(C, args.window, device=0)
+    raw = torch.empty((C, T, 12), dtype=torch.float32, device=frames.device)
+    sm = torch.empty_like(raw)
+    for _ in range(args.warmup + args.steps):
+        an.process_frames(frames, out_raw=raw, out_smoothed=sm)
+    an.sync()
+    an.close()
 
 
 def stream_bench(fx, args, C, T, N, device):
@@ -151,31 +304,29 @@ def _free_port():
     return port
 
 
+def visible_gpus():
+    """GPU count as seen by a short-lived child, so that the launching parent never starts a HIP runtime of its own."""
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"],
+                             capture_output=True, text=True, timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
 def self_launch(args):
-    """`python bench.py --gpus N` from a bare shell: this process has made no GPU call; it starts the N ranks
-    as fresh children (torch.distributed.run, one process per GPU), lets rank 0's JSON line through on stdout
-    and exits with their status.  Never an exec of a GPU-initialised process."""
-    import subprocess
-    import torch
-    if args.backend == "nccl" and torch.cuda.device_count() < args.gpus:
+    """`python bench.py --gpus N` from a bare shell: this process makes no GPU call of its own (the device count comes from
+    a short-lived child); it starts the N ranks as fresh children (torch.distributed.run, one process per GPU) under
+    rank_environment(), lets rank 0's JSON line through on stdout and exits with their status.  Never an exec of a
+    GPU-initialised process."""
+    n = visible_gpus()
+    if args.backend == "nccl" and n is not None and n < args.gpus:
         raise SystemExit("--gpus %d but only %d GPU(s) visible; RCCL needs one GPU per rank "
-                         "(use --backend gloo to let ranks share devices for debugging)" % (args.gpus, torch.cuda.device_count()))
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "4")
+                         "(use --backend gloo to let ranks share devices for debugging)" % (args.gpus, n))
+    env = rank_environment(dict(os.environ))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
-
-
-def valu_model(window):
-    """VALU instructions per frame and their mean issue cost, from committed rocprofv3 / microbenchmark records
-    (profiles/valu_model.json, written by tools/valu_model.py); None if there is no record for this window."""
-    try:
-        rec = json.load(open(os.path.join(ROOT, "profiles", "valu_model.json")))
-        return rec.get(str(window))
-    except Exception:
-        return None
 
 
 def time_steps(an, frames, raw, sm, steps, warmup=2):
@@ -198,7 +349,35 @@ def time_steps(an, frames, raw, sm, steps, warmup=2):
     return frames.shape[0] * frames.shape[1] * steps / dt, fms / max(calls, 1)
 
 
-def main():
+class GpuEngine:
+    """Where a rank's data lives and what analyses it: the product library on this rank's GPU.  (tests/test_sharded_cpu.py
+    drives rank_main() with a CPU stand-in of the same shape to check the N>1 control flow and the shard arithmetic.)"""
+    name = "gpu"
+
+    def __init__(self, local_rank, backend):
+        import torch
+        self.torch = torch
+        if backend == "gloo":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+        self.device = local_rank
+        torch.cuda.set_device(local_rank)
+        self.fx = importlib.import_module("feature-extractor_amd")
+        self.rccl_capable = True
+
+    def frames(self, host):
+        return self.torch.from_numpy(host).cuda(self.device)
+
+    def empty(self, shape):
+        return self.torch.empty(shape, dtype=self.torch.float32, device="cuda:%d" % self.device)
+
+    def analyser(self, count, window, **kw):
+        return self.fx.BatchAnalyser(count, window, device=self.device, **kw)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize()
+
+
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -207,10 +386,12 @@ def main():
                     help="default: 1024 at --gpus 1 (BASELINE configs[1]), 8192 at --gpus N>1 (configs[3])")
     ap.add_argument("--frames", type=int, default=None,
                     help="consecutive frames per channel per step (SURVEY 8d: T >= 64); default 512 at --gpus 1, 128 at --gpus N>1 "
-                         "(8192 channels x 128 frames = 4.3 GB of input per GPU; 1.81e8 frames/s per GPU, as the single-GPU line)")
+                         "(8192 channels x 128 frames = 4.3 GB of input per GPU)")
     ap.add_argument("--window", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements (spectral-only, noise / silence, other windows)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements (spectral-only, noise / silence, other windows, live cadence)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not read hardware counters in this run (rocprofv3 --pmc children)")
+    ap.add_argument("--write-counters", action="store_true", help="also store this run's counters in profiles/counters.json (the labelled fallback)")
     ap.add_argument("--signal", default="synth", choices=["synth", "noise", "silence"],
                     help="synth = the BASELINE synthetic mix (default); noise / silence probe data-dependent paths")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -222,29 +403,43 @@ def main():
     ap.add_argument("--debug-collective", action="store_true",
                     help="with --gpus 1: create a one-rank RCCL communicator and run the N>1 code path (gather included), "
                          "then check the gathered block against the local one")
-    args = ap.parse_args()
+    ap.add_argument("--rank-timeout", type=int, default=600, help="seconds a rank may spend joining the group / communicator or in one barrier before it gives up")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--input-file", default=None, help=argparse.SUPPRESS)
+    return ap
 
+
+def main():
+    args = build_parser().parse_args()
+    rank_environment()                      # before anything can start the HIP runtime (both launch forms)
+    if args.pmc_child:
+        return pmc_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
-
-    import torch
-    import torch.distributed as dist
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.backend == "gloo":
-        local_rank = local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
+    out = rank_main(args, GpuEngine(local_rank, args.backend), rank, world)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+def rank_main(args, engine, rank, world):
+    """One rank of the bench: its shard of the channels, the timed steps, the gather to the sink; rank 0 returns the line."""
+    import torch
+    import torch.distributed as dist
+    from datetime import timedelta
+
     collective = world > 1 or args.debug_collective
     if collective:
         # control plane (barriers, the communicator id, the max over ranks): a CPU group.  The data-path exchange is
         # RCCL inside the library.
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        with Watchdog(args.rank_timeout, "joining the gloo control group (world %d)" % world):
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=timedelta(seconds=args.rank_timeout))
 
     fx = importlib.import_module("feature-extractor_amd")
     sharded = importlib.import_module("feature-extractor_amd.sharded")
@@ -252,7 +447,7 @@ def main():
     C = args.channels_per_gpu if args.channels_per_gpu is not None else (1024 if world == 1 else 8192)
     T = args.frames if args.frames is not None else (512 if world == 1 else 128)
     if args.stream:
-        return stream_bench(fx, args, C, T, N, local_rank)
+        return stream_bench(fx, args, C, T, N, engine.device)
     total_channels = C * world
     first, count = sharded.my_shard(total_channels, rank, world)
 
@@ -261,24 +456,36 @@ def main():
         host_frames = np.random.default_rng(first).normal(0, 0.1, host_frames.shape).astype(np.float32)
     elif args.signal == "silence":
         host_frames = np.zeros_like(host_frames)
-    frames = torch.from_numpy(host_frames).cuda(local_rank)
+    want_pmc = (world == 1 and engine.name == "gpu" and not args.no_pmc and not args.debug_collective)
+    input_file = None
+    if want_pmc:
+        try:
+            fd, input_file = tempfile.mkstemp(prefix="fx_bench_in_", suffix=".npy", dir="/tmp")
+            os.close(fd)
+            np.save(input_file, host_frames)      # the counter passes analyse the same bytes
+        except OSError:
+            input_file = None
+    frames = engine.frames(host_frames)
     del host_frames
-    an = fx.BatchAnalyser(count, N, device=local_rank)
-    raw = torch.empty((count, T, 12), dtype=torch.float32, device=frames.device)
-    sm = torch.empty((count, T, 12), dtype=torch.float32, device=frames.device)
+    an = engine.analyser(count, N)
+    raw = engine.empty((count, T, 12))
+    sm = engine.empty((count, T, 12))
 
     # What travels between GPUs is what the OSC sink samples (ref OSCFeatureAnalysisOutput.h:89-113): the latest
     # smoothed vector of every channel, [C][12] per rank per step, gathered to rank 0.
-    rccl = collective and args.backend == "nccl"
+    rccl = collective and args.backend == "nccl" and engine.rccl_capable
     gathered = None
     if rccl:
         ident = [fx.BatchAnalyser.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)
-        an.comm_create(rank, world, ident[0])
+        with Watchdog(args.rank_timeout, "fx_comm_create (ncclCommInitRank, world %d)" % world):
+            an.comm_create(rank, world, ident[0])
         total, firsts = an.comm_layout()
-        assert total == total_channels and firsts[rank] == first, (total, firsts, first)
+        if total != total_channels or firsts[rank] != first:
+            raise SystemExit("rank %d: communicator layout (%d channels, mine from %d) differs from the shard plan (%d, %d)"
+                             % (rank, total, firsts[rank], total_channels, first))
         if rank == 0:      # two destination buffers: a consumer may read one while the next gather fills the other
-            gathered = [torch.empty((total_channels, 12), dtype=torch.float32, device=frames.device) for _ in range(2)]
+            gathered = [engine.empty((total_channels, 12)) for _ in range(2)]
     host_pending = [None]
     counter = [0]
 
@@ -291,10 +498,10 @@ def main():
 
     def barrier():
         drain()
-        torch.cuda.synchronize()
+        engine.synchronize()
         if collective:
             dist.barrier()
-            torch.cuda.synchronize()
+            engine.synchronize()
 
     def step():
         slot = counter[0] & 1
@@ -310,7 +517,9 @@ def main():
                                                       async_op=True, single_rank_collective=True)
 
     if collective:
-        step()                  # one untimed exchange so that the communicator's channels exist even with --warmup 0
+        with Watchdog(args.rank_timeout, "the first gather (communicator channels are set up here)"):
+            step()              # one untimed exchange so that the communicator's channels exist even with --warmup 0
+            drain()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -347,6 +556,7 @@ def main():
     _flush_c_stdio()
     if collective:
         dist.barrier()
+    out = None
     if rank == 0:
         frames_total = total_channels * T * args.steps
         value = frames_total / dt
@@ -354,24 +564,48 @@ def main():
         launch_bytes = bytes_per_frame * count * T
         avg_launch_s = frame_ms / 1e3 / max(calls, 1)
         achieved = launch_bytes / avg_launch_s / 1e9
+        achieved_tflops = flops_per_frame(N) * count * T / avg_launch_s / 1e12
         cfg = "configs[1]" if world == 1 else "configs[3]"
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": load_traffic(N, count, T),
+        roof = {"bound": "valu",
+                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                 "kernel": "fx_frame_kernel<%d>" % N, "avg_launch_ms": avg_launch_s * 1e3,
                 "algorithmic_bytes_per_launch": launch_bytes, "launches_timed": calls,
                 "epilogue_ms_per_step": epi_ms / max(calls, 1),
-                "limiter": "valu",
-                "note": "algorithmic bytes = (4*N + 48) B/frame x frames per launch, against the HBM peak as SURVEY 8(d) defines the "
-                        "roofline; the kernel's binding unit is VALU issue (see valu_issue_frac and DESIGN.md 3.3)"}
-        vm = valu_model(N)
-        if vm:
-            # time the kernel's VALU instructions need at the measured per-class issue costs (tools/ubench), as a fraction
-            # of the kernel's duration: the binding unit's utilisation
-            simds = 1024
-            need_s = vm["valu_per_frame"] * vm["mean_issue_ns"] * 1e-9 * count * T / simds
-            roof["valu_issue_frac"] = need_s / avg_launch_s
-            roof["valu_insts_per_frame"] = vm["valu_per_frame"]
-            roof["valu_model_source"] = vm.get("source")
+                "compute": {"flops_per_frame": flops_per_frame(N), "achieved_tflops": achieved_tflops,
+                            "peak_tflops": FP32_VECTOR_PEAK_TFLOPS, "peak_no_fma": FP32_NO_FMA_PEAK_TFLOPS,
+                            "frac": achieved_tflops / FP32_NO_FMA_PEAK_TFLOPS, "frac_of_fma_peak": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS,
+                            "note": "algorithmic flops (SURVEY 8d: 4 FFTs x 5 N log2 N + 30 N) x frames per launch / the frame kernel's "
+                                    "HIP-event time; the FFT's rounding DAG is the reference's, which never fuses a*b+c, so the "
+                                    "usable vector peak is the no-FMA half; `frac` is against that"},
+                "note": "achieved / peak / frac are SURVEY 8(d)'s HBM figures (algorithmic bytes = (4*N + 48) B/frame x frames per launch / "
+                        "HIP-event kernel time against 8 TB/s): HBM traffic is ~1.05x the algorithmic bytes, nothing is re-read, and at "
+                        "~57 flop/B the binding unit is VALU issue -- `bound` names it and `compute` is its roofline"}
+        if want_pmc and input_file:
+            pmc, note = measure_counters(N, count, T, input_file)
+            if pmc is None:
+                rec, why = committed_counters(N, count, T)
+                roof["counters_source"] = "not read in this run (%s); %s" % (note, why)
+                pmc = rec["pmc"] if rec else None
+            else:
+                roof["counters_source"] = note
+            if pmc:
+                roof.update(counters_to_fields(pmc, count * T))
+                if args.write_counters and "rocprofv3" in roof["counters_source"] and "not read" not in roof["counters_source"]:
+                    path = os.path.join(ROOT, "profiles", "counters.json")
+                    try:
+                        allrec = json.load(open(path))
+                    except Exception:
+                        allrec = {}
+                    allrec["%d:%d:%d" % (N, count, T)] = {"pmc": pmc, "kernel_sources_sha": kernel_sources_sha(),
+                                                          "avg_launch_ms_unprofiled": avg_launch_s * 1e3}
+                    json.dump(allrec, open(path, "w"), indent=1, sort_keys=True)
+        else:
+            roof["counters_source"] = "not requested (--no-pmc, N>1 or debug run)"
+        if input_file:
+            try:
+                os.unlink(input_file)
+            except OSError:
+                pass
         out = {
             "metric": "frames/sec (1024-pt FFT, 10-feature bundle)" if N == 1024 else "frames/sec (%d-pt FFT, 10-feature bundle)" % N,
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -387,84 +621,138 @@ def main():
                                    if collective else "single GPU"},
             "roofline": roof,
         }
-        if world == 1 and not args.no_extra and not args.debug_collective:
-            extra_steps = 10
-            # BASELINE configs[1] read literally is the spectral analyser alone ("fused window + FFT +
-            # magnitude + SpectralCharacteristics reductions in one kernel"); the same workload with only the
-            # RealTimeSpectralAnalyser constructed, as an extra (never `value`)
-            an_s = fx.BatchAnalyser(count, N, device=local_rank, analysers="spectral")
-            fps, fms = time_steps(an_s, frames, raw, sm, extra_steps, warmup=3)
-            an_s.close()
-            ach = launch_bytes / (fms / 1e3) / 1e9
-            out["spectral_only"] = {"value": fps, "unit": "frames/s",
-                                    "kernel": "fx_frame_kernel<%d, spectral>" % N, "avg_launch_ms": fms,
-                                    "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS},
-                                    "note": "FX_SPECTRAL_ONLY: RMS, centroid, spread, flatness, LER, flux, slope, onset (8 of the 12 slots)"}
-            # data-dependent paths (ref PitchAnalyser.h:161-190: the lag search ends early on tonal input and runs to the
-            # arg-min fallback on noise; silence takes every early exit): same shape, other contents
-            dd = {}
-            for name in ("noise", "silence"):
-                if name == "noise":
-                    g = torch.Generator(device=frames.device)
-                    g.manual_seed(1234)
-                    other = torch.randn(frames.shape, generator=g, device=frames.device, dtype=torch.float32) * 0.1
-                else:
-                    other = torch.zeros_like(frames)
-                fps, fms = time_steps(an, other, raw, sm, extra_steps)
-                dd[name] = {"value": fps, "unit": "frames/s", "frame_kernel_ms": fms,
-                            "relative_to_synth": (avg_launch_s * 1e3) / fms}
-                del other
-            dd["note"] = "same shape as the headline run; noise = N(0, 0.1^2) white, silence = zeros; relative_to_synth = synth kernel time / this kernel time"
-            out["data_dependence"] = dd
-            an.reset_state()
-            # the reference application's default window (AnalyserTrackController.h:20-21) and the streaming config's window
-            others = {}
-            for (n2, c2, t2, label) in ((2048, 4096, 64, "configs[2] shape: 4096 channels x 2048-pt"), (4096, 1024, 64, "configs[4] window: 1024 channels x 4096-pt")):
-                if n2 == N:
-                    continue
-                fr2 = torch.from_numpy(fx.synth.frames(c2, t2, n2)).cuda(local_rank)
-                an2 = fx.BatchAnalyser(c2, n2, device=local_rank)
-                # (best of two passes: the first launches on a fresh context run up to 8 % slow -- clocks, first touch of the
-                # scratch buffers -- and this is an extra, not the timed region)
-                fps, fms = max(time_steps(an2, fr2, None, None, 2 * extra_steps, warmup=5) for _ in range(2))
-                an2.close()
-                b2 = (4 * n2 + 48) * c2 * t2
-                others[str(n2)] = {"value": fps, "unit": "frames/s", "frame_kernel_ms": fms, "workload": "%s, %d frames per step" % (label, t2),
-                                   "hbm_frac": b2 / (fms / 1e3) / 1e9 / HBM_PEAK_GBPS}
-                del fr2
-            out["other_windows"] = others
-            # BASELINE configs[4]: 1 channel, 4096-pt windows, fp16 samples, ONE hop per call through the pinned ring
-            # (fx_hop_kernel: the whole step in one launch, the host polls a flag) -- per-hop round trip as this
-            # interpreter sees it (tools/stream_latency.cpp measures the same from C++, a few microseconds less)
-            try:
-                an4 = fx.BatchAnalyser(1, 4096, device=local_rank)
-                st4 = fx.HopStream(an4, 1, slots=3, dtype=np.float16)
-                h4 = fx.synth.hops(1, 64, 4096, first_channel=24).astype(np.float16)
-                n_calls = 2000
-                for k in range(n_calls + 200):
-                    if k == 200:
-                        t_s = time.perf_counter()
-                    st4.slot()[...] = h4[:, k % 64:k % 64 + 1]
-                    st4.submit()
-                    st4.collect(want_raw=False)
-                us = (time.perf_counter() - t_s) / n_calls * 1e6
-                st4.close()
-                an4.close()
-                out["streaming_hop"] = {"round_trip_us": us, "unit": "us per 2048-sample hop", "calls": n_calls,
-                                        "workload": "configs[4]: 1 channel x 4096-pt windows, fp16 samples, one hop per call, submit + collect from Python"}
-            except Exception as e:          # never let an extra take the headline line down
-                out["streaming_hop"] = {"error": str(e)}
+        if world == 1 and not args.no_extra and not args.debug_collective and engine.name == "gpu":
+            extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes, avg_launch_s)
         if not args.no_cpu_baseline and world == 1 and not args.debug_collective:
-            out["cpu_baseline"] = cpu_baseline(fx, N, T)
+            try:
+                out["cpu_baseline"] = cpu_baseline(fx, N, T)
+            except Exception as e:          # the headline line must come out whatever happens to a side measurement
+                out["cpu_baseline"] = {"error": str(e)}
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
 
     if collective:
         dist.barrier()
         if rccl:
             an.comm_destroy()
         dist.destroy_process_group()
+    return out
+
+
+def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes, avg_launch_s):
+    """Side measurements on the same line (never `value`).  Each one is guarded: a failure is reported in its own field
+    and the headline line still comes out."""
+    import torch
+    extra_steps = 10
+    dev = engine.device
+
+    def guarded(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    def spectral_only():
+        # BASELINE configs[1] read literally is the spectral analyser alone ("fused window + FFT + magnitude +
+        # SpectralCharacteristics reductions in one kernel"): the same workload with only the RealTimeSpectralAnalyser
+        an_s = fx.BatchAnalyser(count, N, device=dev, analysers="spectral")
+        fps, fms = time_steps(an_s, frames, raw, sm, extra_steps, warmup=3)
+        an_s.close()
+        ach = launch_bytes / (fms / 1e3) / 1e9
+        return {"value": fps, "unit": "frames/s", "kernel": "fx_frame_kernel<%d, spectral>" % N, "avg_launch_ms": fms,
+                "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS},
+                "note": "FX_SPECTRAL_ONLY: RMS, centroid, spread, flatness, LER, flux, slope, onset (8 of the 12 slots)"}
+
+    def data_dependence():
+        # data-dependent paths (ref PitchAnalyser.h:161-190: the lag search ends early on tonal input and runs to the
+        # arg-min fallback on noise; silence takes every early exit): same shape, other contents
+        dd = {}
+        for name in ("noise", "silence"):
+            if name == "noise":
+                g = torch.Generator(device=frames.device)
+                g.manual_seed(1234)
+                other = torch.randn(frames.shape, generator=g, device=frames.device, dtype=torch.float32) * 0.1
+            else:
+                other = torch.zeros_like(frames)
+            fps, fms = time_steps(an, other, raw, sm, extra_steps)
+            dd[name] = {"value": fps, "unit": "frames/s", "frame_kernel_ms": fms, "relative_to_synth": (avg_launch_s * 1e3) / fms}
+            del other
+        dd["note"] = "same shape as the headline run; noise = N(0, 0.1^2) white, silence = zeros; relative_to_synth = synth kernel time / this kernel time"
+        an.reset_state()
+        return dd
+
+    def other_windows():
+        # the reference application's default window (AnalyserTrackController.h:20-21) and the streaming config's window
+        others = {}
+        for (n2, c2, t2, label) in ((2048, 4096, 64, "configs[2] shape: 4096 channels x 2048-pt"), (4096, 1024, 64, "configs[4] window: 1024 channels x 4096-pt")):
+            if n2 == N:
+                continue
+            fr2 = torch.from_numpy(fx.synth.frames(c2, t2, n2)).cuda(dev)
+            an2 = fx.BatchAnalyser(c2, n2, device=dev)
+            # (best of two passes: the first launches on a fresh context run up to 8 % slow -- clocks, first touch of the
+            # scratch buffers -- and this is an extra, not the timed region)
+            fps, fms = max(time_steps(an2, fr2, None, None, 2 * extra_steps, warmup=5) for _ in range(2))
+            an2.close()
+            b2 = (4 * n2 + 48) * c2 * t2
+            tf = flops_per_frame(n2) * c2 * t2 / (fms / 1e3) / 1e12
+            others[str(n2)] = {"value": fps, "unit": "frames/s", "frame_kernel_ms": fms, "workload": "%s, %d frames per step" % (label, t2),
+                               "hbm_frac": b2 / (fms / 1e3) / 1e9 / HBM_PEAK_GBPS, "achieved_tflops": tf, "compute_frac_no_fma": tf / FP32_NO_FMA_PEAK_TFLOPS}
+            del fr2
+        return others
+
+    def live_cadence():
+        # The reference's own cadence at scale: every channel's analysers run once per hop as it arrives
+        # (ref AudioDataCollector.h:66-94, RealTimeAnalyser.h:201-234): MANY channels x ONE hop per call, device-resident
+        # hops through fx_push_hops, which runs such a call as one launch of fx_hop_kernel.
+        res = {}
+        for c3 in (1024, 8192):
+            hops = torch.from_numpy(fx.synth.hops(c3, 16, N)).cuda(dev)
+            an3 = fx.BatchAnalyser(c3, N, device=dev)
+            r3 = torch.empty((c3, 1, 12), dtype=torch.float32, device=hops.device)
+            s3 = torch.empty_like(r3)
+            views = [hops[:, k:k + 1].contiguous() for k in range(16)]
+            n_calls = 400
+            for k in range(n_calls + 50):
+                if k == 50:
+                    an3.sync()
+                    t_s = time.perf_counter()
+                an3.push_hops(views[k % 16], out_raw=r3, out_smoothed=s3)
+            an3.sync()
+            dt3 = time.perf_counter() - t_s
+            an3.close()
+            res[str(c3)] = {"value": c3 * n_calls / dt3, "unit": "frames/s", "us_per_call": dt3 / n_calls * 1e6,
+                            "real_time_factor": (c3 * n_calls / dt3) / (c3 * 48000.0 / (N // 2))}
+            del hops, views
+        res["note"] = ("%d-pt windows, ONE hop (%d samples) per channel per call, calls back to back on one stream (fx_push_hops, device-resident "
+                       "hops, fx_hop_kernel: three wavefronts per channel + the hop's tail in one launch); real_time_factor = frames/s over the "
+                       "frames/s that many live 48 kHz channels produce" % (N, N // 2))
+        return res
+
+    def streaming_hop():
+        # BASELINE configs[4]: 1 channel, 4096-pt windows, fp16 samples, ONE hop per call through the pinned ring
+        # (fx_hop_kernel: the whole step in one launch, the host polls a flag) -- per-hop round trip as this
+        # interpreter sees it (tools/stream_latency.cpp measures the same from C++, a few microseconds less)
+        an4 = fx.BatchAnalyser(1, 4096, device=dev)
+        st4 = fx.HopStream(an4, 1, slots=3, dtype=np.float16)
+        h4 = fx.synth.hops(1, 64, 4096, first_channel=24).astype(np.float16)
+        n_calls = 2000
+        for k in range(n_calls + 200):
+            if k == 200:
+                t_s = time.perf_counter()
+            st4.slot()[...] = h4[:, k % 64:k % 64 + 1]
+            st4.submit()
+            st4.collect(want_raw=False)
+        us = (time.perf_counter() - t_s) / n_calls * 1e6
+        st4.close()
+        an4.close()
+        return {"round_trip_us": us, "unit": "us per 2048-sample hop", "calls": n_calls,
+                "workload": "configs[4]: 1 channel x 4096-pt windows, fp16 samples, one hop per call, submit + collect from Python"}
+
+    guarded("spectral_only", spectral_only)
+    guarded("data_dependence", data_dependence)
+    guarded("other_windows", other_windows)
+    guarded("live_cadence", live_cadence)
+    guarded("streaming_hop", streaming_hop)
 
 
 if __name__ == "__main__":

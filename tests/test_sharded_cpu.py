@@ -107,3 +107,88 @@ def test_sink_sends_udp_datagrams_at_60hz_to_both_targets(fx, oracle):
     assert 0.12 < dt < 1.0                         # 11 periods of 1/60 s = 0.18 s, generous bounds for CI
     for r in rx:
         r.close()
+
+
+# ---- bench.py's own rank path (rank_main) under world_size 2, gloo, CPU: the oracle stands in for the GPU analyser ----
+class _OracleAnalyser:
+    """The slice of BatchAnalyser's interface bench.rank_main uses, backed by the CPU oracle (test infrastructure)."""
+
+    def __init__(self, count, window):
+        from oracle import fx_oracle as fo
+        self.ch = [fo.Channel(window) for _ in range(count)]
+        self.latest = np.zeros((count, 12), np.float32)
+        self.calls = 0
+
+    def process_frames(self, frames, out_raw=None, out_smoothed=None):
+        for c, ch in enumerate(self.ch):
+            raw, sm = ch.process_frames(frames[c].numpy())
+            out_raw[c] = torch.from_numpy(raw)
+            out_smoothed[c] = torch.from_numpy(sm)
+            self.latest[c] = sm[-1]
+        self.calls += 1
+
+    def get_features(self):
+        return self.latest.copy()
+
+    def sync(self):
+        pass
+
+    def profile_begin(self):
+        self.calls = 0
+
+    def profile_end(self):
+        return 1.0 * self.calls, 0.1 * self.calls, self.calls
+
+    def reset_state(self):
+        [ch.reset() for ch in self.ch]
+
+    def close(self):
+        pass
+
+
+class _OracleEngine:
+    name = "cpu-oracle"
+    device = None
+    rccl_capable = False
+
+    def frames(self, host):
+        return torch.from_numpy(host)
+
+    def empty(self, shape):
+        return torch.zeros(shape, dtype=torch.float32)
+
+    def analyser(self, count, window, **kw):
+        return _OracleAnalyser(count, window)
+
+    def synchronize(self):
+        pass
+
+
+def _bench_rank(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["RANK"] = str(rank)
+    import bench
+    args = bench.build_parser().parse_args(["--gpus", str(world), "--backend", "gloo", "--channels-per-gpu", "3", "--frames", "4",
+                                            "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--rank-timeout", "120"])
+    out = bench.rank_main(args, _OracleEngine(), rank, world)
+    if rank == 0:
+        import json
+        json.dump(out, open(out_path, "w"))
+    else:
+        assert out is None
+
+
+def test_bench_rank_path_two_ranks_gloo_cpu(tmp_path):
+    """bench.py's N>1 entry (rank_main: shard plan, control group, per-step gather to the sink, the max over ranks, the
+    sink's check of its block, one line from rank 0) with world_size 2 on CPU: a stand-in engine analyses each rank's shard
+    with the oracle, everything else is the code `bench.py --gpus N` runs.  A wrong shard offset or gather order fails the
+    run's own collective check (exit 3)."""
+    import json
+    out = str(tmp_path / "line.json")
+    mp.spawn(_bench_rank, args=(2, _free_port(), out), nprocs=2, join=True)
+    d = json.load(open(out))
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["total_channels"] == 6 and d["config"]["channels_per_gpu"] == 3
+    assert d["value"] > 0 and d["steps"] == 2 and "gloo" in d["config"]["sharding"]
+    assert d["roofline"]["bound"] == "valu" and d["roofline"]["compute"]["flops_per_frame"] > 2e5
