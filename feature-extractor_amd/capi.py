@@ -24,7 +24,7 @@ EXPORTS = ["fx_create", "fx_destroy", "fx_reset_state", "fx_set_sample_rate", "f
            "fx_stream_create", "fx_stream_destroy", "fx_stream_acquire", "fx_stream_submit", "fx_stream_collect", "fx_stream_in_flight", "fx_pack_osc12",
            "fx_pack_osc10", "fx_osc_encode", "fx_last_error", "fx_abi_version",
            "fx_comm_unique_id", "fx_comm_create", "fx_comm_destroy", "fx_comm_layout", "fx_gather_smoothed", "fx_comm_sync",
-           "fx_plan_units", "fx_tuning_defaults", "fx_tuning_from_env", "fx_get_tuning", "fx_set_tuning"]
+           "fx_plan_units", "fx_tuning_defaults", "fx_tuning_from_env", "fx_get_tuning", "fx_set_tuning", "fx_debug_read_stamps"]
 COMM_ID_BYTES = 128
 ABI_VERSION = 3
 MAX_UNITS = 24
@@ -123,6 +123,7 @@ def load_library(build_if_missing=True):
     L.fx_tuning_from_env.restype = None
     L.fx_get_tuning.argtypes = [vp, ctypes.POINTER(Tuning)]
     L.fx_set_tuning.argtypes = [vp, ctypes.POINTER(Tuning)]
+    L.fx_debug_read_stamps.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong)]
     L.fx_pack_osc12.argtypes = [fp, fp]
     L.fx_pack_osc12.restype = None
     L.fx_pack_osc10.argtypes = [fp, fp]

@@ -29,6 +29,11 @@ fx_status fx_fail(fx_status code, const char* fmt, ...)
     return code;
 }
 
+// which window sizes run the pair kernel unless fx_tuning::waves_per_frame says otherwise (measured: DESIGN.md 3.1)
+#ifndef FX_PAIR_BY_DEFAULT
+#define FX_PAIR_BY_DEFAULT(n) 0
+#endif
+
 namespace {
 
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -171,6 +176,22 @@ extern "C" fx_status fx_set_tuning(fx_context* c, const fx_tuning* t)
         t->unit_plan_len < 0 || t->unit_plan_len > FX_MAX_UNITS || t->handover_spin_limit < 0)
         return fx_fail(FX_ERR_INVALID_ARGUMENT, "tuning value out of range");
     c->tuning = *t;
+    if ((t->debug_flags & 2) && !c->d_stamps) {              // diagnostic builds: room for the kernels' cycle stamps
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipMalloc((void**) &c->d_stamps, 128 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(c->d_stamps, 0, 128 * sizeof(unsigned long long)));
+    }
+    return FX_OK;
+}
+
+// diagnostic: the 128 cycle stamps a -DFX_PAIR_STAMPS build of the pair kernel leaves (zeros otherwise); synchronises
+extern "C" fx_status fx_debug_read_stamps(fx_context* c, unsigned long long* out128)
+{
+    if (!c || !out128) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    if (!c->d_stamps) return fx_fail(FX_ERR_INVALID_ARGUMENT, "no stamp buffer (fx_tuning::debug_flags bit 1)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out128, c->d_stamps, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return FX_OK;
 }
 
@@ -192,7 +213,13 @@ struct Step {
     fxk::EpilogueParams ep;
     int analysers = 3;
     int waves = 1;
+    bool pair = false;      // fx_pair_kernel: one frame across two wavefronts (fp.waves_per_ch counts pairs)
 };
+
+hipError_t launch_frames(const fx_context* c, const Step& st)
+{
+    return st.pair ? fxk::launch_pair_kernel(c->N, st.fp, c->stream) : fxk::launch_frame_kernel(c->N, st.fp, st.analysers, c->stream);
+}
 
 // Fill the kernel arguments of a step over T frames per channel from the context's current state.  `part` / `raw`
 // default to the context's own (growable) scratch; a captured step passes buffers it owns, because a graph keeps the
@@ -224,27 +251,35 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     // context has fewer or the LDS holds fewer (one twiddle table per workgroup, one flux state per channel, one
     // transform buffer per wave).  fx_tuning overrides for experiments.
     const size_t lds_cu = 160 * 1024;
+    st->analysers = (c->flags & FX_SPECTRAL_ONLY) ? 1 : ((c->flags & FX_HARMONIC_ONLY) ? 2 : 3);
+    // Windows of 2048 / 4096 points with both analysers: one frame across a PAIR of wavefronts (fx_pair_kernel) -- twice the
+    // wavefronts per CU for the same LDS, half the registers per lane.  fx_tuning::waves_per_frame forces either kernel.
+    st->pair = fxk::pair_kernel_available(c->N) && st->analysers == 3 &&
+               (c->tuning.waves_per_frame == 2 || (c->tuning.waves_per_frame == 0 && FX_PAIR_BY_DEFAULT(c->N)));
     {
-        const int kcap = fxk::frame_kernel_max_waves(c->N);
+        const int kcap = st->pair ? fxk::pair_kernel_max_pairs(c->N) : fxk::frame_kernel_max_waves(c->N);
+        auto lds_bytes = [&](int ch_, int k_) { return st->pair ? fxk::pair_kernel_lds_bytes(c->N, ch_, k_) : fxk::frame_kernel_lds_bytes(c->N, ch_, k_); };
         int ch = 1, k = 1;
-        fxk::frame_kernel_preferred_shape(c->N, &ch, &k);
+        if (st->pair) { ch = 1; k = kcap; }
+        else fxk::frame_kernel_preferred_shape(c->N, &ch, &k);
         if (c->tuning.waves_per_channel >= 1) k = c->tuning.waves_per_channel;
         if (c->tuning.channels_per_workgroup >= 1) ch = c->tuning.channels_per_workgroup;
         if (k > T) k = T;
         if (k > kcap) k = kcap;
         if (ch > c->C) ch = c->C;
-        while (ch > 1 && (ch * k > kcap || fxk::frame_kernel_lds_bytes(c->N, ch, k) > lds_cu)) ch--;
-        while (k > 1 && fxk::frame_kernel_lds_bytes(c->N, ch, k) > lds_cu) k--;
-        if (fxk::frame_kernel_lds_bytes(c->N, ch, k) > lds_cu)
+        while (ch > 1 && (ch * k > kcap || lds_bytes(ch, k) > lds_cu)) ch--;
+        while (k > 1 && lds_bytes(ch, k) > lds_cu) k--;
+        if (lds_bytes(ch, k) > lds_cu)
             return fx_fail(FX_ERR_UNSUPPORTED, "window size %d does not fit the LDS", c->N);
         fp.ch_per_wg = ch;
         fp.waves_per_ch = k;
-        st->waves = ch * k;
+        st->waves = ch * k * (st->pair ? 2 : 1);
         fp.num_chunks = 1;
         fp.queue = nullptr;
         fp.err = c->d_err;
         fp.spin_limit = c->tuning.handover_spin_limit > 0 ? (unsigned) c->tuning.handover_spin_limit : (1u << 22);
         fp.debug_flags = (unsigned) c->tuning.debug_flags;
+        fp.stamps = c->d_stamps;
         for (int i = 0; i <= fxk::FX_MAX_CHUNKS; i++) fp.chunk_begin[i] = 0;
         if (!dyn && c->d_queue) {
             int sizes[fxk::FX_MAX_CHUNKS];
@@ -276,7 +311,6 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     ep.onset_type = c->onset_type;
     ep.onset_multiplier = c->onset_multiplier;
     ep.order_mode = (int) (c->flags & FX_ORDER_MASK);
-    st->analysers = (c->flags & FX_SPECTRAL_ONLY) ? 1 : ((c->flags & FX_HARMONIC_ONLY) ? 2 : 3);
     ep.analysers = st->analysers;
     ep.dyn = dyn;
     return FX_OK;
@@ -377,7 +411,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     } else {
         if (step.fp.num_chunks > 1) HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned) * (1 + (size_t) c->C), c->stream));
         HIP_TRY(hipEventRecord(e0, c->stream));
-        HIP_TRY(fxk::launch_frame_kernel(c->N, step.fp, step.analysers, c->stream));
+        HIP_TRY(launch_frames(c, step));
         HIP_TRY(hipEventRecord(e1, c->stream));
         HIP_TRY(fxk::launch_epilogue_kernels(step.ep, c->stream));
         HIP_TRY(hipEventRecord(e2, c->stream));
@@ -439,6 +473,7 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
     {
         hipError_t e = fxk::prepare_kernels(window_size);
         if (e == hipSuccess) e = fxk::prepare_hop_kernel(window_size);
+        if (e == hipSuccess) e = fxk::prepare_pair_kernel(window_size);
         if (e != hipSuccess) return cleanup(fx_fail(FX_ERR_HIP, "kernel preparation failed: %s", hipGetErrorString(e)));
     }
 #define TRY_OR_CLEAN(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return cleanup(fx_fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); } while (0)
@@ -506,6 +541,7 @@ fx_status fx_destroy(fx_context* c)
                     c->d_raw, c->d_part, c->d_in, c->d_out_raw, c->d_queue};
     for (void* b : bufs) if (b) (void) hipFree(b);
     if (c->h_err) (void) hipHostFree(c->h_err);
+    if (c->d_stamps) (void) hipFree(c->d_stamps);
     for (int i = 0; i < 3; i++) if (c->ev[i]) (void) hipEventDestroy(c->ev[i]);
     for (hipEvent_t e : c->prof_events) (void) hipEventDestroy(e);
     if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -856,7 +892,7 @@ fx_status fx_stream_submit(fx_stream* s)
                 e = hipMemcpyAsync(sl.d_in, sl.h_in, s->in_bytes, hipMemcpyHostToDevice, c->stream);
                 if (e == hipSuccess) e = hipMemcpyAsync(sl.d_dyn, sl.h_dyn, sizeof(fxk::DynParams), hipMemcpyHostToDevice, c->stream);
             }
-            if (e == hipSuccess) e = fxk::launch_frame_kernel(c->N, step.fp, step.analysers, c->stream);
+            if (e == hipSuccess) e = launch_frames(c, step);
             if (e == hipSuccess) e = fxk::launch_epilogue_kernels(step.ep, c->stream);
             if (!zero_copy) {
                 if (e == hipSuccess) e = hipMemcpyAsync(sl.h_raw, sl.d_raw, s->out_bytes, hipMemcpyDeviceToHost, c->stream);

@@ -52,6 +52,7 @@ struct fx_context {
     fx_tuning tuning;             // launch-shape knobs: taken from the environment ONCE, in fx_create (fx_set_tuning replaces them)
     unsigned* h_err = nullptr;    // pinned, coherent: a kernel stores 1 here when a work unit gave up waiting for its predecessor (sticky)
     unsigned* d_err = nullptr;    // device view of h_err
+    unsigned long long* d_stamps = nullptr;   // diagnostic builds only (fx_tuning::debug_flags bit 1): FrameParams::stamps
     unsigned* d_queue = nullptr;  // [1 + C]: ticket counter and per-channel chunk counts of a frame-kernel launch cut in time (FrameParams::queue)
 
     float* d_raw = nullptr;       // [C][T_cap][12]

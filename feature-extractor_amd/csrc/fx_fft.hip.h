@@ -441,7 +441,12 @@ template <int N> struct TwRegs {
 #else
     static constexpr bool USE = N == 2048;
 #endif
-    static constexpr int GB = USE ? (N / 16) / 64 : 1;
+#ifdef FX_EXP_2048_TW_PARTIAL
+    static constexpr bool USE_C = false;            // experiment: only the second pass's 15 twiddles in registers (<= 168 VGPRs, 3 waves per SIMD)
+#else
+    static constexpr bool USE_C = USE;
+#endif
+    static constexpr int GB = USE_C ? (N / 16) / 64 : 1;
     f2 b[15];
     f2 c[GB][15];
     __device__ __forceinline__ void load(const f2* tw, int lane)
@@ -451,7 +456,7 @@ template <int N> struct TwRegs {
 #pragma unroll
         for (int i = 0; i < 15; i++) b[i] = t1[i * PL::L1];
 #pragma unroll
-        for (int g = 0; g < GB; g++) {
+        for (int g = 0; g < (USE_C ? GB : 0); g++) {
             const f2* t2 = tw + PL::OFF2 + lane + 64 * g;
 #pragma unroll
             for (int i = 0; i < 15; i++) c[g][i] = t2[i * PL::L2];
@@ -694,7 +699,7 @@ __device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cb
 #pragma unroll
         for (int gl = 0; gl < HB; gl++) {
             const int g = h * HB + gl, k = lane + 64 * g;
-            if constexpr (TwRegs<N>::USE) { const f2 (&wr)[15] = twr->c[g]; item16_last<INV, OUT>(ec[gl], [&](int i) { return wr[i]; }, g == 0); }
+            if constexpr (TwRegs<N>::USE_C) { const f2 (&wr)[15] = twr->c[g]; item16_last<INV, OUT>(ec[gl], [&](int i) { return wr[i]; }, g == 0); }
             else { const f2* t2 = tw + PL::OFF2 + k; item16_last<INV, OUT>(ec[gl], [&](int i) { return t2[i * L2]; }, g == 0); }
             last_item_reduce<N, OUT>(ec[gl], k, scale, res[g], aux);
             if (OUT == OUT_LAG && g == 0) { const float d = ec[0][0].y * scale; aux = d * d * (float) N; }

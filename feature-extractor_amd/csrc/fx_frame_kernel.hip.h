@@ -143,6 +143,90 @@ __device__ __forceinline__ FlatProd fp_mul2(FlatProd a, FlatProd b)
     return r;
 }
 
+// a13 / a14 (ref PitchAnalyser.h:129-217), one 64-sample block at a time, for ONE wavefront whose lane l holds v[64*blk + l]:
+// the running fp32 sum (:138-150) -- serial by definition -- as a chain across the lanes, then cnd = v/sum (:146-154) and
+// a14's search (:161-190) advanced over the block:
+//   first  = first s >= 2 with cnd[s] < 0.01
+//   stop   = first s' >= first with !(cnd[s'+1] < cnd[s'])   (or N-1)
+//   lag    = cnd[stop] <= cnd[stop+1] ? stop : stop+1        (ref :192-203)
+//   otherwise the global minimum over [2, N), first occurrence (ref :171-175).
+// Shared by the one-wavefront-per-frame kernel (FrameWave::lag_search) and the pair kernel (PairWave).
+template <int N> struct LagSearch {
+    float lag, run, carry, best;
+    int first, best_i;
+    bool done;
+    __device__ __forceinline__ void begin()
+    {
+        lag = -1.0f;
+        run = 0.0f;                 // the running sum after the previous block (wave-uniform)
+        carry = 0.0f;               // cnd of the last sample of the previous block
+        first = 0x7fffffff;
+        done = false;
+        best = 100.0f; best_i = 0x7fffffff;
+    }
+    // (Round 3 tried the running sum as a parallel prefix -- six DPP additions instead of the chain of 63 -- with every
+    // comparison taken only outside a guard band of N * 6.5e-8 and an exact redo otherwise: bit-exact, 30 VALU instructions
+    // fewer per frame at 1024 points and no faster; at 2048 / 4096 points the wider band sent enough searches to the redo
+    // that instructions went UP 3-4 %.  The chain's latency is covered by the other wavefronts; its 63 issue slots are
+    // 2 % of a frame.  Not kept.)
+    __device__ __forceinline__ void block(int lane, int blk, float v)
+    {
+        // The 64 dependent adds of the block run as a chain across the lanes: x[l] = x[l-1] + v[l] with a
+        // wave_shr:1 DPP operand, 63 times.  After pass k lanes 0..k hold their final prefix sums (a lane whose
+        // left neighbour is final recomputes the same value), lane 0 is never written (no source lane), so every
+        // lane ends with the running sum of its own sample -- the same additions in the same order as the
+        // reference's loop, with no LDS traffic at all.
+        const int s_ = 64 * blk + lane;
+        const float addend = (s_ == 0) ? 0.0f : v;                     // the sum starts at sample 1
+        float sm = lane == 0 ? run + addend : addend;
+#pragma unroll
+        for (int k = 1; k < 64; k++)                                   // (s_nop: a DPP read needs 2 wait states after the write)
+            asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(sm) : "v"(addend));
+        run = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 63));
+        const float c_ = (sm != 0.0f) ? v / sm : 0.0f;
+        const float p_ = shift_up1(c_, carry);                         // cnd of the previous sample
+        carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_), 63));
+        if (s_ >= 2 && c_ < best) { best = c_; best_i = s_; }
+        if (first == 0x7fffffff) {
+            const unsigned long long hit = __ballot(s_ >= 2 && c_ < 0.01f);
+            if (hit) first = 64 * blk + (int) __builtin_ctzll(hit);
+        }
+        if (first != 0x7fffffff) {
+            // sample s-1 ends the walk if it is past `first` and cnd does not keep falling
+            const unsigned long long st = __ballot(s_ - 1 >= first && !(c_ < p_));
+            if (st) {
+                const int src = (int) __builtin_ctzll(st);
+                const float pc = lane_get(p_, src), cc = lane_get(c_, src);
+                const int sstar = 64 * blk + src;
+                lag = (pc <= cc) ? (float) (sstar - 1) : (float) sstar;
+                done = true;
+            }
+        }
+    }
+    // v_end = v[N] (from imag[0] of the inverse transform), valid in lane 0
+    __device__ __forceinline__ float finish(int lane, float v_end)
+    {
+        if (!done) {
+            if (first != 0x7fffffff) {
+                // the walk ran to N-1 (ref :178: sample + 1 < numSamples); compare with cnd[N]
+                float cn = 0.0f;
+                if (lane == 0) { run += v_end; cn = (run != 0.0f) ? v_end / run : 0.0f; }
+                cn = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cn)));
+                lag = (carry <= cn) ? (float) (N - 1) : (float) N;
+            } else {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov = __shfl_xor(best, o, 64);
+                    const int oi = __shfl_xor(best_i, o, 64);
+                    if (ov < best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
+                }
+                lag = best_i == 0x7fffffff ? -1.0f : (float) best_i;
+            }
+        }
+        return lag;
+    }
+};
+
 // waves per SIMD the register allocator must leave room for (LDS bounds residency as well)
 #ifndef FX_OCC_SMALL
 #define FX_OCC_SMALL 4
@@ -156,12 +240,12 @@ template <int N> struct Occ {
     //   2048 points   : 3 x 4 = 12 waves, one workgroup   -> 3 per SIMD, <= 168 VGPRs
     //   4096 points   : 1 x 7 (the 160 KB to the byte)    -> 2 per SIMD at most, <= 256 VGPRs (the split transform keeps a
     //                   lane's 64 second-pass results in registers)
-#ifdef FX_EXP_2048_LDS_TW
+#if defined(FX_EXP_2048_LDS_TW) || defined(FX_EXP_2048_TW_PARTIAL)
     static constexpr int WAVES_PER_SIMD = N <= 1024 ? FX_OCC_SMALL : (N == 2048 ? 3 : 2);
 #else
     static constexpr int WAVES_PER_SIMD = N <= 1024 ? FX_OCC_SMALL : 2;
 #endif
-#ifdef FX_EXP_2048_LDS_TW
+#if defined(FX_EXP_2048_LDS_TW) || defined(FX_EXP_2048_TW_PARTIAL)
     static constexpr int MAX_THREADS = N <= 1024 ? 512 : (N == 2048 ? 768 : 448);
 #else
     static constexpr int MAX_THREADS = N <= 2048 ? 512 : 448;
@@ -648,90 +732,36 @@ FX_MARK("lpf");
     {
 FX_MARK("scan");
         lane = FX_OPQ(4, lane);
-        float lag = -1.0f;
-        float run = 0.0f;                 // the running sum after the previous block (wave-uniform)
-        float carry = 0.0f;               // cnd of the last sample of the previous block
-        int first = 0x7fffffff;
-        bool done = false;
-        float best = 100.0f; int best_i = 0x7fffffff;
-        auto block = [&](int blk, float v) {
-            // The 64 dependent adds of the block run as a chain across the lanes: x[l] = x[l-1] + v[l] with a
-            // wave_shr:1 DPP operand, 63 times.  After pass k lanes 0..k hold their final prefix sums (a lane whose
-            // left neighbour is final recomputes the same value), lane 0 is never written (no source lane), so every
-            // lane ends with the running sum of its own sample -- the same additions in the same order as the
-            // reference's loop, with no LDS traffic at all.
-            const int s_ = 64 * blk + lane;
-            const float addend = (s_ == 0) ? 0.0f : v;                     // the sum starts at sample 1
-            float sm = lane == 0 ? run + addend : addend;
-#pragma unroll
-            for (int k = 1; k < 64; k++)                                   // (s_nop: a DPP read needs 2 wait states after the write)
-                asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(sm) : "v"(addend));
-            run = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sm), 63));
-            const float c_ = (sm != 0.0f) ? v / sm : 0.0f;
-            const float p_ = shift_up1(c_, carry);                         // cnd of the previous sample
-            carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_), 63));
-            if (s_ >= 2 && c_ < best) { best = c_; best_i = s_; }
-            if (first == 0x7fffffff) {
-                const unsigned long long hit = __ballot(s_ >= 2 && c_ < 0.01f);
-                if (hit) first = 64 * blk + (int) __builtin_ctzll(hit);
-            }
-            if (first != 0x7fffffff) {
-                // sample s-1 ends the walk if it is past `first` and cnd does not keep falling
-                const unsigned long long st = __ballot(s_ - 1 >= first && !(c_ < p_));
-                if (st) {
-                    const int src = (int) __builtin_ctzll(st);
-                    const float pc = lane_get(p_, src), cc = lane_get(c_, src);
-                    const int sstar = 64 * blk + src;
-                    lag = (pc <= cc) ? (float) (sstar - 1) : (float) sstar;
-                    done = true;
-                }
-            }
-        };
+        LagSearch<N> ls;
+        ls.begin();
 #ifndef FX_EXP_SKIP_SCAN
-        block(0, vreg[0]);
-        if (!done && P > 1) block(1, vreg[1]);
-        if (!done && P > 2) {
+        ls.block(lane, 0, vreg[0]);
+        if (!ls.done && P > 1) ls.block(lane, 1, vreg[1]);
+        if (!ls.done && P > 2) {
             // rare: the search goes past the second block; the remaining blocks pick their samples from the buffer
             float* vbuf = rbuf;                                            // [N] plain layout
             if constexpr (LAZY) {
                 vbuf[64 * 2 + lane] = lz->head(2);
                 vbuf[64 * 3 + lane] = lz->head(3);
                 wave_fence();
-                for (int blk = 2; blk < P && !done; blk++) {
+                for (int blk = 2; blk < P && !ls.done; blk++) {
                     if (blk == 4) {                                        // past sample 255: the rest of the transform
                         v_end = lz->rest(vreg);
 #pragma unroll
                         for (int m = 4; m < P; m++) vbuf[64 * m + lane] = vreg[m];
                         wave_fence();
                     }
-                    block(blk, vbuf[64 * blk + lane]);
+                    ls.block(lane, blk, vbuf[64 * blk + lane]);
                 }
             } else {
 #pragma unroll
                 for (int m = 2; m < P; m++) vbuf[64 * m + lane] = vreg[m];
                 wave_fence();
-                for (int blk = 2; blk < P && !done; blk++) block(blk, vbuf[64 * blk + lane]);
+                for (int blk = 2; blk < P && !ls.done; blk++) ls.block(lane, blk, vbuf[64 * blk + lane]);
             }
         }
 #endif
-        if (!done) {
-            if (first != 0x7fffffff) {
-                // the walk ran to N-1 (ref :178: sample + 1 < numSamples); compare with cnd[N]
-                float cn = 0.0f;
-                if (lane == 0) { run += v_end; cn = (run != 0.0f) ? v_end / run : 0.0f; }
-                cn = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cn)));
-                lag = (carry <= cn) ? (float) (N - 1) : (float) N;
-            } else {
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ov = __shfl_xor(best, o, 64);
-                    const int oi = __shfl_xor(best_i, o, 64);
-                    if (ov < best || (ov == best && oi < best_i)) { best = ov; best_i = oi; }
-                }
-                lag = best_i == 0x7fffffff ? -1.0f : (float) best_i;
-            }
-        }
-        return lag;
+        return ls.finish(lane, v_end);
     }
 
     // pitch: low-pass -> window -> FFT -> re^2 -> inverse FFT -> lag; returns f0 = sampleRate / lag (ref PitchAnalyser.h:57)

@@ -79,6 +79,7 @@ struct FrameParams {
     unsigned*    err;
     unsigned     spin_limit;
     unsigned     debug_flags;
+    unsigned long long* stamps;  // diagnostic builds (-DFX_PAIR_STAMPS): [2 waves][64] shader-clock stamps of channel 0's last frame; else unused
     int          chunk_begin[FX_MAX_CHUNKS + 1];   // chunk k analyses frames [chunk_begin[k], chunk_begin[k + 1]); the last entry used is T
     float        gain;          // hop mode only (ref AudioDataCollector.h:88)
     const float* tail_in;       // [C][N/2] second half of the previous window (already gained)
@@ -145,6 +146,13 @@ hipError_t launch_frame_kernel(int window_size, const FrameParams& p, int analys
 hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t stream);
 hipError_t prepare_kernels(int window_size);   // raises the kernels' dynamic-LDS limit on the CURRENT device (every fx_create: the attribute is per device)
 hipError_t prepare_hop_kernel(int window_size);   // the same for fx_hop_kernel; hipSuccess where there is none for this size
+// One frame across a PAIR of wavefronts (windows of 2048 / 4096 points, both analysers): p.waves_per_ch is then the number
+// of pairs (= frames of a channel in flight) and a workgroup has p.ch_per_wg * p.waves_per_ch * 128 threads.
+bool pair_kernel_available(int window_size);
+int pair_kernel_max_pairs(int window_size);
+size_t pair_kernel_lds_bytes(int window_size, int channels_per_wg, int pairs_per_channel);
+hipError_t prepare_pair_kernel(int window_size);
+hipError_t launch_pair_kernel(int window_size, const FrameParams& p, hipStream_t stream);
 // One hop per channel, whole step in one launch (three wavefronts per channel + the tail), results and completion flag
 // written by the kernel itself; p.T must be 1, p.hop_mode 1, both analysers on.  Window sizes: hop_kernel_available().
 bool hop_kernel_available(int window_size);

@@ -52,6 +52,9 @@ namespace fxk {
 #if FX_PART == 0 || FX_PART == 1
 #define FX_WITH_TAIL_KERNELS
 #endif
+#if FX_PART == 0 || FX_PART == 2
+#include "fx_pair_kernel.hip.h"
+#endif
 #if FX_PART != 2
 #include "fx_tail_kernels.hip.h"
 #endif
@@ -122,6 +125,42 @@ template <int N> hipError_t launch_t(const FrameParams& p, int analysers, hipStr
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
+
+#if FX_PART == 0 || FX_PART == 2
+// ---- the pair kernel (one frame across two wavefronts; windows of 2048 and 4096 points) ----
+template <int N> static size_t pair_lds_bytes_t(int ch, int k)
+{
+    typedef PGeo<N> PG;
+    return sizeof(f2) * N + (size_t) ch * sizeof(float) * PG::PREV_FLOATS + (size_t) ch * k * (PG::BUF_BYTES + PG::PAIR_EXTRA);
+}
+template <int N> static hipError_t launch_pair_t(const FrameParams& p, hipStream_t stream)
+{
+    const size_t lds = pair_lds_bytes_t<N>(p.ch_per_wg, p.waves_per_ch);
+    const dim3 grid((unsigned) ((p.C + p.ch_per_wg - 1) / p.ch_per_wg) * (unsigned) (p.num_chunks > 1 ? p.num_chunks : 1)),
+               block((unsigned) (p.ch_per_wg * p.waves_per_ch) * 128);
+    hipLaunchKernelGGL((fx_pair_kernel<N>), grid, block, lds, stream, p);
+    return hipGetLastError();
+}
+bool pair_kernel_available(int n) { return n == 2048 || n == 4096; }
+int pair_kernel_max_pairs(int n) { return n == 2048 ? POcc<2048>::MAX_PAIRS : (n == 4096 ? POcc<4096>::MAX_PAIRS : 0); }
+size_t pair_kernel_lds_bytes(int n, int ch, int k) { return n == 2048 ? pair_lds_bytes_t<2048>(ch, k) : (n == 4096 ? pair_lds_bytes_t<4096>(ch, k) : 0); }
+hipError_t prepare_pair_kernel(int n)
+{
+    if (n == 2048) return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_pair_kernel<2048>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (n == 4096) return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_pair_kernel<4096>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return hipSuccess;
+}
+hipError_t launch_pair_kernel(int n, const FrameParams& p, hipStream_t stream)
+{
+    if (p.C <= 0 || p.T <= 0) return hipSuccess;
+    if (!pair_kernel_available(n) || p.ch_per_wg < 1 || p.waves_per_ch < 1 || p.ch_per_wg * p.waves_per_ch > pair_kernel_max_pairs(n)) return hipErrorInvalidValue;
+    if (p.num_chunks > 1) {
+        if (!p.queue || p.num_chunks > FX_MAX_CHUNKS || p.chunk_begin[0] != 0 || p.chunk_begin[p.num_chunks] != p.T) return hipErrorInvalidValue;
+        for (int k = 0; k < p.num_chunks; k++) if (p.chunk_begin[k + 1] <= p.chunk_begin[k]) return hipErrorInvalidValue;
+    }
+    return n == 2048 ? launch_pair_t<2048>(p, stream) : launch_pair_t<4096>(p, stream);
+}
+#endif
 
 #if FX_PART == 1
 extern template hipError_t prepare_t<2048>();

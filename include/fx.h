@@ -184,12 +184,15 @@ typedef struct fx_tuning {
                                     batch kernels instead of the one-launch hop kernel; -1 = hop kernel when it applies */
     int handover_spin_limit;     /* FX_HANDOVER_SPINS: polls a work unit spends waiting for its predecessor's flux state
                                     before it gives up and the call is reported failed (FX_ERR_HIP); 0 = default (1 << 22) */
-    int debug_flags;             /* FX_DEBUG_FLAGS: bit 0 = work units do not publish their hand-over (forces the time-out; tests) */
+    int debug_flags;             /* FX_DEBUG_FLAGS: bit 0 = work units do not publish their hand-over (forces the time-out; tests);
+                                    bit 1 = keep a buffer for the cycle stamps of diagnostic kernel builds (fx_debug_read_stamps) */
 } fx_tuning;
 void fx_tuning_defaults(fx_tuning* t);     /* every knob "measured best" */
 void fx_tuning_from_env(fx_tuning* t);     /* defaults overridden by the FX_* variables set right now */
 fx_status fx_get_tuning(fx_context* ctx, fx_tuning* out);
 fx_status fx_set_tuning(fx_context* ctx, const fx_tuning* t);
+/* Diagnostic (tools/pair_stamps.py): 128 shader-clock stamps left by a library built with -DFX_PAIR_STAMPS; zeros otherwise. */
+fx_status fx_debug_read_stamps(fx_context* ctx, unsigned long long* out128);
 
 /* Host-only arithmetic, exposed for testing: how a call of `num_frames` frames per channel is cut into
  * work units for the frame kernel (several workgroups per channel, each analysing a run of consecutive

@@ -1,6 +1,7 @@
 """Static per-section instruction counts of fx_frame_kernel<N> from the FXMARK comments in the ISA."""
 import re, subprocess, sys, os, tempfile
 N = sys.argv[1] if len(sys.argv) > 1 else "1024"
+PAIR = len(sys.argv) > 2 and sys.argv[2] == "pair"      # the pair kernel (2048 / 4096) instead of fx_frame_kernel
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = tempfile.mkdtemp()
 sys.path.insert(0, os.path.join(root, "feature-extractor_amd"))
@@ -8,7 +9,7 @@ import build as fxbuild
 subprocess.run(["hipcc"] + fxbuild.flags_for_window(int(N)) + ["-x", "hip", "-c", os.path.join(root, "feature-extractor_amd/csrc/fx_kernels.hip"), "-o", os.path.join(d, "fx.o"), "-save-temps"],
                cwd=d, stderr=subprocess.DEVNULL)
 src = open(os.path.join(d, "fx_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
-start = src.index("_ZN3fxk15fx_frame_kernelILi%sELb1ELb1EEEvNS_11FrameParamsE:" % N)
+start = src.index(("_ZN3fxk14fx_pair_kernelILi%sEEEvNS_11FrameParamsE:" if PAIR else "_ZN3fxk15fx_frame_kernelILi%sELb1ELb1EEEvNS_11FrameParamsE:") % N)
 body = src[start:src.index("s_endpgm", start)]
 sec = "pre"; counts = {}; order = []
 for line in body.splitlines():
