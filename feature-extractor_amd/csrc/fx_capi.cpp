@@ -30,6 +30,9 @@ fx_status fx_fail(fx_status code, const char* fmt, ...)
 }
 
 // which window sizes run the pair kernel unless fx_tuning::waves_per_frame says otherwise (measured: DESIGN.md 3.1)
+#ifndef FX_HOP_PAIRS_BY_DEFAULT
+#define FX_HOP_PAIRS_BY_DEFAULT(n) 0
+#endif
 #ifndef FX_PAIR_BY_DEFAULT
 #define FX_PAIR_BY_DEFAULT(n) 0
 #endif
@@ -214,6 +217,7 @@ struct Step {
     int analysers = 3;
     int waves = 1;
     bool pair = false;      // fx_pair_kernel: one frame across two wavefronts (fp.waves_per_ch counts pairs)
+    bool hop_pairs = false; // a one-frame call through fx_hop_pair_kernel (six wavefronts per channel) instead of fx_hop_kernel (three)
 };
 
 hipError_t launch_frames(const fx_context* c, const Step& st)
@@ -256,6 +260,8 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     // wavefronts per CU for the same LDS, half the registers per lane.  fx_tuning::waves_per_frame forces either kernel.
     st->pair = fxk::pair_kernel_available(c->N) && st->analysers == 3 &&
                (c->tuning.waves_per_frame == 2 || (c->tuning.waves_per_frame == 0 && FX_PAIR_BY_DEFAULT(c->N)));
+    st->hop_pairs = fxk::pair_kernel_available(c->N) && st->analysers == 3 &&
+                    (c->tuning.waves_per_frame == 2 || (c->tuning.waves_per_frame == 0 && FX_HOP_PAIRS_BY_DEFAULT(c->N)));
     {
         const int kcap = st->pair ? fxk::pair_kernel_max_pairs(c->N) : fxk::frame_kernel_max_waves(c->N);
         auto lds_bytes = [&](int ch_, int k_) { return st->pair ? fxk::pair_kernel_lds_bytes(c->N, ch_, k_) : fxk::frame_kernel_lds_bytes(c->N, ch_, k_); };
@@ -405,7 +411,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     if (one_hop) {
         const fxk::HopSignal none = {nullptr, nullptr, 0u, 0u, nullptr};
         HIP_TRY(hipEventRecord(e0, c->stream));
-        HIP_TRY(fxk::launch_hop_kernel(c->N, step.fp, step.ep, none, c->stream));
+        HIP_TRY(fxk::launch_hop_kernel(c->N, step.fp, step.ep, none, c->stream, step.hop_pairs));
         HIP_TRY(hipEventRecord(e1, c->stream));
         HIP_TRY(hipEventRecord(e2, c->stream));
     } else {
@@ -854,7 +860,7 @@ fx_status fx_stream_submit(fx_stream* s)
         if (++s->next_seq == 0) s->next_seq = 1;            // 0 = "nothing completed yet"
         sl.seq = s->next_seq;
         const fxk::HopSignal sig = {s->d_arrivals, flag_dev, sl.seq, 0u, s->d_stage};
-        const hipError_t e = fxk::launch_hop_kernel(c->N, step.fp, step.ep, sig, c->stream);
+        const hipError_t e = fxk::launch_hop_kernel(c->N, step.fp, step.ep, sig, c->stream, step.hop_pairs);
         if (e != hipSuccess) { s->acquired = false; return fx_fail(FX_ERR_HIP, "launching the hop kernel failed: %s", hipGetErrorString(e)); }
         c->ev_valid = false;
         advance(c, 1);

@@ -151,6 +151,148 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same for windows of 2048 / 4096 points with every analyser on a PAIR of wavefronts (fx_pair_kernel.hip.h): a workgroup
+// is one channel and six wavefronts -- pitch pair, spectral pair, harmonic pair -- running the sections of PairWave, i.e.
+// bit for bit what fx_pair_kernel computes.  A frame across two wavefronts halves the arithmetic on the critical path (the
+// pitch estimate: two transforms, the low-pass, the lag search), which is what a one-hop call waits for.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int N> struct HopPairGeo {
+    typedef PGeo<N> PG;
+    static constexpr size_t PAIR_BYTES = PG::BUF_BYTES + PG::PAIR_EXTRA;
+    static constexpr size_t OFF_PREV = sizeof(f2) * N;
+    static constexpr size_t OFF_PAIRS = OFF_PREV + sizeof(float) * PG::PREV_FLOATS;
+    static constexpr size_t OFF_PART = OFF_PAIRS + 3 * PAIR_BYTES;
+    static constexpr size_t OFF_HIST = OFF_PART + sizeof(FramePart);
+    static constexpr size_t OFF_RAW = OFF_HIST + sizeof(float) * HLEN * FX_NUM_FEATURES;
+    static constexpr size_t OFF_ONSET = OFF_RAW + sizeof(float) * 16;
+    static constexpr size_t BYTES = OFF_ONSET + sizeof(float) * 64;
+    static_assert(OFF_PAIRS % 16 == 0 && OFF_PART % 16 == 0 && PAIR_BYTES % 16 == 0, "16-byte aligned sections");
+};
+
+template <int N>
+__global__ void __launch_bounds__(384, 1)
+fx_hop_pair_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSignal sig)
+{
+    FrameParams p = p_arg;
+    typedef PGeo<N> PG;
+    typedef HopPairGeo<N> HG;
+    constexpr int M = PG::M;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f2*    tw   = reinterpret_cast<f2*>(smem);
+    float* prev = reinterpret_cast<float*>(smem + HG::OFF_PREV);
+    int*   turn2 = reinterpret_cast<int*>(prev + M);
+    FramePart* part = reinterpret_cast<FramePart*>(smem + HG::OFF_PART);
+    float* s_hist = reinterpret_cast<float*>(smem + HG::OFF_HIST);
+    float* s_raw  = reinterpret_cast<float*>(smem + HG::OFF_RAW);
+    float* s_onset = reinterpret_cast<float*>(smem + HG::OFF_ONSET);
+
+    const int wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int pair = wave >> 1, w = wave & 1;
+    const int c = blockIdx.x;
+    unsigned char* mine = smem + HG::OFF_PAIRS + HG::PAIR_BYTES * pair;
+    f2* cbuf = reinterpret_cast<f2*>(mine);
+    double* mbox = reinterpret_cast<double*>(mine + PG::BUF_BYTES);
+    unsigned* flags = reinterpret_cast<unsigned*>(mine + PG::BUF_BYTES + 8 * PG::MBOX_DOUBLES);
+
+    // prologue: twiddle table, flux state, history of raw values, the hop itself -- 16 bytes per lane per load
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(p.tw);
+        uint4* dst = reinterpret_cast<uint4*>(tw);
+#pragma unroll 4
+        for (int i = threadIdx.x; i < N / 2; i += 384) dst[i] = src[i];
+        const f4* ps = reinterpret_cast<const f4*>(p.prev_re + (size_t) c * M);
+        for (int i = threadIdx.x; i < M / 4; i += 384) reinterpret_cast<f4*>(prev)[i] = ps[i];
+        const uint4* hs4 = reinterpret_cast<const uint4*>(ep_arg.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES);
+        for (int i = threadIdx.x; i < HLEN * FX_NUM_FEATURES / 4; i += 384) reinterpret_cast<uint4*>(s_hist)[i] = hs4[i];
+    }
+    if (threadIdx.x == 0) { turn2[0] = 0; part->flags = 0; }
+    if (lane == 0) flags[w] = 0u;
+    if (sig.stage) {
+        const size_t hop_bytes = (size_t) (N / 2) * (p.sample_format == FX_SAMPLE_F16 ? 2 : 4);
+        const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(p.in) + (size_t) c * hop_bytes);
+        uint4* dst = reinterpret_cast<uint4*>(static_cast<unsigned char*>(sig.stage) + (size_t) c * hop_bytes);
+        for (int i = threadIdx.x; i < (int) (hop_bytes / 16); i += blockDim.x) dst[i] = src[i];
+        p.in = sig.stage;
+    }
+    __syncthreads();
+
+    const double nyquist = p.nyquist;
+    PairWave<N> pw{p, tw, prev, turn2, cbuf, reinterpret_cast<float*>(cbuf), mbox, flags, part,
+                   nyquist, 1.0 / nyquist, nyquist / (double) M, 1.0f / (float) N, c, 1, 0, w, 0u, 0u
+#ifdef FX_PAIR_STAMPS
+                   , 0
+#endif
+    };
+    typename PairWave<N>::HarmonicSpectrum hs;
+    if (pair == 0) {
+        // a1 + the pitch estimate (a10-a14): the window into this pair's real image, low-pass, two transforms, lag search
+        (void) pw.load_half_window(lane);
+        pw.pair_sync(lane);
+        (void) pw.pitch(lane);                                  // leaves the lag in the record
+    } else if (pair == 1) {
+        // a2 + the spectral analyser (a3-a7): the sum of squares exactly as fx_pair_kernel takes it (each wave its half of the
+        // window, wave 0 + wave 1), then the windowed transform and its sums
+        const double ssq_wave = pw.load_half_window(lane);
+        if (lane == 0) *pw.slot(w, 0) = ssq_wave;
+        pw.pair_sync(lane);
+        const double sum_sq = *pw.slot(0, 0) + *pw.slot(1, 0);
+        pw.next_exchange();
+        if (w == 0 && lane == 0) part->sum_sq = sum_sq;
+        // (the image itself is not used here; each wave wrote its half into its own region before the exchange above)
+        pw.spectral(lane, sum_sq);
+        pw.pair_sync(lane);                                     // both waves' shares of the record are written
+        if (w == 0 && lane == 0) {                              // this analyser's slots (ref RealTimeAnalyser.h:209-226), while the pitch estimate is still running
+            EpilogueParams e1 = ep_arg; e1.analysers = 1;
+            float out[FX_NUM_FEATURES];
+            finalise_values(e1, *part, out);
+            s_raw[FX_ONSET] = 0.0f; s_raw[FX_RMS] = out[FX_RMS]; s_raw[FX_CENTROID] = out[FX_CENTROID]; s_raw[FX_SPREAD] = out[FX_SPREAD];
+            s_raw[FX_FLATNESS] = out[FX_FLATNESS]; s_raw[FX_LER] = out[FX_LER]; s_raw[FX_FLUX] = out[FX_FLUX]; s_raw[FX_SLOPE] = out[FX_SLOPE];
+        }
+    } else {
+        pw.harmonic_spectrum(lane, hs);                         // a15, up to where the pitch is needed
+    }
+    __syncthreads();                                            // the lag is known
+    if (pair == 2) {
+        const double f0 = (nyquist * 2.0) / (double) part->lag; // ref PitchAnalyser.h:57
+        pw.harmonic_tail(lane, hs, f0);                         // a16-a18
+        if (w == 0 && lane == 0) {                              // the harmonic analyser's slots (ref RealTimeAnalyser.h:150-172)
+            EpilogueParams e2 = ep_arg; e2.analysers = 2;
+            float out[FX_NUM_FEATURES];
+            finalise_values(e2, *part, out);
+            s_raw[FX_F0] = out[FX_F0]; s_raw[FX_HER] = out[FX_HER]; s_raw[FX_OER] = out[FX_OER]; s_raw[FX_INHARM] = out[FX_INHARM];
+        }
+    }
+    __syncthreads();                                            // the record is complete, the flux state is final
+    for (int i = threadIdx.x; i < M; i += blockDim.x) p.prev_re[(size_t) c * M + i] = prev[i];
+    if (wave != 0) return;
+
+    EpilogueParams ep = ep_arg;
+    ep.raw = s_raw - (size_t) c * FX_NUM_FEATURES;
+    ep.hist_in = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
+    epilogue_hop(ep, c, lane, s_onset);
+    for (int i = lane; i < HLEN * FX_NUM_FEATURES; i += 64) history_value(ep, (long long) c * HLEN * FX_NUM_FEATURES + i);
+    if (lane == 0 && sig.host_flag) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        const unsigned before = __hip_atomic_fetch_add(sig.arrivals, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (before + 1 == gridDim.x) {
+            __hip_atomic_store(sig.arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(sig.host_flag, sig.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+template <int N> hipError_t hop_pair_prepare_t()
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_hop_pair_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+template <int N> hipError_t hop_pair_launch_t(const FrameParams& p, const EpilogueParams& ep, const HopSignal& sig, hipStream_t stream)
+{
+    hipLaunchKernelGGL((fx_hop_pair_kernel<N>), dim3((unsigned) p.C), dim3(384), HopPairGeo<N>::BYTES, stream, p, ep, sig);
+    return hipGetLastError();
+}
+
 template <int N> hipError_t hop_prepare_t()
 {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_hop_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

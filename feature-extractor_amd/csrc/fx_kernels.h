@@ -156,7 +156,8 @@ hipError_t launch_pair_kernel(int window_size, const FrameParams& p, hipStream_t
 // One hop per channel, whole step in one launch (three wavefronts per channel + the tail), results and completion flag
 // written by the kernel itself; p.T must be 1, p.hop_mode 1, both analysers on.  Window sizes: hop_kernel_available().
 bool hop_kernel_available(int window_size);
-hipError_t launch_hop_kernel(int window_size, const FrameParams& p, const EpilogueParams& ep, const HopSignal& sig, hipStream_t stream);
+// pairs: windows of 2048 / 4096 points with every analyser on a pair of wavefronts (six per channel; fx_hop_pair_kernel)
+hipError_t launch_hop_kernel(int window_size, const FrameParams& p, const EpilogueParams& ep, const HopSignal& sig, hipStream_t stream, bool pairs = false);
 
 } // namespace fxk
 #endif

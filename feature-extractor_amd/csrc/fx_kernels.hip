@@ -52,7 +52,7 @@ namespace fxk {
 #if FX_PART == 0 || FX_PART == 1
 #define FX_WITH_TAIL_KERNELS
 #endif
-#if FX_PART == 0 || FX_PART == 2
+#if FX_PART == 0 || FX_PART == 2 || FX_PART == 3
 #include "fx_pair_kernel.hip.h"
 #endif
 #if FX_PART != 2
@@ -69,18 +69,21 @@ bool hop_kernel_available(int n) { return n == 1024 || n == 2048 || n == 4096; }
 // so there is no process-wide "already prepared" state to go stale when a second device or thread comes along.
 hipError_t prepare_hop_kernel(int n)
 {
+    hipError_t e = hipSuccess;
     switch (n) {
         case 1024: return hop_prepare_t<1024>();
-        case 2048: return hop_prepare_t<2048>();
-        case 4096: return hop_prepare_t<4096>();
+        case 2048: e = hop_prepare_t<2048>(); return e != hipSuccess ? e : hop_pair_prepare_t<2048>();
+        case 4096: e = hop_prepare_t<4096>(); return e != hipSuccess ? e : hop_pair_prepare_t<4096>();
         default:   return hipSuccess;
     }
 }
-hipError_t launch_hop_kernel(int n, const FrameParams& p, const EpilogueParams& ep, const HopSignal& sig, hipStream_t stream)
+hipError_t launch_hop_kernel(int n, const FrameParams& p, const EpilogueParams& ep, const HopSignal& sig, hipStream_t stream, bool pairs)
 {
     if (p.C <= 0) return hipSuccess;
     if (p.T != 1 || ep.T != 1 || ep.analysers != 3) return hipErrorInvalidValue;
     if (!hop_kernel_available(n)) return hipErrorInvalidValue;
+    if (pairs && n == 2048) return hop_pair_launch_t<2048>(p, ep, sig, stream);
+    if (pairs && n == 4096) return hop_pair_launch_t<4096>(p, ep, sig, stream);
     switch (n) {
         case 1024: return hop_launch_t<1024>(p, ep, sig, stream);
         case 2048: return hop_launch_t<2048>(p, ep, sig, stream);

@@ -680,7 +680,11 @@ FX_MARK("p_spec_x2");
     }
 
     // ---- harmonic analyser (ref RealTimeAnalyser.h:161,169-172; HarmonicCharacteristics.h:46-244) ---------------------------
-    __device__ __forceinline__ void harmonic(int lane, double f0) const
+    // What the tail needs of the raw spectrum: |re| of the lane's own bins and of the three bins around them, the sums
+    struct HarmonicSpectrum { float hre[U2]; float left2, left1, right1; double sum; float max_re; };
+
+    // part 1: the raw (un-windowed) frame's spectrum and its sums (:161, HarmonicCharacteristics.h:61-69) -- needs no pitch yet
+    __device__ __forceinline__ void harmonic_spectrum(int lane, HarmonicSpectrum& hs) const
     {
         const int gl = 64 * w + lane;
         {
@@ -691,19 +695,18 @@ FX_MARK("p_harm_in");
         }
 FX_MARK("p_harm_sums");
         const float* relin = rbuf;                                             // bins image: re of every bin < M
-        float hre[U2];
         const int b0 = U2 * gl;
-        lds_load_block<U2>(relin + pbim<N>(b0), hre);
-        const float h_left2  = b0 >= 2 ? fabsf(relin[pbim<N>(b0 - 2)]) : 0.0f;
-        const float h_left1  = b0 >= 1 ? fabsf(relin[pbim<N>(b0 - 1)]) : 0.0f;
-        const float h_right1 = b0 + U2 < M ? fabsf(relin[pbim<N>(b0 + U2 < M ? b0 + U2 : 0)]) : 0.0f;
+        lds_load_block<U2>(relin + pbim<N>(b0), hs.hre);
+        hs.left2  = b0 >= 2 ? fabsf(relin[pbim<N>(b0 - 2)]) : 0.0f;
+        hs.left1  = b0 >= 1 ? fabsf(relin[pbim<N>(b0 - 1)]) : 0.0f;
+        hs.right1 = b0 + U2 < M ? fabsf(relin[pbim<N>(b0 + U2 < M ? b0 + U2 : 0)]) : 0.0f;
         double h_sum = 0.0;
         float h_max_re = 0.0f;
 #pragma unroll
         for (int j = 0; j < U2; j++) {                                         // ref HarmonicCharacteristics.h:61-69
-            const double v = (double) hre[j];
+            const double v = (double) hs.hre[j];
             h_sum += v * v;
-            h_max_re = fmaxf(h_max_re, fabsf(hre[j]));
+            h_max_re = fmaxf(h_max_re, fabsf(hs.hre[j]));
         }
         h_sum = wave_sum(h_sum);
         h_max_re = wave_maxf(h_max_re);
@@ -711,11 +714,21 @@ FX_MARK("p_harm_sums");
         pair_sync(lane);
         {
             const double* s0 = slot(0, 0); const double* s1 = slot(1, 0);
-            h_sum = s0[0] + s1[0];
-            h_max_re = fmaxf((float) s0[1], (float) s1[1]);
+            hs.sum = s0[0] + s1[0];
+            hs.max_re = fmaxf((float) s0[1], (float) s1[1]);
         }
         next_exchange();
-        const double h_max = (double) h_max_re * (double) h_max_re;
+    }
+
+    // part 2: peaks, harmonic energy ratio, inharmonicity (HarmonicCharacteristics.h:71-105), once the pitch is known
+    __device__ __forceinline__ void harmonic_tail(int lane, HarmonicSpectrum& hs, double f0) const
+    {
+        const int gl = 64 * w + lane;
+        const float* relin = rbuf;
+        float (&hre)[U2] = hs.hre;
+        const float h_left2 = hs.left2, h_left1 = hs.left1, h_right1 = hs.right1;
+        double h_sum = hs.sum;
+        const double h_max = (double) hs.max_re * (double) hs.max_re;
         if (h_sum < 0.005) return;                                             // :88-89 (the same decision in both waves)
 
         double mean_mag = h_sum / (double) M;                                  // :86
@@ -938,7 +951,7 @@ fx_pair_kernel(const FrameParams p_arg)
         if (!(FX_EXP_PAIR_SKIP & 1)) lag = pw.pitch(ln);
         const double f0 = (nyquist * 2.0) / (double) lag;                      // ref PitchAnalyser.h:57
         if (!(FX_EXP_PAIR_SKIP & 2)) pw.spectral(opaque(ln), sum_sq);
-        if (!(FX_EXP_PAIR_SKIP & 4)) pw.harmonic(opaque(ln), f0);
+        if (!(FX_EXP_PAIR_SKIP & 4)) { typename PairWave<N>::HarmonicSpectrum hs; pw.harmonic_spectrum(opaque(ln), hs); pw.harmonic_tail(opaque(ln), hs, f0); }
 #ifdef FX_PAIR_STAMPS
         pw.stamp(ln);
 #endif

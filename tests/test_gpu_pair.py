@@ -98,3 +98,69 @@ def test_pair_kernel_fp16_frames_orders_and_settings(gpu_fx, oracle, N):
     o2 = oracle.process_frames(frames, N)
     close(g2[0], o2[0], "pair frames raw")
     close(g2[1], o2[1], "pair frames smoothed")
+
+
+@pytest.mark.parametrize("N,C", [(2048, 5), (4096, 1), (4096, 9)])
+def test_one_hop_calls_on_pairs_equal_the_pair_kernel_bitwise(gpu_fx, oracle, N, C):
+    """One hop per call with every analyser on a pair of wavefronts (fx_hop_pair_kernel: six wavefronts per channel, one launch)
+    -- through the pinned ring and through fx_push_hops -- runs the sections fx_pair_kernel runs: bit for bit the batch
+    path's values (pair kernel + fused tail), with setter calls in between, and the oracle's within the parity bar."""
+    nb = 30
+    hops = np.concatenate([signals.bursts(C, nb // 2, N, seed=15), signals.low_tones(C, nb - nb // 2, N)], axis=1)
+
+    def settings(an, b):
+        if b == 6:
+            an.set_gain(0.5)
+            an.set_onset_window_length(4)
+        if b == 13:
+            an.set_onset_detection_type(2)
+            an.set_onset_detection_sensitivity(0.2)
+        if b == 21:
+            an.sample_rate_changed(44100.0)
+
+    ref = gpu_fx.BatchAnalyser(C, N)
+    ref.set_tuning(waves_per_frame=2, one_hop_kernel=0)           # fx_pair_kernel + fx_tail_fused_kernel
+    want = []
+    for b in range(nb):
+        settings(ref, b)
+        want.append(ref.push_hops(hops[:, b:b + 1]))
+    want = tuple(np.concatenate([x[k] for x in want], 1) for k in (0, 1))
+
+    direct = gpu_fx.BatchAnalyser(C, N)
+    direct.set_tuning(waves_per_frame=2)                          # one-frame calls: fx_hop_pair_kernel
+    got = []
+    for b in range(nb):
+        settings(direct, b)
+        got.append(direct.push_hops(hops[:, b:b + 1]))
+    for k in (0, 1):
+        assert np.array_equal(np.concatenate([g[k] for g in got], 1), want[k], equal_nan=True), k
+
+    an = gpu_fx.BatchAnalyser(C, N)
+    an.set_tuning(waves_per_frame=2)
+    st = gpu_fx.HopStream(an, 1, slots=3)
+    got = []
+    for b in range(nb):
+        settings(an, b)
+        if st.in_flight() == 2:
+            got.append(st.collect())
+        st.push(hops[:, b:b + 1])
+    while st.in_flight():
+        got.append(st.collect())
+    st.close()
+    for k in (0, 1):
+        assert np.array_equal(np.concatenate([g[k] for g in got], 1), want[k], equal_nan=True), k
+    assert np.array_equal(an.get_features(), ref.get_features(), equal_nan=True)
+
+    chans = [oracle.Channel(N) for _ in range(C)]
+    oraw, osm = [], []
+    for b in range(nb):
+        if b == 6:
+            [(ch.set_gain(0.5), ch.set_onset_window(4)) for ch in chans]
+        if b == 13:
+            [(ch.set_onset_type(2), ch.set_onset_sensitivity(0.2)) for ch in chans]
+        if b == 21:
+            [ch.set_sample_rate(44100.0) for ch in chans]
+        r = [ch.push_hops(hops[c, b:b + 1]) for c, ch in enumerate(chans)]
+        oraw.append(np.stack([x[0] for x in r])); osm.append(np.stack([x[1] for x in r]))
+    close(want[0], np.concatenate(oraw, 1), "hop pairs raw")
+    close(want[1], np.concatenate(osm, 1), "hop pairs smoothed")
