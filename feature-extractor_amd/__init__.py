@@ -10,7 +10,7 @@ from .capi import (FEATURE_NAMES, NUM_FEATURES, FxError, load_library, library_p
                    ORDER_SPECTRAL_THEN_HARMONIC, ORDER_HARMONIC_THEN_SPECTRAL, ORDER_ISOLATED,
                    pack_osc12, pack_osc10, osc_encode)
 from .analyser import BatchAnalyser, HopStream
-from . import capi, synth, wav
+from . import capi, offline, synth, wav
 
 __all__ = ["BatchAnalyser", "HopStream", "FxError", "load_library", "library_path", "synth", "wav", "FEATURE_NAMES",
            "NUM_FEATURES", "pack_osc12", "pack_osc10", "osc_encode"]

@@ -24,7 +24,9 @@ EXPORTS = ["fx_create", "fx_destroy", "fx_reset_state", "fx_set_sample_rate", "f
            "fx_stream_create", "fx_stream_destroy", "fx_stream_acquire", "fx_stream_submit", "fx_stream_collect", "fx_stream_in_flight", "fx_pack_osc12",
            "fx_pack_osc10", "fx_osc_encode", "fx_last_error", "fx_abi_version",
            "fx_comm_unique_id", "fx_comm_create", "fx_comm_destroy", "fx_comm_layout", "fx_gather_smoothed", "fx_comm_sync",
-           "fx_plan_units", "fx_tuning_defaults", "fx_tuning_from_env", "fx_get_tuning", "fx_set_tuning", "fx_debug_read_stamps"]
+           "fx_plan_units", "fx_tuning_defaults", "fx_tuning_from_env", "fx_get_tuning", "fx_set_tuning", "fx_debug_read_stamps",
+           "fx_offline_create", "fx_offline_destroy", "fx_offline_reset", "fx_offline_sync", "fx_offline_get_previous_f0", "fx_offline_zero_crosses",
+           "fx_offline_log_attack_time", "fx_offline_fft_lbp", "fx_offline_harmonic_characteristics"]
 COMM_ID_BYTES = 128
 ABI_VERSION = 3
 MAX_UNITS = 24
@@ -124,6 +126,15 @@ def load_library(build_if_missing=True):
     L.fx_get_tuning.argtypes = [vp, ctypes.POINTER(Tuning)]
     L.fx_set_tuning.argtypes = [vp, ctypes.POINTER(Tuning)]
     L.fx_debug_read_stamps.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong)]
+    L.fx_offline_create.argtypes = [ctypes.POINTER(vp), i, i, d]
+    L.fx_offline_destroy.argtypes = [vp]
+    L.fx_offline_reset.argtypes = [vp]
+    L.fx_offline_sync.argtypes = [vp]
+    L.fx_offline_get_previous_f0.argtypes = [vp, ctypes.POINTER(d)]
+    L.fx_offline_zero_crosses.argtypes = [vp, vp, i, i, vp, i]
+    L.fx_offline_log_attack_time.argtypes = [vp, vp, i, i, i, i, vp, i]
+    L.fx_offline_fft_lbp.argtypes = [vp, vp, vp, i, vp, vp, vp, i]
+    L.fx_offline_harmonic_characteristics.argtypes = [vp, vp, i, vp, i]
     L.fx_pack_osc12.argtypes = [fp, fp]
     L.fx_pack_osc12.restype = None
     L.fx_pack_osc10.argtypes = [fp, fp]

@@ -1,0 +1,427 @@
+// fx_offline.hip -- the reference's LEGACY offline analyser (struct AudioAnalyser, ref AudioAnalysis.h) on
+// gfx950: zero crossings, log attack time, FFT-LBP and the histogram F0 / harmonic energy ratio / inharmonicity, behind the
+// fx_offline_* entries of include/fx.h.  "ref:" citations are relative to the reference's Source/.
+//
+// None of this is on the real-time path (the reference never instantiates AudioAnalyser); the kernels are written for exact
+// agreement with the reference's arithmetic -- integer counts, fp32 comparisons as written, fp64 sums in the reference's own
+// order where the order decides a comparison -- one workgroup per channel (per downsample step for the zero crossings).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "fx_context.h"
+
+#pragma clang fp contract(off)
+
+struct fx_offline {
+    int device = 0;
+    int C = 0;
+    double nyquist = 24000.0;
+    hipStream_t stream = nullptr;
+    double* d_prev_f0 = nullptr;        // [C] previousF0 of each channel's analyser (ref AudioAnalysis.h:109,293,697)
+    void*   d_in = nullptr;  size_t in_cap = 0;      // staging for host buffers
+    void*   d_out = nullptr; size_t out_cap = 0;
+};
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAX_BINS = 4097;          // windowSize / 2 + 1 for windows up to 8192 (ref AudioAnalysis.h:113)
+
+// ---- ref AudioAnalysis.h:517-541 analyseNormalisedZeroCrosses: block = (channel, downsample step) ----
+__global__ void __launch_bounds__(NT) zero_crosses_kernel(const float* audio, int num_samples, int num_downsamples, float* out)
+{
+    __shared__ int s_cnt[NT / 64];
+    const int c = blockIdx.x / num_downsamples, i = blockIdx.x % num_downsamples;
+    const int step = num_samples / num_downsamples;                        // :521 (int division)
+    const float* a = audio + (size_t) c * num_samples + (size_t) i * step; // :528
+    int n = 0;
+    for (int s = threadIdx.x; s < step - 1; s += NT) {                     // :529
+        const float first = a[s], second = a[s + 1];
+        const float d = first - second;
+        if ((first > 0.0f && d > first) || (first < 0.0f && d < first)) n++;        // :534-535
+    }
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0;
+        for (int w = 0; w < NT / 64; w++) total += s_cnt[w];
+        out[(size_t) c * num_downsamples + i] = (float) total * 2.0f / (float) step;       // :538 (a float count is exact below 2^24)
+    }
+}
+
+// ---- ref AudioAnalysis.h:611-622 setLogAttackTime: one block ----
+__global__ void __launch_bounds__(NT) log_attack_time_kernel(const float* env, int n, int num_input_samples, int num_downsamples, int sample_rate, float* out)
+{
+    __shared__ float s_max[NT];
+    __shared__ int s_idx[NT];
+    float m = -__builtin_huge_valf();
+    bool any = false;
+    for (int k = threadIdx.x; k < n; k += NT) { const float v = env[k]; if (!any || v > m) { m = v; any = true; } }   // findMinMax(...).getEnd(), :615
+    s_max[threadIdx.x] = any ? m : -__builtin_huge_valf();
+    __syncthreads();
+    if (threadIdx.x == 0) { float mm = s_max[0]; for (int k = 1; k < NT; k++) if (s_max[k] > mm) mm = s_max[k]; s_max[0] = mm; }
+    __syncthreads();
+    const float max_energy = s_max[0];
+    int first = n;                                                         // first index holding the maximum, :616-618
+    for (int k = threadIdx.x; k < n; k += NT) if (env[k] == max_energy) { first = k; break; }
+    s_idx[threadIdx.x] = first;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int i = n;
+        for (int k = 0; k < NT; k++) if (s_idx[k] < i) i = s_idx[k];
+        const double ms_per_sample = 1.0 / (double) (sample_rate / 1000);  // :619 (sampleRate is an int: AudioFeatures.h:303)
+        const int samples_per_step = num_input_samples / num_downsamples;  // :620
+        out[0] = (float) log10((double) (float) (i * samples_per_step) * (float) ms_per_sample);   // :621
+    }
+}
+
+// ---- ref AudioAnalysis.h:543-564 calculateFFTLBP: block = channel ----
+__global__ void __launch_bounds__(NT) fft_lbp_kernel(const float* cur, const float* prev, int num_bins, unsigned char* bits, float* highest_ratio, float* activity_ratio)
+{
+    __shared__ int s_cnt[NT], s_hi[NT];
+    const int c = blockIdx.x;
+    const float threshold = 0.1f;                                          // :546
+    int cnt = 0, hi = 0;
+    for (int i = threadIdx.x; i < num_bins; i += NT) {
+        const float diff = fabsf(cur[(size_t) c * num_bins + i] - prev[(size_t) c * num_bins + i]);    // :554
+        const int b = diff > threshold;
+        bits[(size_t) c * num_bins + i] = (unsigned char) b;               // :555
+        cnt += b;
+        if (b && i > hi) hi = i;                                           // :558-559: the last bin over the threshold
+    }
+    s_cnt[threadIdx.x] = cnt; s_hi[threadIdx.x] = hi;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int total = 0, highest = 0;
+        for (int k = 0; k < NT; k++) { total += s_cnt[k]; if (s_hi[k] > highest) highest = s_hi[k]; }
+        highest_ratio[c] = (float) highest / (float) num_bins;             // :563 (float counts are exact here)
+        activity_ratio[c] = (float) total / (float) num_bins;
+    }
+}
+
+// ---- ref AudioAnalysis.h:253-303 calculateHarmonicCharacteristics: block = channel ----
+__device__ __forceinline__ bool bin_is_peak(int bin, const float* mag, int num_bins, double mean)        // :375-393
+{
+    const double m = (double) mag[bin];
+    if (m <= mean) return false;
+    const int left = bin < 2 ? 2 - bin : 0;
+    const int right = bin >= num_bins - 2 ? 2 - ((num_bins - 1) - bin) : 0;
+    for (int nb = bin - (2 - left); nb < bin + (2 - right); nb++)
+        if (nb != bin && (double) mag[nb] > m) return false;
+    return true;
+}
+__device__ __forceinline__ double harmonic_energy_ratio(const float* mag, int num_bins, double frequency, double frpb, double total)   // :80-98, 15 harmonics
+{
+    double score = 0.0;
+    for (double h = 1.0; h < 15.0 + 1.0; h++) {
+        const double hf = frequency * h;
+        const int bin = (int) ceil(hf / frpb);
+        if (bin >= num_bins) break;
+        score += (double) mag[bin];
+    }
+    return score / total;
+}
+
+__global__ void __launch_bounds__(NT) harmonic_characteristics_kernel(const float* mags, int num_bins, double nyquist, double* prev_f0, float* out3)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* mag = reinterpret_cast<float*>(smem);                           // [num_bins]
+    int* peaks = reinterpret_cast<int*>(mag + num_bins + (num_bins & 1));  // [num_bins] ascending peak bins
+    int* cnt = peaks + num_bins + (num_bins & 1);                          // [num_bins] histogram: pairs of peaks that many bins apart
+    int* key = cnt + num_bins + (num_bins & 1);                            // [num_bins] where the interval first entered the histogram
+    double* term = reinterpret_cast<double*>(cnt);                         // [<= num_bins] inharmonicity terms (cnt / key are free by then)
+    __shared__ double s_sum, s_f0, s_her;
+    __shared__ int s_chunk[NT], s_np;
+    __shared__ double s_w[NT], s_fr[NT], s_hr[NT];
+    __shared__ int s_k[NT];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < num_bins; i += NT) { mag[i] = mags[(size_t) c * num_bins + i]; cnt[i] = 0; key[i] = 0x7fffffff; }
+    __syncthreads();
+    if (tid == 0) {                                                        // :264-268: the reference's serial sum (its last bit decides `mag > mean`)
+        double s = 0.0;
+        for (int i = 0; i < num_bins; i++) s += (double) mag[i];
+        s_sum = s;
+    }
+    __syncthreads();
+    const double sum = s_sum;
+    const double mean = sum / (double) num_bins;
+    if (sum < 0.001) {                                                     // :270-271 (previousF0 untouched)
+        if (tid < 3) out3[(size_t) c * 3 + tid] = 0.0f;
+        return;
+    }
+    // peaks, in ascending order (:350-364): every thread a contiguous run of bins
+    const int run = (num_bins + NT - 1) / NT, b0 = tid * run, b1 = min(num_bins, b0 + run);
+    int mine = 0;
+    for (int b = b0; b < b1; b++) mine += bin_is_peak(b, mag, num_bins, mean) ? 1 : 0;
+    s_chunk[tid] = mine;
+    __syncthreads();
+    if (tid == 0) { int acc = 0; for (int k = 0; k < NT; k++) { const int v = s_chunk[k]; s_chunk[k] = acc; acc += v; } s_np = acc; }
+    __syncthreads();
+    {
+        int at = s_chunk[tid];
+        for (int b = b0; b < b1; b++) if (bin_is_peak(b, mag, num_bins, mean)) peaks[at++] = b;
+    }
+    __syncthreads();
+    const int np = s_np;
+    // the frequency histogram (:395-408): one entry per distinct distance between two peaks, counting the pairs; the reference
+    // appends an interval when it first meets it -- scanning new peaks j upwards and, for each, earlier peaks p upwards -- and
+    // that order breaks ties below
+    for (int j = tid; j < np; j += NT)
+        for (int p = 0; p < j; p++) {
+            const int d = peaks[j] - peaks[p];
+            atomicAdd(&cnt[d], 1);
+            atomicMin(&key[d], j * 8192 + p);
+        }
+    __syncthreads();
+    // estimateF0AndHERFromFrequencyHistogram (:419-441): the candidate with the largest count x harmonic energy ratio, the
+    // first such in histogram order (`>` against a running maximum that starts at 0)
+    const double frpb = nyquist / (double) num_bins;                       // :428
+    double best_w = 0.0, best_f = 0.0, best_h = 0.0;
+    int best_k = 0x7fffffff;
+    for (int d = 1 + tid; d < num_bins; d += NT) {
+        if (cnt[d] == 0) continue;
+        const double freq = (double) d * frpb;                             // :59-62
+        const double her = harmonic_energy_ratio(mag, num_bins, freq, frpb, sum);
+        const double w = (double) cnt[d] * her;                            // :64-67
+        if (w > best_w || (w == best_w && w > 0.0 && key[d] < best_k)) { best_w = w; best_f = freq; best_h = her; best_k = key[d]; }
+    }
+    s_w[tid] = best_w; s_fr[tid] = best_f; s_hr[tid] = best_h; s_k[tid] = best_k;
+    __syncthreads();
+    if (tid == 0) {
+        double w = 0.0, f0 = 0.0, her = 0.0;
+        int k = 0x7fffffff;
+        for (int q = 0; q < NT; q++)
+            if (s_w[q] > w || (s_w[q] == w && w > 0.0 && s_k[q] < k)) { w = s_w[q]; f0 = s_fr[q]; her = s_hr[q]; k = s_k[q]; }
+        const double previous = prev_f0[c];
+        if (previous != f0 && previous > 10.0) {                           // :273-291
+            const double top = previous > f0 ? previous : f0;
+            const double bottom = top == previous ? f0 : previous;
+            const double ratio = top / bottom;
+            if (ratio > 2.0) {
+                const double eps = 0.1;
+                if (ratio - floor(ratio) < eps) {
+                    f0 = previous;
+                    her = harmonic_energy_ratio(mag, num_bins, f0, nyquist / (double) num_bins, sum);
+                }
+            }
+        }
+        prev_f0[c] = f0;                                                   // :293
+        s_f0 = f0; s_her = her;
+    }
+    __syncthreads();                                                       // (cnt / key are no longer read: `term` may overwrite them)
+    const double f0 = s_f0;
+    // calculateInharmonicity (:305-336): one term per peak, added in peak order
+    if (f0 > 0.0) {
+        const int f0_bin = (int) ceil(f0 / (nyquist / (double) num_bins)); // :443-448
+        for (int k = tid; k < np; k += NT) {
+            const int bin = peaks[k];
+            double t = 0.0;                                                // (a skipped peak adds nothing: x + 0.0 == x)
+            if (f0_bin != bin) {
+                double fs = bin * frpb;
+                if (fs == 0.0) fs = frpb * 0.5;
+                const double fe = (double) (bin + 1) * frpb;
+                const double rs = fs == f0 ? 1.0 : (fs > f0 ? fs : f0) / (fs > f0 ? f0 : fs);       // :338-346
+                const double re = fe == f0 ? 1.0 : (fe > f0 ? fe : f0) / (fe > f0 ? f0 : fe);
+                if (floor(rs) == floor(re)) {
+                    const double r = rs < re ? rs : re;
+                    t = (r - floor(r)) * ((double) mag[bin] / sum);
+                }
+            }
+            term[k] = t;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double inh = 0.0;
+        if (f0 > 0.0) for (int k = 0; k < np; k++) inh += term[k];
+        out3[(size_t) c * 3 + 0] = (float) f0; out3[(size_t) c * 3 + 1] = (float) s_her; out3[(size_t) c * 3 + 2] = (float) inh;   // :302
+    }
+}
+
+size_t harmonic_lds_bytes(int num_bins) { return 4 * (size_t) (num_bins + (num_bins & 1)) * sizeof(float); }
+
+fx_status grow_bytes(void** ptr, size_t* cap, size_t need)
+{
+    if (need <= *cap) return FX_OK;
+    if (*ptr) HIP_TRY(hipFree(*ptr));
+    *ptr = nullptr; *cap = 0;
+    HIP_TRY(hipMalloc(ptr, need));
+    *cap = need;
+    return FX_OK;
+}
+
+// input(s) on the device: the caller's pointers, or a staged copy of host buffers (two inputs back to back)
+fx_status stage_in(fx_offline* o, int mem_kind, const void* a, size_t a_bytes, const void* b, size_t b_bytes, const void** da, const void** db)
+{
+    if (mem_kind == FX_MEM_DEVICE) { *da = a; *db = b; return FX_OK; }
+    fx_status st = grow_bytes(&o->d_in, &o->in_cap, a_bytes + b_bytes);
+    if (st != FX_OK) return st;
+    HIP_TRY(hipMemcpyAsync(o->d_in, a, a_bytes, hipMemcpyHostToDevice, o->stream));
+    *da = o->d_in;
+    *db = nullptr;
+    if (b) {
+        HIP_TRY(hipMemcpyAsync(static_cast<char*>(o->d_in) + a_bytes, b, b_bytes, hipMemcpyHostToDevice, o->stream));
+        *db = static_cast<char*>(o->d_in) + a_bytes;
+    }
+    return FX_OK;
+}
+
+fx_status check_args(fx_offline* o, const void* in, const void* out, int mem_kind)
+{
+    if (!o || !in || !out) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    if (mem_kind != FX_MEM_HOST && mem_kind != FX_MEM_DEVICE) return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown memory kind %d", mem_kind);
+    HIP_TRY(hipSetDevice(o->device));
+    return FX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+fx_status fx_offline_create(fx_offline** out, int device_id, int num_channels, double nyquist)
+{
+    if (!out) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null output pointer");
+    *out = nullptr;
+    if (num_channels <= 0 || !(nyquist > 0.0)) return fx_fail(FX_ERR_INVALID_ARGUMENT, "num_channels and nyquist must be positive");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void) hipGetLastError();
+        return fx_fail(FX_ERR_NO_DEVICE, "no HIP device available (this library has no CPU path)");
+    }
+    if (device_id < 0 || device_id >= count) return fx_fail(FX_ERR_INVALID_ARGUMENT, "device_id %d out of range [0,%d)", device_id, count);
+    HIP_TRY(hipSetDevice(device_id));
+    fx_offline* o = new (std::nothrow) fx_offline();
+    if (!o) return fx_fail(FX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    o->device = device_id; o->C = num_channels; o->nyquist = nyquist;
+    hipError_t e = hipStreamCreateWithFlags(&o->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**) &o->d_prev_f0, sizeof(double) * (size_t) num_channels);
+    if (e == hipSuccess) e = hipMemsetAsync(o->d_prev_f0, 0, sizeof(double) * (size_t) num_channels, o->stream);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&harmonic_characteristics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int) harmonic_lds_bytes(MAX_BINS));      // (beside ~9 KB of static LDS)
+    if (e == hipSuccess) e = hipStreamSynchronize(o->stream);
+    if (e != hipSuccess) { fx_offline_destroy(o); return fx_fail(FX_ERR_HIP, "setting up the offline analyser failed: %s", hipGetErrorString(e)); }
+    *out = o;
+    return FX_OK;
+}
+
+fx_status fx_offline_destroy(fx_offline* o)
+{
+    if (!o) return FX_OK;
+    (void) hipSetDevice(o->device);
+    if (o->stream) (void) hipStreamSynchronize(o->stream);
+    if (o->d_prev_f0) (void) hipFree(o->d_prev_f0);
+    if (o->d_in) (void) hipFree(o->d_in);
+    if (o->d_out) (void) hipFree(o->d_out);
+    if (o->stream) (void) hipStreamDestroy(o->stream);
+    delete o;
+    return FX_OK;
+}
+
+fx_status fx_offline_reset(fx_offline* o)
+{
+    if (!o) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(o->device));
+    HIP_TRY(hipMemsetAsync(o->d_prev_f0, 0, sizeof(double) * (size_t) o->C, o->stream));
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    return FX_OK;
+}
+
+fx_status fx_offline_get_previous_f0(fx_offline* o, double* out)
+{
+    if (!o || !out) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(o->device));
+    HIP_TRY(hipMemcpyAsync(out, o->d_prev_f0, sizeof(double) * (size_t) o->C, hipMemcpyDeviceToHost, o->stream));
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    return FX_OK;
+}
+
+fx_status fx_offline_zero_crosses(fx_offline* o, const float* audio, int num_samples, int num_downsamples, float* out, int mem_kind)
+{
+    fx_status st = check_args(o, audio, out, mem_kind);
+    if (st != FX_OK) return st;
+    if (num_downsamples < 1 || num_samples < num_downsamples) return fx_fail(FX_ERR_INVALID_ARGUMENT, "need 1 <= num_downsamples <= num_samples (stepSize > 0, ref AudioAnalysis.h:521)");
+    const size_t in_bytes = sizeof(float) * (size_t) o->C * num_samples, out_bytes = sizeof(float) * (size_t) o->C * num_downsamples;
+    const void *da, *db;
+    if ((st = stage_in(o, mem_kind, audio, in_bytes, nullptr, 0, &da, &db)) != FX_OK) return st;
+    float* d_out = out;
+    if (mem_kind == FX_MEM_HOST) { if ((st = grow_bytes(&o->d_out, &o->out_cap, out_bytes)) != FX_OK) return st; d_out = static_cast<float*>(o->d_out); }
+    hipLaunchKernelGGL(zero_crosses_kernel, dim3((unsigned) (o->C * num_downsamples)), dim3(NT), 0, o->stream, static_cast<const float*>(da), num_samples, num_downsamples, d_out);
+    HIP_TRY(hipGetLastError());
+    if (mem_kind == FX_MEM_HOST) { HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, o->stream)); HIP_TRY(hipStreamSynchronize(o->stream)); }
+    return FX_OK;
+}
+
+fx_status fx_offline_log_attack_time(fx_offline* o, const float* envelope, int n, int num_input_samples, int num_downsamples, int sample_rate,
+                                     float* out, int mem_kind)
+{
+    fx_status st = check_args(o, envelope, out, mem_kind);
+    if (st != FX_OK) return st;
+    if (n < 1 || num_downsamples < 1 || sample_rate < 1000) return fx_fail(FX_ERR_INVALID_ARGUMENT, "need n >= 1, num_downsamples >= 1, sample_rate >= 1000 (sampleRate / 1000 is an int division, ref AudioAnalysis.h:619)");
+    const void *da, *db;
+    if ((st = stage_in(o, mem_kind, envelope, sizeof(float) * (size_t) n, nullptr, 0, &da, &db)) != FX_OK) return st;
+    float* d_out = out;
+    if (mem_kind == FX_MEM_HOST) { if ((st = grow_bytes(&o->d_out, &o->out_cap, sizeof(float))) != FX_OK) return st; d_out = static_cast<float*>(o->d_out); }
+    hipLaunchKernelGGL(log_attack_time_kernel, dim3(1), dim3(NT), 0, o->stream, static_cast<const float*>(da), n, num_input_samples, num_downsamples, sample_rate, d_out);
+    HIP_TRY(hipGetLastError());
+    if (mem_kind == FX_MEM_HOST) { HIP_TRY(hipMemcpyAsync(out, d_out, sizeof(float), hipMemcpyDeviceToHost, o->stream)); HIP_TRY(hipStreamSynchronize(o->stream)); }
+    return FX_OK;
+}
+
+fx_status fx_offline_fft_lbp(fx_offline* o, const float* cur, const float* prev, int num_bins, unsigned char* bits, float* highest_ratio,
+                             float* activity_ratio, int mem_kind)
+{
+    fx_status st = check_args(o, cur, bits, mem_kind);
+    if (st != FX_OK) return st;
+    if (!prev || !highest_ratio || !activity_ratio || num_bins < 1) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument or num_bins < 1");
+    const size_t in_bytes = sizeof(float) * (size_t) o->C * num_bins;
+    const void *da, *db;
+    if ((st = stage_in(o, mem_kind, cur, in_bytes, prev, in_bytes, &da, &db)) != FX_OK) return st;
+    unsigned char* d_bits = bits; float* d_hi = highest_ratio; float* d_act = activity_ratio;
+    const size_t bits_bytes = (size_t) o->C * num_bins, bits_pad = (bits_bytes + 15) & ~(size_t) 15;
+    if (mem_kind == FX_MEM_HOST) {
+        if ((st = grow_bytes(&o->d_out, &o->out_cap, bits_pad + 2 * sizeof(float) * (size_t) o->C)) != FX_OK) return st;
+        d_bits = static_cast<unsigned char*>(o->d_out);
+        d_hi = reinterpret_cast<float*>(d_bits + bits_pad);
+        d_act = d_hi + o->C;
+    }
+    hipLaunchKernelGGL(fft_lbp_kernel, dim3((unsigned) o->C), dim3(NT), 0, o->stream, static_cast<const float*>(da), static_cast<const float*>(db), num_bins, d_bits, d_hi, d_act);
+    HIP_TRY(hipGetLastError());
+    if (mem_kind == FX_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(bits, d_bits, bits_bytes, hipMemcpyDeviceToHost, o->stream));
+        HIP_TRY(hipMemcpyAsync(highest_ratio, d_hi, sizeof(float) * (size_t) o->C, hipMemcpyDeviceToHost, o->stream));
+        HIP_TRY(hipMemcpyAsync(activity_ratio, d_act, sizeof(float) * (size_t) o->C, hipMemcpyDeviceToHost, o->stream));
+        HIP_TRY(hipStreamSynchronize(o->stream));
+    }
+    return FX_OK;
+}
+
+fx_status fx_offline_harmonic_characteristics(fx_offline* o, const float* magnitudes, int num_bins, float* out3, int mem_kind)
+{
+    fx_status st = check_args(o, magnitudes, out3, mem_kind);
+    if (st != FX_OK) return st;
+    if (num_bins < 4 || num_bins > MAX_BINS) return fx_fail(FX_ERR_INVALID_ARGUMENT, "num_bins must be in [4, %d]", MAX_BINS);
+    const size_t in_bytes = sizeof(float) * (size_t) o->C * num_bins, out_bytes = sizeof(float) * 3 * (size_t) o->C;
+    const void *da, *db;
+    if ((st = stage_in(o, mem_kind, magnitudes, in_bytes, nullptr, 0, &da, &db)) != FX_OK) return st;
+    float* d_out = out3;
+    if (mem_kind == FX_MEM_HOST) { if ((st = grow_bytes(&o->d_out, &o->out_cap, out_bytes)) != FX_OK) return st; d_out = static_cast<float*>(o->d_out); }
+    hipLaunchKernelGGL(harmonic_characteristics_kernel, dim3((unsigned) o->C), dim3(NT), harmonic_lds_bytes(num_bins), o->stream,
+                       static_cast<const float*>(da), num_bins, o->nyquist, o->d_prev_f0, d_out);
+    HIP_TRY(hipGetLastError());
+    if (mem_kind == FX_MEM_HOST) { HIP_TRY(hipMemcpyAsync(out3, d_out, out_bytes, hipMemcpyDeviceToHost, o->stream)); HIP_TRY(hipStreamSynchronize(o->stream)); }
+    return FX_OK;
+}
+
+fx_status fx_offline_sync(fx_offline* o)
+{
+    if (!o) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(hipSetDevice(o->device));
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    return FX_OK;
+}
+
+} // extern "C"

@@ -242,6 +242,34 @@ fx_status fx_gather_smoothed(fx_context* ctx, int dst_rank, float* out, int mem_
 /* Wait for every gather issued so far on this context. */
 fx_status fx_comm_sync(fx_context* ctx);
 
+/* ---- the reference's LEGACY offline analyser: struct AudioAnalyser (AudioAnalysis.h), SURVEY.md 8(f) rank 4 ----
+ * Never instantiated by the reference application (AudioAnalysis.h:221-246 is commented out); provided for hosts that
+ * want its features.  An fx_offline stands for `num_channels` AudioAnalyser objects (one per channel: the histogram-F0
+ * estimate keeps `previousF0`, AudioAnalysis.h:109,273-293,697) on one GPU.  Buffers are [num_channels][...] row-major,
+ * FX_MEM_HOST (copied synchronously) or FX_MEM_DEVICE (asynchronous on the object's stream; fx_offline_sync waits). */
+typedef struct fx_offline fx_offline;
+/* AudioAnalyser (windowSize, numChannels, nyquistFrequency, ...), AudioAnalysis.h:107-125 */
+fx_status fx_offline_create(fx_offline** out, int device_id, int num_channels, double nyquist);
+fx_status fx_offline_destroy(fx_offline* o);
+fx_status fx_offline_reset(fx_offline* o);                         /* previousF0 := 0, as constructed (AudioAnalysis.h:109) */
+fx_status fx_offline_sync(fx_offline* o);
+fx_status fx_offline_get_previous_f0(fx_offline* o, double* out /*[num_channels]*/);
+/* AudioAnalyser::analyseNormalisedZeroCrosses, AudioAnalysis.h:517-541: audio [C][num_samples] ->
+ * out [C][num_downsamples] (the ZeroCrosses feature row, AudioAnalysis.h:538) */
+fx_status fx_offline_zero_crosses(fx_offline* o, const float* audio, int num_samples, int num_downsamples, float* out, int mem_kind);
+/* AudioAnalyser::setLogAttackTime, AudioAnalysis.h:611-622: envelope [n] (channel 0 of the energy envelope), the length of the
+ * analysed audio, its number of downsamples and the (integer, AudioFeatures.h:303) sample rate -> estimatedLogAttackTime */
+fx_status fx_offline_log_attack_time(fx_offline* o, const float* envelope, int n, int num_input_samples, int num_downsamples,
+                                     int sample_rate, float* out, int mem_kind);
+/* AudioAnalyser::calculateFFTLBP, AudioAnalysis.h:543-564 (which only prints): cur, prev [C][num_bins] magnitude frames ->
+ * bits [C][num_bins] (|cur - prev| > 0.1f), highest_ratio [C] (last bin over the threshold / num_bins), activity_ratio [C] */
+fx_status fx_offline_fft_lbp(fx_offline* o, const float* cur, const float* prev, int num_bins, unsigned char* bits,
+                             float* highest_ratio, float* activity_ratio, int mem_kind);
+/* AudioAnalyser::calculateHarmonicCharacteristics, AudioAnalysis.h:253-303 (peaks :350-393, frequency histogram :395-417,
+ * estimateF0AndHERFromFrequencyHistogram :419-441, the octave rule :273-291, calculateInharmonicity :305-336):
+ * magnitudes [C][num_bins] of one frame -> out3 [C][3] = f0, harmonicEnergyRatio, inharmonicity; 4 <= num_bins <= 4097 */
+fx_status fx_offline_harmonic_characteristics(fx_offline* o, const float* magnitudes, int num_bins, float* out3, int mem_kind);
+
 /* ---- OSC sink helpers (host side, no GPU) ---- */
 /* Re-order one 12-slot vector into the wire order of
  * sender.send(bundleAddress, onset, rms, f0, centroid, slope, spread, flatness,

@@ -25,7 +25,7 @@ def build(force=False):
     """Compile the oracle with gcc (recipe: oracle/Makefile)."""
     src = os.path.join(_HERE, "fx_oracle.c")
     if (force or not os.path.exists(_LIB_PATH)
-            or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src),
+            or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "fx_offline.c")),
                                                  os.path.getmtime(os.path.join(_HERE, "fx_oracle.h")))):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libfx_oracle.so"])
     return _LIB_PATH
@@ -70,6 +70,11 @@ def lib():
         L.fxo_estimate_pitch.argtypes = [ctypes.c_int, ctypes.c_double, fp, fp, fp]
         L.fxo_lpf_a.restype = ctypes.c_float
         L.fxo_lpf_b.restype = ctypes.c_float
+        L.fxo_offline_zero_crosses.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp]
+        L.fxo_offline_log_attack_time.restype = ctypes.c_float
+        L.fxo_offline_log_attack_time.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.fxo_offline_fft_lbp.argtypes = [fp, fp, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte), fp, fp]
+        L.fxo_offline_harmonic_characteristics.argtypes = [fp, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double), fp]
         L.fxo_osc_message.restype = ctypes.c_int
         L.fxo_osc_message.argtypes = [ctypes.c_char_p, fp, ctypes.POINTER(ctypes.c_ubyte), ctypes.c_int]
         _lib = L
@@ -254,3 +259,43 @@ def osc_message(address, smoothed12):
     if n < 0:
         raise ValueError("address too long")
     return bytes(buf[:n])
+
+
+# ---- the legacy offline analyser (ref AudioAnalysis.h; oracle/fx_offline.c) ----
+def offline_zero_crosses(audio, num_downsamples):
+    """audio [C][num_samples] -> [C][num_downsamples] (ref AudioAnalysis.h:517-541)."""
+    audio = _f32(audio)
+    out = np.empty((audio.shape[0], num_downsamples), np.float32)
+    for c in range(audio.shape[0]):
+        lib().fxo_offline_zero_crosses(_fp(audio[c]), audio.shape[1], int(num_downsamples), _fp(out[c]))
+    return out
+
+
+def offline_log_attack_time(envelope, num_input_samples, num_downsamples, sample_rate):
+    """ref AudioAnalysis.h:611-622; envelope = channel 0 of the energy envelope."""
+    envelope = _f32(envelope)
+    return np.float32(lib().fxo_offline_log_attack_time(_fp(envelope), envelope.shape[0], int(num_input_samples), int(num_downsamples), int(sample_rate)))
+
+
+def offline_fft_lbp(cur, prev):
+    """cur, prev [C][num_bins] -> (bits [C][num_bins] uint8, highest_ratio [C], activity_ratio [C]) (ref AudioAnalysis.h:543-564)."""
+    cur, prev = _f32(cur), _f32(prev)
+    C, B = cur.shape
+    bits = np.empty((C, B), np.uint8)
+    hi, act = np.empty(C, np.float32), np.empty(C, np.float32)
+    for c in range(C):
+        lib().fxo_offline_fft_lbp(_fp(cur[c]), _fp(prev[c]), B, bits[c].ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), _fp(hi[c:c + 1]), _fp(act[c:c + 1]))
+    return bits, hi, act
+
+
+def offline_harmonic_characteristics(mags, nyquist, previous_f0):
+    """mags [C][num_bins], previous_f0 [C] float64 (updated in place) -> [C][3] = f0, harmonic energy ratio, inharmonicity
+    (ref AudioAnalysis.h:253-303)."""
+    mags = _f32(mags)
+    C, B = mags.shape
+    out = np.empty((C, 3), np.float32)
+    for c in range(C):
+        pf = ctypes.c_double(float(previous_f0[c]))
+        lib().fxo_offline_harmonic_characteristics(_fp(mags[c]), B, float(nyquist), ctypes.byref(pf), _fp(out[c]))
+        previous_f0[c] = pf.value
+    return out

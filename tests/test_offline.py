@@ -1,0 +1,108 @@
+"""The reference's legacy offline analyser (struct AudioAnalyser, ref AudioAnalysis.h): the oracle
+(oracle/fx_offline.c) against vectors produced by the reference's own header (tests/golden/offline/cases.npz, made by
+tests/golden/make_offline_cases.py from the unmodified AudioAnalysis.h) and -- with a GPU -- the HIP kernels behind
+fx_offline_* against both, bit for bit: counts and bit patterns are integers, the float outputs are single roundings of
+fp64 expressions evaluated in the reference's own order."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from make_offline_cases import offline_inputs  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "offline", "cases.npz")
+
+
+def same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def test_oracle_equals_the_reference_headers_vectors(oracle):
+    g, cases = np.load(GOLDEN), offline_inputs()
+    assert "AudioAnalysis.h" in str(g["source"])
+    for k, (audio, nd) in enumerate(cases["zc"]):
+        assert same(oracle.offline_zero_crosses(audio, nd), g["zc_%d" % k]), k
+    for k, (env, ns, nd, sr) in enumerate(cases["lat"]):
+        assert same(oracle.offline_log_attack_time(env, ns, nd, sr), g["lat_%d" % k]), k
+    assert np.isneginf(g["lat_1"])                                  # the maximum in the first step: log10 (0), as the reference returns it
+    for k, (cur, prev) in enumerate(cases["lbp"]):
+        bits, hi, act = oracle.offline_fft_lbp(cur, prev)
+        assert same(bits, g["lbp_%d_bits" % k]) and same(hi, g["lbp_%d_hi" % k]) and same(act, g["lbp_%d_act" % k]), k
+    for k, (mags, nyq) in enumerate(cases["hc"]):
+        pf = np.zeros(mags.shape[1])
+        for t in range(mags.shape[0]):
+            out = oracle.offline_harmonic_characteristics(mags[t], nyq, pf)
+            assert same(out, g["hc_%d_out" % k][t]) and same(pf, g["hc_%d_prev" % k][t]), (k, t)
+    # the cases exercise what they are meant to: the octave rule keeps the previous F0 (frame 2, channel 0), silence returns zeros
+    o = g["hc_0_out"]
+    assert o[2, 0, 0] == o[1, 0, 0] and o[3, 0, 0] == o[1, 0, 0] and not o[:, 3].any() and (o[:, :3, 0] > 0).all()
+
+
+@pytest.mark.gpu
+def test_offline_kernels_equal_the_reference_headers_vectors(gpu_fx, oracle):
+    g, cases = np.load(GOLDEN), offline_inputs()
+    for k, (audio, nd) in enumerate(cases["zc"]):
+        an = gpu_fx.offline.AudioAnalyser(audio.shape[0])
+        assert same(an.analyse_normalised_zero_crosses(audio, nd), g["zc_%d" % k]), k
+    an = gpu_fx.offline.AudioAnalyser(1)
+    for k, (env, ns, nd, sr) in enumerate(cases["lat"]):
+        assert same(an.set_log_attack_time(env, ns, nd, sr), g["lat_%d" % k]), k
+    for k, (cur, prev) in enumerate(cases["lbp"]):
+        bits, hi, act = gpu_fx.offline.AudioAnalyser(cur.shape[0]).calculate_fft_lbp(cur, prev)
+        assert same(bits, g["lbp_%d_bits" % k]) and same(hi, g["lbp_%d_hi" % k]) and same(act, g["lbp_%d_act" % k]), k
+    for k, (mags, nyq) in enumerate(cases["hc"]):
+        an = gpu_fx.offline.AudioAnalyser(mags.shape[1], nyq)
+        for t in range(mags.shape[0]):
+            out = an.calculate_harmonic_characteristics(mags[t])
+            assert same(out, g["hc_%d_out" % k][t]), (k, t, out, g["hc_%d_out" % k][t])
+            assert same(an.previous_f0, g["hc_%d_prev" % k][t]), (k, t)
+        an.reset()
+        assert not an.previous_f0.any()
+
+
+@pytest.mark.gpu
+def test_offline_kernels_equal_the_oracle_on_random_inputs(gpu_fx, oracle):
+    """Sizes and contents beyond the fixture: many channels, windows up to 8192 points (4097 magnitudes), spectra with thousands
+    of peaks (a histogram of ~10^6 pairs), ties in the weighted counts, device-resident buffers."""
+    import torch
+    rng = np.random.default_rng(7)
+    for C, S, nd in ((3, 48000, 100), (40, 4097, 4096), (2, 100000, 3)):
+        audio = rng.normal(0, 1, (C, S)).astype(np.float32)
+        audio[:, ::7] = 0.0
+        assert same(gpu_fx.offline.AudioAnalyser(C).analyse_normalised_zero_crosses(audio, nd), oracle.offline_zero_crosses(audio, nd)), (C, S, nd)
+    for n in (1, 5, 1000):
+        env = np.abs(rng.normal(0, 1, n)).astype(np.float32)
+        assert same(gpu_fx.offline.AudioAnalyser(1).set_log_attack_time(env, 44100 * 3, max(1, n), 44100), oracle.offline_log_attack_time(env, 44100 * 3, max(1, n), 44100))
+    for C, B in ((7, 4097), (1, 5), (33, 1025)):
+        cur = np.abs(rng.normal(0, 0.3, (C, B))).astype(np.float32)
+        prev = np.abs(rng.normal(0, 0.3, (C, B))).astype(np.float32)
+        got, want = gpu_fx.offline.AudioAnalyser(C).calculate_fft_lbp(cur, prev), oracle.offline_fft_lbp(cur, prev)
+        assert all(same(a, b) for a, b in zip(got, want)), (C, B)
+    for C, B, nyq in ((12, 4097, 24000.0), (5, 2049, 22050.0), (3, 513, 8000.0), (2, 4, 100.0)):
+        an = gpu_fx.offline.AudioAnalyser(C, nyq)
+        pf = np.zeros(C)
+        for t in range(5):
+            mags = np.abs(rng.normal(0, 1.0, (C, B))).astype(np.float32)
+            if B > 100:
+                mags[:, (17 + 3 * t)::(17 + 3 * t)] += 12.0                # a harmonic comb whose spacing moves from frame to frame
+                mags[0, :] = np.round(mags[0, :] * 4) / 4                  # quantised magnitudes: ties between candidates
+            if t == 3:
+                mags[1] = 1e-8                                             # below the 0.001 gate: zeros, previousF0 untouched
+            got = an.calculate_harmonic_characteristics(mags)
+            want = oracle.offline_harmonic_characteristics(mags, nyq, pf)
+            assert same(got, want), (C, B, t, got, want)
+            assert same(an.previous_f0, pf), (C, B, t)
+    # device-resident buffers through the C ABI
+    C, B = 4, 1025
+    mags = np.abs(rng.normal(0, 1.0, (C, B))).astype(np.float32)
+    mags[:, 40::40] += 9.0
+    an = gpu_fx.offline.AudioAnalyser(C, 24000.0)
+    d_in, d_out = torch.from_numpy(mags).cuda(), torch.zeros((C, 3), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    import ctypes
+    gpu_fx.capi.check(an._lib.fx_offline_harmonic_characteristics(an._h, ctypes.c_void_p(d_in.data_ptr()), B, ctypes.c_void_p(d_out.data_ptr()), gpu_fx.capi.MEM_DEVICE))
+    gpu_fx.capi.check(an._lib.fx_offline_sync(an._h))
+    assert same(d_out.cpu().numpy(), oracle.offline_harmonic_characteristics(mags, 24000.0, np.zeros(C)))

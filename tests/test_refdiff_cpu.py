@@ -82,3 +82,35 @@ def test_committed_fixtures_come_from_the_reference_headers():
         assert str(g["source"]).startswith("reference headers"), p
         raw, sm = refdiff.run(g["hops"], int(g["window_size"]), order=int(g["order"]), sample_rate=float(g["sample_rate"]), mode="cr")
         assert _same_bits(raw, g["raw"]).all() and _same_bits(sm, g["smoothed"]).all(), p
+
+
+def test_legacy_offline_analyser_oracle_equals_the_reference_header():
+    """oracle/fx_offline.c against the reference's LEGACY AudioAnalysis.h, compiled unmodified (tools/refdiff/refdiff_legacy.cpp):
+    bit for bit on the seeded cases the committed fixture holds -- and the fixture itself is what that header produces now."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_offline_cases import offline_inputs
+    from oracle import fx_oracle as fo
+    if not refdiff.legacy_available():
+        pytest.skip("reference sources not present")
+    g, cases = np.load(os.path.join(ROOT, "tests", "golden", "offline", "cases.npz")), offline_inputs()
+    audio, nd = cases["zc"][0]
+    ref = refdiff.legacy_zero_crosses(audio, nd)
+    assert ref.tobytes() == g["zc_0"].tobytes() == fo.offline_zero_crosses(audio, nd).tobytes()
+    env, ns, ndn, sr = cases["lat"][2]
+    assert np.float32(refdiff.legacy_log_attack_time(env, ns, ndn, sr)).tobytes() == g["lat_2"].tobytes() == fo.offline_log_attack_time(env, ns, ndn, sr).tobytes()
+    cur, prev = cases["lbp"][0]
+    rb, rh, ra = refdiff.legacy_fft_lbp(cur, prev)
+    ob, oh, oa = fo.offline_fft_lbp(cur, prev)
+    assert np.array_equal(rb, ob) and rh.tobytes() == oh.tobytes() and ra.tobytes() == oa.tobytes()
+    mags, nyq = cases["hc"][0]
+    ro, rp = refdiff.legacy_harmonic_characteristics(mags, nyq)
+    assert ro.tobytes() == g["hc_0_out"].tobytes() and rp.tobytes() == g["hc_0_prev"].tobytes()
+    # fresh random spectra beyond the fixture
+    rng = np.random.default_rng(99)
+    m2 = np.abs(rng.normal(0, 1.0, (4, 3, 513))).astype(np.float32)
+    m2[:, :, 23::23] += 10.0
+    ro, rp = refdiff.legacy_harmonic_characteristics(m2, 11025.0)
+    pf = np.zeros(3)
+    for t in range(4):
+        assert fo.offline_harmonic_characteristics(m2[t], 11025.0, pf).tobytes() == ro[t].tobytes() and pf.tobytes() == rp[t].tobytes()

@@ -11,6 +11,7 @@
 #ifndef JUCE_STANDIN_H
 #define JUCE_STANDIN_H
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -45,6 +46,35 @@ const double double_Pi = 3.14159265358979323846;
 #define DBG(x)          ((void) 0)
 #define JUCE_DECLARE_NON_COPYABLE_WITH_LEAK_DETECTOR(T) T (const T&) = delete; T& operator= (const T&) = delete;
 template <typename... A> void ignoreUnused (A&&...) {}
+#define JUCE_LIVE_CONSTANT(x) (x)
+template <typename T> T jmax (T a, T b) { return a < b ? b : a; }
+
+// ---- what only the LEGACY headers (AudioFeatures.h, AudioAnalysis.h) touch ----
+template <typename T> class Range
+{
+public:
+    Range() : a(), b() {}
+    Range (T s, T e) : a (s), b (e < s ? s : e) {}
+    T getStart() const { return a; }
+    T getEnd() const { return b; }
+    void setStart (T s) { a = s; if (b < s) b = s; }
+    void setEnd (T e) { b = e; if (e < a) a = e; }
+private:
+    T a, b;
+};
+class ReferenceCountedObject { public: virtual ~ReferenceCountedObject() {} };
+template <typename T> class ReferenceCountedObjectPtr { public: ReferenceCountedObjectPtr() : p (nullptr) {} T* p; };
+template <typename T> class HeapBlock
+{
+public:
+    HeapBlock() {}
+    explicit HeapBlock (size_t n) : d (n) {}
+    template <typename I> T& operator[] (I i) { return d[(size_t) i]; }
+    T* getData() { return d.data(); }
+    void allocate (size_t n, bool) { d.assign (n, T()); }
+private:
+    std::vector<T> d;
+};
 
 class String
 {
@@ -165,6 +195,16 @@ public:
         for (int i = 0; i < n; i++) { const float s = p[i]; sum += s * s; }
         return (float) std::sqrt (sum / n);
     }
+    // (legacy headers) the range of a stretch of samples, a gain over a stretch of channel 0
+    Range<float> findMinMax (int c, int start, int n) const
+    {
+        if (n <= 0 || cleared) return Range<float>();
+        const float* p = getReadPointer (c) + start;
+        float lo = p[0], hi = p[0];
+        for (int i = 1; i < n; i++) { if (p[i] < lo) lo = p[i]; if (p[i] > hi) hi = p[i]; }
+        return Range<float> (lo, hi);
+    }
+    void applyGain (int start, int n, float g) { for (int c = 0; c < nch; c++) { float* p = d.data() + (size_t) c * ns + start; for (int i = 0; i < n; i++) p[i] *= g; } }
     // max |x| (via the range's min and max)
     float getMagnitude (int c, int start, int n) const
     {
@@ -208,6 +248,14 @@ public:
                     r == 4 ? bfly4 (out + base + k, len, k * stride) : bfly2 (out + base + k, len, k * stride);
             len *= r;
         }
+    }
+    // (legacy headers; not exercised by the harness: AudioAnalysis.h:197 only) magnitudes of the first half of the spectrum
+    void performFrequencyOnlyForwardTransform (float* d) const
+    {
+        std::vector<Complex> a ((size_t) n), b ((size_t) n);
+        for (int i = 0; i < n; i++) { a[(size_t) i].r = d[i]; a[(size_t) i].i = 0.0f; }
+        perform (a.data(), b.data());
+        for (int i = 0; i < n; i++) d[i] = std::sqrt (b[(size_t) i].r * b[(size_t) i].r + b[(size_t) i].i * b[(size_t) i].i);
     }
     void performRealOnlyForwardTransform (float* d) const
     {

@@ -59,3 +59,62 @@ def run(hops, window_size, order=0, onset_type=1, onset_window=5, onset_sensitiv
         out = np.fromfile(fout, np.float32)
     n = C * T * 12
     return out[:n].reshape(C, T, 12), out[n:2 * n].reshape(C, T, 12)
+
+
+# ---- the legacy offline analyser (AudioAnalysis.h / AudioFeatures.h) ----
+LEGACY_HEADERS = ["AudioAnalysis.h", "AudioFeatures.h"]
+
+
+def legacy_available():
+    return all(os.path.exists(os.path.join(REFERENCE, h)) for h in LEGACY_HEADERS)
+
+
+def build_legacy():
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "refdiff_legacy")
+    srcs = [os.path.join(HERE, "refdiff_legacy.cpp"), os.path.join(HERE, "juce_standin.h")]
+    if os.path.exists(exe) and all(os.path.getmtime(s) <= os.path.getmtime(exe) for s in srcs):
+        return exe
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-w", "-ffp-contract=off", "-fno-fast-math", "-DREFDIFF_LOG10_CR",
+                           "-I", REFERENCE, "-I", HERE, srcs[0], "-o", exe])
+    return exe
+
+
+def _legacy(op, a, b, c, d, x, payload):
+    import tempfile
+    exe = build_legacy()
+    with tempfile.TemporaryDirectory() as tmp:
+        fin, fout = os.path.join(tmp, "in.bin"), os.path.join(tmp, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<5i4xd", op, a, b, c, d, x))          # (struct Header: 5 x int32, padding, float64)
+            f.write(np.ascontiguousarray(payload, np.float32).tobytes())
+        subprocess.check_call([exe, fin, fout])
+        return open(fout, "rb").read()
+
+
+def legacy_zero_crosses(audio, num_downsamples):
+    """AudioAnalyser::analyseNormalisedZeroCrosses of the reference on audio [C][S] -> [C][num_downsamples]."""
+    audio = np.ascontiguousarray(audio, np.float32)
+    out = _legacy(1, audio.shape[0], audio.shape[1], num_downsamples, 0, 0.0, audio)
+    return np.frombuffer(out, np.float32).reshape(audio.shape[0], num_downsamples).copy()
+
+
+def legacy_log_attack_time(envelope, num_input_samples, num_downsamples, sample_rate):
+    envelope = np.ascontiguousarray(envelope, np.float32)
+    return np.frombuffer(_legacy(2, envelope.shape[0], num_input_samples, num_downsamples, sample_rate, 0.0, envelope), np.float32)[0]
+
+
+def legacy_fft_lbp(cur, prev):
+    cur, prev = np.ascontiguousarray(cur, np.float32), np.ascontiguousarray(prev, np.float32)
+    C, B = cur.shape
+    out = np.frombuffer(_legacy(3, C, B, 0, 0, 0.0, np.concatenate([cur, prev])), np.float32).reshape(C, B + 2)
+    return out[:, :B].astype(np.uint8), out[:, B].copy(), out[:, B + 1].copy()
+
+
+def legacy_harmonic_characteristics(mags, nyquist):
+    """mags [T][C][B]: T successive frames through one AudioAnalyser per channel -> (out [T][C][3], previousF0 [T][C])."""
+    mags = np.ascontiguousarray(mags, np.float32)
+    T, C, B = mags.shape
+    out = _legacy(4, C, B, T, 0, float(nyquist), mags)
+    n = T * C * 3 * 4
+    return np.frombuffer(out[:n], np.float32).reshape(T, C, 3).copy(), np.frombuffer(out[n:], np.float64).reshape(T, C).copy()
