@@ -272,6 +272,9 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
         if (c->tuning.channels_per_workgroup >= 1) ch = c->tuning.channels_per_workgroup;
         if (k > T) k = T;
         if (k > kcap) k = kcap;
+        // one frame per call through the batch kernels: one wavefront per channel, so let four channels share a workgroup's
+        // twiddle table (measured: 2048 points, 4096 channels x 1 hop 152 us against 193 us; no difference at 1024 points)
+        if (T == 1 && !st->pair && c->tuning.channels_per_workgroup < 1) ch = 4;
         if (ch > c->C) ch = c->C;
         while (ch > 1 && (ch * k > kcap || lds_bytes(ch, k) > lds_cu)) ch--;
         while (k > 1 && lds_bytes(ch, k) > lds_cu) k--;
@@ -407,7 +410,10 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     // ONE frame per channel -- the reference's own cadence, an analysis per hop as it arrives (AudioDataCollector.h:66-94,
     // RealTimeAnalyser.h:201-234) -- is one launch of fx_hop_kernel: three wavefronts per channel (pitch / spectral /
     // harmonic) and the hop's tail, instead of one wavefront per channel and a second launch.
-    const bool one_hop = T == 1 && step.analysers == 3 && c->tuning.one_hop_kernel != 0 && fxk::hop_kernel_available(c->N);
+    // (measured, tools/live_cadence.py: at 2048 / 4096 points the batch kernels take over above ~1000 channels -- 152 against 166 us at
+    // 4096 channels x 2048-pt -- where the chip is full either way and three wavefronts per channel only add scheduling)
+    const bool one_hop = T == 1 && step.analysers == 3 && fxk::hop_kernel_available(c->N) &&
+                         (c->tuning.one_hop_kernel == 1 || (c->tuning.one_hop_kernel < 0 && (c->N <= 1024 || c->C <= 1024)));
     if (one_hop) {
         const fxk::HopSignal none = {nullptr, nullptr, 0u, 0u, nullptr};
         HIP_TRY(hipEventRecord(e0, c->stream));

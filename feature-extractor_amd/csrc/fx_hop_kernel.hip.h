@@ -97,13 +97,26 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
             sum_sq = w.sum_squares(lane, xr);
         }
         w.spectral(lane, xr, sum_sq);
-        // this analyser's slots of the raw vector (ref RealTimeAnalyser.h:209-226), while the pitch estimate is still running
+        // this analyser's slots of the raw vector (ref RealTimeAnalyser.h:209-226), while the pitch estimate is still running.
+        // (-DFX_EXP_HOP_EARLY_EPILOGUE also finishes their smoothing, the onset and the history rows that merely move up here, leaving
+        // four slots and one row behind the last barrier: measured 1-3 us SLOWER per hop at every size -- the early stores to the
+        // pinned host slot are in the way of the later ones -- so everything is finished at the end.)
         if (lane == 0) {
             EpilogueParams e1 = ep_arg; e1.analysers = 1;
             float out[FX_NUM_FEATURES];
             finalise_values(e1, *part, out);
             s_raw[FX_ONSET] = 0.0f; s_raw[FX_RMS] = out[FX_RMS]; s_raw[FX_CENTROID] = out[FX_CENTROID]; s_raw[FX_SPREAD] = out[FX_SPREAD];
             s_raw[FX_FLATNESS] = out[FX_FLATNESS]; s_raw[FX_LER] = out[FX_LER]; s_raw[FX_FLUX] = out[FX_FLUX]; s_raw[FX_SLOPE] = out[FX_SLOPE];
+        }
+        wave_fence();
+        {
+            EpilogueParams ep = ep_arg;
+            ep.raw = s_raw - (size_t) c * FX_NUM_FEATURES;
+            ep.hist_in = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
+#ifdef FX_EXP_HOP_EARLY_EPILOGUE
+            epilogue_hop(ep, c, lane, s_onset, SLOTS_SPECTRAL);
+            for (int i = lane; i < (HLEN - 1) * FX_NUM_FEATURES; i += 64) history_value(ep, (long long) c * HLEN * FX_NUM_FEATURES + i);
+#endif
         }
     } else {
         float xr[P];
@@ -137,8 +150,13 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
     EpilogueParams ep = ep_arg;
     ep.raw = s_raw - (size_t) c * FX_NUM_FEATURES;              // epilogue_hop / history_value index by channel
     ep.hist_in = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
+#ifdef FX_EXP_HOP_EARLY_EPILOGUE
+    epilogue_hop(ep, c, lane, s_onset, SLOTS_HARMONIC);
+    if (lane < FX_NUM_FEATURES) history_value(ep, ((long long) c * HLEN + (HLEN - 1)) * FX_NUM_FEATURES + lane);
+#else
     epilogue_hop(ep, c, lane, s_onset);
     for (int i = lane; i < HLEN * FX_NUM_FEATURES; i += 64) history_value(ep, (long long) c * HLEN * FX_NUM_FEATURES + i);
+#endif
 
     // completion: this workgroup's results (pinned host memory) are visible system-wide before it counts itself in
     if (lane == 0 && sig.host_flag) {
@@ -166,7 +184,8 @@ template <int N> struct HopPairGeo {
     static constexpr size_t OFF_HIST = OFF_PART + sizeof(FramePart);
     static constexpr size_t OFF_RAW = OFF_HIST + sizeof(float) * HLEN * FX_NUM_FEATURES;
     static constexpr size_t OFF_ONSET = OFF_RAW + sizeof(float) * 16;
-    static constexpr size_t BYTES = OFF_ONSET + sizeof(float) * 64;
+    static constexpr size_t OFF_READY = OFF_ONSET + sizeof(float) * 64;          // loader wavefronts that have finished the prologue's tables
+    static constexpr size_t BYTES = OFF_READY + 16;
     static_assert(OFF_PAIRS % 16 == 0 && OFF_PART % 16 == 0 && PAIR_BYTES % 16 == 0, "16-byte aligned sections");
 };
 
@@ -186,6 +205,7 @@ fx_hop_pair_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const H
     float* s_hist = reinterpret_cast<float*>(smem + HG::OFF_HIST);
     float* s_raw  = reinterpret_cast<float*>(smem + HG::OFF_RAW);
     float* s_onset = reinterpret_cast<float*>(smem + HG::OFF_ONSET);
+    unsigned* s_ready = reinterpret_cast<unsigned*>(smem + HG::OFF_READY);
 
     const int wave = threadIdx.x >> 6;
     const int lane = threadIdx.x & 63;
@@ -196,27 +216,50 @@ fx_hop_pair_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const H
     double* mbox = reinterpret_cast<double*>(mine + PG::BUF_BYTES);
     unsigned* flags = reinterpret_cast<unsigned*>(mine + PG::BUF_BYTES + 8 * PG::MBOX_DOUBLES);
 
-    // prologue: twiddle table, flux state, history of raw values, the hop itself -- 16 bytes per lane per load
-    {
+    // Prologue, split by who needs what first.  The pitch pair -- the hop's critical path -- copies the hop out of the pinned
+    // slot (16 bytes per lane, once: the slot is un-cached memory across PCIe) and starts on it at once; meanwhile the other two
+    // pairs bring in the twiddle table, the flux state and the history of raw values.  Nobody waits for anybody he does not
+    // need: each of the four loading wavefronts counts itself in when its loads are in LDS and goes on when all four are; the
+    // pitch pair looks at that count only after its low-pass, right before its first transform reads a twiddle.
+    auto tables_loaded = [&] {
+        while (__hip_atomic_load(s_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 4u) { }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (threadIdx.x == 0) { turn2[0] = 0; part->flags = 0; s_ready[0] = 0u; s_ready[1] = 0u; }
+    if (lane == 0) flags[w] = 0u;
+    __syncthreads();                                            // (every pair's arrival counters are zero before any pair synchronises on them)
+    if (pair == 0) {
+        if (sig.stage) {
+            const size_t hop_bytes = (size_t) (N / 2) * (p.sample_format == FX_SAMPLE_F16 ? 2 : 4);
+            const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(p.in) + (size_t) c * hop_bytes);
+            uint4* dst = reinterpret_cast<uint4*>(static_cast<unsigned char*>(sig.stage) + (size_t) c * hop_bytes);
+            for (int i = threadIdx.x; i < (int) (hop_bytes / 16); i += 128) dst[i] = src[i];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wavefront's part of the copy is in memory ...
+            if (lane == 0) __hip_atomic_fetch_add(s_ready + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // ... before it says so
+        }
+    } else {
+        const int tid = threadIdx.x - 128;
         const uint4* src = reinterpret_cast<const uint4*>(p.tw);
         uint4* dst = reinterpret_cast<uint4*>(tw);
 #pragma unroll 4
-        for (int i = threadIdx.x; i < N / 2; i += 384) dst[i] = src[i];
+        for (int i = tid; i < N / 2; i += 256) dst[i] = src[i];
         const f4* ps = reinterpret_cast<const f4*>(p.prev_re + (size_t) c * M);
-        for (int i = threadIdx.x; i < M / 4; i += 384) reinterpret_cast<f4*>(prev)[i] = ps[i];
+        for (int i = tid; i < M / 4; i += 256) reinterpret_cast<f4*>(prev)[i] = ps[i];
         const uint4* hs4 = reinterpret_cast<const uint4*>(ep_arg.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES);
-        for (int i = threadIdx.x; i < HLEN * FX_NUM_FEATURES / 4; i += 384) reinterpret_cast<uint4*>(s_hist)[i] = hs4[i];
+        for (int i = tid; i < HLEN * FX_NUM_FEATURES / 4; i += 256) reinterpret_cast<uint4*>(s_hist)[i] = hs4[i];
     }
-    if (threadIdx.x == 0) { turn2[0] = 0; part->flags = 0; }
-    if (lane == 0) flags[w] = 0u;
-    if (sig.stage) {
-        const size_t hop_bytes = (size_t) (N / 2) * (p.sample_format == FX_SAMPLE_F16 ? 2 : 4);
-        const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(p.in) + (size_t) c * hop_bytes);
-        uint4* dst = reinterpret_cast<uint4*>(static_cast<unsigned char*>(sig.stage) + (size_t) c * hop_bytes);
-        for (int i = threadIdx.x; i < (int) (hop_bytes / 16); i += blockDim.x) dst[i] = src[i];
-        p.in = sig.stage;
+    if (sig.stage) p.in = sig.stage;
+    if (pair != 0) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wavefront's share of the tables is in LDS
+        if (lane == 0) __hip_atomic_fetch_add(s_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        tables_loaded();
+        if (sig.stage) {                                        // the hop itself: staged by the pitch pair's two wavefronts
+            while (__hip_atomic_load(s_ready + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2u) { }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
-    __syncthreads();
 
     const double nyquist = p.nyquist;
     PairWave<N> pw{p, tw, prev, turn2, cbuf, reinterpret_cast<float*>(cbuf), mbox, flags, part,
@@ -228,9 +271,10 @@ fx_hop_pair_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const H
     typename PairWave<N>::HarmonicSpectrum hs;
     if (pair == 0) {
         // a1 + the pitch estimate (a10-a14): the window into this pair's real image, low-pass, two transforms, lag search
+        pw.pair_sync(lane);                                     // both halves of the hop are staged (and this pair's flags are initialised)
         (void) pw.load_half_window(lane);
         pw.pair_sync(lane);
-        (void) pw.pitch(lane);                                  // leaves the lag in the record
+        (void) pw.pitch(lane, tables_loaded);                   // leaves the lag in the record; the tables are awaited before the transforms
     } else if (pair == 1) {
         // a2 + the spectral analyser (a3-a7): the sum of squares exactly as fx_pair_kernel takes it (each wave its half of the
         // window, wave 0 + wave 1), then the windowed transform and its sums
@@ -242,13 +286,25 @@ fx_hop_pair_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const H
         if (w == 0 && lane == 0) part->sum_sq = sum_sq;
         // (the image itself is not used here; each wave wrote its half into its own region before the exchange above)
         pw.spectral(lane, sum_sq);
-        pw.pair_sync(lane);                                     // both waves' shares of the record are written
-        if (w == 0 && lane == 0) {                              // this analyser's slots (ref RealTimeAnalyser.h:209-226), while the pitch estimate is still running
-            EpilogueParams e1 = ep_arg; e1.analysers = 1;
-            float out[FX_NUM_FEATURES];
-            finalise_values(e1, *part, out);
-            s_raw[FX_ONSET] = 0.0f; s_raw[FX_RMS] = out[FX_RMS]; s_raw[FX_CENTROID] = out[FX_CENTROID]; s_raw[FX_SPREAD] = out[FX_SPREAD];
-            s_raw[FX_FLATNESS] = out[FX_FLATNESS]; s_raw[FX_LER] = out[FX_LER]; s_raw[FX_FLUX] = out[FX_FLUX]; s_raw[FX_SLOPE] = out[FX_SLOPE];
+        pw.pair_sync(lane);                                     // both waves' shares of the record are written, the flux state is final
+        for (int i = 64 * w + lane; i < M; i += 128) p.prev_re[(size_t) c * M + i] = prev[i];
+        if (w == 0) {
+            // this analyser's slots (ref RealTimeAnalyser.h:209-226), while the pitch estimate is still running
+            if (lane == 0) {
+                EpilogueParams e1 = ep_arg; e1.analysers = 1;
+                float out[FX_NUM_FEATURES];
+                finalise_values(e1, *part, out);
+                s_raw[FX_ONSET] = 0.0f; s_raw[FX_RMS] = out[FX_RMS]; s_raw[FX_CENTROID] = out[FX_CENTROID]; s_raw[FX_SPREAD] = out[FX_SPREAD];
+                s_raw[FX_FLATNESS] = out[FX_FLATNESS]; s_raw[FX_LER] = out[FX_LER]; s_raw[FX_FLUX] = out[FX_FLUX]; s_raw[FX_SLOPE] = out[FX_SLOPE];
+            }
+            wave_fence();
+            EpilogueParams ep = ep_arg;
+            ep.raw = s_raw - (size_t) c * FX_NUM_FEATURES;
+            ep.hist_in = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
+#ifdef FX_EXP_HOP_EARLY_EPILOGUE
+            epilogue_hop(ep, c, lane, s_onset, SLOTS_SPECTRAL);
+            for (int i = lane; i < (HLEN - 1) * FX_NUM_FEATURES; i += 64) history_value(ep, (long long) c * HLEN * FX_NUM_FEATURES + i);
+#endif
         }
     } else {
         pw.harmonic_spectrum(lane, hs);                         // a15, up to where the pitch is needed
@@ -264,15 +320,19 @@ fx_hop_pair_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const H
             s_raw[FX_F0] = out[FX_F0]; s_raw[FX_HER] = out[FX_HER]; s_raw[FX_OER] = out[FX_OER]; s_raw[FX_INHARM] = out[FX_INHARM];
         }
     }
-    __syncthreads();                                            // the record is complete, the flux state is final
-    for (int i = threadIdx.x; i < M; i += blockDim.x) p.prev_re[(size_t) c * M + i] = prev[i];
+    __syncthreads();                                            // the record is complete
     if (wave != 0) return;
 
     EpilogueParams ep = ep_arg;
     ep.raw = s_raw - (size_t) c * FX_NUM_FEATURES;
     ep.hist_in = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
+#ifdef FX_EXP_HOP_EARLY_EPILOGUE
+    epilogue_hop(ep, c, lane, s_onset, SLOTS_HARMONIC);         // (the other slots left with the spectral pair)
+    if (lane < FX_NUM_FEATURES) history_value(ep, ((long long) c * HLEN + (HLEN - 1)) * FX_NUM_FEATURES + lane);      // the newest row
+#else
     epilogue_hop(ep, c, lane, s_onset);
     for (int i = lane; i < HLEN * FX_NUM_FEATURES; i += 64) history_value(ep, (long long) c * HLEN * FX_NUM_FEATURES + i);
+#endif
     if (lane == 0 && sig.host_flag) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         const unsigned before = __hip_atomic_fetch_add(sig.arrivals, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);

@@ -360,7 +360,10 @@ FX_MARK("p_fft_out");
     }
 
     // ---- pitch (ref PitchAnalyser.h:24-217, RealTimeAnalyser.h:152-166) -------------------------------------------------
-    __device__ __forceinline__ float pitch(int lane) const
+    // `before_transforms`: called by both waves once the filtered window is written, before the first twiddle is read (the one-hop
+    // kernel joins its workgroup barrier there: the other pairs load the twiddle table while this pair loads and filters)
+    template <typename Hook>
+    __device__ __forceinline__ float pitch(int lane, Hook before_transforms) const
     {
         const int gl = 64 * w + lane;
         // a10 AudioFilter::filterAudio (ref RealTimeAudioAnalysis.h:106-125): y[0] = x[0]; y[n] = (a*x[n]) + (b*y[n-1]) in fp32,
@@ -440,6 +443,7 @@ FX_MARK("p_lpf");
             }
         }
         pair_sync(lane);
+        before_transforms();
 FX_MARK("p_pitch_in");
         float xf[P2];
         inputs_from_image(lane, xf);
@@ -466,6 +470,8 @@ FX_MARK("p_lag");
         next_exchange();
         return lag;
     }
+
+    __device__ __forceinline__ float pitch(int lane) const { return pitch(lane, [] {}); }
 
     // ---- the flatness gate (see FrameWave::gate_threshold): each wave brackets for its own bins ---------------------------
     __device__ __forceinline__ float gate_threshold(double sum_sq, const float (&re)[U2]) const

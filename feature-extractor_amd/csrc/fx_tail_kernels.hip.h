@@ -314,7 +314,13 @@ __device__ __forceinline__ bool detect_onset_wave(const EpilogueParams& p, const
 // The same for the single frame of a one-hop call (T == 1) with the twelve slots spread over twelve lanes: lane s
 // evaluates slot s (the onset lane the detector, the RMS lane the double-insert mean), so the hop's tail takes the time
 // of its longest slot instead of the sum of all.  Same expressions, same order of the fp32 additions as epilogue_frame.
-__device__ __forceinline__ void epilogue_hop(const EpilogueParams& p, int c, int lane, float* scratch)
+// `slots`: bit s set = this call finishes slot s.  The one-hop kernels finish the spectral analyser's slots (and the onset, which reads
+// flux and RMS only) as soon as that analyser is done -- while the pitch estimate is still running -- and the harmonic analyser's four
+// at the end.  All 64 lanes of the calling wavefront must take part when the onset slot is among them.
+constexpr unsigned SLOTS_ALL = (1u << FX_NUM_FEATURES) - 1u;
+constexpr unsigned SLOTS_HARMONIC = (1u << FX_F0) | (1u << FX_HER) | (1u << FX_OER) | (1u << FX_INHARM);
+constexpr unsigned SLOTS_SPECTRAL = SLOTS_ALL & ~SLOTS_HARMONIC;
+__device__ __forceinline__ void epilogue_hop(const EpilogueParams& p, int c, int lane, float* scratch, unsigned slots = SLOTS_ALL)
 {
     RawView v;
     v.raw = p.raw + (size_t) c * p.T * FX_NUM_FEATURES;
@@ -325,27 +331,34 @@ __device__ __forceinline__ void epilogue_hop(const EpilogueParams& p, int c, int
     const bool spec = p.analysers & 1, harm = p.analysers & 2;
     const int order_mode = (spec && harm) ? p.order_mode : FX_ORDER_ISOLATED;
     const float never = __int_as_float(0x7fc00000);
-    const bool onset = detect_onset_wave(p, v, t, order_mode, spec, lane, scratch);       // all 64 lanes
-    if (lane >= FX_NUM_FEATURES) return;
-    float rw = v.get(t, s), sm;
-    if (s == FX_ONSET) {
-        rw = onset ? 1.0f : 0.0f;
-        sm = spec ? (0.0f + rw) / 1.0f : never;
-    } else if (s == FX_FLUX) {
-        sm = spec ? (0.0f + rw) / 1.0f : never;
-    } else if (s == FX_RMS) {
-        sm = rms_value(v, t, order_mode, 2);
-    } else {
-        long long rec10 = p.frames_before + t + 1; if (rec10 > 10) rec10 = 10;
-        const bool harm_slot = s == FX_F0 || s == FX_HER || s == FX_OER || s == FX_INHARM;
-        float total = 0.0f;
+    bool onset = false;
+    if (slots & (1u << FX_ONSET)) onset = detect_onset_wave(p, v, t, order_mode, spec, lane, scratch);       // all 64 lanes
+    const bool mine = lane < FX_NUM_FEATURES && ((slots >> lane) & 1u);
+    float rw = 0.0f, sm = 0.0f;
+    if (mine) {
+        rw = v.get(t, s);
+        if (s == FX_ONSET) {
+            rw = onset ? 1.0f : 0.0f;
+            sm = spec ? (0.0f + rw) / 1.0f : never;
+        } else if (s == FX_FLUX) {
+            sm = spec ? (0.0f + rw) / 1.0f : never;
+        } else if (s == FX_RMS) {
+            sm = rms_value(v, t, order_mode, 2);
+        } else {
+            long long rec10 = p.frames_before + t + 1; if (rec10 > 10) rec10 = 10;
+            const bool harm_slot = s == FX_F0 || s == FX_HER || s == FX_OER || s == FX_INHARM;
+            float total = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 10; i++) { const int f = t - 9 + i; total += v.valid(f) ? v.get(f, s) : 0.0f; }
-        sm = (harm_slot ? harm : spec) ? total / (float) rec10 : never;
+            for (int i = 0; i < 10; i++) { const int f = t - 9 + i; total += v.valid(f) ? v.get(f, s) : 0.0f; }
+            sm = (harm_slot ? harm : spec) ? total / (float) rec10 : never;
+        }
     }
-    const size_t o = ((size_t) c * p.T + t) * FX_NUM_FEATURES + s;
-    if (p.out_raw) p.out_raw[o] = rw;
-    if (p.out_smoothed) p.out_smoothed[o] = sm;
+    const size_t o = ((size_t) c * p.T + t) * FX_NUM_FEATURES;
+    // (Round 3 also tried the twelve slots as three 16-byte stores per vector -- a one-hop call's results go to a pinned host slot,
+    // every store a transaction across PCIe: no measurable difference in the hop's round trip, not kept.)
+    if (!mine) return;
+    if (p.out_raw) p.out_raw[o + s] = rw;
+    if (p.out_smoothed) p.out_smoothed[o + s] = sm;
     p.latest[(size_t) c * FX_NUM_FEATURES + s] = sm;
 }
 

@@ -28,6 +28,7 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
     worst = 0.0
     inexact = np.zeros(12, np.int64)      # values that are within tolerance but not bit-identical, per slot
     ring_cases = [0]
+    pair_cases = [0]
     last_note = time.time()
     while time.time() < t_end and (max_cases is None or cases < max_cases):
         N = int(rng.choice([256, 512, 1024, 1024, 2048, 2048, 4096]))
@@ -47,6 +48,10 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
         an = fx.BatchAnalyser(C, N, order=order, analysers=which)
         an.set_onset_detection_type(otype); an.set_onset_window_length(owin)
         an.set_onset_detection_sensitivity(sens); an.set_gain(gain)
+        if which == "both" and N >= 2048 and rng.random() < 0.5:
+            # one frame across a PAIR of wavefronts: fx_pair_kernel for the batch calls, fx_hop_pair_kernel for one-hop calls
+            an.set_tuning(waves_per_frame=2)
+            pair_cases[0] += 1
         split = int(rng.integers(0, T + 1))
         ring = which == "both" and N >= 1024 and T <= 24 and rng.random() < 0.25
         if ring:
@@ -91,7 +96,7 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
                     print("MISMATCH %s N=%d C=%d T=%d order=%d otype=%d owin=%d: %d values; first c=%d t=%d %s gpu=%r oracle=%r"
                           % (name, N, C, T, order, otype, owin, len(bad), c, t, fx.FEATURE_NAMES[f], g[c, t, f], w[c, t, f]), flush=True)
     if verbose:
-        print("cases run one hop per call through the ring (fx_hop_kernel): %d" % ring_cases[0], flush=True)
+        print("cases run one hop per call through the ring (fx_hop_kernel / fx_hop_pair_kernel): %d; cases on wavefront pairs (fx_pair_kernel): %d" % (ring_cases[0], pair_cases[0]), flush=True)
     if verbose and inexact.any():
         print("raw values not bit-identical (within tolerance), per slot:", dict((fx.FEATURE_NAMES[i], int(n)) for i, n in enumerate(inexact) if n), flush=True)
     return cases, frames, bad_cases, worst
