@@ -140,6 +140,11 @@ public:
     }
     float getValue (int channel, AudioFeatures::eAudioFeature f) { return getValues (channel)[(std::size_t) f]; }
 
+    // launch-shape knobs (struct fx_tuning of fx.h; e.g. waves_per_frame = 2: every frame on a pair of wavefronts, the lower
+    // one-hop latency at 2048 / 4096 points).  No knob changes a result bit within a kernel family.
+    fx_tuning getTuning()                  { fx_tuning t; check (fx_get_tuning (ctx, &t)); return t; }
+    void setTuning (const fx_tuning& t)    { check (fx_set_tuning (ctx, &t)); }
+
     int getNumChannels() const { return channels; }
     int getWindowSize() const  { return window; }
     fx_context* handle()       { return ctx; }
@@ -148,6 +153,56 @@ private:
     fx_context* ctx = nullptr;
     int channels, window;
     std::vector<float> latest;
+};
+
+// The reference's LEGACY offline analyser (struct AudioAnalyser, ref Source/AudioAnalysis.h), one per channel, on the GPU: the
+// members a host would have called, with the reference's names.  Buffers are host memory, [numChannels][...] row-major.
+class AudioAnalyser
+{
+public:
+    struct HarmonicCharacteristics { float f0, harmonicEnergyRatio, inharmonicity; };     // ref AudioAnalysis.h:31-42
+
+    AudioAnalyser (int numberOfChannels, double nyquistFrequency, int deviceId = 0) : channels (numberOfChannels)   // ref :107
+    {
+        check (fx_offline_create (&off, deviceId, numberOfChannels, nyquistFrequency));
+    }
+    ~AudioAnalyser() { fx_offline_destroy (off); }
+    AudioAnalyser (const AudioAnalyser&) = delete;
+    AudioAnalyser& operator= (const AudioAnalyser&) = delete;
+
+    // ref :517-541: audio [channels][numSamples] -> the ZeroCrosses feature row [channels][numDownsamples]
+    std::vector<float> analyseNormalisedZeroCrosses (const float* audio, int numSamples, int numDownsamples)
+    {
+        std::vector<float> out ((std::size_t) channels * numDownsamples);
+        check (fx_offline_zero_crosses (off, audio, numSamples, numDownsamples, out.data(), FX_MEM_HOST));
+        return out;
+    }
+    // ref :611-622: channel 0 of the energy envelope -> estimatedLogAttackTime
+    float setLogAttackTime (const float* energyEnvelope, int numEnvelopeSamples, int numInputSamples, int numDownsamples, int sampleRate)
+    {
+        float v = 0.0f;
+        check (fx_offline_log_attack_time (off, energyEnvelope, numEnvelopeSamples, numInputSamples, numDownsamples, sampleRate, &v, FX_MEM_HOST));
+        return v;
+    }
+    // ref :543-564 (the reference prints these): bits [channels][numBins], the last bin over the threshold / numBins, the share of bins over it
+    void calculateFFTLBP (const float* fftResults, const float* previousFFTFrame, int numBins, unsigned char* bits, float* highestRatio, float* activityRatio)
+    {
+        check (fx_offline_fft_lbp (off, fftResults, previousFFTFrame, numBins, bits, highestRatio, activityRatio, FX_MEM_HOST));
+    }
+    // ref :253-303: magnitudes [channels][numBins] of one frame; previousF0 is kept per channel across calls
+    std::vector<HarmonicCharacteristics> calculateHarmonicCharacteristics (const float* fftResults, int numBins)
+    {
+        std::vector<float> raw ((std::size_t) channels * 3);
+        check (fx_offline_harmonic_characteristics (off, fftResults, numBins, raw.data(), FX_MEM_HOST));
+        std::vector<HarmonicCharacteristics> out ((std::size_t) channels);
+        for (int c = 0; c < channels; c++) out[(std::size_t) c] = { raw[3 * (std::size_t) c], raw[3 * (std::size_t) c + 1], raw[3 * (std::size_t) c + 2] };
+        return out;
+    }
+    fx_offline* handle() { return off; }
+
+private:
+    fx_offline* off = nullptr;
+    int channels;
 };
 
 // The datagram OSCSender::send (bundleAddress, onset, rmsLevel, f0, centroid, slope, spread, flatness,

@@ -111,6 +111,33 @@ int main (int argc, char** argv)
         std::vector<float> latest = an.getValues (c);
         for (int k = 0; k < 12; k++) EXPECT (latest[k] == sm[((size_t) c * T + T - 1) * 12 + k] || std::isnan (latest[k]));
     }
+    // the tuning struct round-trips, and frames on wavefront pairs (2048-pt) give the same onsets as the default kernels
+    {
+        const int C2 = 2, T2 = 12, N2 = 2048, H2 = N2 / 2;
+        std::vector<float> h2 ((size_t) C2 * T2 * H2), ra ((size_t) C2 * T2 * 12), sa (ra.size()), rb (ra.size()), sb (ra.size());
+        for (size_t i = 0; i < h2.size(); i++) h2[i] = ((i / H2) % 5 < 3 ? 0.4f : 0.0f) * std::sin (0.03f * (float) (i % 4096));
+        fx::RealTimeBatchAnalyser one (C2, N2), two (C2, N2);
+        fx_tuning t = two.getTuning();
+        EXPECT (t.waves_per_frame == 0 && t.frames_per_unit == -1);
+        t.waves_per_frame = 2;
+        two.setTuning (t);
+        EXPECT (two.getTuning().waves_per_frame == 2);
+        one.pushHops (h2.data(), T2, ra.data(), sa.data());
+        two.pushHops (h2.data(), T2, rb.data(), sb.data());
+        for (size_t i = 0; i < ra.size(); i += 12) { EXPECT (ra[i] == rb[i]); EXPECT (ra[i + FX_F0] == rb[i + FX_F0]); }
+    }
+    // the legacy offline analyser's mirror (ref AudioAnalysis.h)
+    {
+        const int C3 = 2, S = 4000, B = 513;
+        std::vector<float> audio ((size_t) C3 * S), mags ((size_t) C3 * B, 0.01f);
+        for (size_t i = 0; i < audio.size(); i++) audio[i] = std::sin (0.5f * (float) i);
+        for (int c = 0; c < C3; c++) for (int b = 25; b < B; b += 25) mags[(size_t) c * B + b] = 5.0f;
+        fx::AudioAnalyser legacy (C3, 24000.0);
+        const std::vector<float> zc = legacy.analyseNormalisedZeroCrosses (audio.data(), S, 4);
+        EXPECT (zc.size() == 8 && zc[0] > 0.28f && zc[0] < 0.36f);                   // a sine of 0.5 rad per sample changes sign every ~6.3 samples: 2 / 6.3
+        const std::vector<fx::AudioAnalyser::HarmonicCharacteristics> hc = legacy.calculateHarmonicCharacteristics (mags.data(), B);
+        EXPECT (hc.size() == 2 && hc[0].f0 == hc[1].f0 && std::fabs (hc[0].f0 - 25.0f * 24000.0f / 513.0f) < 1.0f);   // the comb's spacing
+    }
     std::printf (failures ? "host_mirror --gpu: %d failure(s)\n" : "host_mirror --gpu: ok\n", failures);
     return failures ? 1 : 0;
 }
