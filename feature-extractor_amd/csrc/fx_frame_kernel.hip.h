@@ -4,6 +4,16 @@
 #define FX_HOIST_MASK 0
 #endif
 #define FX_OPQ(n, x) (((FX_HOIST_MASK) >> (n)) & 1 ? (x) : opaque(x))
+// Costing builds only (-DFX_EXP_STOP_AT=k, tools/section_costs.sh): the frame's work ends at stop point k, the values it has
+// formed so far kept alive; the differences of the instruction counters between consecutive k are the sections' dynamic
+// costs.  Results are garbage and nothing waits for a frame that stopped early (the flux turn is taken at stop 8, which every
+// frame of a build reaches or none does).
+#ifdef FX_EXP_STOP_AT
+#define FX_STOP(k, ...) if (FX_EXP_STOP_AT == (k)) { __VA_ARGS__; }      // (no do-while: the arguments `continue` the frame loop)
+#else
+#define FX_STOP(k, ...)
+#endif
+#define FX_KEEP(v) asm volatile("" :: "v"(v))
 // fx_frame_kernel.hip.h -- frame load and fx_frame_kernel: every reduction over samples, bins and lags of a frame
 // Included by fx_kernels.hip inside namespace fxk (one translation unit: every kernel sees the same
 // inlined helpers); not a stand-alone header.
@@ -401,14 +411,14 @@ FX_MARK("rms");
     // prefixes pass through.  If no prefix of the serial product can have left the normal range, the product is the
     // scan's total.  Otherwise the product is continued in plain IEEE double from the start of the first lane where
     // that may happen, lane to lane in bin order, until it is exactly 0 or inf (both absorbing) or the bins end.
-    __device__ __forceinline__ double flatness_product(int lane, const float (&re)[U], float tg) const
+    // part 1, per lane: the exponent-extended product of the lane's gated magnitudes in bin order and the range of exponents its
+    // prefixes pass through.  Called right behind the spectral sums' loop over the same bins, so that the conversions, the
+    // squares and the gate compares are shared.
+    __device__ __forceinline__ void flatness_local(const float (&re)[U], float tg, FlatProd& loc, int& emin, int& emax) const
     {
-FX_MARK("flatprod");
-#ifdef FX_EXP_SKIP_FLATPROD
-        return 1.0;
-#endif
-        FlatProd loc = {0.5, 1};                                           // 1.0
-        int emin = 1, emax = 1;                                            // exponents of the lane's own prefixes (1 = the empty one)
+        loc = FlatProd{0.5, 1};                                            // 1.0
+        emin = 1; emax = 1;                                                // exponents of the lane's own prefixes (1 = the empty one)
+#ifndef FX_EXP_SKIP_FLATPROD
 #pragma unroll
         for (int j = 0; j < U; j++) {
             const double v = (double) re[j];
@@ -419,6 +429,15 @@ FX_MARK("flatprod");
                 emax = loc.exp > emax ? loc.exp : emax;
             }
         }
+#endif
+    }
+    // part 2: across the lanes
+    __device__ __forceinline__ double flatness_product(int lane, const float (&re)[U], float tg, FlatProd loc, int emin, int emax) const
+    {
+FX_MARK("flatprod");
+#ifdef FX_EXP_SKIP_FLATPROD
+        return 1.0;
+#endif
         // inclusive / exclusive scan of lane totals in lane (= bin) order; identity = 1.0 = (0.5, 1)
         FlatProd inc = loc;
 #define FX_FP_STEP(CTRL, ROW_MASK) { FlatProd nb; nb.mant = dpp_d<CTRL, ROW_MASK>(0.5, inc.mant); nb.exp = dpp_i<CTRL, ROW_MASK>(1, inc.exp); inc = fp_mul2(nb, inc); }
@@ -486,6 +505,7 @@ FX_MARK("spec_fft");
             }
             spec_aux = fft_from_regs<N, false, OUT_RE_LOW_MAXABS>(xw, cbuf, tw, p.first_tw, lane, 0.0f, nullptr, twr);   // a4
         }
+        FX_STOP(6, FX_KEEP(spec_aux); return);
 FX_MARK("spec_sums");
         {
             // lane owns bins [U*lane, U*lane + U)
@@ -520,19 +540,22 @@ FX_MARK("spec_sums");
                 if (gate) flat_sum += mag;
                 max_re = fmaxf(max_re, fabsf(re[j]));
             }
+            FlatProd floc; int femin, femax;
+            flatness_local(re, tg, floc, femin, femax);
             const double ul = (double) (U * lane);
             double mag_sum = Ts;                                               // B0
             double b1 = ul * Ts + Vs;
             double b2 = (ul * ul) * Ts + ((ul + ul) * Vs + ((Ws + Ws) - Vs));
             double lhr = lane < LQ ? Ts : (lane == LQ ? Ts - t_after : 0.0);
             wave_sum4(lane, mag_sum, b1, b2, lhr);
-            flat_sum = wave_sum(flat_sum);
-            const double wsum = frpb * (b1 + 0.5 * mag_sum);                   // :95 sum fc * mag
+            // (flat_sum, like flux and the second pass's sums, is only recorded: they share one reduction further down)
             max_re = wave_maxf(max_re);
             const double max_mag = (double) max_re * (double) max_re;
             maxabs = wave_maxf(maxabs);
             const bool accepted = mag_sum > 0.05;                              // :121-123
 
+            FX_STOP(7, FX_KEEP(mag_sum); FX_KEEP(b1); FX_KEEP(b2); FX_KEEP(lhr); FX_KEEP(max_mag); FX_KEEP(maxabs); FX_KEEP(flat_sum); FX_KEEP(cnt);
+                       FX_KEEP(floc.mant); FX_KEEP(floc.exp); FX_KEEP(femin); FX_KEEP(femax); return);
 FX_MARK("flux");
             // ---- flux against the previous accepted frame; hand-off between waves ----
             double flux = 0.0;
@@ -555,34 +578,36 @@ FX_MARK("flux");
                     flux += fmax(diff, 0.0);                                   // :77-79 (a NaN difference adds nothing, as `if (diff > 0)`)
                 }
             }
-            flux = wave_sum(flux);
-
+            FX_STOP(8, FX_KEEP(mag_sum); FX_KEEP(b1); FX_KEEP(b2); FX_KEEP(lhr); FX_KEEP(max_mag); FX_KEEP(maxabs); FX_KEEP(flat_sum); FX_KEEP(cnt);
+                       FX_KEEP(floc.mant); FX_KEEP(floc.exp); FX_KEEP(femin); FX_KEEP(femax); FX_KEEP(flux); return);
             lane = FX_OPQ(1, lane);
-            const double prod = flatness_product(lane, re, tg);
+            const double prod = flatness_product(lane, re, tg, floc, femin, femax);
+            FX_STOP(9, FX_KEEP(mag_sum); FX_KEEP(b1); FX_KEEP(b2); FX_KEEP(lhr); FX_KEEP(max_mag); FX_KEEP(maxabs); FX_KEEP(flat_sum); FX_KEEP(cnt);
+                       FX_KEEP(prod); FX_KEEP(flux); return);
 
 FX_MARK("spec_pass2");
-            // spread needs the centroid (:135-139): from the moments above; the slope needs sum (mag - mean)^2 (:182-188):
-            // a second pass over the lane's bins.  Everything after these sums is scalar and is finished by
-            // fx_finalise_kernel.
+            // The slope needs sum (mag - mean)^2 (:182-188): a second pass over the lane's bins.  The spread (:135-141) and the
+            // centroid (:127) are formed by fx_finalise_kernel from the moments B0 (mag_sum), B1, B2 -- one thread per frame
+            // instead of a wave-wide fp64 division here -- unless the moment form, which loses (centroid / bandwidth)^2 in
+            // relative precision (~1e-11 for any windowed signal: the Bartlett main lobe is several bins wide), cannot be
+            // trusted: the weighted variance below 1e-9 of cn^2 * B0, or not finite.  In moments that test is
+            // S2 * B0 - W^2 > 1e-9 * W^2 with S2 = B2 + B1 + B0/4 and W = B1 + B0/2 (no division); where it fails the sum is
+            // taken here as the reference writes it.
             {
-                const float centroid = (float) (wsum / mag_sum);               // :127
-                const double cn = (double) centroid * rnyq;
-                const double rm = 1.0 / (double) M;
-                double var = ((b2 + b1 + 0.25 * mag_sum) * rm - (cn + cn) * (b1 + 0.5 * mag_sum)) * rm + (cn * cn) * mag_sum;
                 const double mu = mag_sum * (1.0 / (double) M);
                 double vsum = 0.0;
 #pragma unroll
                 for (int j = 0; j < U; j++) {
                     const double v = (double) re[j];
-                    const double dv = v * v - mu;
-                    vsum += dv * dv;
+                    const double dv = __builtin_fma(v, v, -mu);                // = v * v - mu (v * v is exact in fp64)
+                    vsum = __builtin_fma(dv, dv, vsum);                        // (one rounding fewer than the reference's; ~1e-16)
                 }
-                // The moment form loses (centroid/bandwidth)^2 in relative precision: ~1e-11 for any windowed signal (the
-                // Bartlett main lobe is several bins wide).  Should the weighted variance ever be below 1e-9 of cn^2 * B0
-                // (or not finite), take the sum as the reference writes it.
+                const double wm = b1 + 0.5 * mag_sum, s2b0 = (b2 + b1 + 0.25 * mag_sum) * mag_sum, ww = wm * wm;
+                const bool refine = accepted && (!(s2b0 - ww > 1e-9 * ww) || !(s2b0 < __builtin_huge_val()));
                 double direct = 0.0;
-                const bool refine = !(var > 1e-9 * (cn * cn) * mag_sum) || !(var < __builtin_huge_val());
                 if (refine) {
+                    const float centroid = (float) ((frpb * wm) / mag_sum);    // :95, :127
+                    const double cn = (double) centroid * rnyq;
 #pragma unroll
                     for (int j = 0; j < U; j++) {
                         const double v = (double) re[j];
@@ -590,15 +615,14 @@ FX_MARK("spec_pass2");
                         direct += (d * d) * (v * v);
                     }
                 }
-                wave_sum2(lane, direct, vsum);
-                if (refine) var = direct;
-                if (lane == 0) { fpl->var = var; fpl->vsum = vsum; fpl->centroid = centroid; }
+                wave_sum4(lane, flux, vsum, flat_sum, direct);                 // one reduction for everything that is only recorded
+                if (lane == 0) { fpl->var = direct; fpl->refined = refine ? 1 : 0; fpl->vsum = vsum; }
             }
             double max_e = (double) maxabs;                                    // :153
             if (max_mag > max_e) max_e = max_mag;                              // :161-162
             if (lane == 0) {
                 fpl->mag_sum = mag_sum; fpl->lhr = lhr; fpl->flux = flux; fpl->flat_sum = flat_sum; fpl->prod = prod;
-                fpl->max_e = max_e; fpl->wsum = wsum; fpl->cnt = (float) cnt;
+                fpl->max_e = max_e; fpl->b1 = b1; fpl->b2 = b2; fpl->cnt = (float) cnt;
             }
         }
         wave_fence();
@@ -626,8 +650,7 @@ FX_MARK("harm1");
 #pragma unroll
             for (int j = 0; j < U; j++) {                                      // ref HarmonicCharacteristics.h:61-69
                 const double v = (double) hre[j];
-                const double mag = v * v;
-                h_sum += mag;
+                h_sum += v * v;
                 h_max_re = fmaxf(h_max_re, fabsf(hre[j]));
             }
             h_sum = wave_sum(h_sum);
@@ -648,7 +671,7 @@ FX_MARK("lpf");
         // recurrence (|b| = 0.208) forgets the guess; the value it reaches at P*l-1 must be
         // bit-identical to what lane l-1 produced there, otherwise the chunk is redone from the
         // neighbour's value until every hand-over matches (exact by induction from lane 0).
-        constexpr int KW = 16;
+                constexpr int KW = 16;
         const float a = p.lpf_a, b = p.lpf_b;
         // (the pitch path runs first, while the real image of the raw frame that load_frame left in the buffer is
         // still intact)
@@ -768,6 +791,7 @@ FX_MARK("scan");
     __device__ __forceinline__ double pitch(int lane) const
     {
         lowpass_window(FX_OPQ(5, lane));
+        FX_STOP(2, return 1.0);
 FX_MARK("pitch_fft");
         lane = FX_OPQ(6, lane);
         float xf[P];
@@ -780,6 +804,7 @@ FX_MARK("pitch_fft");
         // inverse transform's first pass wants it
         float xp[P];
         fft_from_regs<N, false, OUT_POWER>(xf, cbuf, tw, p.first_tw, lane, 0.0f, xp, twr);  // ref RealTimeAnalyser.h:160
+        FX_STOP(3, for (int j = 0; j < P; j++) FX_KEEP(xp[j]); return 1.0);
 FX_MARK("power");
         lane = FX_OPQ(7, lane);
         if constexpr (G::GA == 1) {
@@ -801,6 +826,7 @@ FX_MARK("ifft");
             lz.load(xf, cbuf, tw, p.first_tw, lane, scale);
             vreg[0] = lz.head(0);
             vreg[1] = lz.head(1);
+            FX_STOP(4, FX_KEEP(vreg[0]); FX_KEEP(vreg[1]); return 1.0);
             lag = lag_search<true>(lane, vreg, 0.0f, &lz);
         } else
 #endif
@@ -840,10 +866,10 @@ FX_MARK("harm2");
                 // below runs a little more often)
                 const float root_mean = __builtin_amdgcn_sqrtf((float) mean_mag);
                 const float band = root_mean * 3e-6f;
-                bool near = false;
+                unsigned long long near = 0;                                   // (lane masks: a bool would be packed into bytes)
 #pragma unroll
-                for (int j = 0; j < U; j++) near |= fabsf(fabsf(hre[j]) - root_mean) <= band;
-                if (__any(near)) {
+                for (int j = 0; j < U; j++) near |= __ballot(fabsf(fabsf(hre[j]) - root_mean) <= band);
+                if (near) {
                     double run = 0.0;
                     for (int l = 0; l < 64; l++) {
                         double mine = run;
@@ -859,20 +885,18 @@ FX_MARK("harm2");
             const double r_hmax = 1.0 / h_max;
             const double sum_normed = h_sum * r_hmax;                          // :77 sum of mag / max over all bins
             int npk_lane = 0;
+            // binIsPeak :127-145: above the mean and none of bins -2,-1,+1 larger (windows are clipped at the ends, :136-138: no
+            // +1 neighbour for the last two bins).  mag = (double) re^2 is exact, so comparing |re| compares magnitudes exactly.
 #pragma unroll
             for (int j = 0; j < U; j++) {
                 const double v = (double) hre[j];
-                const double mag = v * v;
-                // binIsPeak :127-145: above the mean and none of bins -2,-1,+1 larger (windows are
-                // clipped at the ends, :136-138: no +1 neighbour for the last two bins).
-                // mag = (double) re^2 is exact, so comparing |re| compares magnitudes exactly.
                 const float me = fabsf(hre[j]);
                 const float l2 = j >= 2 ? fabsf(hre[j >= 2 ? j - 2 : 0]) : (j == 1 ? h_left1 : h_left2);
                 const float l1 = j >= 1 ? fabsf(hre[j >= 1 ? j - 1 : 0]) : h_left1;
                 const float r1 = j + 1 < U ? fabsf(hre[j + 1 < U ? j + 1 : 0]) : h_right1;
                 // Neighbours that do not exist (below bin 0, above bin M-1) were loaded as 0 and are never greater;
                 // the one clipped neighbour that does exist is bin M-1 seen from bin M-2 (lane 63, j = U-2).
-                bool is_peak = (mag > mean_mag) && !(l2 > me) && !(l1 > me);
+                bool is_peak = v * v > mean_mag && !(l2 > me) && !(l1 > me);
                 if (j == U - 2) is_peak = is_peak && (!(r1 > me) || lane == 63);
                 else            is_peak = is_peak && !(r1 > me);
                 pk[j] = is_peak;
@@ -880,7 +904,7 @@ FX_MARK("harm2");
             }
             // the probes below need the normalised magnitudes (float)(mag / max) (:75) of a few bins only; the
             // normalisation is monotone, so the largest of a neighbourhood is the normalised largest |re|
-            lds_store_block<U>(normed + bimg<N>(U * lane), hre);
+            // (the bins image is still as the raw frame's transform left it: harmonic_spectrum only read it)
             // compact the peak list
             const int pre = wave_scan_incl_i(npk_lane);
             const int total_peaks = __builtin_amdgcn_readlane(pre, 63);
@@ -1068,15 +1092,20 @@ fx_frame_kernel(const FrameParams p_arg)
         // transforms below overwrite.  (The order of the two analysers only matters for the smoothed RMS, which
         // fx_epilogue_kernel derives from the order flag.)
         double f0 = 0.0;
+        FX_STOP(1, FX_KEEP(sum_sq); FX_KEEP(xr[0]); continue);
         if constexpr (HARM) f0 = w.pitch(lane);
+        FX_STOP(2, continue); FX_STOP(3, continue); FX_STOP(4, continue);
+        FX_STOP(5, FX_KEEP(f0); continue);
         if constexpr (SPEC) {
             if constexpr (G::SPLIT) w.load_raw(lane, xr);
             w.spectral(lane, xr, sum_sq);
         }
+        FX_STOP(6, continue); FX_STOP(7, continue); FX_STOP(8, continue); FX_STOP(9, continue); FX_STOP(10, continue);
         if constexpr (HARM) {
             typename FrameWave<N>::HarmonicSpectrum hs;
             if constexpr (G::SPLIT) w.load_raw(lane, xr);
             w.harmonic_spectrum(lane, xr, hs);
+            FX_STOP(11, FX_KEEP(hs.sum); FX_KEEP(hs.max); FX_KEEP(hs.left2); FX_KEEP(hs.left1); FX_KEEP(hs.right1); for (int j = 0; j < G::U; j++) FX_KEEP(hs.hre[j]); continue);
             w.harmonic_tail(lane, hs, f0);
         }
     }

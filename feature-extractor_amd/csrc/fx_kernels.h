@@ -20,24 +20,24 @@ constexpr int FUSED_TAIL_MAX_FRAMES = 8;
 // fx_finalise_kernel, where 64 frames share an instruction instead of one.
 struct FramePart {
     double mag_sum;     // sum of re^2 over the M bins of the windowed spectrum
-    double var;         // sum ((fc/nyq) - (centroid/nyq))^2 * mag          (ref SpectralCharacteristics.h:137)
+    double var;         // sum ((fc/nyq) - (centroid/nyq))^2 * mag (ref SpectralCharacteristics.h:137), summed as the reference writes it:
+                        // valid only where `refined` is set; otherwise the finalise kernel forms it from the moments mag_sum, b1, b2
     double lhr;         // magnitudeSum at bin M/5 (inclusive)               (ref :86-87)
     double flux;        // sum of rectified differences, not yet / maxFlux   (ref :76-79)
     double flat_sum;    // flatnessMagnitudeSum                              (ref :91)
     double prod;        // magnitudeProduct with the serial IEEE semantics   (ref :92)
     double max_e;       // maxFFTMagnitude of the slope                      (ref :153-163)
-    double wsum;        // weightedMagnitudeSum                              (ref :95)
+    double b1;          // sum m * mag over the bins m: weightedMagnitudeSum (ref :95) = frpb * (b1 + mag_sum / 2), formed by the finalise kernel
     double vsum;        // sum (mag - mag_sum/M)^2
     double inh;         // inharmonicity before the log                      (ref HarmonicCharacteristics.h:239)
     double her_score;   // sum of the 18 probe maxima                        (ref :157-184)
     double sum_normed;  // sum of mag / max over all bins                    (ref :77); her = score / sum_normed
     double sum_sq;      // sum of the frame's squared samples: rms = (float) sqrt(sum_sq / N)  (ref RealTimeAnalyser.h:207)
-    float  unused_;
-    float  centroid;    // (float)(wsum / mag_sum)                           (ref SpectralCharacteristics.h:127)
+    double b2;          // sum m^2 * mag: with mag_sum and b1 the moments the centroid (:127) and the spread (:135-141) are formed from
     float  cnt;         // numMagnitudesUsedInFlatnessCalculation
     float  lag;         // ref PitchAnalyser.h:188-189
     int    flags;       // bit 0: harmonic analyser ran past the 0.005 gate  (ref HarmonicCharacteristics.h:88)
-    int    pad_;
+    int    refined;     // `var` holds the reference's own sum (the moment form was not trustworthy for this frame, or the pair kernel summed it)
 };
 static_assert(sizeof(FramePart) == 128, "one 128-byte line per frame");
 

@@ -650,8 +650,8 @@ FX_MARK("p_spec_x2");
                 s[0] = bcast63(inc.mant); s[1] = (double) __builtin_amdgcn_readlane(inc.exp, 63); s[2] = risky_lanes ? 1.0 : 0.0; s[3] = pr_end;
                 s[4] = flux; s[5] = vsum; s[6] = direct;
                 const double max_e = max_mag > (double) maxabs ? max_mag : (double) maxabs;        // :153, :161-162
-                fpl->mag_sum = mag_sum; fpl->lhr = lhr; fpl->flat_sum = flat_sum; fpl->max_e = max_e; fpl->wsum = wsum;
-                fpl->cnt = (float) cnt; fpl->centroid = centroid;
+                fpl->mag_sum = mag_sum; fpl->lhr = lhr; fpl->flat_sum = flat_sum; fpl->max_e = max_e; fpl->b1 = b1; fpl->b2 = b2;
+                fpl->cnt = (float) cnt;
             }
         }
         pair_sync(lane);
@@ -679,7 +679,8 @@ FX_MARK("p_spec_x2");
             }
             if (lane == 0) {
                 fpl->flux = s[4] + flux; fpl->prod = prod; fpl->vsum = s[5] + vsum;
-                fpl->var = refine ? s[6] + direct : var;
+                fpl->var = refine ? s[6] + direct : var;        // (this kernel forms the spread's sum itself, from its own centroid)
+                fpl->refined = 1;
             }
         }
         next_exchange();

@@ -37,8 +37,10 @@ __device__ __forceinline__ void finalise_values(const EpilogueParams& p, const F
     out[FX_RMS] = log_rms;
 
     const bool spec = p.analysers & 1, harm = p.analysers & 2;
+    // weightedMagnitudeSum (:95) from the moments: fc[m] = (m + 1/2) * frpb (:70), so sum fc * mag = frpb * (b1 + mag_sum / 2)
+    const double wsum = (nyquist / (double) M) * (f.b1 + 0.5 * f.mag_sum);
     if (spec && f.mag_sum > 0.05) {                                            // :121-123
-        const float centroid = f.centroid;
+        const float centroid = (float) (wsum / f.mag_sum);                     // :127
         const double dcnt = (double) f.cnt;
         const double inv_n = 1.0 / (dcnt > 0.0 ? dcnt : 1.0);                  // :129-130
         // :57-60 `flatnessMagnitudeSum > epsilon`: every gated bin alone exceeds epsilon (>= 0) and the terms are positive,
@@ -49,7 +51,14 @@ __device__ __forceinline__ void finalise_values(const EpilogueParams& p, const F
         out[FX_CENTROID] = (float) log10((double) (cc * 9.0f + 1.0f));         // :134
         const double cn = (double) centroid / nyquist;
         const float max_spread = (float) (cn * (1.0 - cn));                    // :140
-        out[FX_SPREAD] = (float) ((f.var / f.mag_sum) / (double) max_spread);  // :141
+        // the spread's sum ((fc - centroid) / nyq)^2 * mag (:135-139) = (b2 + b1 + mag_sum/4) / M^2 - 2 cn (b1 + mag_sum/2) / M + cn^2 mag_sum;
+        // where that form loses too much (the frame kernel's test) the kernel has taken the sum as the reference writes it
+        double var = f.var;
+        if (!f.refined) {
+            const double cm = (double) centroid * (1.0 / nyquist), rm = 1.0 / (double) M;
+            var = ((f.b2 + f.b1 + 0.25 * f.mag_sum) * rm - (cm + cm) * (f.b1 + 0.5 * f.mag_sum)) * rm + (cm * cm) * f.mag_sum;
+        }
+        out[FX_SPREAD] = (float) ((var / f.mag_sum) / (double) max_spread);    // :141
         out[FX_LER] = (float) (f.lhr / f.mag_sum);                             // :125
         const float max_flux = (float) (M * (M + 1)) / 2.0f;                   // :111
         out[FX_FLUX] = (float) (f.flux / (double) max_flux);
@@ -59,7 +68,7 @@ __device__ __forceinline__ void finalise_values(const EpilogueParams& p, const F
         const double rmax = 1.0 / f.max_e;
         const double se = f.mag_sum * rmax;
         const double frpb = nyquist / (double) M;
-        const double s1 = (f.wsum - (frpb / 2.0) * f.mag_sum) / frpb;          // sum m * mag
+        const double s1 = (wsum - (frpb / 2.0) * f.mag_sum) / frpb;            // sum m * mag
         const double ps = s1 * rmax;                                           // :175
         const double mean_e = se / (double) M;                                 // :177
         const double ev = f.vsum * rmax * rmax / (double) M;                   // :187,190

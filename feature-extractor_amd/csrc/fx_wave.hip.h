@@ -21,7 +21,8 @@ __device__ __forceinline__ void wave_fence()
 #ifdef FX_EXP_NO_OPAQUE
 __device__ __forceinline__ int opaque(int v) { return v; }
 #else
-__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+// (a lane index: saying so lets the compiler drop the sign handling of its divisions and the trip tests of per-lane item loops)
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); __builtin_assume((unsigned) v < 64u); return v; }
 #endif
 
 // ---------------------------------------------------------------------------------------------
@@ -136,15 +137,19 @@ __device__ __forceinline__ float wave_sum_f32(float v)
     v += dppz_f<DPP_BCAST31>(v);
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-// maximum of values that are >= 0 (or NaN, which never wins -- as in `if (x > max) max = x`)
+// maximum of values that are >= 0 (or NaN, which never wins -- as in `if (x > max) max = x`).
+// One v_max_f32 with a DPP operand per step, written out: from fmaxf() the compiler emits the DPP move, a v_max x, x to quiet
+// a signalling NaN that cannot be there, and the maximum -- 19 instructions per reduction instead of 7.  (s_nop 1: a DPP read
+// needs two wait states behind the VALU write of its source; rows without a source lane read 0.)
+#define FX_MAX_DPP(v, ctrl) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(v))
 __device__ __forceinline__ float wave_maxf(float v)
 {
-    v = fmaxf(v, dppz_f<DPP_XOR1>(v));
-    v = fmaxf(v, dppz_f<DPP_XOR2>(v));
-    v = fmaxf(v, dppz_f<DPP_HALF_MIRROR>(v));
-    v = fmaxf(v, dppz_f<DPP_MIRROR>(v));
-    v = fmaxf(v, dppz_f<DPP_BCAST15>(v));
-    v = fmaxf(v, dppz_f<DPP_BCAST31>(v));
+    FX_MAX_DPP(v, "quad_perm:[1,0,3,2]");
+    FX_MAX_DPP(v, "quad_perm:[2,3,0,1]");
+    FX_MAX_DPP(v, "row_half_mirror");
+    FX_MAX_DPP(v, "row_mirror");
+    FX_MAX_DPP(v, "row_bcast:15");
+    FX_MAX_DPP(v, "row_bcast:31");
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ int wave_min_i(int v)

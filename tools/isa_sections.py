@@ -12,11 +12,13 @@ src = open(os.path.join(d, "fx_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")).read()
 start = src.index(("_ZN3fxk14fx_pair_kernelILi%sEEEvNS_11FrameParamsE:" if PAIR else "_ZN3fxk15fx_frame_kernelILi%sELb1ELb1EEEvNS_11FrameParamsE:") % N)
 body = src[start:src.index("s_endpgm", start)]
 sec = "pre"; counts = {}; order = []
+DUMP = sys.argv[3] if len(sys.argv) > 3 and sys.argv[2] == "dump" else None    # print one section's ISA instead of the table
 for line in body.splitlines():
     l = line.strip()
     m = re.match(r"; FXMARK (\w+)", l)
     if m:
         sec = m.group(1); continue
+    if DUMP == sec and l and not l.startswith(";"): print(l.split(";")[0].rstrip())
     if not l or l.startswith(";") or l.startswith(".") or l.endswith(":"): continue
     op = l.split()[0]
     if sec not in counts:
@@ -29,6 +31,7 @@ for line in body.splitlines():
     elif op.startswith("s_"): c["s"] += 1
     elif op.startswith("ds_"): c["ds"] += 1
     elif op.startswith(("global_", "buffer_", "scratch_", "flat_")): c["vmem"] += 1
+if DUMP: sys.exit(0)
 tot = dict(v=0, s=0, ds=0)
 print("%-12s %6s %6s %6s %6s %6s %6s" % ("section", "valu", "pk", "f64", "salu", "lds", "vmem"))
 for k in order:
