@@ -6,7 +6,7 @@
 // (+1 %, 126 VGPRs); everywhere else lane-derived values are re-materialised per frame (opaque(): hoisting them all
 // spills 85 registers at 1024 points).
 #ifdef FX_EXP_FFT_NO_HOIST
-#define FFT_OPAQUE(x) opaque(x)
+#define FFT_OPAQUE(x) opaque<N>(x)
 #else
 #define FFT_OPAQUE(x) (x)
 #endif
@@ -637,7 +637,7 @@ __device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cb
     typedef Plan<N> PL;
     constexpr int RA = G::RA, GA = G::GA, L1 = PL::L1, L2 = PL::L2, GB = (N / 16) / 64, HB = GB / 2;
     static_assert(PL::R1 == 16 && PL::R2 == 16 && GA == 4 && GB >= 2 && GB % 2 == 0, "split plan: three passes, even item counts");
-    lane = opaque(lane);
+    lane = opaque<N>(lane);
     f2 ta[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) ta[i] = f2{ftw[2 * i], ftw[2 * i + 1]};

@@ -3,7 +3,7 @@
 #ifndef FX_HOIST_MASK
 #define FX_HOIST_MASK 0
 #endif
-#define FX_OPQ(n, x) (((FX_HOIST_MASK) >> (n)) & 1 ? (x) : opaque(x))
+#define FX_OPQ(n, x) (((FX_HOIST_MASK) >> (n)) & 1 ? (x) : opaque<N>(x))
 // Costing builds only (-DFX_EXP_STOP_AT=k, tools/section_costs.sh): the frame's work ends at stop point k, the values it has
 // formed so far kept alive; the differences of the instruction counters between consecutive k are the sections' dynamic
 // costs.  Results are garbage and nothing waits for a frame that stopped early (the flux turn is taken at stop 8, which every
@@ -198,12 +198,14 @@ template <int N> struct LagSearch {
         carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c_), 63));
         if (s_ >= 2 && c_ < best) { best = c_; best_i = s_; }
         if (first == 0x7fffffff) {
-            const unsigned long long hit = __ballot(s_ >= 2 && c_ < 0.01f);
+            // (lane-index conditions as scalar masks: a ballot of anything but a plain compare costs a select and a second compare)
+            const unsigned long long hit = wave_ballot(c_ < 0.01f) & (blk == 0 ? ~3ull : ~0ull);           // s_ >= 2
             if (hit) first = 64 * blk + (int) __builtin_ctzll(hit);
         }
         if (first != 0x7fffffff) {
             // sample s-1 ends the walk if it is past `first` and cnd does not keep falling
-            const unsigned long long st = __ballot(s_ - 1 >= first && !(c_ < p_));
+            const int k0 = first + 1 - 64 * blk;                                                           // s_ - 1 >= first <=> lane >= k0
+            const unsigned long long st = wave_ballot(!(c_ < p_)) & (k0 <= 0 ? ~0ull : (k0 >= 64 ? 0ull : ~0ull << k0));
             if (st) {
                 const int src = (int) __builtin_ctzll(st);
                 const float pc = lane_get(p_, src), cc = lane_get(c_, src);
@@ -394,7 +396,7 @@ FX_MARK("rms");
         bool inside = false;
 #pragma unroll
         for (int j = 0; j < U; j++) inside |= (fabsf(re[j]) > t_lo) && !(fabsf(re[j]) > t_hi);
-        if (!__any(inside)) return t_hi;              // (a NaN anywhere above lands here too: NaN thresholds gate nothing, as `mag > NaN`)
+        if (!wave_any(inside)) return t_hi;              // (a NaN anywhere above lands here too: NaN thresholds gate nothing, as `mag > NaN`)
         // exact: eps as the reference forms it, then the largest float whose square does not exceed it
         const double eps = 0.01 * (double) exact_log_rms(sum_sq);          // :108
         float t = (float) sqrt(eps);
@@ -455,8 +457,7 @@ FX_MARK("flatprod");
         // mantissa product lies in [0.25,1), so its normalised exponent is exc.exp + e - 1 or exc.exp + e.
         //   overflow  : value >= 2^1024  <=> exponent >= 1025
         //   subnormal : value <  2^-1022 <=> exponent <= -1022
-        const bool risky = (exc.exp + emax >= 1025) || (exc.exp + emin - 1 <= -1022);
-        const unsigned long long risky_lanes = __ballot(risky);
+        const unsigned long long risky_lanes = wave_ballot(exc.exp + emax >= 1025) | wave_ballot(exc.exp + emin - 1 <= -1022);
         if (risky_lanes == 0)
             return ldexp(bcast63(inc.mant), __builtin_amdgcn_readlane(inc.exp, 63));
         // every prefix before the first risky lane is normal, so the serial IEEE product equals the scan there (to
@@ -536,12 +537,14 @@ FX_MARK("spec_sums");
                 if (j >= 1) { Vs += Ts; Ws += Vs; }
                 if (j == LR + 1) t_after = Ts;                                 // sum of the lane's bins after bin LR
                 const bool gate = fabsf(re[j]) > tg;                           // :89 `binMagnitude > epsilon`
-                cnt += __builtin_popcountll(__ballot(gate));
+                cnt += __builtin_popcountll(wave_ballot(gate));
                 if (gate) flat_sum += mag;
                 max_re = fmaxf(max_re, fabsf(re[j]));
             }
             FlatProd floc; int femin, femax;
-            flatness_local(re, tg, floc, femin, femax);
+            // (beside the loop above the two share conversions and squares; at the split sizes, with 16 / 32 bins a lane and the
+            // registers full, that sharing spills, and the product is formed where it is needed)
+            if constexpr (!G::SPLIT) flatness_local(re, tg, floc, femin, femax);
             const double ul = (double) (U * lane);
             double mag_sum = Ts;                                               // B0
             double b1 = ul * Ts + Vs;
@@ -581,6 +584,7 @@ FX_MARK("flux");
             FX_STOP(8, FX_KEEP(mag_sum); FX_KEEP(b1); FX_KEEP(b2); FX_KEEP(lhr); FX_KEEP(max_mag); FX_KEEP(maxabs); FX_KEEP(flat_sum); FX_KEEP(cnt);
                        FX_KEEP(floc.mant); FX_KEEP(floc.exp); FX_KEEP(femin); FX_KEEP(femax); FX_KEEP(flux); return);
             lane = FX_OPQ(1, lane);
+            if constexpr (G::SPLIT) flatness_local(re, tg, floc, femin, femax);
             const double prod = flatness_product(lane, re, tg, floc, femin, femax);
             FX_STOP(9, FX_KEEP(mag_sum); FX_KEEP(b1); FX_KEEP(b2); FX_KEEP(lhr); FX_KEEP(max_mag); FX_KEEP(maxabs); FX_KEEP(flat_sum); FX_KEEP(cnt);
                        FX_KEEP(prod); FX_KEEP(flux); return);
@@ -660,6 +664,17 @@ FX_MARK("harm1");
         wave_fence();
     }
 
+    // out[i] = a * in[i], formed two at a time and hidden from the vectoriser, which otherwise pairs a*x with b*y of the
+    // recurrence below (a packed multiply, a move and a horizontal add per sample instead of a multiply and an add)
+    template <int K> static __device__ __forceinline__ void scaled_pairs(float a, const float* in, float* out)
+    {
+#pragma unroll
+        for (int i = 0; i < K; i += 2) {
+            const f2 t = f2{in[i], in[i + 1]} * a;
+            out[i] = t.x; out[i + 1] = t.y;
+            asm volatile("" : "+v"(out[i]), "+v"(out[i + 1]));
+        }
+    }
     // returns f0 = sampleRate / lag (ref PitchAnalyser.h:57) and records the lag
     // a10 + ref RealTimeAnalyser.h:157: the one-pole low-pass of the raw frame, windowed, left in the real image
     __device__ __forceinline__ void lowpass_window(int lane) const
@@ -690,33 +705,43 @@ FX_MARK("lpf");
                 if (n0 >= 0) {
                     const f4 v = *reinterpret_cast<const f4*>(&rbuf[rimg<N>(n0)]);
                     const float w[4] = {v.x, v.y, v.z, v.w};
+                    float aw[4];
+                    scaled_pairs<4>(a, w, aw);
 #pragma unroll
                     for (int e = 0; e < 4; e++)       // sample 0 starts the filter exactly; the first
-                        yin = (n0 + e == 0 || (q == 0 && e == 0)) ? w[e] : (a * w[e]) + (b * yin);   // warm-up sample is a guess
+                        yin = (n0 + e == 0 || (q == 0 && e == 0)) ? w[e] : aw[e] + (b * yin);        // warm-up sample is a guess
                 }
             }
         }
         wave_fence();
         float y[P];
         float ylast;
+        // a * x[n], two products per instruction; the chain is then one multiply and one add a sample.  All P of them where
+        // the registers have room (they serve the redo below as well), four at a time at the split sizes.
+        constexpr int AXN = G::SPLIT ? 4 : P;
+        float ax[AXN];
         {
             float yy = yin;
 #pragma unroll
-            for (int i = 0; i < P; i++) {
-                yy = (lane == 0 && i == 0) ? x[0] : (a * x[i]) + (b * yy);
-                y[i] = yy;
+            for (int i = 0; i < P; i += AXN) {
+                scaled_pairs<AXN>(a, &x[i], ax);
+#pragma unroll
+                for (int e = 0; e < AXN; e++) {
+                    yy = (lane == 0 && i + e == 0) ? x[0] : ax[e] + (b * yy);
+                    y[i + e] = yy;
+                }
             }
             ylast = yy;
         }
         for (int iter = 0; iter < 64; iter++) {
             const float pe = shift_up1(ylast, 0.0f);
-            const bool bad = lane > 0 && (__float_as_uint(pe) != __float_as_uint(yin));
-            if (!__any(bad)) break;
-            if (bad) {
+            const unsigned long long bad_lanes = wave_ballot(__float_as_uint(pe) != __float_as_uint(yin)) & ~1ull;     // lanes > 0
+            if (!bad_lanes) break;
+            if ((bad_lanes >> lane) & 1) {
                 yin = pe;
                 float yy = yin;
 #pragma unroll
-                for (int i = 0; i < P; i++) { yy = (a * x[i]) + (b * yy); y[i] = yy; }
+                for (int i = 0; i < P; i++) { yy = (AXN == P ? ax[i % AXN] : a * x[i]) + (b * yy); y[i] = yy; }
                 ylast = yy;
             }
         }
@@ -868,7 +893,7 @@ FX_MARK("harm2");
                 const float band = root_mean * 3e-6f;
                 unsigned long long near = 0;                                   // (lane masks: a bool would be packed into bytes)
 #pragma unroll
-                for (int j = 0; j < U; j++) near |= __ballot(fabsf(fabsf(hre[j]) - root_mean) <= band);
+                for (int j = 0; j < U; j++) near |= wave_ballot(fabsf(fabsf(hre[j]) - root_mean) <= band);
                 if (near) {
                     double run = 0.0;
                     for (int l = 0; l < 64; l++) {

@@ -410,7 +410,7 @@ FX_MARK("p_lpf");
             for (int iter = 0; iter < 130; iter++) {
                 const float pe = shift_up1(ylast, from_left);
                 const bool bad = gl > 0 && (__float_as_uint(pe) != __float_as_uint(yin));
-                if (!__any(bad)) break;
+                if (!wave_any(bad)) break;
                 if (bad) {
                     yin = pe;
                     float yy = yin;
@@ -486,7 +486,7 @@ FX_MARK("p_lag");
         bool inside = false;
 #pragma unroll
         for (int j = 0; j < U2; j++) inside |= (fabsf(re[j]) > t_lo) && !(fabsf(re[j]) > t_hi);
-        if (!__any(inside)) return t_hi;          // gates this wave's bins exactly as the true threshold would
+        if (!wave_any(inside)) return t_hi;          // gates this wave's bins exactly as the true threshold would
         const double eps = 0.01 * (double) FrameWave<N>::exact_log_rms(sum_sq);
         float tt = (float) sqrt(eps);
         const float up = __uint_as_float(__float_as_uint(tt) + 1u);
@@ -523,7 +523,7 @@ FX_MARK("p_spec_sums");
             if (j >= 1) { Vs += Ts; Ws += Vs; }
             if (j == LR + 1) t_after = Ts;
             const bool gate = fabsf(re[j]) > tg;                               // :89
-            cnt += __builtin_popcountll(__ballot(gate));
+            cnt += __builtin_popcountll(wave_ballot(gate));
             if (gate) flat_sum += mag;
             max_re = fmaxf(max_re, fabsf(re[j]));
         }
@@ -639,7 +639,7 @@ FX_MARK("p_spec_x2");
         // exchange 2: wave 0 -> wave 1, which finishes flux, product, vsum (and the direct spread) and records them
         if (w == 0) {
             const bool risky = (exc.exp + emax >= 1025) || (exc.exp + emin - 1 <= -1022);
-            const unsigned long long risky_lanes = __ballot(risky);
+            const unsigned long long risky_lanes = wave_ballot(risky);
             double pr_end = 0.0;
             if (risky_lanes) {
                 const int owner = (int) __builtin_ctzll(risky_lanes);
@@ -668,7 +668,7 @@ FX_MARK("p_spec_x2");
             } else {
                 const FlatProd ex = fp_mul2(tot0, exc);                        // prefix before this lane, wave 0's bins included
                 const bool risky = (ex.exp + emax >= 1025) || (ex.exp + emin - 1 <= -1022);
-                const unsigned long long risky_lanes = __ballot(risky);
+                const unsigned long long risky_lanes = wave_ballot(risky);
                 if (risky_lanes) {
                     const int owner = (int) __builtin_ctzll(risky_lanes);
                     prod = serial_from(ldexp(lane_get(ex.mant, owner), lane_get(ex.exp, owner)), owner);
@@ -748,7 +748,7 @@ FX_MARK("p_harm_sums");
             bool near = false;
 #pragma unroll
             for (int j = 0; j < U2; j++) near |= fabsf(fabsf(hre[j]) - root_mean) <= band;
-            const bool near_wave = __any(near);
+            const bool near_wave = wave_any(near);
             if (lane == 0) *slot(w, 0) = near_wave ? 1.0 : 0.0;
             pair_sync(lane);
             const bool near_any = *slot(0, 0) != 0.0 || *slot(1, 0) != 0.0;
@@ -934,7 +934,7 @@ fx_pair_kernel(const FrameParams p_arg)
 #endif
     };
     for (int t = live ? t_begin + slot : t_end; t < t_end; t += K) {
-        const int ln = opaque(lane);
+        const int ln = opaque<N>(lane);
         pw.t = t;
 #ifdef FX_PAIR_STAMPS
         pw.stamp_i = 0;
@@ -957,8 +957,8 @@ fx_pair_kernel(const FrameParams p_arg)
         float lag = 100.0f;
         if (!(FX_EXP_PAIR_SKIP & 1)) lag = pw.pitch(ln);
         const double f0 = (nyquist * 2.0) / (double) lag;                      // ref PitchAnalyser.h:57
-        if (!(FX_EXP_PAIR_SKIP & 2)) pw.spectral(opaque(ln), sum_sq);
-        if (!(FX_EXP_PAIR_SKIP & 4)) { typename PairWave<N>::HarmonicSpectrum hs; pw.harmonic_spectrum(opaque(ln), hs); pw.harmonic_tail(opaque(ln), hs, f0); }
+        if (!(FX_EXP_PAIR_SKIP & 2)) pw.spectral(opaque<N>(ln), sum_sq);
+        if (!(FX_EXP_PAIR_SKIP & 4)) { typename PairWave<N>::HarmonicSpectrum hs; pw.harmonic_spectrum(opaque<N>(ln), hs); pw.harmonic_tail(opaque<N>(ln), hs, f0); }
 #ifdef FX_PAIR_STAMPS
         pw.stamp(ln);
 #endif

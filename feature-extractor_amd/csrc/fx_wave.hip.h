@@ -7,6 +7,10 @@
 typedef float  __attribute__((ext_vector_type(2))) f2;
 typedef float  __attribute__((ext_vector_type(4))) f4;
 
+// lane mask of a condition, straight from the compare (HIP's __ballot / __any take an int: a select to 0 / 1 and a second compare)
+__device__ __forceinline__ unsigned long long wave_ballot(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+__device__ __forceinline__ bool wave_any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0; }
+
 __device__ __forceinline__ void wave_fence()
 {
     // LDS operations of one wavefront execute in order; this only stops the compiler from moving
@@ -19,10 +23,19 @@ __device__ __forceinline__ void wave_fence()
 // loop (loop-invariant code motion would otherwise keep hundreds of addresses, window gains and
 // shuffle indices live across the whole loop and spill them).
 #ifdef FX_EXP_NO_OPAQUE
-__device__ __forceinline__ int opaque(int v) { return v; }
+template <int N = 0> __device__ __forceinline__ int opaque(int v) { return v; }
 #else
 // (a lane index: saying so lets the compiler drop the sign handling of its divisions and the trip tests of per-lane item loops)
-__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); __builtin_assume((unsigned) v < 64u); return v; }
+// FX_LANE_RANGE_MAX: largest window whose kernels are told so (experiments)
+#ifndef FX_LANE_RANGE_MAX
+#define FX_LANE_RANGE_MAX 4096
+#endif
+template <int N = 0> __device__ __forceinline__ int opaque(int v)
+{
+    asm volatile("" : "+v"(v));
+    if constexpr (N <= FX_LANE_RANGE_MAX) __builtin_assume((unsigned) v < 64u);
+    return v;
+}
 #endif
 
 // ---------------------------------------------------------------------------------------------
