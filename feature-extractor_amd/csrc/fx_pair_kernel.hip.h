@@ -389,9 +389,11 @@ FX_MARK("p_lpf");
                 if (n0 >= 0) {
                     const f4 v = *reinterpret_cast<const f4*>(&rbuf[prim<N>(n0)]);
                     const float wv[4] = {v.x, v.y, v.z, v.w};
+                    float aw[4];
+                    FrameWave<N>::template scaled_pairs<4>(a, wv, aw);        // (see FrameWave::lowpass_window)
 #pragma unroll
                     for (int e = 0; e < 4; e++)
-                        yin = (n0 + e == 0 || (q == 0 && e == 0)) ? wv[e] : (a * wv[e]) + (b * yin);
+                        yin = (n0 + e == 0 || (q == 0 && e == 0)) ? wv[e] : aw[e] + (b * yin);
                 }
             }
         }
@@ -400,18 +402,23 @@ FX_MARK("p_lpf");
         {
             float yy = yin;
 #pragma unroll
-            for (int i = 0; i < P2; i++) {
-                yy = (gl == 0 && i == 0) ? x[0] : (a * x[i]) + (b * yy);
-                y[i] = yy;
+            for (int i = 0; i < P2; i += 4) {
+                float ax[4];
+                FrameWave<N>::template scaled_pairs<4>(a, &x[i], ax);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    yy = (gl == 0 && i + e == 0) ? x[0] : ax[e] + (b * yy);
+                    y[i + e] = yy;
+                }
             }
             ylast = yy;
         }
         auto converge = [&](float from_left) {
             for (int iter = 0; iter < 130; iter++) {
                 const float pe = shift_up1(ylast, from_left);
-                const bool bad = gl > 0 && (__float_as_uint(pe) != __float_as_uint(yin));
-                if (!wave_any(bad)) break;
-                if (bad) {
+                const unsigned long long bad_lanes = wave_ballot(__float_as_uint(pe) != __float_as_uint(yin)) & (w == 0 ? ~1ull : ~0ull);   // gl > 0
+                if (!bad_lanes) break;
+                if ((bad_lanes >> lane) & 1) {
                     yin = pe;
                     float yy = yin;
 #pragma unroll
@@ -638,8 +645,7 @@ FX_MARK("p_pass2");
 FX_MARK("p_spec_x2");
         // exchange 2: wave 0 -> wave 1, which finishes flux, product, vsum (and the direct spread) and records them
         if (w == 0) {
-            const bool risky = (exc.exp + emax >= 1025) || (exc.exp + emin - 1 <= -1022);
-            const unsigned long long risky_lanes = wave_ballot(risky);
+            const unsigned long long risky_lanes = wave_ballot(exc.exp + emax >= 1025) | wave_ballot(exc.exp + emin - 1 <= -1022);
             double pr_end = 0.0;
             if (risky_lanes) {
                 const int owner = (int) __builtin_ctzll(risky_lanes);
@@ -667,8 +673,7 @@ FX_MARK("p_spec_x2");
                 prod = (pr0_end == 0.0 || pr0_end == __builtin_huge_val()) ? pr0_end : serial_from(pr0_end, 0);
             } else {
                 const FlatProd ex = fp_mul2(tot0, exc);                        // prefix before this lane, wave 0's bins included
-                const bool risky = (ex.exp + emax >= 1025) || (ex.exp + emin - 1 <= -1022);
-                const unsigned long long risky_lanes = wave_ballot(risky);
+                const unsigned long long risky_lanes = wave_ballot(ex.exp + emax >= 1025) | wave_ballot(ex.exp + emin - 1 <= -1022);
                 if (risky_lanes) {
                     const int owner = (int) __builtin_ctzll(risky_lanes);
                     prod = serial_from(ldexp(lane_get(ex.mant, owner), lane_get(ex.exp, owner)), owner);
@@ -745,10 +750,10 @@ FX_MARK("p_harm_sums");
         {
             const float root_mean = __builtin_amdgcn_sqrtf((float) mean_mag);
             const float band = root_mean * 3e-6f;
-            bool near = false;
+            unsigned long long near = 0;                                       // (lane masks: a bool would be packed into bytes)
 #pragma unroll
-            for (int j = 0; j < U2; j++) near |= fabsf(fabsf(hre[j]) - root_mean) <= band;
-            const bool near_wave = wave_any(near);
+            for (int j = 0; j < U2; j++) near |= wave_ballot(fabsf(fabsf(hre[j]) - root_mean) <= band);
+            const bool near_wave = near != 0;
             if (lane == 0) *slot(w, 0) = near_wave ? 1.0 : 0.0;
             pair_sync(lane);
             const bool near_any = *slot(0, 0) != 0.0 || *slot(1, 0) != 0.0;
