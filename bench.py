@@ -195,12 +195,24 @@ def _parse_counter_csv(out_dir, kernel_substr):
     return {c: sums[c] / counts[c] for c in sums}, (max(counts.values()) if counts else 0)
 
 
+def under_profiler(environ=None):
+    """True when this process was started by rocprofv3 / rocprof (their tool libraries ride in on these variables)."""
+    e = os.environ if environ is None else environ
+    if any("rocprof" in e.get(k, "").lower() for k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY")):
+        return True
+    return any(k.startswith(("ROCPROF_", "ROCPROFILER_")) for k in e)
+
+
 def measure_counters(window, channels, frames, input_file, timeout_s=150):
     """Per-launch counters of the frame kernel at this shape, read now: each pass is a child `rocprofv3 --pmc ... --
     python3 bench.py --pmc-child ...` (a fresh process; this one is never re-executed).  Returns (dict or None, note)."""
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    if under_profiler():
+        # a child launcher would inherit the tool library, initialise the GPU with it and then exec its target: the one thing
+        # a GPU-initialised process must not do on this pool.  The outer profiler is collecting what it was asked for.
+        return None, "not read: this run is itself under a profiler"
     tmp = tempfile.mkdtemp(prefix="fx_pmc_", dir="/tmp")
     env = dict(os.environ)
     env["TMPDIR"] = "/tmp"
@@ -709,7 +721,7 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
     def live_cadence():
         # The reference's own cadence at scale: every channel's analysers run once per hop as it arrives
         # (ref AudioDataCollector.h:66-94, RealTimeAnalyser.h:201-234): MANY channels x ONE hop per call, device-resident
-        # hops through fx_push_hops, which runs such a call as one launch of fx_hop_kernel.
+        # hops through fx_push_hops (which picks fx_hop_kernel or the batch kernels by the size of the call).
         res = {}
         for c3 in (1024, 8192):
             hops = torch.from_numpy(fx.synth.hops(c3, 16, N)).cuda(dev)
@@ -730,8 +742,9 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
                             "real_time_factor": (c3 * n_calls / dt3) / (c3 * 48000.0 / (N // 2))}
             del hops, views
         res["note"] = ("%d-pt windows, ONE hop (%d samples) per channel per call, calls back to back on one stream (fx_push_hops, device-resident "
-                       "hops, fx_hop_kernel: three wavefronts per channel + the hop's tail in one launch); real_time_factor = frames/s over the "
-                       "frames/s that many live 48 kHz channels produce" % (N, N // 2))
+                       "hops; up to 2^20 samples per call one launch of fx_hop_kernel -- three wavefronts per channel + the hop's tail -- above "
+                       "that the frame kernel with four channels per workgroup + the fused tail with a lane per slot); real_time_factor = "
+                       "frames/s over the frames/s that many live 48 kHz channels produce" % (N, N // 2))
         return res
 
     def streaming_hop():

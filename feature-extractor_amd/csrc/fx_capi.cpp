@@ -410,10 +410,12 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     // ONE frame per channel -- the reference's own cadence, an analysis per hop as it arrives (AudioDataCollector.h:66-94,
     // RealTimeAnalyser.h:201-234) -- is one launch of fx_hop_kernel: three wavefronts per channel (pitch / spectral /
     // harmonic) and the hop's tail, instead of one wavefront per channel and a second launch.
-    // (measured, tools/live_cadence.py: at 2048 / 4096 points the batch kernels take over above ~1000 channels -- 152 against 166 us at
-    // 4096 channels x 2048-pt -- where the chip is full either way and three wavefronts per channel only add scheduling)
+    // (measured, tools/live_cadence.py, profiles/r03_variants.txt (c): once the call holds more than ~a million samples -- 1024 channels of
+    // 1024 points, 512 of 2048, 256 of 4096 -- the chip is full either way and the batch kernels take over: one wavefront per channel
+    // with four channels sharing a twiddle table, then the fused tail with a lane per slot: 153 against 176 us at 8192 channels x
+    // 1024-pt, 103 against 140 us at 1024 channels x 4096-pt)
     const bool one_hop = T == 1 && step.analysers == 3 && fxk::hop_kernel_available(c->N) &&
-                         (c->tuning.one_hop_kernel == 1 || (c->tuning.one_hop_kernel < 0 && (c->N <= 1024 || c->C <= 1024)));
+                         (c->tuning.one_hop_kernel == 1 || (c->tuning.one_hop_kernel < 0 && (long long) c->C * c->N <= (1ll << 20)));
     if (one_hop) {
         const fxk::HopSignal none = {nullptr, nullptr, 0u, 0u, nullptr};
         HIP_TRY(hipEventRecord(e0, c->stream));

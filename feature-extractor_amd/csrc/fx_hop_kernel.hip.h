@@ -101,10 +101,10 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
         // (-DFX_EXP_HOP_EARLY_EPILOGUE also finishes their smoothing, the onset and the history rows that merely move up here, leaving
         // four slots and one row behind the last barrier: measured 1-3 us SLOWER per hop at every size -- the early stores to the
         // pinned host slot are in the way of the later ones -- so everything is finished at the end.)
+        EpilogueParams e1 = ep_arg; e1.analysers = 1;
+        float out[FX_NUM_FEATURES];
+        finalise_wave(e1, *part, lane, out);                    // (every lane: the logarithms side by side)
         if (lane == 0) {
-            EpilogueParams e1 = ep_arg; e1.analysers = 1;
-            float out[FX_NUM_FEATURES];
-            finalise_values(e1, *part, out);
             s_raw[FX_ONSET] = 0.0f; s_raw[FX_RMS] = out[FX_RMS]; s_raw[FX_CENTROID] = out[FX_CENTROID]; s_raw[FX_SPREAD] = out[FX_SPREAD];
             s_raw[FX_FLATNESS] = out[FX_FLATNESS]; s_raw[FX_LER] = out[FX_LER]; s_raw[FX_FLUX] = out[FX_FLUX]; s_raw[FX_SLOPE] = out[FX_SLOPE];
         }
@@ -135,10 +135,10 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
     if (wave == 2) {
         const double f0 = (nyquist * 2.0) / (double) part->lag; // ref PitchAnalyser.h:57
         w.harmonic_tail(lane, hs, f0);
+        EpilogueParams e2 = ep_arg; e2.analysers = 2;
+        float out[FX_NUM_FEATURES];
+        finalise_wave(e2, *part, lane, out);
         if (lane == 0) {                                        // the harmonic analyser's slots (ref RealTimeAnalyser.h:150-172)
-            EpilogueParams e2 = ep_arg; e2.analysers = 2;
-            float out[FX_NUM_FEATURES];
-            finalise_values(e2, *part, out);
             s_raw[FX_F0] = out[FX_F0]; s_raw[FX_HER] = out[FX_HER]; s_raw[FX_OER] = out[FX_OER]; s_raw[FX_INHARM] = out[FX_INHARM];
         }
     }
@@ -290,10 +290,10 @@ fx_hop_pair_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const H
         for (int i = 64 * w + lane; i < M; i += 128) p.prev_re[(size_t) c * M + i] = prev[i];
         if (w == 0) {
             // this analyser's slots (ref RealTimeAnalyser.h:209-226), while the pitch estimate is still running
+            EpilogueParams e1 = ep_arg; e1.analysers = 1;
+            float out[FX_NUM_FEATURES];
+            finalise_wave(e1, *part, lane, out);                // (every lane: the logarithms side by side)
             if (lane == 0) {
-                EpilogueParams e1 = ep_arg; e1.analysers = 1;
-                float out[FX_NUM_FEATURES];
-                finalise_values(e1, *part, out);
                 s_raw[FX_ONSET] = 0.0f; s_raw[FX_RMS] = out[FX_RMS]; s_raw[FX_CENTROID] = out[FX_CENTROID]; s_raw[FX_SPREAD] = out[FX_SPREAD];
                 s_raw[FX_FLATNESS] = out[FX_FLATNESS]; s_raw[FX_LER] = out[FX_LER]; s_raw[FX_FLUX] = out[FX_FLUX]; s_raw[FX_SLOPE] = out[FX_SLOPE];
             }
@@ -313,11 +313,11 @@ fx_hop_pair_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const H
     if (pair == 2) {
         const double f0 = (nyquist * 2.0) / (double) part->lag; // ref PitchAnalyser.h:57
         pw.harmonic_tail(lane, hs, f0);                         // a16-a18
-        if (w == 0 && lane == 0) {                              // the harmonic analyser's slots (ref RealTimeAnalyser.h:150-172)
+        if (w == 0) {                                           // the harmonic analyser's slots (ref RealTimeAnalyser.h:150-172)
             EpilogueParams e2 = ep_arg; e2.analysers = 2;
             float out[FX_NUM_FEATURES];
-            finalise_values(e2, *part, out);
-            s_raw[FX_F0] = out[FX_F0]; s_raw[FX_HER] = out[FX_HER]; s_raw[FX_OER] = out[FX_OER]; s_raw[FX_INHARM] = out[FX_INHARM];
+            finalise_wave(e2, *part, lane, out);
+            if (lane == 0) { s_raw[FX_F0] = out[FX_F0]; s_raw[FX_HER] = out[FX_HER]; s_raw[FX_OER] = out[FX_OER]; s_raw[FX_INHARM] = out[FX_INHARM]; }
         }
     }
     __syncthreads();                                            // the record is complete

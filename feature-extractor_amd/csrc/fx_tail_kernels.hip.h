@@ -24,7 +24,12 @@ __device__ __forceinline__ EpilogueParams with_dyn(const EpilogueParams& in)
 // the harmonic logs (ref HarmonicCharacteristics.h:101-105) and the slot mapping of
 // RealTimeAnalyser.h:165-172,219-224.  Output: raw[C][T][12] with the onset slot still 0.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void finalise_values(const EpilogueParams& p, const FramePart& f, float (&out)[FX_NUM_FEATURES])
+// Five of the twelve values end in (float) log10(x) -- logRMS, flatness, centroid, HER, inharmonicity -- and those logarithms are
+// half of this function's instructions.  `logs[5]` receives their arguments (1.0, whose logarithm is +0, where the reference
+// leaves the slot at 0); the caller takes the logarithms -- one after the other in a thread that owns a frame, or side by
+// side in five lanes of a wavefront that finishes one hop -- and stores them with finalise_logs().
+enum { LOG_RMS = 0, LOG_FLATNESS = 1, LOG_CENTROID = 2, LOG_HER = 3, LOG_INHARM = 4, NUM_LOGS = 5 };
+__device__ __forceinline__ void finalise_values(const EpilogueParams& p, const FramePart& f, float (&out)[FX_NUM_FEATURES], double (&logs)[NUM_LOGS])
 {
     const int M = p.window / 2;
     const double nyquist = p.nyquist;
@@ -33,8 +38,8 @@ __device__ __forceinline__ void finalise_values(const EpilogueParams& p, const F
     // a2, ref RealTimeAnalyser.h:207-208: log10 of a float, correctly rounded -- it also gates bins through eps, so it
     // must equal the CPU oracle's to the last bit (see oracle/fx_oracle.c)
     const float rms = (float) sqrt(f.sum_sq / (double) p.window);
-    const float log_rms = (float) log10((double) (rms * 9.0f + 1.0f));
-    out[FX_RMS] = log_rms;
+    logs[LOG_RMS] = (double) (rms * 9.0f + 1.0f);
+    logs[LOG_FLATNESS] = 1.0; logs[LOG_CENTROID] = 1.0; logs[LOG_HER] = 1.0; logs[LOG_INHARM] = 1.0;
 
     const bool spec = p.analysers & 1, harm = p.analysers & 2;
     // weightedMagnitudeSum (:95) from the moments: fc[m] = (m + 1/2) * frpb (:70), so sum fc * mag = frpb * (b1 + mag_sum / 2)
@@ -46,9 +51,9 @@ __device__ __forceinline__ void finalise_values(const EpilogueParams& p, const F
         // :57-60 `flatnessMagnitudeSum > epsilon`: every gated bin alone exceeds epsilon (>= 0) and the terms are positive,
         // so the test is "at least one bin passed the gate"
         const float flatness = f.cnt > 0.0f ? (float) (pow(f.prod, inv_n) / (inv_n * f.flat_sum)) : 0.0f;
-        out[FX_FLATNESS] = (float) log10((double) flatness * 9.0 + 1.0);       // :132
+        logs[LOG_FLATNESS] = (double) flatness * 9.0 + 1.0;                    // :132
         const float cc = centroid / (float) (nyquist / 2.0);                   // :133
-        out[FX_CENTROID] = (float) log10((double) (cc * 9.0f + 1.0f));         // :134
+        logs[LOG_CENTROID] = (double) (cc * 9.0f + 1.0f);                      // :134
         const double cn = (double) centroid / nyquist;
         const float max_spread = (float) (cn * (1.0 - cn));                    // :140
         // the spread's sum ((fc - centroid) / nyq)^2 * mag (:135-139) = (b2 + b1 + mag_sum/4) / M^2 - 2 cn (b1 + mag_sum/2) / M + cn^2 mag_sum;
@@ -85,22 +90,62 @@ __device__ __forceinline__ void finalise_values(const EpilogueParams& p, const F
         if (her > 1.0) her = 1.0;
         if (her < 0.0) her = 0.0;
         her = (double) (float) her;                                            // struct of floats, :197
-        const float log_her = (float) log10(her * 9.0 + 1.0);                  // :101
-        out[FX_HER] = log_her;
-        out[FX_OER] = log_her;                                                 // ref RealTimeAnalyser.h:171 writes HER into the OER slot
-        out[FX_INHARM] = (float) log10(f.inh * 9.0 + 1.0);                     // :102
+        logs[LOG_HER] = her * 9.0 + 1.0;                                       // :101
+        logs[LOG_INHARM] = f.inh * 9.0 + 1.0;                                  // :102
     }
+}
+__device__ __forceinline__ void finalise_logs(const float (&y)[NUM_LOGS], float (&out)[FX_NUM_FEATURES])
+{
+    out[FX_RMS] = y[LOG_RMS];
+    out[FX_FLATNESS] = y[LOG_FLATNESS];
+    out[FX_CENTROID] = y[LOG_CENTROID];
+    out[FX_HER] = y[LOG_HER];
+    out[FX_OER] = y[LOG_HER];                                                  // ref RealTimeAnalyser.h:171 writes HER into the OER slot
+    out[FX_INHARM] = y[LOG_INHARM];
 }
 
 __device__ __forceinline__ void finalise_frame(const EpilogueParams& p, long long idx)
 {
     const FramePart f = p.part[idx];
     float out[FX_NUM_FEATURES];
-    finalise_values(p, f, out);
+    double logs[NUM_LOGS];
+    float y[NUM_LOGS];
+    finalise_values(p, f, out, logs);
+#pragma unroll
+    for (int i = 0; i < NUM_LOGS; i++) y[i] = (float) log10(logs[i]);
+    finalise_logs(y, out);
     f4* dst = reinterpret_cast<f4*>(p.raw + idx * FX_NUM_FEATURES);
     dst[0] = f4{out[0], out[1], out[2], out[3]};
     dst[1] = f4{out[4], out[5], out[6], out[7]};
     dst[2] = f4{out[8], out[9], out[10], out[11]};
+}
+
+// The same for the one frame of a one-hop call, by a whole wavefront: every lane forms the values (they are uniform), lanes
+// 0..4 take one logarithm each, lane 0 stores.  Bit for bit what finalise_frame writes.
+__device__ __forceinline__ void finalise_wave(const EpilogueParams& p, const FramePart& f, int lane, float (&out)[FX_NUM_FEATURES])
+{
+    double logs[NUM_LOGS];
+    float y[NUM_LOGS];
+    finalise_values(p, f, out, logs);
+    double mine = logs[0];
+#pragma unroll
+    for (int i = 1; i < NUM_LOGS; i++) mine = lane == i ? logs[i] : mine;
+    const float ym = (float) log10(mine);
+#pragma unroll
+    for (int i = 0; i < NUM_LOGS; i++) y[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ym), i));
+    finalise_logs(y, out);
+}
+__device__ __forceinline__ void finalise_hop(const EpilogueParams& p, long long idx, int lane)
+{
+    const FramePart f = p.part[idx];
+    float out[FX_NUM_FEATURES];
+    finalise_wave(p, f, lane, out);
+    if (lane == 0) {
+        f4* dst = reinterpret_cast<f4*>(p.raw + idx * FX_NUM_FEATURES);
+        dst[0] = f4{out[0], out[1], out[2], out[3]};
+        dst[1] = f4{out[4], out[5], out[6], out[7]};
+        dst[2] = f4{out[8], out[9], out[10], out[11]};
+    }
 }
 
 #ifdef FX_WITH_TAIL_KERNELS
@@ -449,10 +494,12 @@ fx_tail_fused_kernel(const EpilogueParams p_arg)
 {
     __shared__ float s_hist[HLEN * FX_NUM_FEATURES];
     __shared__ float s_raw[FUSED_TAIL_MAX_FRAMES * FX_NUM_FEATURES];
+    __shared__ float s_scratch[64];
     EpilogueParams p = with_dyn(p_arg);
     const int c = blockIdx.x, lane = threadIdx.x;
     for (int i = lane; i < HLEN * FX_NUM_FEATURES; i += 64) s_hist[i] = p.hist_in[(size_t) c * HLEN * FX_NUM_FEATURES + i];
-    if (lane < p.T) finalise_frame(p, (long long) c * p.T + lane);
+    if (p.T == 1) finalise_hop(p, (long long) c, lane);
+    else if (lane < p.T) finalise_frame(p, (long long) c * p.T + lane);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");           // the wave's raw values are written before any lane reads them back
     __builtin_amdgcn_s_barrier();
     for (int i = lane; i < p.T * FX_NUM_FEATURES; i += 64) s_raw[i] = p.raw[(size_t) c * p.T * FX_NUM_FEATURES + i];
@@ -462,7 +509,8 @@ fx_tail_fused_kernel(const EpilogueParams p_arg)
     const float* g_raw = p.raw; const float* g_hist = p.hist_in;
     p.raw = s_raw - (size_t) c * p.T * FX_NUM_FEATURES;
     p.hist_in = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
-    if (lane < p.T) epilogue_frame(p, c, lane);
+    if (p.T == 1) epilogue_hop(p, c, lane, s_scratch);                // one hop: a lane per slot, the onset detector's candidates side by side
+    else if (lane < p.T) epilogue_frame(p, c, lane);
     p.raw = const_cast<float*>(g_raw); p.hist_in = g_hist;
     for (int i = lane; i < HLEN * FX_NUM_FEATURES; i += 64) history_value(p, (long long) c * HLEN * FX_NUM_FEATURES + i);
 }

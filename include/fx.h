@@ -181,7 +181,7 @@ typedef struct fx_tuning {
     int stream_hop_kernel;       /* FX_STREAM_HOP_KERNEL: 0 forbids the one-launch hop kernel in the ring; -1 = when it applies */
     int stream_zero_copy;        /* FX_STREAM_ZEROCOPY: 1 / 0 force / forbid zero-copy slots in the captured step; -1 = by size */
     int one_hop_kernel;          /* FX_ONE_HOP_KERNEL: 0 / 1 = fx_push_hops / fx_process_frames of ONE frame per channel never / always run
-                                    the one-launch hop kernel; -1 = where it is the faster of the two (windows <= 1024 points, or <= 1024 channels) */
+                                    the one-launch hop kernel; -1 = where it is the faster of the two (channels x window <= 2^20 samples) */
     int handover_spin_limit;     /* FX_HANDOVER_SPINS: polls a work unit spends waiting for its predecessor's flux state
                                     before it gives up and the call is reported failed (FX_ERR_HIP); 0 = default (1 << 22) */
     int debug_flags;             /* FX_DEBUG_FLAGS: bit 0 = work units do not publish their hand-over (forces the time-out; tests);

@@ -129,3 +129,13 @@ def test_gpus_n_without_a_launcher_starts_its_own_ranks(monkeypatch):
         raise AssertionError("expected SystemExit")
     except SystemExit as e:
         assert "only 1 GPU" in str(e.code)
+
+
+def test_no_nested_profiler_children():
+    """A bench.py that runs under rocprofv3 must not start rocprofv3 children of its own (they would inherit the tool library,
+    initialise the GPU in the launcher and then exec)."""
+    import bench
+    assert not bench.under_profiler({})
+    assert bench.under_profiler({"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so"})
+    assert bench.under_profiler({"ROCPROF_OUTPUT_PATH": "/tmp/x"})
+    assert bench.under_profiler({"ROCP_TOOL_LIBRARIES": "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"})

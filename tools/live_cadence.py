@@ -1,11 +1,11 @@
 """On the GPU box: microseconds per call of ONE hop per channel (device-resident hops, fx_push_hops back to back), hop kernel against
-the batch kernels at several workgroup shapes.  Usage: python3 tools/live_cadence.py [N]"""
+the batch kernels at several workgroup shapes.  Usage: python3 tools/live_cadence.py [N [C ...]]"""
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 fx = importlib.import_module("feature-extractor_amd")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-for C in (1, 64, 256, 512, 1024, 2048, 4096, 8192):
+for C in ([int(a) for a in sys.argv[2:]] or (1, 64, 256, 512, 1024, 2048, 4096, 8192)):
     hops = torch.from_numpy(fx.synth.hops(C, 8, N)).cuda()
     views = [hops[:, k:k + 1].contiguous() for k in range(8)]
     r = torch.empty((C, 1, 12), dtype=torch.float32, device="cuda")

@@ -6,9 +6,9 @@ TAG=${1:-r01}; shift || true
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra $*"
+BENCH="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra --no-pmc $*"
 # the trace pass runs the bench default step count so its per-kernel average is comparable with bench.py's own
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-extra $* > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline --no-extra --no-pmc $* > $OUT/trace.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- $BENCH > $OUT/pmc_$c.log 2>&1
 done
