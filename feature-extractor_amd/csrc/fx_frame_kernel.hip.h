@@ -243,19 +243,24 @@ template <int N> struct LagSearch {
 #ifndef FX_OCC_SMALL
 #define FX_OCC_SMALL 4
 #endif
+#ifndef FX_OCC_TINY
+#define FX_OCC_TINY 6
+#endif
 template <int N> struct Occ {
     // Residency is set by the LDS; the waves of a CU should spread evenly over its four SIMDs (a workgroup's waves go
     // round the SIMDs, so 6 waves are 2+2+1+1 and two such workgroups in the same rotation leave two SIMDs with 4 waves
     // and two with 2 -- measured no faster than 8 waves per CU).  Hence workgroups of CH channels x K waves with
     // CH*K a multiple of 4, sharing one twiddle table:
-    //   <= 1024 points: 1 x 8, two workgroups per CU      -> 4 waves per SIMD, <= 128 VGPRs
+    //   <= 512 points : 1 x 8, three workgroups per CU    -> 6 waves per SIMD, <= 80 VGPRs (the 4 KB images leave the LDS room;
+    //                   +6 % at 512 points over 4 waves per SIMD, round 3: the kernels are bound by latency, not by issue)
+    //   1024 points   : 1 x 8, two workgroups per CU      -> 4 waves per SIMD, <= 128 VGPRs (all the LDS holds)
     //   2048 points   : 3 x 4 = 12 waves, one workgroup   -> 3 per SIMD, <= 168 VGPRs
     //   4096 points   : 1 x 7 (the 160 KB to the byte)    -> 2 per SIMD at most, <= 256 VGPRs (the split transform keeps a
     //                   lane's 64 second-pass results in registers)
 #if defined(FX_EXP_2048_LDS_TW) || defined(FX_EXP_2048_TW_PARTIAL)
     static constexpr int WAVES_PER_SIMD = N <= 1024 ? FX_OCC_SMALL : (N == 2048 ? 3 : 2);
 #else
-    static constexpr int WAVES_PER_SIMD = N <= 1024 ? FX_OCC_SMALL : 2;
+    static constexpr int WAVES_PER_SIMD = N <= 512 ? FX_OCC_TINY : (N <= 1024 ? FX_OCC_SMALL : 2);
 #endif
 #if defined(FX_EXP_2048_LDS_TW) || defined(FX_EXP_2048_TW_PARTIAL)
     static constexpr int MAX_THREADS = N <= 1024 ? 512 : (N == 2048 ? 768 : 448);
