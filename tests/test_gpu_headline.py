@@ -141,6 +141,27 @@ def test_large_one_frame_calls_take_the_batch_kernels_and_equal_the_hop_kernel(g
     assert np.array_equal(np.concatenate([g[0] for g in got], 1)[sel][..., 0], oraw[..., 0])          # onsets, exactly
 
 
+def test_calls_on_the_library_stream_need_no_cross_stream_waits(gpu_fx):
+    """`with torch.cuda.stream(analyser.torch_stream())`: producer, analysis and consumer are ordered by the stream itself; device-buffer
+    calls then skip their waits against torch's current stream and give what the ordinary path gives."""
+    import torch
+    N, C, T = 1024, 9, 12
+    hops = signals.tone_vibrato_noise(C, T, N, seed=5)
+    want = gpu_fx.BatchAnalyser(C, N).push_hops(hops)
+    an = gpu_fx.BatchAnalyser(C, N)
+    got = []
+    with torch.cuda.stream(an.torch_stream()):
+        assert torch.cuda.current_stream().cuda_stream == an.torch_stream().cuda_stream
+        dev = torch.from_numpy(hops).cuda(non_blocking=False)
+        for t in range(T):
+            x = (dev[:, t:t + 1] * 1.0).contiguous()                 # produced on the library's stream, right before the call
+            r, s = an.push_hops(x)
+            got.append((r.clone(), s.clone()))                       # consumed on it, right after
+    an.sync()
+    for k in (0, 1):
+        assert np.array_equal(np.concatenate([g[k].cpu().numpy() for g in got], 1), want[k], equal_nan=True), k
+
+
 def test_contexts_created_and_streamed_from_two_threads(gpu_fx):
     """Two contexts on device 0, each created and driven by its own thread, streaming one hop per call (fx_hop_kernel
     through the pinned ring): kernel preparation is per context / device, with no process-wide "already prepared" state
