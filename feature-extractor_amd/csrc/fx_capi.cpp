@@ -139,7 +139,7 @@ extern "C" void fx_tuning_defaults(fx_tuning* t)
     if (!t) return;
     memset(t, 0, sizeof *t);
     t->frames_per_unit = -1;
-    t->stream_graph = t->stream_hop_kernel = t->stream_zero_copy = t->one_hop_kernel = -1;
+    t->stream_graph = t->stream_hop_kernel = t->stream_zero_copy = t->one_hop_kernel = t->call_timing = -1;
 }
 
 // The ONLY place the library reads the environment: called once per context, by fx_create.
@@ -161,6 +161,7 @@ extern "C" void fx_tuning_from_env(fx_tuning* t)
     geti("FX_STREAM_HOP_KERNEL", &t->stream_hop_kernel, 0);
     geti("FX_STREAM_ZEROCOPY", &t->stream_zero_copy, 0);
     geti("FX_ONE_HOP_KERNEL", &t->one_hop_kernel, 0);
+    geti("FX_CALL_TIMING", &t->call_timing, 0);
     geti("FX_HANDOVER_SPINS", &t->handover_spin_limit, 1);
     geti("FX_DEBUG_FLAGS", &t->debug_flags, 0);
 }
@@ -395,8 +396,12 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     Step step;
     if ((st = prepare_step(c, d_in, T, sample_format, hop_mode, d_or, d_os, c->d_part, c->d_raw, nullptr, &step)) != FX_OK) return st;
 
+    // The three events fx_last_kernel_ms() reads.  Each is a barrier packet between launches, which a call of milliseconds does not
+    // notice and a one-frame call does (back to back 27 us per call with them, 14.6 without): those record none unless asked to.
+    const bool timed = c->profiling || c->tuning.call_timing == 1 || (c->tuning.call_timing < 0 && T > 1);
+#define FX_EV(e) do { if (timed) HIP_TRY(hipEventRecord(e, c->stream)); } while (0)
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1], e2 = c->ev[2];
-    bool last_valid = true;
+    bool last_valid = timed;
     if (c->profiling && c->prof_used + 3 <= 3 * 4096) {
         while (c->prof_events.size() < c->prof_used + 3) {
             hipEvent_t e;
@@ -418,18 +423,19 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
                          (c->tuning.one_hop_kernel == 1 || (c->tuning.one_hop_kernel < 0 && (long long) c->C * c->N <= (1ll << 20)));
     if (one_hop) {
         const fxk::HopSignal none = {nullptr, nullptr, 0u, 0u, nullptr};
-        HIP_TRY(hipEventRecord(e0, c->stream));
+        FX_EV(e0);
         HIP_TRY(fxk::launch_hop_kernel(c->N, step.fp, step.ep, none, c->stream, step.hop_pairs));
-        HIP_TRY(hipEventRecord(e1, c->stream));
-        HIP_TRY(hipEventRecord(e2, c->stream));
+        FX_EV(e1);
+        FX_EV(e2);
     } else {
         if (step.fp.num_chunks > 1) HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned) * (1 + (size_t) c->C), c->stream));
-        HIP_TRY(hipEventRecord(e0, c->stream));
+        FX_EV(e0);
         HIP_TRY(launch_frames(c, step));
-        HIP_TRY(hipEventRecord(e1, c->stream));
+        FX_EV(e1);
         HIP_TRY(fxk::launch_epilogue_kernels(step.ep, c->stream));
-        HIP_TRY(hipEventRecord(e2, c->stream));
+        FX_EV(e2);
     }
+#undef FX_EV
     c->ev_valid = last_valid;
     advance(c, T);
 
@@ -655,7 +661,7 @@ fx_status fx_get_stream(fx_context* c, void** stream)
 fx_status fx_last_kernel_ms(fx_context* c, float* frame_ms, float* epi_ms)
 {
     if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
-    if (!c->ev_valid) return fx_fail(FX_ERR_INVALID_ARGUMENT, "no analysis call has been made yet");
+    if (!c->ev_valid) return fx_fail(FX_ERR_INVALID_ARGUMENT, "the last analysis call recorded no timing (none made yet, a profiled one, or a one-frame call without fx_tuning::call_timing = 1)");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipEventSynchronize(c->ev[2]));
     float a = 0.f, b = 0.f;

@@ -136,7 +136,9 @@ fx_status fx_get_stream(fx_context* ctx, void** stream);
 
 /* Device time of the analysis kernels of the most recent fx_push_hops /
  * fx_process_frames call, measured with HIP events on the context's stream
- * (milliseconds; synchronises). kernel 0 = frame kernel, 1 = smoothing/onset. */
+ * (milliseconds; synchronises). kernel 0 = frame kernel, 1 = smoothing/onset.
+ * FX_ERR_INVALID_ARGUMENT if that call recorded none: by default one-frame calls
+ * do not (fx_tuning::call_timing). */
 fx_status fx_last_kernel_ms(fx_context* ctx, float* frame_kernel_ms, float* epilogue_kernel_ms);
 
 /* ---- streaming ingest: replaces AudioDataCollector's ring + busy-wait reader ----
@@ -182,6 +184,10 @@ typedef struct fx_tuning {
     int stream_zero_copy;        /* FX_STREAM_ZEROCOPY: 1 / 0 force / forbid zero-copy slots in the captured step; -1 = by size */
     int one_hop_kernel;          /* FX_ONE_HOP_KERNEL: 0 / 1 = fx_push_hops / fx_process_frames of ONE frame per channel never / always run
                                     the one-launch hop kernel; -1 = where it is the faster of the two (channels x window <= 2^20 samples) */
+    int call_timing;             /* FX_CALL_TIMING: whether an analysis call records the three events fx_last_kernel_ms() reads: 1 / 0 = every /
+                                    no call; -1 = calls of more than one frame per channel (a one-frame call is the live, latency-critical
+                                    case, and the events cost it 13 of its 27 us back to back: each is a barrier packet between launches).
+                                    Calls between fx_profile_begin / fx_profile_end are timed regardless */
     int handover_spin_limit;     /* FX_HANDOVER_SPINS: polls a work unit spends waiting for its predecessor's flux state
                                     before it gives up and the call is reported failed (FX_ERR_HIP); 0 = default (1 << 22) */
     int debug_flags;             /* FX_DEBUG_FLAGS: bit 0 = work units do not publish their hand-over (forces the time-out; tests);

@@ -130,11 +130,11 @@ def test_tuning_comes_from_the_environment_once(fx, monkeypatch):
     capi = import_module("feature-extractor_amd.capi")
     fx.load_library(build_if_missing=True)
     for var in ("FX_WAVES", "FX_CHANNELS_PER_WG", "FX_WAVES_PER_FRAME", "FX_FRAMES_PER_CHUNK", "FX_CHUNK_PLAN", "FX_STREAM_GRAPH",
-                "FX_STREAM_HOP_KERNEL", "FX_STREAM_ZEROCOPY", "FX_ONE_HOP_KERNEL", "FX_HANDOVER_SPINS", "FX_DEBUG_FLAGS"):
+                "FX_STREAM_HOP_KERNEL", "FX_STREAM_ZEROCOPY", "FX_ONE_HOP_KERNEL", "FX_CALL_TIMING", "FX_HANDOVER_SPINS", "FX_DEBUG_FLAGS"):
         monkeypatch.delenv(var, raising=False)
     d, e = capi.Tuning.defaults(), capi.Tuning.from_env()
     assert bytes(d) == bytes(e)
-    assert (d.waves_per_channel, d.frames_per_unit, d.stream_graph, d.one_hop_kernel, d.handover_spin_limit, d.debug_flags) == (0, -1, -1, -1, 0, 0)
+    assert (d.waves_per_channel, d.frames_per_unit, d.stream_graph, d.one_hop_kernel, d.call_timing, d.handover_spin_limit, d.debug_flags) == (0, -1, -1, -1, -1, 0, 0)
     monkeypatch.setenv("FX_WAVES", "3")
     monkeypatch.setenv("FX_FRAMES_PER_CHUNK", "0")
     monkeypatch.setenv("FX_CHUNK_PLAN", "300,200,12")

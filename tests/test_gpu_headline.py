@@ -162,6 +162,26 @@ def test_calls_on_the_library_stream_need_no_cross_stream_waits(gpu_fx):
         assert np.array_equal(np.concatenate([g[k].cpu().numpy() for g in got], 1), want[k], equal_nan=True), k
 
 
+def test_one_frame_calls_record_timing_events_only_when_asked(gpu_fx):
+    """fx_last_kernel_ms() reads three HIP events around the launches; each is a barrier packet, which halves the rate of back-to-back
+    one-frame calls -- so those record none by default (fx_tuning::call_timing), and fx_last_kernel_ms says so instead of returning a stale time."""
+    N, C = 1024, 5
+    hops = signals.tone_vibrato_noise(C, 6, N, seed=2)
+    an = gpu_fx.BatchAnalyser(C, N)
+    an.push_hops(hops[:, :3])
+    assert an.last_kernel_ms()[0] > 0.0                              # a call of several frames is timed
+    an.push_hops(hops[:, 3:4])
+    with pytest.raises(gpu_fx.FxError):
+        an.last_kernel_ms()
+    an.set_tuning(call_timing=1)
+    an.push_hops(hops[:, 4:5])
+    assert an.last_kernel_ms()[0] > 0.0
+    an.set_tuning(call_timing=0)
+    an.push_hops(hops[:, 5:6])
+    with pytest.raises(gpu_fx.FxError):
+        an.last_kernel_ms()
+
+
 def test_contexts_created_and_streamed_from_two_threads(gpu_fx):
     """Two contexts on device 0, each created and driven by its own thread, streaming one hop per call (fx_hop_kernel
     through the pinned ring): kernel preparation is per context / device, with no process-wide "already prepared" state

@@ -8,7 +8,7 @@ for N in (2048, 4096):
         hops = fx.synth.hops(C, 40, N, first_channel=24)
         for wpf in (1, 2):
             an = fx.BatchAnalyser(C, N)
-            an.set_tuning(waves_per_frame=wpf, one_hop_kernel=0)
+            an.set_tuning(waves_per_frame=wpf, one_hop_kernel=0, call_timing=1)       # (one-frame calls record no timing events by default)
             ts = []
             for t in range(40):
                 an.push_hops(hops[:, t:t + 1])
