@@ -121,7 +121,7 @@ __device__ __forceinline__ void finalise_frame(const EpilogueParams& p, long lon
 }
 
 // The same for the one frame of a one-hop call, by a whole wavefront: every lane forms the values (they are uniform), lanes
-// 0..4 take one logarithm each, lane 0 stores.  Bit for bit what finalise_frame writes.
+// 0..4 take one logarithm each; `out` is the full vector in every lane.  Bit for bit what finalise_frame writes.
 __device__ __forceinline__ void finalise_wave(const EpilogueParams& p, const FramePart& f, int lane, float (&out)[FX_NUM_FEATURES])
 {
     double logs[NUM_LOGS];
@@ -135,19 +135,6 @@ __device__ __forceinline__ void finalise_wave(const EpilogueParams& p, const Fra
     for (int i = 0; i < NUM_LOGS; i++) y[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ym), i));
     finalise_logs(y, out);
 }
-__device__ __forceinline__ void finalise_hop(const EpilogueParams& p, long long idx, int lane)
-{
-    const FramePart f = p.part[idx];
-    float out[FX_NUM_FEATURES];
-    finalise_wave(p, f, lane, out);
-    if (lane == 0) {
-        f4* dst = reinterpret_cast<f4*>(p.raw + idx * FX_NUM_FEATURES);
-        dst[0] = f4{out[0], out[1], out[2], out[3]};
-        dst[1] = f4{out[4], out[5], out[6], out[7]};
-        dst[2] = f4{out[8], out[9], out[10], out[11]};
-    }
-}
-
 #ifdef FX_WITH_TAIL_KERNELS
 __global__ void __launch_bounds__(256)
 fx_finalise_kernel(const EpilogueParams p_arg)
@@ -492,26 +479,40 @@ fx_history_kernel(const EpilogueParams p)
 __global__ void __launch_bounds__(64)
 fx_tail_fused_kernel(const EpilogueParams p_arg)
 {
-    __shared__ float s_hist[HLEN * FX_NUM_FEATURES];
+    __shared__ __attribute__((aligned(16))) float s_hist[HLEN * FX_NUM_FEATURES];
     __shared__ float s_raw[FUSED_TAIL_MAX_FRAMES * FX_NUM_FEATURES];
     __shared__ float s_scratch[64];
     EpilogueParams p = with_dyn(p_arg);
     const int c = blockIdx.x, lane = threadIdx.x;
-    for (int i = lane; i < HLEN * FX_NUM_FEATURES; i += 64) s_hist[i] = p.hist_in[(size_t) c * HLEN * FX_NUM_FEATURES + i];
-    if (p.T == 1) finalise_hop(p, (long long) c, lane);
-    else if (lane < p.T) finalise_frame(p, (long long) c * p.T + lane);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");           // the wave's raw values are written before any lane reads them back
-    __builtin_amdgcn_s_barrier();
-    for (int i = lane; i < p.T * FX_NUM_FEATURES; i += 64) s_raw[i] = p.raw[(size_t) c * p.T * FX_NUM_FEATURES + i];
+    {
+        const uint4* h4 = reinterpret_cast<const uint4*>(p.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES);
+        for (int i = lane; i < HLEN * FX_NUM_FEATURES / 4; i += 64) reinterpret_cast<uint4*>(s_hist)[i] = h4[i];
+    }
+    if (p.T == 1) {
+        // one hop: the scalar tail by the whole wavefront (its logarithms side by side), straight into the LDS row -- the
+        // raw vector never makes the trip through global memory
+        const FramePart f = p.part[c];
+        float out[FX_NUM_FEATURES];
+        finalise_wave(p, f, lane, out);
+        if (lane < FX_NUM_FEATURES) {
+            float mine = out[0];
+#pragma unroll
+            for (int k = 1; k < FX_NUM_FEATURES; k++) mine = lane == k ? out[k] : mine;
+            s_raw[lane] = mine;
+        }
+    } else {
+        if (lane < p.T) finalise_frame(p, (long long) c * p.T + lane);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // the wave's raw values are written before any lane reads them back
+        __builtin_amdgcn_s_barrier();
+        for (int i = lane; i < p.T * FX_NUM_FEATURES; i += 64) s_raw[i] = p.raw[(size_t) c * p.T * FX_NUM_FEATURES + i];
+    }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_s_barrier();
-    // the smoothing reads channel c's rows through (raw + c*T*12, hist_in + c*HLEN*12): point those at the LDS copies
-    const float* g_raw = p.raw; const float* g_hist = p.hist_in;
+    // the smoothing and the history rows read channel c's rows through (raw + c*T*12, hist_in + c*HLEN*12): point those at the LDS copies
     p.raw = s_raw - (size_t) c * p.T * FX_NUM_FEATURES;
     p.hist_in = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
     if (p.T == 1) epilogue_hop(p, c, lane, s_scratch);                // one hop: a lane per slot, the onset detector's candidates side by side
     else if (lane < p.T) epilogue_frame(p, c, lane);
-    p.raw = const_cast<float*>(g_raw); p.hist_in = g_hist;
     for (int i = lane; i < HLEN * FX_NUM_FEATURES; i += 64) history_value(p, (long long) c * HLEN * FX_NUM_FEATURES + i);
 }
 #endif
