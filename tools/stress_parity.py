@@ -29,6 +29,7 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
     inexact = np.zeros(12, np.int64)      # values that are within tolerance but not bit-identical, per slot
     ring_cases = [0]
     pair_cases = [0]
+    hop_cases = [0]
     last_note = time.time()
     while time.time() < t_end and (max_cases is None or cases < max_cases):
         N = int(rng.choice([256, 512, 1024, 1024, 2048, 2048, 4096]))
@@ -66,6 +67,13 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
                 parts.append(st.collect())
             st.close()
             ring_cases[0] += 1
+        elif T <= 40 and rng.random() < 0.2:
+            # hop by hop through fx_push_hops: fx_hop_kernel, or -- every other such case -- the batch kernels forced
+            # (frame kernel + the one-frame form of fx_tail_fused_kernel: a lane per slot, the logarithms side by side)
+            if hop_cases[0] % 2:
+                an.set_tuning(one_hop_kernel=0)          # (keyword form: changes this field of the context's current knobs)
+            hop_cases[0] += 1
+            parts = [an.push_hops(hops[:, t:t + 1]) for t in range(T)]
         else:
             parts = [an.push_hops(hops[:, :split]), an.push_hops(hops[:, split:])]
         raw = np.concatenate([p[0] for p in parts], 1); sm = np.concatenate([p[1] for p in parts], 1)
@@ -96,7 +104,8 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
                     print("MISMATCH %s N=%d C=%d T=%d order=%d otype=%d owin=%d: %d values; first c=%d t=%d %s gpu=%r oracle=%r"
                           % (name, N, C, T, order, otype, owin, len(bad), c, t, fx.FEATURE_NAMES[f], g[c, t, f], w[c, t, f]), flush=True)
     if verbose:
-        print("cases run one hop per call through the ring (fx_hop_kernel / fx_hop_pair_kernel): %d; cases on wavefront pairs (fx_pair_kernel): %d" % (ring_cases[0], pair_cases[0]), flush=True)
+        print("cases run one hop per call through the ring (fx_hop_kernel / fx_hop_pair_kernel): %d; cases on wavefront pairs (fx_pair_kernel): %d; "
+              "cases hop by hop through fx_push_hops (half of them on the batch kernels + one-frame fused tail): %d" % (ring_cases[0], pair_cases[0], hop_cases[0]), flush=True)
     if verbose and inexact.any():
         print("raw values not bit-identical (within tolerance), per slot:", dict((fx.FEATURE_NAMES[i], int(n)) for i, n in enumerate(inexact) if n), flush=True)
     return cases, frames, bad_cases, worst
