@@ -229,9 +229,29 @@ template <int N> struct Plan {
 // cpad(base + L0*i) - cpad(base) is a compile-time constant because base = blk*(R*L0) + k, k < L0
 __host__ __device__ constexpr int item_off(int L0, int i) { return L0 * i + (L0 >= 16 ? (L0 / 16) * i : ((L0 * i) >> 4)); }
 
+// The first exchange of a REAL-input transform need not carry the whole item.  A 16-element first-pass item is a 16-point
+// transform of real data: e[3], e[7], e[11], e[15] are formed as the bitwise conjugates of e[13], e[9], e[5], e[1] (first_pass_item),
+// e[12] is the bitwise conjugate of e[4] (bfly4_real), and the consumer -- the next pass's item k = lane % 16 reads element k of
+// sixteen first-pass items -- can take the twin and flip a sign instead.  Eleven stores per item instead of sixteen: LDS stores are
+// what a wavefront's exchange waits for (round 3: five stores more per transform cost the 1024-point kernel 4 %).
+// Layout: [item][11] float2, no padding (rows of 88 B: the 16 lanes of a ds_write_b64 group and the 32 of a ds_read_b64 group fall
+// on distinct banks; lanes that want the same element of the same item read one address).
+template <int N> struct RealExchange {
+#ifdef FX_EXP_FULL_FIRST_EXCHANGE
+    static constexpr bool USE = false;
+#else
+    static constexpr bool USE = N == 1024;                 // RA == 16, one item per lane, next pass at stride 16
+#endif
+    static constexpr int SLOTS = 11;
+    // element k of an item -> the slot that holds it or its twin (4 bits each), and whether it is the twin (conjugate)
+    static constexpr unsigned long long SLOT_OF = 0x1a93487675439210ull;     // stored elements in slot order: 0 1 2 4 5 6 8 9 10 13 14
+    static constexpr unsigned TWIN = (1u << 3) | (1u << 7) | (1u << 11) | (1u << 12) | (1u << 15);
+};
+
 // A later pass: every item of R elements (stride L0) is loaded from the complex image, its 1 or 2
 // radix-4 stages run in registers, and it is stored back to the same positions.
-template <int N, int R, int L0, int TWOFF, bool INV>
+// FROM_REAL: this is the pass behind the first exchange of a transform whose first pass used RealExchange.
+template <int N, int R, int L0, int TWOFF, bool INV, bool FROM_REAL = false>
 __device__ __forceinline__ void fft_pass(f2* cbuf, const f2* tw, int lane)
 {
     lane = FFT_OPAQUE(lane);
@@ -242,8 +262,21 @@ __device__ __forceinline__ void fft_pass(f2* cbuf, const f2* tw, int lane)
         const int base = (it / L0) * (R * L0) + k;
         f2* img = cbuf + cpad(base);
         const f2* t1 = tw + TWOFF + k;
+        if constexpr (FROM_REAL) {
+            // element k of the first-pass items (it / 16) * 16 + i: from its slot, or from its twin's with the sign of im flipped
+            static_assert(R == 16 && L0 == 16 && ITEMS == 64, "the pass behind a 16-element real first pass");
+            const int slot = (int) ((RealExchange<N>::SLOT_OF >> (4 * k)) & 15ull);
+            const unsigned flip = ((RealExchange<N>::TWIN >> k) & 1u) << 31;
+            const f2* src = cbuf + (it / L0) * (16 * RealExchange<N>::SLOTS) + slot;
 #pragma unroll
-        for (int i = 0; i < R; i++) e[i] = img[item_off(L0, i)];
+            for (int i = 0; i < R; i++) {
+                const f2 v = src[i * RealExchange<N>::SLOTS];
+                e[i] = f2{v.x, __uint_as_float(__float_as_uint(v.y) ^ flip)};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < R; i++) e[i] = img[item_off(L0, i)];
+        }
         // stage 1: butterflies over i = q + 4*g
         {
             const f2 w1 = t1[0], w2 = t1[L0], w3 = t1[2 * L0];
@@ -361,9 +394,17 @@ __device__ __forceinline__ void fft_first_pass(const float (&xin)[Geo<N>::P], f2
     for (int g = 0; g < G::GA; g++) {
         f2 e[R];
         first_pass_item<N, INV>(&xin[g * R], ta, e);
-        f2* img = cbuf + cpad((lane + 64 * g) * R);
+        if constexpr (RealExchange<N>::USE) {
+            static_assert(R == 16 && G::GA == 1, "one 16-element item per lane");
+            f2* img = cbuf + lane * RealExchange<N>::SLOTS;
+            constexpr int stored[RealExchange<N>::SLOTS] = {0, 1, 2, 4, 5, 6, 8, 9, 10, 13, 14};
 #pragma unroll
-        for (int i = 0; i < R; i++) img[i] = e[i];         // R <= 16 contiguous positions: no pad inside
+            for (int q = 0; q < RealExchange<N>::SLOTS; q++) img[q] = e[stored[q]];
+        } else {
+            f2* img = cbuf + cpad((lane + 64 * g) * R);
+#pragma unroll
+            for (int i = 0; i < R; i++) img[i] = e[i];         // R <= 16 contiguous positions: no pad inside
+        }
     }
     wave_fence();
 }
@@ -585,7 +626,7 @@ template <int N> struct LazyLag {
     __device__ __forceinline__ void load(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, const float (&ftw)[18], int lane_, float scale_)
     {
         fft_first_pass<N, true>(xin, cbuf, ftw, lane_);
-        fft_pass<N, PL::R1, PL::L1, PL::OFF1, true>(cbuf, tw, lane_);
+        fft_pass<N, PL::R1, PL::L1, PL::OFF1, true, RealExchange<N>::USE>(cbuf, tw, lane_);
         lane = FFT_OPAQUE(lane_);
         scale = scale_;
         t1 = tw + PL::OFF2 + lane;
@@ -730,7 +771,7 @@ __device__ __forceinline__ float fft_from_regs(const float (&xin)[Geo<N>::P], f2
         return fft_split<N, INV, OUT>(xin, cbuf, tw, ftw, lane, scale, regs_out, twr);
     } else {
         fft_first_pass<N, INV>(xin, cbuf, ftw, lane);
-        fft_pass<N, PL::R1, PL::L1, PL::OFF1, INV>(cbuf, tw, lane);
+        fft_pass<N, PL::R1, PL::L1, PL::OFF1, INV, RealExchange<N>::USE>(cbuf, tw, lane);
         return fft_last_pass_fused<N, INV, OUT>(cbuf, tw, lane, scale, regs_out);
     }
 }
