@@ -240,7 +240,7 @@ template <int N> struct RealExchange {
 #ifdef FX_EXP_FULL_FIRST_EXCHANGE
     static constexpr bool USE = false;
 #else
-    static constexpr bool USE = N == 1024;                 // RA == 16, one item per lane, next pass at stride 16
+    static constexpr bool USE = N == 1024 || N == 4096;    // RA == 16 and the next pass at stride 16 (un-split: one item per lane; split: two per half)
 #endif
     static constexpr int SLOTS = 11;
     // element k of an item -> the slot that holds it or its twin (4 bits each), and whether it is the twin (conjugate)
@@ -690,18 +690,39 @@ __device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cb
         for (int gl = 0; gl < GA / 2; gl++) {
             f2 e[RA];
             first_pass_item<N, INV>(&xin[(h * (GA / 2) + gl) * RA], ta, e);
-            f2* img = cbuf + cpad((lane + 64 * gl) * RA);
+            if constexpr (RealExchange<N>::USE) {
+                static_assert(RA == 16 && L1 == 16, "16-element real items, next pass at stride 16");
+                f2* img = cbuf + (lane + 64 * gl) * RealExchange<N>::SLOTS;
+                constexpr int stored[RealExchange<N>::SLOTS] = {0, 1, 2, 4, 5, 6, 8, 9, 10, 13, 14};
 #pragma unroll
-            for (int i = 0; i < RA; i++) img[i] = e[i];
+                for (int q = 0; q < RealExchange<N>::SLOTS; q++) img[q] = e[stored[q]];
+            } else {
+                f2* img = cbuf + cpad((lane + 64 * gl) * RA);
+#pragma unroll
+                for (int i = 0; i < RA; i++) img[i] = e[i];
+            }
         }
         wave_fence();
         // second-pass items of this half: local item lane + 64*jl
 #pragma unroll
         for (int jl = 0; jl < HB; jl++) {
             const int it = lane + 64 * jl;
-            const f2* img = cbuf + cpad((it / L1) * (16 * L1) + it % L1);
+            if constexpr (RealExchange<N>::USE) {
+                // element k = it % 16 of the first-pass items (it / 16) * 16 + i: its slot, or its twin's with the sign of im flipped
+                const int k = it % L1;
+                const int slot = (int) ((RealExchange<N>::SLOT_OF >> (4 * k)) & 15ull);
+                const unsigned flip = ((RealExchange<N>::TWIN >> k) & 1u) << 31;
+                const f2* src = cbuf + (it / L1) * (16 * RealExchange<N>::SLOTS) + slot;
 #pragma unroll
-            for (int i = 0; i < 16; i++) eb[h * HB + jl][i] = img[item_off(L1, i)];
+                for (int i = 0; i < 16; i++) {
+                    const f2 v = src[i * RealExchange<N>::SLOTS];
+                    eb[h * HB + jl][i] = f2{v.x, __uint_as_float(__float_as_uint(v.y) ^ flip)};
+                }
+            } else {
+                const f2* img = cbuf + cpad((it / L1) * (16 * L1) + it % L1);
+#pragma unroll
+                for (int i = 0; i < 16; i++) eb[h * HB + jl][i] = img[item_off(L1, i)];
+            }
         }
         wave_fence();             // every lane has its inputs: the next half may overwrite the image
 #pragma unroll
