@@ -240,12 +240,31 @@ template <int N> struct RealExchange {
 #ifdef FX_EXP_FULL_FIRST_EXCHANGE
     static constexpr bool USE = false;
 #else
-    static constexpr bool USE = N == 1024 || N == 4096;    // RA == 16 and the next pass at stride 16 (un-split: one item per lane; split: two per half)
+    // 1024 (un-split, one item per lane) and 4096 (split, two per half): 16-element items, next pass at stride 16.
+    // 2048 (split) has 8-element items (a radix-2 and a radix-4 stage) of which only e[6] = conj(e[2]) is exact: 7 stores of 8 are
+    // the same four store instructions and the sign flips cost 1 % (measured, FX_EXP_REAL_EXCHANGE_2048): not used there.
+#ifdef FX_EXP_REAL_EXCHANGE_2048
+    static constexpr bool USE = N == 1024 || N == 2048 || N == 4096;
+#else
+    static constexpr bool USE = N == 1024 || N == 4096;
 #endif
-    static constexpr int SLOTS = 11;
+#endif
+    static constexpr int RA = Geo<N>::RA;
+    static constexpr int SLOTS = RA == 16 ? 11 : 7;
+    // float2 of padding behind every 16 items: 7-slot rows need it to keep the 32 lanes of a read group on distinct banks
+    static constexpr int GROUP_PAD = RA == 16 ? 0 : 8;
     // element k of an item -> the slot that holds it or its twin (4 bits each), and whether it is the twin (conjugate)
-    static constexpr unsigned long long SLOT_OF = 0x1a93487675439210ull;     // stored elements in slot order: 0 1 2 4 5 6 8 9 10 13 14
-    static constexpr unsigned TWIN = (1u << 3) | (1u << 7) | (1u << 11) | (1u << 12) | (1u << 15);
+    static constexpr unsigned long long SLOT_OF = RA == 16 ? 0x1a93487675439210ull     // stored, in slot order: 0 1 2 4 5 6 8 9 10 13 14
+                                                           : 0x62543210ull;            // 0 1 2 3 4 5 7
+    static constexpr unsigned TWIN = RA == 16 ? (1u << 3) | (1u << 7) | (1u << 11) | (1u << 12) | (1u << 15) : (1u << 6);
+    __host__ __device__ static constexpr int stored(int q)
+    {
+        constexpr int s16[11] = {0, 1, 2, 4, 5, 6, 8, 9, 10, 13, 14};
+        constexpr int s8[7] = {0, 1, 2, 3, 4, 5, 7};
+        return RA == 16 ? s16[q < 11 ? q : 0] : s8[q < 7 ? q : 0];
+    }
+    // position (float2) of slot 0 of first-pass item `item` (an index within the image being exchanged)
+    __host__ __device__ static constexpr int row(int item) { return item * SLOTS + GROUP_PAD * (item / 16); }
 };
 
 // A later pass: every item of R elements (stride L0) is loaded from the complex image, its 1 or 2
@@ -267,7 +286,7 @@ __device__ __forceinline__ void fft_pass(f2* cbuf, const f2* tw, int lane)
             static_assert(R == 16 && L0 == 16 && ITEMS == 64, "the pass behind a 16-element real first pass");
             const int slot = (int) ((RealExchange<N>::SLOT_OF >> (4 * k)) & 15ull);
             const unsigned flip = ((RealExchange<N>::TWIN >> k) & 1u) << 31;
-            const f2* src = cbuf + (it / L0) * (16 * RealExchange<N>::SLOTS) + slot;
+            const f2* src = cbuf + RealExchange<N>::row((it / L0) * 16) + slot;
 #pragma unroll
             for (int i = 0; i < R; i++) {
                 const f2 v = src[i * RealExchange<N>::SLOTS];
@@ -396,10 +415,9 @@ __device__ __forceinline__ void fft_first_pass(const float (&xin)[Geo<N>::P], f2
         first_pass_item<N, INV>(&xin[g * R], ta, e);
         if constexpr (RealExchange<N>::USE) {
             static_assert(R == 16 && G::GA == 1, "one 16-element item per lane");
-            f2* img = cbuf + lane * RealExchange<N>::SLOTS;
-            constexpr int stored[RealExchange<N>::SLOTS] = {0, 1, 2, 4, 5, 6, 8, 9, 10, 13, 14};
+            f2* img = cbuf + RealExchange<N>::row(lane);
 #pragma unroll
-            for (int q = 0; q < RealExchange<N>::SLOTS; q++) img[q] = e[stored[q]];
+            for (int q = 0; q < RealExchange<N>::SLOTS; q++) img[q] = e[RealExchange<N>::stored(q)];
         } else {
             f2* img = cbuf + cpad((lane + 64 * g) * R);
 #pragma unroll
@@ -691,11 +709,10 @@ __device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cb
             f2 e[RA];
             first_pass_item<N, INV>(&xin[(h * (GA / 2) + gl) * RA], ta, e);
             if constexpr (RealExchange<N>::USE) {
-                static_assert(RA == 16 && L1 == 16, "16-element real items, next pass at stride 16");
-                f2* img = cbuf + (lane + 64 * gl) * RealExchange<N>::SLOTS;
-                constexpr int stored[RealExchange<N>::SLOTS] = {0, 1, 2, 4, 5, 6, 8, 9, 10, 13, 14};
+                static_assert(RA == L1, "the next pass's stride is the item's length: its lanes read ONE element index each");
+                f2* img = cbuf + RealExchange<N>::row(lane + 64 * gl);
 #pragma unroll
-                for (int q = 0; q < RealExchange<N>::SLOTS; q++) img[q] = e[stored[q]];
+                for (int q = 0; q < RealExchange<N>::SLOTS; q++) img[q] = e[RealExchange<N>::stored(q)];
             } else {
                 f2* img = cbuf + cpad((lane + 64 * gl) * RA);
 #pragma unroll
@@ -708,11 +725,11 @@ __device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cb
         for (int jl = 0; jl < HB; jl++) {
             const int it = lane + 64 * jl;
             if constexpr (RealExchange<N>::USE) {
-                // element k = it % 16 of the first-pass items (it / 16) * 16 + i: its slot, or its twin's with the sign of im flipped
+                // element k = it % L1 of the first-pass items (it / L1) * 16 + i: its slot, or its twin's with the sign of im flipped
                 const int k = it % L1;
                 const int slot = (int) ((RealExchange<N>::SLOT_OF >> (4 * k)) & 15ull);
                 const unsigned flip = ((RealExchange<N>::TWIN >> k) & 1u) << 31;
-                const f2* src = cbuf + (it / L1) * (16 * RealExchange<N>::SLOTS) + slot;
+                const f2* src = cbuf + RealExchange<N>::row((it / L1) * 16) + slot;
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
                     const f2 v = src[i * RealExchange<N>::SLOTS];
