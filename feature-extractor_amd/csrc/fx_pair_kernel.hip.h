@@ -291,12 +291,30 @@ FX_MARK("p_fft_ab");
             for (int q = 0; q < R; q++) {
 #pragma unroll
                 for (int f = 0; f < FA; f++) {
-                    f2* img = priv + cpad((lane + 64 * f) * RA);
+                    if constexpr (RealExchange<N>::USE) {
+                        // (fx_fft.hip.h: only the elements of a real-input item that are not bitwise conjugates of stored ones)
+                        f2* img = priv + RealExchange<N>::row(lane + 64 * f);
 #pragma unroll
-                    for (int i = 0; i < RA; i++) img[i] = e[f][i];
+                        for (int sl = 0; sl < RealExchange<N>::SLOTS; sl++) img[sl] = e[f][RealExchange<N>::stored(sl)];
+                    } else {
+                        f2* img = priv + cpad((lane + 64 * f) * RA);
+#pragma unroll
+                        for (int i = 0; i < RA; i++) img[i] = e[f][i];
+                    }
                 }
                 wave_fence();
-                {
+                if constexpr (RealExchange<N>::USE) {
+                    static_assert(!RealExchange<N>::USE || RA == L1, "the next pass's lanes read one element index each");
+                    const int k = lane % L1;
+                    const int slot = (int) ((RealExchange<N>::SLOT_OF >> (4 * k)) & 15ull);
+                    const unsigned flip = ((RealExchange<N>::TWIN >> k) & 1u) << 31;
+                    const f2* src = priv + RealExchange<N>::row((lane / L1) * 16) + slot;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const f2 v = src[i * RealExchange<N>::SLOTS];
+                        eb[q][i] = f2{v.x, __uint_as_float(__float_as_uint(v.y) ^ flip)};
+                    }
+                } else {
                     const f2* img = priv + cpad((lane / L1) * (16 * L1) + lane % L1);
 #pragma unroll
                     for (int i = 0; i < 16; i++) eb[q][i] = img[item_off(L1, i)];
