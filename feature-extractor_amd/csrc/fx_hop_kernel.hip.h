@@ -229,7 +229,14 @@ fx_hop_pair_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const H
     if (threadIdx.x == 0) { turn2[0] = 0; part->flags = 0; s_ready[0] = 0u; s_ready[1] = 0u; }
     if (lane == 0) flags[w] = 0u;
     __syncthreads();                                            // (every pair's arrival counters are zero before any pair synchronises on them)
+    f2 early_b[15];
     if (pair == 0) {
+        {
+            typedef Plan<N> PL;
+            const f2* g = reinterpret_cast<const f2*>(p.tw) + PL::OFF1 + lane % PL::L1;
+#pragma unroll
+            for (int i = 0; i < 15; i++) early_b[i] = g[i * PL::L1];
+        }
         if (sig.stage) {
             const size_t hop_bytes = (size_t) (N / 2) * (p.sample_format == FX_SAMPLE_F16 ? 2 : 4);
             const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(p.in) + (size_t) c * hop_bytes);
@@ -274,7 +281,9 @@ fx_hop_pair_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const H
         pw.pair_sync(lane);                                     // both halves of the hop are staged (and this pair's flags are initialised)
         (void) pw.load_half_window(lane);
         pw.pair_sync(lane);
-        (void) pw.pitch(lane, tables_loaded);                   // leaves the lag in the record; the tables are awaited before the transforms
+        // the tables are awaited where the first transform's LAST pass is about to read them: its second pass runs on the 15
+        // twiddles this lane fetched from global memory at kernel entry (`early_b`, the same values as the LDS copy)
+        (void) pw.pitch(lane, tables_loaded, &early_b);         // leaves the lag in the record
     } else if (pair == 1) {
         // a2 + the spectral analyser (a3-a7): the sum of squares exactly as fx_pair_kernel takes it (each wave its half of the
         // window, wave 0 + wave 1), then the windowed transform and its sums

@@ -270,8 +270,13 @@ FX_MARK("p_load");
     //   OUT_LAG              : v[s] = (re_s / N)^2 * s for every sample in the buffer, plain layout; returns v[N] in lane 0 of wave 0
     // `entry_pending`: the caller has issued an arrive() after its last read of the buffer and left the wait() to us -- it is
     // taken after the first-pass arithmetic, right before the first write.
-    template <bool INV, int OUT>
-    __device__ __forceinline__ float transform(int lane, const float (&x)[P2], bool entry_pending = false) const
+    // `early_b` / `before_last`: the one-hop kernel's pitch pair runs its first transform before the workgroup's twiddle table is in
+    // LDS -- the second pass's 15 twiddles come from registers it filled from global memory at kernel entry, and `before_last()`
+    // (the wait for the table) is called where the last pass is about to read its own.
+    struct NoWait { __device__ __forceinline__ void operator()() const {} };
+    template <bool INV, int OUT, typename Hook = NoWait>
+    __device__ __forceinline__ float transform(int lane, const float (&x)[P2], bool entry_pending = false,
+                                               const f2 (*early_b)[15] = nullptr, Hook before_last = Hook{}) const
     {
 FX_MARK("p_fft_ab");
         f2 ta[9];
@@ -326,8 +331,14 @@ FX_MARK("p_fft_ab");
                 wave_fence();
             }
         }
+        if (early_b) {
 #pragma unroll
-        for (int q = 0; q < R; q++) item16_stages<L1, INV>(eb[q], tw + PL::OFF1 + lane % L1);
+            for (int q = 0; q < R; q++) item16_stages_r<INV>(eb[q], *early_b);
+        } else {
+#pragma unroll
+            for (int q = 0; q < R; q++) item16_stages<L1, INV>(eb[q], tw + PL::OFF1 + lane % L1);
+        }
+        before_last();
 FX_MARK("p_fft_c");
         // Second exchange, all-to-all between the two waves: round h carries the elements that feed last-pass items
         // k = 128 h + (0..127).  Element i of second-pass item it sits in row it / L1, column it % L1 + L1 * i of the last
@@ -380,8 +391,10 @@ FX_MARK("p_fft_out");
     // ---- pitch (ref PitchAnalyser.h:24-217, RealTimeAnalyser.h:152-166) -------------------------------------------------
     // `before_transforms`: called by both waves once the filtered window is written, before the first twiddle is read (the one-hop
     // kernel joins its workgroup barrier there: the other pairs load the twiddle table while this pair loads and filters)
+    // `early_b` (optional): the second pass's twiddles of this lane in registers; the first transform then starts without the
+    // table and `before_transforms` is called before its last pass instead.
     template <typename Hook>
-    __device__ __forceinline__ float pitch(int lane, Hook before_transforms) const
+    __device__ __forceinline__ float pitch(int lane, Hook before_transforms, const f2 (*early_b)[15] = nullptr) const
     {
         const int gl = 64 * w + lane;
         // a10 AudioFilter::filterAudio (ref RealTimeAudioAnalysis.h:106-125): y[0] = x[0]; y[n] = (a*x[n]) + (b*y[n-1]) in fp32,
@@ -468,12 +481,13 @@ FX_MARK("p_lpf");
             }
         }
         pair_sync(lane);
-        before_transforms();
+        if (!early_b) before_transforms();
 FX_MARK("p_pitch_in");
         float xf[P2];
         inputs_from_image(lane, xf);
         arrive(lane);                 // the image has been read (the transform waits for the partner's before it writes)
-        transform<false, OUT_POWER>(lane, xf, true);                           // ref RealTimeAnalyser.h:160; a11: re * re, imag := 0
+        if (early_b) transform<false, OUT_POWER>(lane, xf, true, early_b, before_transforms);
+        else         transform<false, OUT_POWER>(lane, xf, true);              // ref RealTimeAnalyser.h:160; a11: re * re, imag := 0
         inputs_from_image(lane, xf);                                           // already squared
         arrive(lane);
         const float v_end = transform<true, OUT_LAG>(lane, xf, true);          // a12 inverse, ref PitchAnalyser.h:110-121
