@@ -24,6 +24,7 @@ import json
 import math
 import os
 import shutil
+import signal
 import subprocess
 import sys
 import tempfile
@@ -213,6 +214,11 @@ def measure_counters(window, channels, frames, input_file, timeout_s=150):
         # a child launcher would inherit the tool library, initialise the GPU with it and then exec its target: the one thing
         # a GPU-initialised process must not do on this pool.  The outer profiler is collecting what it was asked for.
         return None, "not read: this run is itself under a profiler"
+    # never compile under the profiler: the child only LOADS the library (a stale one makes it exit non-zero), so build here, in
+    # the parent, where no tool library is preloaded and the GPU has not been touched by a launcher chain
+    fxbuild = importlib.import_module("feature-extractor_amd.build")
+    if fxbuild.needs_build():
+        fxbuild.build()
     tmp = tempfile.mkdtemp(prefix="fx_pmc_", dir="/tmp")
     env = dict(os.environ)
     env["TMPDIR"] = "/tmp"
@@ -223,15 +229,27 @@ def measure_counters(window, channels, frames, input_file, timeout_s=150):
             cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
                                                "--pmc-child", "--window", str(window), "--channels-per-gpu", str(channels),
                                                "--frames", str(frames), "--input-file", input_file, "--steps", "3", "--warmup", "1"]
+            # its own session: on a time-out the whole group goes (launcher AND the wrapped bench.py, which would otherwise keep
+            # the GPU busy under the measurements that follow)
+            p = subprocess.Popen(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
             try:
-                p = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+                _, err = p.communicate(timeout=timeout_s)
             except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                p.communicate()
                 return None, "rocprofv3 pass '%s' exceeded %d s" % (name, timeout_s)
             if p.returncode != 0:
-                return None, "rocprofv3 pass '%s' failed (rc %d): %s" % (name, p.returncode, (p.stderr or "").strip().splitlines()[-1:] or "")
-            vals, n = _parse_counter_csv(out, "fx_frame_kernel<%d" % window)
+                return None, "rocprofv3 pass '%s' failed (rc %d): %s" % (name, p.returncode, (err or "").strip().splitlines()[-1:] or "")
+            vals, n = {}, 0
+            for kern in ("fx_frame_kernel<%d" % window, "fx_pair_kernel<%d" % window):       # (FX_WAVES_PER_FRAME=2 in the environment runs pairs)
+                vals, n = _parse_counter_csv(out, kern)
+                if vals:
+                    break
             if not vals:
-                return None, "rocprofv3 pass '%s' recorded no fx_frame_kernel dispatch" % name
+                return None, "rocprofv3 pass '%s' recorded no frame-kernel dispatch" % name
             got.update(vals)
             launches = max(launches, n)
     finally:
@@ -261,6 +279,9 @@ def pmc_child(args):
     """The process rocprofv3 wraps: the same launches as the timed region, on the same input bytes, nothing else."""
     import torch
     fx = importlib.import_module("feature-extractor_amd")
+    if importlib.import_module("feature-extractor_amd.build").needs_build():
+        raise SystemExit("bench.py --pmc-child: libfx_hip.so is older than its sources; build it first (never under the profiler)")
+    fx.load_library(build_if_missing=False)
     torch.cuda.set_device(0)
     frames = torch.from_numpy(np.load(args.input_file)).cuda(0)
     C, T = frames.shape[0], frames.shape[1]
@@ -709,9 +730,8 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
             tf = flops_per_frame(n2) * c2 * t2 / (fms / 1e3) / 1e12
             others[str(n2)] = {"value": fps, "unit": "frames/s", "frame_kernel_ms": fms, "workload": "%s, %d frames per step" % (label, t2),
                                "hbm_frac": b2 / (fms / 1e3) / 1e9 / HBM_PEAK_GBPS, "achieved_tflops": tf, "compute_frac_no_fma": tf / FP32_NO_FMA_PEAK_TFLOPS}
-            # the same launches with every frame on a PAIR of wavefronts (fx_pair_kernel, fx_tuning::waves_per_frame = 2)
-            an2 = fx.BatchAnalyser(c2, n2, device=dev)
-            an2.set_tuning(waves_per_frame=2)
+            # the same launches in the low-latency family: every frame on a PAIR of wavefronts (fx_pair_kernel, FX_LOW_LATENCY)
+            an2 = fx.BatchAnalyser(c2, n2, device=dev, low_latency=True)
             fps_p, fms_p = max(time_steps(an2, fr2, None, None, 2 * extra_steps, warmup=5) for _ in range(2))
             an2.close()
             others[str(n2)]["pair_kernel"] = {"value": fps_p, "unit": "frames/s", "frame_kernel_ms": fms_p}
@@ -750,30 +770,116 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
         return res
 
     def streaming_hop():
-        # BASELINE configs[4]: 1 channel, 4096-pt windows, fp16 samples, ONE hop per call through the pinned ring
-        # (fx_hop_kernel: the whole step in one launch, the host polls a flag) -- per-hop round trip as this
-        # interpreter sees it (tools/stream_latency.cpp measures the same from C++, a few microseconds less)
-        an4 = fx.BatchAnalyser(1, 4096, device=dev)
-        st4 = fx.HopStream(an4, 1, slots=3, dtype=np.float16)
+        # BASELINE configs[4]: 1 channel, 4096-pt windows, fp16 samples, ONE hop per call through the pinned ring (one launch of
+        # fx_hop_kernel / fx_hop_pair_kernel, the host polls a flag): the round trip of a hop, for the default kernel family and for
+        # FX_LOW_LATENCY (every analyser on a pair of wavefronts), as this interpreter sees it and as a C++ host sees it
+        # (tools/stream_latency.cpp, built by __graft_entry__.build(): a child process, nothing is exec'ed from here)
+        res = {"unit": "us per 2048-sample hop", "workload": "configs[4]: 1 channel x 4096-pt windows, fp16 samples, one hop per call, submit + collect"}
         h4 = fx.synth.hops(1, 64, 4096, first_channel=24).astype(np.float16)
-        n_calls = 2000
-        for k in range(n_calls + 200):
-            if k == 200:
-                t_s = time.perf_counter()
-            st4.slot()[...] = h4[:, k % 64:k % 64 + 1]
-            st4.submit()
-            st4.collect(want_raw=False)
-        us = (time.perf_counter() - t_s) / n_calls * 1e6
-        st4.close()
-        an4.close()
-        return {"round_trip_us": us, "unit": "us per 2048-sample hop", "calls": n_calls,
-                "workload": "configs[4]: 1 channel x 4096-pt windows, fp16 samples, one hop per call, submit + collect from Python"}
+        for name, low in (("default", False), ("low_latency", True)):
+            an4 = fx.BatchAnalyser(1, 4096, device=dev, low_latency=low)
+            st4 = fx.HopStream(an4, 1, slots=3, dtype=np.float16)
+            n_calls = 2000
+            for k in range(n_calls + 200):
+                if k == 200:
+                    t_s = time.perf_counter()
+                st4.slot()[...] = h4[:, k % 64:k % 64 + 1]
+                st4.submit()
+                st4.collect(want_raw=False)
+            res[name] = {"python_round_trip_us": (time.perf_counter() - t_s) / n_calls * 1e6, "calls": n_calls}
+            st4.close()
+            an4.close()
+            exe = os.path.join(ROOT, "tools", "_bin", "stream_latency")
+            if os.path.exists(exe):
+                p = subprocess.run([exe, "4096", "1", "1", "4000", "tone", "lowlat" if low else "default"], capture_output=True, text=True, timeout=120)
+                for line in p.stdout.splitlines():
+                    if line.startswith("JSON "):
+                        res[name]["c_host"] = json.loads(line[5:])
+                if p.returncode != 0 or "c_host" not in res[name]:
+                    res[name]["c_host"] = {"error": (p.stderr or p.stdout)[-300:]}
+            else:
+                res[name]["c_host"] = {"error": "tools/_bin/stream_latency not built (__graft_entry__.build())"}
+        res["round_trip_us"] = res["default"]["python_round_trip_us"]          # (the field earlier rounds reported)
+        return res
+
+    def stream_ingest():
+        # The path a caller with HOST audio stands on (ref AudioDataCollector.h:36-94, AudioFilePlayer.h:41-61): hops in
+        # host memory -> the pinned ring (fx_stream_*) -> H2D on a side stream || analysis || vectors back on a third queue -> host.
+        # PCIe-inclusive by construction, never `value`.  Its roofline is the H2D link: `peak` = what hipMemcpyAsync from pinned
+        # memory reaches for the same bytes in this run, `achieved` = sample bytes per second the ring really moved.  The producer
+        # writes every slot IN PLACE from `fill_threads` threads (one block of channels each, as the reference's per-channel
+        # collectors would); the same loop with the slots left as they are (producer excluded) is reported beside it.
+        from concurrent.futures import ThreadPoolExecutor
+        cores = usable_cores()
+        fill_threads = max(4, min(16, cores))
+        pool = ThreadPoolExecutor(fill_threads)
+        res = {"fill_threads": fill_threads, "slots": 3,
+               "note": "frames/s with host-resident hops, PCIe-inclusive (never `value`); roofline.bound = pcie: achieved = sample bytes/s through the "
+                       "ring with the producer filling slots in place, peak = pinned hipMemcpyAsync H2D of the same bytes measured in this run"}
+
+        def memcpy_rate(nbytes):
+            host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+            devb = torch.empty(nbytes, dtype=torch.uint8, device="cuda:%d" % dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            devb.copy_(host, non_blocking=True)
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(6):
+                devb.copy_(host, non_blocking=True)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            return nbytes * 6 / (e0.elapsed_time(e1) / 1e3) / 1e9
+
+        for (n2, c2, t2) in ((1024, 1024, 64), (2048, 4096, 32)):
+            base = fx.synth.hops(128, t2, n2)
+            src32 = np.ascontiguousarray(np.tile(base, (c2 // 128, 1, 1)))
+            shape = {"workload": "%d channels x %d hops per batch x %d-pt windows (%d new samples per frame)" % (c2, t2, n2, n2 // 2)}
+            for fmt in ("f32", "f16", "s16"):
+                src = src32 if fmt == "f32" else (src32.astype(np.float16) if fmt == "f16" else np.round(src32 * 32767.0).astype(np.int16))
+                peak = memcpy_rate(src.nbytes)
+                an5 = fx.BatchAnalyser(c2, n2, device=dev)
+                st5 = fx.HopStream(an5, t2, slots=3, dtype=src.dtype)
+                bounds = [(k * c2 // fill_threads, (k + 1) * c2 // fill_threads) for k in range(fill_threads)]
+
+                def run(fill, steps, warm=4):
+                    for k in range(steps + warm):
+                        if k == warm:
+                            while st5.in_flight():
+                                st5.collect(want_raw=False)
+                            t0 = time.perf_counter()
+                        if st5.in_flight() == 3:
+                            st5.collect(want_raw=False)
+                        slot = st5.slot()
+                        if fill or k < 3:
+                            list(pool.map(lambda ab: np.copyto(slot[ab[0]:ab[1]], src[ab[0]:ab[1]]), bounds))
+                        st5.submit()
+                    while st5.in_flight():
+                        st5.collect(want_raw=False)
+                    return time.perf_counter() - t0
+
+                steps5 = 24
+                dt_fill = run(True, steps5)
+                dt_nofill = run(False, steps5)
+                st5.close()
+                an5.close()
+                fr = c2 * t2 * steps5
+                shape[fmt] = {"value": fr / dt_fill, "unit": "frames/s", "ms_per_batch": dt_fill / steps5 * 1e3, "bytes_per_batch": src.nbytes,
+                              "producer_excluded": {"value": fr / dt_nofill, "h2d_GBps": src.nbytes * steps5 / dt_nofill / 1e9},
+                              "roofline": {"bound": "pcie", "achieved": src.nbytes * steps5 / dt_fill / 1e9, "peak": peak, "unit": "GB/s",
+                                           "frac": src.nbytes * steps5 / dt_fill / 1e9 / peak,
+                                           "frac_producer_excluded": src.nbytes * steps5 / dt_nofill / 1e9 / peak}}
+                del src
+            res[str(n2)] = shape
+            del src32
+        pool.shutdown()
+        return res
 
     guarded("spectral_only", spectral_only)
     guarded("data_dependence", data_dependence)
     guarded("other_windows", other_windows)
     guarded("live_cadence", live_cadence)
     guarded("streaming_hop", streaming_hop)
+    guarded("stream_ingest", stream_ingest)
 
 
 if __name__ == "__main__":

@@ -18,13 +18,18 @@ def _is_torch(x):
 
 class BatchAnalyser:
     def __init__(self, num_channels, window_size=2048, sample_rate=48000.0, device=0,
-                 order=capi.ORDER_SPECTRAL_THEN_HARMONIC, analysers="both"):
+                 order=capi.ORDER_SPECTRAL_THEN_HARMONIC, analysers="both", low_latency=False):
+        """low_latency: FX_LOW_LATENCY of include/fx.h -- the kernel family for hosts that analyse one hop per call as it
+        arrives and care about that hop's round trip (windows of 2048 / 4096 points: every frame on a pair of wavefronts;
+        decisions identical to the default family, continuous slots may differ in the last bit)."""
         self._lib = capi.load_library()
         self.num_channels = int(num_channels)
         self.window_size = int(window_size)
         self.device = int(device)
         h = ctypes.c_void_p()
         flags = int(order) | {"both": 0, "spectral": capi.SPECTRAL_ONLY, "harmonic": capi.HARMONIC_ONLY}[analysers]
+        if low_latency:
+            flags |= capi.LOW_LATENCY
         capi.check(self._lib.fx_create(ctypes.byref(h), self.device, self.num_channels, self.window_size,
                                        float(sample_rate), flags))
         self._h = h
@@ -59,7 +64,7 @@ class BatchAnalyser:
     def reset_state(self):
         capi.check(self._lib.fx_reset_state(self._h))
 
-    # ---- launch-shape knobs (never change a result bit) ----
+    # ---- launch-shape knobs (within a kernel family they never change a result bit; waves_per_frame selects the family) ----
     def get_tuning(self):
         t = capi.Tuning()
         capi.check(self._lib.fx_get_tuning(self._h, ctypes.byref(t)))
@@ -68,7 +73,10 @@ class BatchAnalyser:
     def set_tuning(self, tuning=None, **knobs):
         """Replace the context's knobs (struct fx_tuning); keyword arguments change single fields of the current ones."""
         t = tuning if tuning is not None else self.get_tuning()
+        names = {f[0] for f in capi.Tuning._fields_}
         for k, v in knobs.items():
+            if k not in names:                      # (setattr on a ctypes.Structure would take a mistyped name silently)
+                raise ValueError("fx_tuning has no knob %r (it has: %s)" % (k, ", ".join(sorted(names))))
             if k == "unit_plan":
                 t.set_plan(v)
             else:
@@ -111,8 +119,10 @@ class BatchAnalyser:
                 fmt = capi.SAMPLE_F32
             elif x.dtype == torch.float16:
                 fmt = capi.SAMPLE_F16
+            elif x.dtype == torch.int16:
+                fmt = capi.SAMPLE_S16            # 16-bit PCM: v / 32768 in the kernels' load stage (include/fx_wav.hpp's scaling)
             else:
-                raise ValueError("samples must be float32 or float16")
+                raise ValueError("samples must be float32, float16 or int16 (PCM)")
             if x.numel() % (C * per_frame):
                 raise ValueError("input size is not a multiple of channels x samples per frame")
             T = x.numel() // (C * per_frame)
@@ -145,6 +155,8 @@ class BatchAnalyser:
         x = np.ascontiguousarray(x)
         if x.dtype == np.float16:
             fmt = capi.SAMPLE_F16
+        elif x.dtype == np.int16:
+            fmt = capi.SAMPLE_S16
         else:
             x = np.ascontiguousarray(x, np.float32)
             fmt = capi.SAMPLE_F32
@@ -256,7 +268,9 @@ class HopStream:
         self.hops = int(hops_per_batch)
         self.slots = int(slots)
         self.dtype = np.dtype(dtype)
-        fmt = capi.SAMPLE_F16 if self.dtype == np.float16 else capi.SAMPLE_F32
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float16), np.dtype(np.int16)):
+            raise ValueError("HopStream samples are float32, float16 or int16 (PCM)")
+        fmt = {np.dtype(np.float16): capi.SAMPLE_F16, np.dtype(np.int16): capi.SAMPLE_S16}.get(self.dtype, capi.SAMPLE_F32)
         h = ctypes.c_void_p()
         capi.check(self._lib.fx_stream_create(analyser._h, self.hops, self.slots, fmt, ctypes.byref(h)))
         self._h = h

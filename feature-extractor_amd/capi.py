@@ -12,9 +12,9 @@ FEATURE_NAMES = ["onset", "rms", "f0", "centroid", "spread", "flatness", "ler", 
                  "slope", "her", "oer", "inharm"]
 ONSET_SPECTRAL, ONSET_AMPLITUDE, ONSET_COMBINATION = 0, 1, 2
 ORDER_SPECTRAL_THEN_HARMONIC, ORDER_HARMONIC_THEN_SPECTRAL, ORDER_ISOLATED = 0, 1, 2
-SPECTRAL_ONLY, HARMONIC_ONLY = 4, 8
+SPECTRAL_ONLY, HARMONIC_ONLY, LOW_LATENCY = 4, 8, 16
 MEM_HOST, MEM_DEVICE = 0, 1
-SAMPLE_F32, SAMPLE_F16 = 0, 1
+SAMPLE_F32, SAMPLE_F16, SAMPLE_S16 = 0, 1, 2
 FX_OK, FX_ERR_INVALID_ARGUMENT, FX_ERR_NO_DEVICE, FX_ERR_HIP, FX_ERR_OUT_OF_MEMORY, FX_ERR_UNSUPPORTED = range(6)
 
 # every symbol include/fx.h declares
@@ -24,16 +24,17 @@ EXPORTS = ["fx_create", "fx_destroy", "fx_reset_state", "fx_set_sample_rate", "f
            "fx_stream_create", "fx_stream_destroy", "fx_stream_acquire", "fx_stream_submit", "fx_stream_collect", "fx_stream_in_flight", "fx_pack_osc12",
            "fx_pack_osc10", "fx_osc_encode", "fx_last_error", "fx_abi_version",
            "fx_comm_unique_id", "fx_comm_create", "fx_comm_destroy", "fx_comm_layout", "fx_gather_smoothed", "fx_comm_sync",
-           "fx_plan_units", "fx_tuning_defaults", "fx_tuning_from_env", "fx_get_tuning", "fx_set_tuning", "fx_debug_read_stamps",
+           "fx_plan_units", "fx_tuning_defaults", "fx_tuning_from_env", "fx_get_tuning", "fx_set_tuning",
            "fx_offline_create", "fx_offline_destroy", "fx_offline_reset", "fx_offline_sync", "fx_offline_get_previous_f0", "fx_offline_zero_crosses",
            "fx_offline_log_attack_time", "fx_offline_fft_lbp", "fx_offline_harmonic_characteristics"]
 COMM_ID_BYTES = 128
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_UNITS = 24
 
 
 class Tuning(ctypes.Structure):
-    """struct fx_tuning of include/fx.h: launch-shape knobs, none of which changes a result bit."""
+    """struct fx_tuning of include/fx.h: launch-shape knobs.  Within a kernel family none changes a result bit;
+    waves_per_frame selects the family (include/fx.h, FX_LOW_LATENCY) and cannot change once frames have been analysed."""
     _fields_ = [("waves_per_channel", ctypes.c_int), ("channels_per_workgroup", ctypes.c_int), ("waves_per_frame", ctypes.c_int),
                 ("frames_per_unit", ctypes.c_int), ("unit_plan_len", ctypes.c_int), ("unit_plan", ctypes.c_int * MAX_UNITS),
                 ("stream_graph", ctypes.c_int), ("stream_hop_kernel", ctypes.c_int), ("stream_zero_copy", ctypes.c_int),
@@ -125,7 +126,6 @@ def load_library(build_if_missing=True):
     L.fx_tuning_from_env.restype = None
     L.fx_get_tuning.argtypes = [vp, ctypes.POINTER(Tuning)]
     L.fx_set_tuning.argtypes = [vp, ctypes.POINTER(Tuning)]
-    L.fx_debug_read_stamps.argtypes = [vp, ctypes.POINTER(ctypes.c_ulonglong)]
     L.fx_offline_create.argtypes = [ctypes.POINTER(vp), i, i, d]
     L.fx_offline_destroy.argtypes = [vp]
     L.fx_offline_reset.argtypes = [vp]

@@ -29,17 +29,18 @@ fx_status fx_fail(fx_status code, const char* fmt, ...)
     return code;
 }
 
-// which window sizes run the pair kernel unless fx_tuning::waves_per_frame says otherwise (measured: DESIGN.md 3.1)
-#ifndef FX_HOP_PAIRS_BY_DEFAULT
-#define FX_HOP_PAIRS_BY_DEFAULT(n) 0
-#endif
-#ifndef FX_PAIR_BY_DEFAULT
-#define FX_PAIR_BY_DEFAULT(n) 0
-#endif
-
 namespace {
 
 bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+// Which kernel family a context runs (include/fx.h, FX_LOW_LATENCY): frames across a PAIR of wavefronts -- windows of 2048 / 4096
+// points with both analysers -- when the create flag asks for it, or when the tuning knob forces either (experiments, tests).
+bool uses_pairs(const fx_context* c, int waves_per_frame)
+{
+    if (!fxk::pair_kernel_available(c->N) || (c->flags & (FX_SPECTRAL_ONLY | FX_HARMONIC_ONLY))) return false;
+    return waves_per_frame == 2 || (waves_per_frame == 0 && (c->flags & FX_LOW_LATENCY));
+}
+bool known_format(int f) { return f == FX_SAMPLE_F32 || f == FX_SAMPLE_F16 || f == FX_SAMPLE_S16; }
+size_t sample_size(int f) { return f == FX_SAMPLE_F32 ? 4 : 2; }
 
 } // namespace
 
@@ -50,10 +51,8 @@ fx_status zero_state(fx_context* c)
 {
     const size_t half = (size_t) c->C * (c->N / 2);
     HIP_TRY(hipMemsetAsync(c->d_prev, 0, half * sizeof(float), c->stream));
-    for (int i = 0; i < 2; i++) {
-        HIP_TRY(hipMemsetAsync(c->d_tail[i], 0, half * sizeof(float), c->stream));
-        HIP_TRY(hipMemsetAsync(c->d_hist[i], 0, (size_t) c->C * fxk::HLEN * FX_NUM_FEATURES * sizeof(float), c->stream));
-    }
+    for (int i = 0; i < 2; i++) HIP_TRY(hipMemsetAsync(c->d_tail[i], 0, half * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_hist, 0, (size_t) c->C * fxk::HLEN * FX_NUM_FEATURES * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_latest, 0, (size_t) c->C * FX_NUM_FEATURES * sizeof(float), c->stream));
     c->frames_seen = 0;
     c->onset_reset_frame = 0;
@@ -179,23 +178,12 @@ extern "C" fx_status fx_set_tuning(fx_context* c, const fx_tuning* t)
     if (t->waves_per_channel < 0 || t->channels_per_workgroup < 0 || t->waves_per_frame < 0 || t->waves_per_frame > 2 ||
         t->unit_plan_len < 0 || t->unit_plan_len > FX_MAX_UNITS || t->handover_spin_limit < 0)
         return fx_fail(FX_ERR_INVALID_ARGUMENT, "tuning value out of range");
-    c->tuning = *t;
-    if ((t->debug_flags & 2) && !c->d_stamps) {              // diagnostic builds: room for the kernels' cycle stamps
-        HIP_TRY(hipSetDevice(c->device));
-        HIP_TRY(hipMalloc((void**) &c->d_stamps, 128 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(c->d_stamps, 0, 128 * sizeof(unsigned long long)));
-    }
-    return FX_OK;
-}
-
-// diagnostic: the 128 cycle stamps a -DFX_PAIR_STAMPS build of the pair kernel leaves (zeros otherwise); synchronises
-extern "C" fx_status fx_debug_read_stamps(fx_context* c, unsigned long long* out128)
-{
-    if (!c || !out128) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
-    if (!c->d_stamps) return fx_fail(FX_ERR_INVALID_ARGUMENT, "no stamp buffer (fx_tuning::debug_flags bit 1)");
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out128, c->d_stamps, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    // the kernel family is fixed while a history exists: the two families' continuous slots may differ in the last bit, and a
+    // channel's smoothing window must not hold values of both
+    if (c->frames_seen > 0 && uses_pairs(c, t->waves_per_frame) != uses_pairs(c, c->tuning.waves_per_frame))
+        return fx_fail(FX_ERR_INVALID_ARGUMENT, "waves_per_frame selects the kernel family and %lld frames have been analysed with the other one; "
+                                                "fx_reset_state first", c->frames_seen);
+    c->tuning = *t;              // (nothing below can fail: a refused call leaves the old knobs in place)
     return FX_OK;
 }
 
@@ -257,12 +245,11 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     // transform buffer per wave).  fx_tuning overrides for experiments.
     const size_t lds_cu = 160 * 1024;
     st->analysers = (c->flags & FX_SPECTRAL_ONLY) ? 1 : ((c->flags & FX_HARMONIC_ONLY) ? 2 : 3);
-    // Windows of 2048 / 4096 points with both analysers: one frame across a PAIR of wavefronts (fx_pair_kernel) -- twice the
-    // wavefronts per CU for the same LDS, half the registers per lane.  fx_tuning::waves_per_frame forces either kernel.
-    st->pair = fxk::pair_kernel_available(c->N) && st->analysers == 3 &&
-               (c->tuning.waves_per_frame == 2 || (c->tuning.waves_per_frame == 0 && FX_PAIR_BY_DEFAULT(c->N)));
-    st->hop_pairs = fxk::pair_kernel_available(c->N) && st->analysers == 3 &&
-                    (c->tuning.waves_per_frame == 2 || (c->tuning.waves_per_frame == 0 && FX_HOP_PAIRS_BY_DEFAULT(c->N)));
+    // The low-latency family (opt-in: FX_LOW_LATENCY, or fx_tuning::waves_per_frame = 2): windows of 2048 / 4096 points with both
+    // analysers run one frame across a PAIR of wavefronts -- fx_pair_kernel for calls of several frames, fx_hop_pair_kernel for
+    // one frame per call.  The default family keeps a frame in one wavefront at every size (pairs are the faster
+    // path for one hop, not for throughput).
+    st->pair = st->hop_pairs = uses_pairs(c, c->tuning.waves_per_frame);
     {
         const int kcap = st->pair ? fxk::pair_kernel_max_pairs(c->N) : fxk::frame_kernel_max_waves(c->N);
         auto lds_bytes = [&](int ch_, int k_) { return st->pair ? fxk::pair_kernel_lds_bytes(c->N, ch_, k_) : fxk::frame_kernel_lds_bytes(c->N, ch_, k_); };
@@ -289,7 +276,6 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
         fp.err = c->d_err;
         fp.spin_limit = c->tuning.handover_spin_limit > 0 ? (unsigned) c->tuning.handover_spin_limit : (1u << 22);
         fp.debug_flags = (unsigned) c->tuning.debug_flags;
-        fp.stamps = c->d_stamps;
         for (int i = 0; i <= fxk::FX_MAX_CHUNKS; i++) fp.chunk_begin[i] = 0;
         if (!dyn && c->d_queue) {
             int sizes[fxk::FX_MAX_CHUNKS];
@@ -308,8 +294,8 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     ep.nyquist = c->sample_rate / 2.0;
     ep.bin_var = c->bin_var;
     ep.window = c->N;
-    ep.hist_in = c->d_hist[c->cur];
-    ep.hist_out = c->d_hist[c->cur ^ 1];
+    ep.hist = c->d_hist;
+    ep.hist_base = (int) (c->frames_seen % fxk::HLEN);
     ep.out_raw = d_or;
     ep.out_smoothed = d_os;
     ep.latest = c->d_latest;
@@ -330,6 +316,7 @@ void fill_dyn(const fx_context* c, fxk::DynParams* d)
 {
     d->nyquist = c->sample_rate / 2.0;
     d->frames_before = c->frames_seen;
+    d->hist_base = (int) (c->frames_seen % fxk::HLEN);
     d->onset_reset_frame = c->onset_reset_frame;
     d->gain = c->gain;
     d->onset_multiplier = c->onset_multiplier;
@@ -350,14 +337,14 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     if (T < 0) return fx_fail(FX_ERR_INVALID_ARGUMENT, "negative frame count");
     if (T == 0) return FX_OK;
     if (!in) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null input buffer");
-    if (sample_format != FX_SAMPLE_F32 && sample_format != FX_SAMPLE_F16)
+    if (!known_format(sample_format))
         return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown sample format %d", sample_format);
     if (mem_kind != FX_MEM_HOST && mem_kind != FX_MEM_DEVICE)
         return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown memory kind %d", mem_kind);
     HIP_TRY(hipSetDevice(c->device));
     { const fx_status es = fx_check_device_error(c); if (es != FX_OK) return es; }     // sticky: an earlier call's hand-over failed
 
-    const size_t esz = sample_format == FX_SAMPLE_F16 ? 2 : 4;
+    const size_t esz = sample_size(sample_format);
     const size_t per_frame = hop_mode ? (size_t) c->N / 2 : (size_t) c->N;
     const size_t in_bytes = (size_t) c->C * T * per_frame * esz;
     const size_t out_elems = (size_t) c->C * T * FX_NUM_FEATURES;
@@ -463,7 +450,7 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
     if (!is_pow2(window_size) || window_size < 256 || window_size > 4096)
         return fx_fail(FX_ERR_INVALID_ARGUMENT, "window_size must be a power of two in [256, 4096], got %d", window_size);
     if (!(sample_rate > 0.0)) return fx_fail(FX_ERR_INVALID_ARGUMENT, "sample_rate must be positive");
-    if ((flags & FX_ORDER_MASK) == 3u || (flags & ~(FX_ORDER_MASK | FX_SPECTRAL_ONLY | FX_HARMONIC_ONLY)) ||
+    if ((flags & FX_ORDER_MASK) == 3u || (flags & ~(FX_ORDER_MASK | FX_SPECTRAL_ONLY | FX_HARMONIC_ONLY | FX_LOW_LATENCY)) ||
         ((flags & FX_SPECTRAL_ONLY) && (flags & FX_HARMONIC_ONLY)))
         return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown or contradictory flags 0x%x", flags);
 
@@ -502,10 +489,8 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
     const size_t half = (size_t) num_channels * (window_size / 2);
     TRY_OR_CLEAN(hipMalloc((void**) &c->d_tw, sizeof(float) * 2 * window_size));
     TRY_OR_CLEAN(hipMalloc((void**) &c->d_prev, sizeof(float) * half));
-    for (int i = 0; i < 2; i++) {
-        TRY_OR_CLEAN(hipMalloc((void**) &c->d_tail[i], sizeof(float) * half));
-        TRY_OR_CLEAN(hipMalloc((void**) &c->d_hist[i], sizeof(float) * (size_t) num_channels * fxk::HLEN * FX_NUM_FEATURES));
-    }
+    for (int i = 0; i < 2; i++) TRY_OR_CLEAN(hipMalloc((void**) &c->d_tail[i], sizeof(float) * half));
+    TRY_OR_CLEAN(hipMalloc((void**) &c->d_hist, sizeof(float) * (size_t) num_channels * fxk::HLEN * FX_NUM_FEATURES));
     TRY_OR_CLEAN(hipMalloc((void**) &c->d_latest, sizeof(float) * (size_t) num_channels * FX_NUM_FEATURES));
     TRY_OR_CLEAN(hipMalloc((void**) &c->d_queue, sizeof(unsigned) * (1 + (size_t) num_channels)));
     TRY_OR_CLEAN(hipHostMalloc((void**) &c->h_err, 64, hipHostMallocCoherent));
@@ -557,11 +542,10 @@ fx_status fx_destroy(fx_context* c)
     (void) hipSetDevice(c->device);
     fx_comm_release(c);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->d_tw, c->d_prev, c->d_tail[0], c->d_tail[1], c->d_hist[0], c->d_hist[1], c->d_latest,
+    void* bufs[] = {c->d_tw, c->d_prev, c->d_tail[0], c->d_tail[1], c->d_hist, c->d_latest,
                     c->d_raw, c->d_part, c->d_in, c->d_out_raw, c->d_queue};
     for (void* b : bufs) if (b) (void) hipFree(b);
     if (c->h_err) (void) hipHostFree(c->h_err);
-    if (c->d_stamps) (void) hipFree(c->d_stamps);
     for (int i = 0; i < 3; i++) if (c->ev[i]) (void) hipEventDestroy(c->ev[i]);
     for (hipEvent_t e : c->prof_events) (void) hipEventDestroy(e);
     if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -709,7 +693,10 @@ struct fx_stream {
     fx_context* ctx = nullptr;
     int hops = 0, slots = 0, fmt = FX_SAMPLE_F32;
     size_t in_bytes = 0, out_bytes = 0;
-    hipStream_t copy = nullptr;
+    // Large batches: three queues, so that PCIe runs in both directions while the kernels run -- `copy` carries batch k+1's samples
+    // to the device, the context's stream analyses batch k, `back` returns batch k-1's vectors.  (Until round 4 the results went
+    // back on `copy`: the next batch's samples then queued behind a copy that waits for the analysis before it, and nothing overlapped.)
+    hipStream_t copy = nullptr, back = nullptr;
     // Small batches are launch-bound (one 4096-pt hop: four kernels, three copies and five events cost ~150 us of host
     // and dispatch time for ~40 us of GPU work): there the whole step -- input copy, per-call scalars, the four
     // kernels, result copies -- is captured once per ring slot and buffer parity into a hipGraph and replayed.
@@ -752,6 +739,7 @@ fx_status fx_stream_destroy(fx_stream* s)
     if (s->ctx) (void) hipSetDevice(s->ctx->device);
     if (s->copy) (void) hipStreamSynchronize(s->copy);
     if (s->ctx && s->ctx->stream) (void) hipStreamSynchronize(s->ctx->stream);
+    if (s->back) (void) hipStreamSynchronize(s->back);
     for (auto& sl : s->ring) {
         if (sl.h_in) (void) hipHostFree(sl.h_in);
         if (sl.h_raw) (void) hipHostFree(sl.h_raw);
@@ -772,6 +760,7 @@ fx_status fx_stream_destroy(fx_stream* s)
     if (s->g_part) (void) hipFree(s->g_part);
     if (s->g_raw) (void) hipFree(s->g_raw);
     if (s->copy) (void) hipStreamDestroy(s->copy);
+    if (s->back) (void) hipStreamDestroy(s->back);
     delete s;
     return FX_OK;
 }
@@ -781,16 +770,17 @@ fx_status fx_stream_create(fx_context* c, int hops_per_batch, int slots, int sam
     if (!c || !out) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
     *out = nullptr;
     if (hops_per_batch < 1 || slots < 1 || slots > 64) return fx_fail(FX_ERR_INVALID_ARGUMENT, "hops_per_batch >= 1 and 1 <= slots <= 64 required");
-    if (sample_format != FX_SAMPLE_F32 && sample_format != FX_SAMPLE_F16) return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown sample format %d", sample_format);
+    if (!known_format(sample_format)) return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown sample format %d", sample_format);
     HIP_TRY(hipSetDevice(c->device));
     fx_stream* s = new (std::nothrow) fx_stream();
     if (!s) return fx_fail(FX_ERR_OUT_OF_MEMORY, "host allocation failed");
     s->ctx = c; s->hops = hops_per_batch; s->slots = slots; s->fmt = sample_format;
-    s->in_bytes = (size_t) c->C * hops_per_batch * (c->N / 2) * (sample_format == FX_SAMPLE_F16 ? 2 : 4);
+    s->in_bytes = (size_t) c->C * hops_per_batch * (c->N / 2) * sample_size(sample_format);
     s->out_bytes = (size_t) c->C * hops_per_batch * FX_NUM_FEATURES * sizeof(float);
     s->ring.resize((size_t) slots);
 #define S_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fx_status st_ = fx_fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); fx_stream_destroy(s); return st_; } } while (0)
     S_TRY(hipStreamCreateWithFlags(&s->copy, hipStreamNonBlocking));
+    S_TRY(hipStreamCreateWithFlags(&s->back, hipStreamNonBlocking));
     // which of the equivalent paths runs: by batch size, unless the context's tuning forces one (experiments, tests)
     s->use_graph = c->tuning.stream_graph >= 0 ? c->tuning.stream_graph != 0 : (size_t) c->C * hops_per_batch <= 4096;
     // (up to 1 MiB of hops per call: the kernel reads each hop out of the pinned slot exactly once, 16 bytes per lane)
@@ -952,10 +942,10 @@ fx_status fx_stream_submit(fx_stream* s)
         return st;
     }
     HIP_TRY(hipEventRecord(sl.done, c->stream));
-    HIP_TRY(hipStreamWaitEvent(s->copy, sl.done, 0));
-    HIP_TRY(hipMemcpyAsync(sl.h_raw, sl.d_raw, s->out_bytes, hipMemcpyDeviceToHost, s->copy));
-    HIP_TRY(hipMemcpyAsync(sl.h_sm, sl.d_sm, s->out_bytes, hipMemcpyDeviceToHost, s->copy));
-    HIP_TRY(hipEventRecord(sl.out, s->copy));
+    HIP_TRY(hipStreamWaitEvent(s->back, sl.done, 0));
+    HIP_TRY(hipMemcpyAsync(sl.h_raw, sl.d_raw, s->out_bytes, hipMemcpyDeviceToHost, s->back));
+    HIP_TRY(hipMemcpyAsync(sl.h_sm, sl.d_sm, s->out_bytes, hipMemcpyDeviceToHost, s->back));
+    HIP_TRY(hipEventRecord(sl.out, s->back));
     s->head = (s->head + 1) % s->slots;
     s->in_flight++;
     s->acquired = false;

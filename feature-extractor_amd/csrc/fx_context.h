@@ -46,13 +46,12 @@ struct fx_context {
     float* d_tw = nullptr;        // [N][2]
     float* d_prev = nullptr;      // [C][N/2]
     float* d_tail[2] = {nullptr, nullptr};   // [C][N/2], ping-pong
-    float* d_hist[2] = {nullptr, nullptr};   // [C][HLEN][12], ping-pong
+    float* d_hist = nullptr;      // [C][HLEN][12]: per channel a ring of the newest HLEN frames' raw values (row = frame index mod HLEN)
     float* d_latest = nullptr;    // [C][12]
     int    cur = 0;
     fx_tuning tuning;             // launch-shape knobs: taken from the environment ONCE, in fx_create (fx_set_tuning replaces them)
     unsigned* h_err = nullptr;    // pinned, coherent: a kernel stores 1 here when a work unit gave up waiting for its predecessor (sticky)
     unsigned* d_err = nullptr;    // device view of h_err
-    unsigned long long* d_stamps = nullptr;   // diagnostic builds only (fx_tuning::debug_flags bit 1): FrameParams::stamps
     unsigned* d_queue = nullptr;  // [1 + C]: ticket counter and per-channel chunk counts of a frame-kernel launch cut in time (FrameParams::queue)
 
     float* d_raw = nullptr;       // [C][T_cap][12]

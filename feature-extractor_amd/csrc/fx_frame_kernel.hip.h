@@ -21,6 +21,46 @@
 // ---------------------------------------------------------------------------------------------
 // frame load: global -> real LDS image, 16 B per lane, coalesced
 // ---------------------------------------------------------------------------------------------
+// Sample formats on the wire (FX_SAMPLE_*, include/fx.h): fp32, fp16, or 16-bit signed PCM, which becomes v / 2^15 -- exactly
+// what the WAV reader makes of a 16-bit file (include/fx_wav.hpp, JUCE's int -> float scaling), so integer audio crosses PCIe
+// at two bytes a sample and loses nothing.  The carried-over window tail is always fp32.
+__device__ __forceinline__ constexpr int sample_bytes(int fmt) { return fmt == FX_SAMPLE_F32 ? 4 : 2; }
+template <int FMT> __device__ __forceinline__ float widen_one(const void* at)
+{
+    if (FMT == FX_SAMPLE_F16) return __half2float(*static_cast<const __half*>(at));
+    if (FMT == FX_SAMPLE_S16) return (float) (int) *static_cast<const short*>(at) * (1.0f / 32768.0f);
+    return *static_cast<const float*>(at);
+}
+// four consecutive samples: r = the 16 bytes of four floats, or (r.x, r.y) = the 8 bytes of four 16-bit samples
+template <int FMT> __device__ __forceinline__ f4 widen_four(uint4 r)
+{
+    if (FMT == FX_SAMPLE_F16) {
+        const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&r.x));
+        const float2 b = __half22float2(*reinterpret_cast<const __half2*>(&r.y));
+        return f4{a.x, a.y, b.x, b.y};
+    }
+    if (FMT == FX_SAMPLE_S16) {
+        const f4 v = f4{(float) ((int) (r.x << 16) >> 16), (float) ((int) r.x >> 16), (float) ((int) (r.y << 16) >> 16), (float) ((int) r.y >> 16)};
+        return v * (1.0f / 32768.0f);                                          // exact: a power of two
+    }
+    return f4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+}
+template <int FMT> __device__ __forceinline__ uint4 fetch_four(const void* src, int i)       // samples i .. i + 3 of src
+{
+    if (FMT == FX_SAMPLE_F32) return *reinterpret_cast<const uint4*>(static_cast<const float*>(src) + i);
+    const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(src) + i);
+    return uint4{v.x, v.y, 0u, 0u};
+}
+// run `CALL` with the constants FA / FB set to the formats of a window's two halves: fb is the call's sample format, fa is
+// either the same or fp32 (the tail)
+#define FX_FORMATS(fa, fb, CALL) do {                                                                                              \
+        if ((fb) == FX_SAMPLE_F16)      { if ((fa) == FX_SAMPLE_F16) { constexpr int FA = FX_SAMPLE_F16, FB = FX_SAMPLE_F16; CALL; }   \
+                                          else                       { constexpr int FA = FX_SAMPLE_F32, FB = FX_SAMPLE_F16; CALL; } } \
+        else if ((fb) == FX_SAMPLE_S16) { if ((fa) == FX_SAMPLE_S16) { constexpr int FA = FX_SAMPLE_S16, FB = FX_SAMPLE_S16; CALL; }   \
+                                          else                       { constexpr int FA = FX_SAMPLE_F32, FB = FX_SAMPLE_S16; CALL; } } \
+        else                            { constexpr int FA = FX_SAMPLE_F32, FB = FX_SAMPLE_F32; CALL; }                                \
+    } while (0)
+
 template <int N, int HALF>
 __device__ __forceinline__ void load_half(const void* src, int sample_format, float gain, bool apply_gain,
                                           float* rbuf, int dst_off, float* tail_out, int lane)
@@ -28,15 +68,9 @@ __device__ __forceinline__ void load_half(const void* src, int sample_format, fl
     // HALF is a multiple of 128 samples; 4 samples per lane per step
     for (int i = lane * 4; i < HALF; i += 256) {
         f4 v;
-        if (sample_format == FX_SAMPLE_F16) {
-            const uint2 raw = *reinterpret_cast<const uint2*>(static_cast<const __half*>(src) + i);
-            const __half2 a = *reinterpret_cast<const __half2*>(&raw.x);
-            const __half2 b = *reinterpret_cast<const __half2*>(&raw.y);
-            const float2 fa = __half22float2(a), fb = __half22float2(b);
-            v = f4{fa.x, fa.y, fb.x, fb.y};
-        } else {
-            v = *reinterpret_cast<const f4*>(static_cast<const float*>(src) + i);
-        }
+        if (sample_format == FX_SAMPLE_F16)      v = widen_four<FX_SAMPLE_F16>(fetch_four<FX_SAMPLE_F16>(src, i));
+        else if (sample_format == FX_SAMPLE_S16) v = widen_four<FX_SAMPLE_S16>(fetch_four<FX_SAMPLE_S16>(src, i));
+        else                                     v = widen_four<FX_SAMPLE_F32>(fetch_four<FX_SAMPLE_F32>(src, i));
         if (apply_gain) v *= gain;                       // ref AudioDataCollector.h:88
         *reinterpret_cast<f4*>(&rbuf[rimg<N>(dst_off + i)]) = v;
         if (tail_out) *reinterpret_cast<f4*>(tail_out + i) = v;
@@ -44,9 +78,9 @@ __device__ __forceinline__ void load_half(const void* src, int sample_format, fl
 }
 
 // Both halves of a window with every global load issued before the first one is consumed (one memory
-// round trip per frame instead of one per 1 KB piece).  F16_A / F16_B: sample format of the source of
+// round trip per frame instead of one per 1 KB piece).  FMT_A / FMT_B: sample format of the source of
 // the first / second half (the carried-over tail is always fp32).  N >= 512.
-template <int N, bool F16_A, bool F16_B>
+template <int N, int FMT_A, int FMT_B>
 __device__ __forceinline__ double load_window(const void* src_a, const void* src_b, float gain_a, float gain_b,
                                               float* rbuf, float* tail_out, int lane)
 {
@@ -54,36 +88,20 @@ __device__ __forceinline__ double load_window(const void* src_a, const void* src
     constexpr int HALF = N / 2, QH = HALF / 256;
     uint4 ra[QH], rb[QH];
 #pragma unroll
-    for (int q = 0; q < QH; q++) {
-        const int i = 256 * q + 4 * lane;
-        if (F16_A) { const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const __half*>(src_a) + i); ra[q] = uint4{v.x, v.y, 0u, 0u}; }
-        else       ra[q] = *reinterpret_cast<const uint4*>(static_cast<const float*>(src_a) + i);
-    }
+    for (int q = 0; q < QH; q++) ra[q] = fetch_four<FMT_A>(src_a, 256 * q + 4 * lane);
+#pragma unroll
+    for (int q = 0; q < QH; q++) rb[q] = fetch_four<FMT_B>(src_b, 256 * q + 4 * lane);
 #pragma unroll
     for (int q = 0; q < QH; q++) {
         const int i = 256 * q + 4 * lane;
-        if (F16_B) { const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const __half*>(src_b) + i); rb[q] = uint4{v.x, v.y, 0u, 0u}; }
-        else       rb[q] = *reinterpret_cast<const uint4*>(static_cast<const float*>(src_b) + i);
-    }
-    auto widen = [](uint4 r, bool f16) -> f4 {
-        if (f16) {
-            const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&r.x));
-            const float2 b = __half22float2(*reinterpret_cast<const __half2*>(&r.y));
-            return f4{a.x, a.y, b.x, b.y};
-        }
-        return f4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
-    };
-#pragma unroll
-    for (int q = 0; q < QH; q++) {
-        const int i = 256 * q + 4 * lane;
-        const f4 v = widen(ra[q], F16_A) * gain_a;             // ref AudioDataCollector.h:88 (x * 1.0f is exact)
+        const f4 v = widen_four<FMT_A>(ra[q]) * gain_a;        // ref AudioDataCollector.h:88 (x * 1.0f is exact)
         *reinterpret_cast<f4*>(&rbuf[rimg<N>(i)]) = v;
         if (Geo<N>::SPLIT) ssq += (double) (v.x * v.x) + (double) (v.y * v.y) + (double) (v.z * v.z) + (double) (v.w * v.w);
     }
 #pragma unroll
     for (int q = 0; q < QH; q++) {
         const int i = 256 * q + 4 * lane;
-        const f4 v = widen(rb[q], F16_B) * gain_b;
+        const f4 v = widen_four<FMT_B>(rb[q]) * gain_b;
         *reinterpret_cast<f4*>(&rbuf[rimg<N>(HALF + i)]) = v;
         if (tail_out) *reinterpret_cast<f4*>(tail_out + i) = v;
         if (Geo<N>::SPLIT) ssq += (double) (v.x * v.x) + (double) (v.y * v.y) + (double) (v.z * v.z) + (double) (v.w * v.w);
@@ -94,7 +112,7 @@ __device__ __forceinline__ double load_window(const void* src_a, const void* src
 // The same window straight from global memory into registers in the order the first FFT pass consumes it (split
 // sizes: the raw frame is not kept in registers across the four transforms; it is fetched again -- from L2 -- when
 // the spectral and the harmonic analyser need it).  For a fixed (g, j) the 64 lanes read 64 consecutive samples.
-template <int N, bool F16_A, bool F16_B>
+template <int N, int FMT_A, int FMT_B>
 __device__ __forceinline__ void load_window_first_pass_order(const void* src_a, const void* src_b, float gain_a, float gain_b,
                                                              int lane, float (&x)[Geo<N>::P])
 {
@@ -106,7 +124,7 @@ __device__ __forceinline__ void load_window_first_pass_order(const void* src_a, 
     // (byte offsets kept in 32 bits: scalar base + 32-bit lane offset + immediate is one addressing mode, a 64-bit
     // element index is a vector add per load)
     const unsigned low = (unsigned) rev4<G::IDIG>(lane);
-    const unsigned off_a = low * (F16_A ? 2u : 4u), off_b = low * (F16_B ? 2u : 4u);
+    const unsigned off_a = low * (unsigned) sample_bytes(FMT_A), off_b = low * (unsigned) sample_bytes(FMT_B);
 #pragma unroll
     for (int g = 0; g < G::GA; g++) {
 #pragma unroll
@@ -114,9 +132,8 @@ __device__ __forceinline__ void load_window_first_pass_order(const void* src_a, 
             const int r = (G::RA == 4) ? j : (G::RA == 8) ? ((j >> 1) + 4 * (j & 1)) : ((j >> 2) + 4 * (j & 3));
             const bool second = r >= G::RA / 2;                                // low + g < ITEMS_A <= N/2
             const int k = g + G::ITEMS_A * (second ? r - G::RA / 2 : r);       // compile-time part of the sample index
-            const bool f16 = second ? F16_B : F16_A;
-            const char* at = static_cast<const char*>(second ? src_b : src_a) + (second ? off_b : off_a) + k * (f16 ? 2 : 4);
-            x[g * G::RA + j] = f16 ? __half2float(*reinterpret_cast<const __half*>(at)) : *reinterpret_cast<const float*>(at);
+            const char* at = static_cast<const char*>(second ? src_b : src_a) + (second ? off_b : off_a) + k * sample_bytes(second ? FMT_B : FMT_A);
+            x[g * G::RA + j] = second ? widen_one<FMT_B>(at) : widen_one<FMT_A>(at);
         }
     }
     if (gain_a != 1.0f || gain_b != 1.0f) {                                   // ref AudioDataCollector.h:88 (wave-uniform)
@@ -294,17 +311,17 @@ template <int N> struct FrameWave {
     struct HarmonicSpectrum { float hre[U]; float left2, left1, right1; double sum, max; };
 
     // where the two halves of this frame's window come from (a1, ref RealTimeAudioAnalysis.h:205-219)
-    struct Sources { const void* a; const void* b; float gain_a, gain_b; bool f16_a, f16_b; };
+    struct Sources { const void* a; const void* b; float gain_a, gain_b; int fmt_a, fmt_b; };
     __device__ __forceinline__ Sources sources() const
     {
-        const size_t esz = p.sample_format == FX_SAMPLE_F16 ? 2 : 4;
+        const size_t esz = (size_t) sample_bytes(p.sample_format);
         const unsigned char* in = static_cast<const unsigned char*>(p.in);
         Sources s;
-        s.f16_a = s.f16_b = p.sample_format == FX_SAMPLE_F16;
+        s.fmt_a = s.fmt_b = p.sample_format;
         if (p.hop_mode) {
             s.gain_a = s.gain_b = p.gain;
             s.b = in + ((size_t) c * T + t) * HALF * esz;
-            if (t == 0) { s.a = p.tail_in + (size_t) c * HALF; s.f16_a = false; s.gain_a = 1.0f; }   // tail is fp32, already gained
+            if (t == 0) { s.a = p.tail_in + (size_t) c * HALF; s.fmt_a = FX_SAMPLE_F32; s.gain_a = 1.0f; }   // tail is fp32, already gained
             else        s.a = in + ((size_t) c * T + (t - 1)) * HALF * esz;
         } else {
             s.gain_a = s.gain_b = 1.0f;
@@ -319,9 +336,7 @@ template <int N> struct FrameWave {
     {
         asm volatile("" ::: "memory");        // a fetch of its own each time: the point is not to keep x live in between
         const Sources s = sources();
-        if (s.f16_a && s.f16_b) load_window_first_pass_order<N, true,  true >(s.a, s.b, s.gain_a, s.gain_b, lane, x);
-        else if (s.f16_b)       load_window_first_pass_order<N, false, true >(s.a, s.b, s.gain_a, s.gain_b, lane, x);
-        else                    load_window_first_pass_order<N, false, false>(s.a, s.b, s.gain_a, s.gain_b, lane, x);
+        FX_FORMATS(s.fmt_a, s.fmt_b, (load_window_first_pass_order<N, FA, FB>(s.a, s.b, s.gain_a, s.gain_b, lane, x)));
     }
 
     // returns the lane's share of the frame's sum of squares (split sizes only; otherwise sum_squares() computes it)
@@ -335,14 +350,11 @@ FX_MARK("load");
             const Sources sr = sources();
             const void* src_a = sr.a; const void* src_b = sr.b;
             const float gain_a = sr.gain_a, gain_b = sr.gain_b;
-            const bool f16_a = sr.f16_a, f16 = sr.f16_b;
             if constexpr (N >= 512) {
-                if (f16_a && f16)       ssq = load_window<N, true,  true >(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane);
-                else if (f16)           ssq = load_window<N, false, true >(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane);
-                else                    ssq = load_window<N, false, false>(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane);
+                FX_FORMATS(sr.fmt_a, sr.fmt_b, (ssq = load_window<N, FA, FB>(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane)));
             } else {
-                load_half<N, HALF>(src_a, f16_a ? FX_SAMPLE_F16 : FX_SAMPLE_F32, gain_a, gain_a != 1.0f, rbuf, 0, nullptr, lane);
-                load_half<N, HALF>(src_b, p.sample_format, gain_b, gain_b != 1.0f, rbuf, HALF, tail_dst, lane);
+                load_half<N, HALF>(src_a, sr.fmt_a, gain_a, gain_a != 1.0f, rbuf, 0, nullptr, lane);
+                load_half<N, HALF>(src_b, sr.fmt_b, gain_b, gain_b != 1.0f, rbuf, HALF, tail_dst, lane);
             }
             wave_fence();
         }

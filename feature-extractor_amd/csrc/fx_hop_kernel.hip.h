@@ -61,13 +61,13 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
         const f4* ps = reinterpret_cast<const f4*>(p.prev_re + (size_t) c * M);
 #pragma unroll 2
         for (int i = threadIdx.x; i < M / 4; i += 192) *reinterpret_cast<f4*>(&prev[bimg<N>(4 * i)]) = ps[i];   // 4 | U: a group stays whole
-        const uint4* hs4 = reinterpret_cast<const uint4*>(ep_arg.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES);
+        const uint4* hs4 = reinterpret_cast<const uint4*>(ep_arg.hist + (size_t) c * HLEN * FX_NUM_FEATURES);     // the channel's ring, row for row
         for (int i = threadIdx.x; i < HLEN * FX_NUM_FEATURES / 4; i += 192) reinterpret_cast<uint4*>(s_hist)[i] = hs4[i];
     }
     if (threadIdx.x == 0) { turn[0] = 0; part->flags = 0; }
     if (sig.stage) {
         // the hop itself: out of the pinned host slot into device memory, 16 bytes per lane, once
-        const size_t hop_bytes = (size_t) (N / 2) * (p.sample_format == FX_SAMPLE_F16 ? 2 : 4);
+        const size_t hop_bytes = (size_t) (N / 2) * (size_t) sample_bytes(p.sample_format);
         const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(p.in) + (size_t) c * hop_bytes);
         uint4* dst = reinterpret_cast<uint4*>(static_cast<unsigned char*>(sig.stage) + (size_t) c * hop_bytes);
         for (int i = threadIdx.x; i < (int) (hop_bytes / 16); i += blockDim.x) dst[i] = src[i];
@@ -98,9 +98,9 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
         }
         w.spectral(lane, xr, sum_sq);
         // this analyser's slots of the raw vector (ref RealTimeAnalyser.h:209-226), while the pitch estimate is still running.
-        // (-DFX_EXP_HOP_EARLY_EPILOGUE also finishes their smoothing, the onset and the history rows that merely move up here, leaving
-        // four slots and one row behind the last barrier: measured 1-3 us SLOWER per hop at every size -- the early stores to the
-        // pinned host slot are in the way of the later ones -- so everything is finished at the end.)
+        // (Round 3 also finished their smoothing and the onset here, leaving four slots behind the last barrier: measured 1-3 us
+        // SLOWER per hop at every size -- the early stores to the pinned host slot are in the way of the later ones -- so everything
+        // is finished at the end: profiles/r03_variants.txt.)
         EpilogueParams e1 = ep_arg; e1.analysers = 1;
         float out[FX_NUM_FEATURES];
         finalise_wave(e1, *part, lane, out);                    // (every lane: the logarithms side by side)
@@ -109,15 +109,6 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
             s_raw[FX_FLATNESS] = out[FX_FLATNESS]; s_raw[FX_LER] = out[FX_LER]; s_raw[FX_FLUX] = out[FX_FLUX]; s_raw[FX_SLOPE] = out[FX_SLOPE];
         }
         wave_fence();
-        {
-            EpilogueParams ep = ep_arg;
-            ep.raw = s_raw - (size_t) c * FX_NUM_FEATURES;
-            ep.hist_in = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
-#ifdef FX_EXP_HOP_EARLY_EPILOGUE
-            epilogue_hop(ep, c, lane, s_onset, SLOTS_SPECTRAL);
-            for (int i = lane; i < (HLEN - 1) * FX_NUM_FEATURES; i += 64) history_value(ep, (long long) c * HLEN * FX_NUM_FEATURES + i);
-#endif
-        }
     } else {
         float xr[P];
         if constexpr (G::SPLIT) {
@@ -149,14 +140,10 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
     // the rest of the hop -- smoothing, onset, history -- as fx_tail_fused_kernel does it for T = 1, from LDS, one slot per lane
     EpilogueParams ep = ep_arg;
     ep.raw = s_raw - (size_t) c * FX_NUM_FEATURES;              // epilogue_hop / history_value index by channel
-    ep.hist_in = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
-#ifdef FX_EXP_HOP_EARLY_EPILOGUE
-    epilogue_hop(ep, c, lane, s_onset, SLOTS_HARMONIC);
-    if (lane < FX_NUM_FEATURES) history_value(ep, ((long long) c * HLEN + (HLEN - 1)) * FX_NUM_FEATURES + lane);
-#else
+    ep.hist = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;     // (the LDS copy of the ring)
     epilogue_hop(ep, c, lane, s_onset);
-    for (int i = lane; i < HLEN * FX_NUM_FEATURES; i += 64) history_value(ep, (long long) c * HLEN * FX_NUM_FEATURES + i);
-#endif
+    ep.hist = ep_arg.hist;                                      // this hop's row of the ring, and nothing else
+    if (lane < FX_NUM_FEATURES) history_value(ep, c, 0, lane);
 
     // completion: this workgroup's results (pinned host memory) are visible system-wide before it counts itself in
     if (lane == 0 && sig.host_flag) {
@@ -238,7 +225,7 @@ fx_hop_pair_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const H
             for (int i = 0; i < 15; i++) early_b[i] = g[i * PL::L1];
         }
         if (sig.stage) {
-            const size_t hop_bytes = (size_t) (N / 2) * (p.sample_format == FX_SAMPLE_F16 ? 2 : 4);
+            const size_t hop_bytes = (size_t) (N / 2) * (size_t) sample_bytes(p.sample_format);
             const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(p.in) + (size_t) c * hop_bytes);
             uint4* dst = reinterpret_cast<uint4*>(static_cast<unsigned char*>(sig.stage) + (size_t) c * hop_bytes);
             for (int i = threadIdx.x; i < (int) (hop_bytes / 16); i += 128) dst[i] = src[i];
@@ -253,7 +240,7 @@ fx_hop_pair_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const H
         for (int i = tid; i < N / 2; i += 256) dst[i] = src[i];
         const f4* ps = reinterpret_cast<const f4*>(p.prev_re + (size_t) c * M);
         for (int i = tid; i < M / 4; i += 256) reinterpret_cast<f4*>(prev)[i] = ps[i];
-        const uint4* hs4 = reinterpret_cast<const uint4*>(ep_arg.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES);
+        const uint4* hs4 = reinterpret_cast<const uint4*>(ep_arg.hist + (size_t) c * HLEN * FX_NUM_FEATURES);     // the channel's ring, row for row
         for (int i = tid; i < HLEN * FX_NUM_FEATURES / 4; i += 256) reinterpret_cast<uint4*>(s_hist)[i] = hs4[i];
     }
     if (sig.stage) p.in = sig.stage;
@@ -270,11 +257,7 @@ fx_hop_pair_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const H
 
     const double nyquist = p.nyquist;
     PairWave<N> pw{p, tw, prev, turn2, cbuf, reinterpret_cast<float*>(cbuf), mbox, flags, part,
-                   nyquist, 1.0 / nyquist, nyquist / (double) M, 1.0f / (float) N, c, 1, 0, w, 0u, 0u
-#ifdef FX_PAIR_STAMPS
-                   , 0
-#endif
-    };
+                   nyquist, 1.0 / nyquist, nyquist / (double) M, 1.0f / (float) N, c, 1, 0, w, 0u, 0u};
     typename PairWave<N>::HarmonicSpectrum hs;
     if (pair == 0) {
         // a1 + the pitch estimate (a10-a14): the window into this pair's real image, low-pass, two transforms, lag search
@@ -307,13 +290,6 @@ fx_hop_pair_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const H
                 s_raw[FX_FLATNESS] = out[FX_FLATNESS]; s_raw[FX_LER] = out[FX_LER]; s_raw[FX_FLUX] = out[FX_FLUX]; s_raw[FX_SLOPE] = out[FX_SLOPE];
             }
             wave_fence();
-            EpilogueParams ep = ep_arg;
-            ep.raw = s_raw - (size_t) c * FX_NUM_FEATURES;
-            ep.hist_in = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
-#ifdef FX_EXP_HOP_EARLY_EPILOGUE
-            epilogue_hop(ep, c, lane, s_onset, SLOTS_SPECTRAL);
-            for (int i = lane; i < (HLEN - 1) * FX_NUM_FEATURES; i += 64) history_value(ep, (long long) c * HLEN * FX_NUM_FEATURES + i);
-#endif
         }
     } else {
         pw.harmonic_spectrum(lane, hs);                         // a15, up to where the pitch is needed
@@ -334,14 +310,10 @@ fx_hop_pair_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const H
 
     EpilogueParams ep = ep_arg;
     ep.raw = s_raw - (size_t) c * FX_NUM_FEATURES;
-    ep.hist_in = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
-#ifdef FX_EXP_HOP_EARLY_EPILOGUE
-    epilogue_hop(ep, c, lane, s_onset, SLOTS_HARMONIC);         // (the other slots left with the spectral pair)
-    if (lane < FX_NUM_FEATURES) history_value(ep, ((long long) c * HLEN + (HLEN - 1)) * FX_NUM_FEATURES + lane);      // the newest row
-#else
+    ep.hist = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;     // (the LDS copy of the ring)
     epilogue_hop(ep, c, lane, s_onset);
-    for (int i = lane; i < HLEN * FX_NUM_FEATURES; i += 64) history_value(ep, (long long) c * HLEN * FX_NUM_FEATURES + i);
-#endif
+    ep.hist = ep_arg.hist;                                      // this hop's row of the ring, and nothing else
+    if (lane < FX_NUM_FEATURES) history_value(ep, c, 0, lane);
     if (lane == 0 && sig.host_flag) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         const unsigned before = __hip_atomic_fetch_add(sig.arrivals, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);

@@ -51,13 +51,14 @@ struct DynParams {
     float     onset_multiplier;
     int       onset_window;
     int       onset_type;
+    int       hist_base;            // frames_before mod HLEN (EpilogueParams::hist_base)
 };
 
 constexpr int FX_MAX_CHUNKS = FX_MAX_UNITS;
 
 struct FrameParams {
     const void*  in;            // frames [C][T][N] or hops [C][T][N/2]
-    int          sample_format; // FX_SAMPLE_F32 / FX_SAMPLE_F16
+    int          sample_format; // FX_SAMPLE_F32 / FX_SAMPLE_F16 / FX_SAMPLE_S16
     int          hop_mode;      // 1: `in` holds hops, windows are assembled from tail + hops
     int          T;             // frames (= hops) per channel in this call
     int          C;
@@ -79,7 +80,6 @@ struct FrameParams {
     unsigned*    err;
     unsigned     spin_limit;
     unsigned     debug_flags;
-    unsigned long long* stamps;  // diagnostic builds (-DFX_PAIR_STAMPS): [2 waves][64] shader-clock stamps of channel 0's last frame; else unused
     int          chunk_begin[FX_MAX_CHUNKS + 1];   // chunk k analyses frames [chunk_begin[k], chunk_begin[k + 1]); the last entry used is T
     float        gain;          // hop mode only (ref AudioDataCollector.h:88)
     const float* tail_in;       // [C][N/2] second half of the previous window (already gained)
@@ -101,8 +101,10 @@ struct EpilogueParams {
     double       nyquist;
     double       bin_var;
     int          window;
-    const float* hist_in;       // [C][HLEN][12] raw values of the HLEN frames before this call
-    float*       hist_out;      // [C][HLEN][12]
+    float*       hist;          // [C][HLEN][12] raw values of the newest HLEN frames, a RING per channel: the row of the frame with
+                                // global index g (frames since the last state reset) is g mod HLEN, so a call only writes the rows of
+                                // its own frames -- one row per channel for a one-hop call, not the whole table
+    int          hist_base;     // frames_before mod HLEN: the ring row this call's first frame goes to
     float*       out_raw;       // [C][T][12] or nullptr
     float*       out_smoothed;  // [C][T][12] or nullptr
     float*       latest;        // [C][12] smoothed values after the last frame
@@ -114,7 +116,7 @@ struct EpilogueParams {
     float        onset_multiplier;
     int          order_mode;    // FX_ORDER_*
     int          analysers;     // bit 0: spectral analyser runs, bit 1: harmonic analyser runs
-    const DynParams* dyn;       // non-null in a captured step: overrides nyquist, frames_before, onset_*
+    const DynParams* dyn;       // non-null in a captured step: overrides nyquist, frames_before, hist_base, onset_*
 };
 
 // Completion signal of a one-hop call (fx_hop_kernel): workgroups count themselves in `arrivals` (device memory, zero

@@ -326,7 +326,7 @@ hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t stream)
     hipLaunchKernelGGL(fx_epilogue_kernel, dim3((unsigned) (p.C * ((p.T + EPI_TILE - 1) / EPI_TILE))), dim3(EPI_TILE), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const long long n2 = (long long) p.C * HLEN * FX_NUM_FEATURES;
+    const long long n2 = (long long) p.C * (p.T < HLEN ? p.T : HLEN) * FX_NUM_FEATURES;      // the call's newest rows go to the ring
     hipLaunchKernelGGL(fx_history_kernel, dim3((unsigned) ((n2 + 255) / 256)), dim3(256), 0, stream, p);
     return hipGetLastError();
 }

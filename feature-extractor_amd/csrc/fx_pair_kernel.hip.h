@@ -83,17 +83,6 @@ template <int N> struct PairWave {
     mutable unsigned gen;   // arrivals so far (wave-uniform; the same in both waves at every pair_sync)
     mutable unsigned xch;   // mailbox exchanges so far
 
-#ifdef FX_PAIR_STAMPS
-    mutable int stamp_i;
-    __device__ __forceinline__ void stamp(int lane) const
-    {
-        if (p.stamps && c == 0 && t == T - 1 && lane == 0 && stamp_i < 64) p.stamps[64 * w + stamp_i] = __builtin_readcyclecounter();
-        stamp_i++;
-    }
-#define FX_STAMP(lane) stamp(lane)
-#else
-#define FX_STAMP(lane) ((void) 0)
-#endif
     // ---- pair synchronisation ------------------------------------------------------------------------------------
     // Every LDS access this wave has issued is complete, then its arrival is published; returns when the partner's is
     // there.  LDS operations of one wavefront execute in order and the LDS is one memory for the CU, so what the partner
@@ -111,34 +100,27 @@ template <int N> struct PairWave {
     }
     __device__ __forceinline__ void wait() const
     {
-        FX_STAMP((int) (threadIdx.x & 63));
-#ifndef FX_EXP_PAIR_NOSYNC
-        while ((int) (__hip_atomic_load(flags + (w ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - gen) < 0) {
-#ifdef FX_EXP_PAIR_SLEEP
-            __builtin_amdgcn_s_sleep(FX_EXP_PAIR_SLEEP);
-#endif
-        }
-#endif
+        // (a poll without s_sleep: the partner is at most one LDS round trip away; with a sleep, measured no different -- r03_pair.txt)
+        while ((int) (__hip_atomic_load(flags + (w ^ 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - gen) < 0) { }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        FX_STAMP((int) (threadIdx.x & 63));
     }
     __device__ __forceinline__ void pair_sync(int lane) const { arrive(lane); wait(); }
     // mailbox slot i of wave `who` in the half the current exchange uses; next_exchange() after the pair_sync that ends it
     __device__ __forceinline__ double* slot(int who, int i) const { return mbox + 16 * (int) (xch & 1u) + 8 * who + i; }
     __device__ __forceinline__ void next_exchange() const { xch++; }
 
-    struct Sources { const void* a; const void* b; float gain_a, gain_b; bool f16_a, f16_b; };
+    struct Sources { const void* a; const void* b; float gain_a, gain_b; int fmt_a, fmt_b; };
     __device__ __forceinline__ Sources sources() const
     {
-        const size_t esz = p.sample_format == FX_SAMPLE_F16 ? 2 : 4;
+        const size_t esz = (size_t) sample_bytes(p.sample_format);
         const unsigned char* in = static_cast<const unsigned char*>(p.in);
         Sources s;
-        s.f16_a = s.f16_b = p.sample_format == FX_SAMPLE_F16;
+        s.fmt_a = s.fmt_b = p.sample_format;
         if (p.hop_mode) {
             s.gain_a = s.gain_b = p.gain;
             s.b = in + ((size_t) c * T + t) * HALF * esz;
-            if (t == 0) { s.a = p.tail_in + (size_t) c * HALF; s.f16_a = false; s.gain_a = 1.0f; }   // tail is fp32, already gained
+            if (t == 0) { s.a = p.tail_in + (size_t) c * HALF; s.fmt_a = FX_SAMPLE_F32; s.gain_a = 1.0f; }   // tail is fp32, already gained
             else        s.a = in + ((size_t) c * T + (t - 1)) * HALF * esz;
         } else {
             s.gain_a = s.gain_b = 1.0f;
@@ -150,29 +132,18 @@ template <int N> struct PairWave {
 
     // a1 (ref RealTimeAudioAnalysis.h:205-219): wave w brings half w of the window into the real image, 16 bytes per lane,
     // every load issued before the first is consumed; returns the wave's share of getRMSLevel's sum (float squares, double sum)
-    template <bool F16>
+    template <int FMT>
     __device__ __forceinline__ double load_half_window_t(int lane, const void* src, float gain, float* tail_dst) const
     {
         constexpr int QH = HALF / 256;
         uint4 r[QH];
 #pragma unroll
-        for (int q = 0; q < QH; q++) {
-            if (F16) { const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const __half*>(src) + 256 * q + 4 * lane); r[q] = uint4{v.x, v.y, 0u, 0u}; }
-            else r[q] = *reinterpret_cast<const uint4*>(static_cast<const float*>(src) + 256 * q + 4 * lane);
-        }
+        for (int q = 0; q < QH; q++) r[q] = fetch_four<FMT>(src, 256 * q + 4 * lane);
         double ssq = 0.0;
         float* img = rbuf + prim<N>(HALF * w + 4 * lane);                  // 256 is a multiple of the padding quantum: immediates from here
 #pragma unroll
         for (int q = 0; q < QH; q++) {
-            f4 v;
-            if (F16) {
-                const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&r[q].x));
-                const float2 b = __half22float2(*reinterpret_cast<const __half2*>(&r[q].y));
-                v = f4{a.x, a.y, b.x, b.y};
-            } else {
-                v = f4{__uint_as_float(r[q].x), __uint_as_float(r[q].y), __uint_as_float(r[q].z), __uint_as_float(r[q].w)};
-            }
-            v *= gain;                                                     // ref AudioDataCollector.h:88 (x * 1.0f is exact)
+            const f4 v = widen_four<FMT>(r[q]) * gain;                     // ref AudioDataCollector.h:88 (x * 1.0f is exact)
             *reinterpret_cast<f4*>(img + prim_step<N>(256 * q)) = v;
             if (tail_dst) *reinterpret_cast<f4*>(tail_dst + 256 * q + 4 * lane) = v;
             ssq += (double) (v.x * v.x) + (double) (v.y * v.y) + (double) (v.z * v.z) + (double) (v.w * v.w);
@@ -184,10 +155,12 @@ template <int N> struct PairWave {
 FX_MARK("p_load");
         const Sources sr = sources();
         const void* src = w ? sr.b : sr.a;
-        const bool f16 = w ? sr.f16_b : sr.f16_a;
+        const int fmt = w ? sr.fmt_b : sr.fmt_a;
         const float gain = w ? sr.gain_b : sr.gain_a;
         float* tail_dst = (w == 1 && t == T - 1) ? p.tail_out + (size_t) c * HALF : nullptr;
-        return f16 ? load_half_window_t<true>(lane, src, gain, tail_dst) : load_half_window_t<false>(lane, src, gain, tail_dst);
+        if (fmt == FX_SAMPLE_F16) return load_half_window_t<FX_SAMPLE_F16>(lane, src, gain, tail_dst);
+        if (fmt == FX_SAMPLE_S16) return load_half_window_t<FX_SAMPLE_S16>(lane, src, gain, tail_dst);
+        return load_half_window_t<FX_SAMPLE_F32>(lane, src, gain, tail_dst);
     }
 
     // ---- first-pass operands -------------------------------------------------------------------------------------
@@ -210,13 +183,13 @@ FX_MARK("p_load");
     // the raw window from global memory (L2-hot after load_half_window), optionally through the Bartlett window (a3).  Every
     // load is a scalar base (the source of its half, advanced by this wave's 2w samples) + ONE per-lane 32-bit offset + an
     // immediate (as load_window_first_pass_order does it: a 64-bit element index would be a vector add per load).
-    template <bool WINDOWED, bool F16_A, bool F16_B>
+    template <bool WINDOWED, int FMT_A, int FMT_B>
     __device__ __forceinline__ void inputs_from_global_t(int lane, float (&x)[P2], const Sources& s) const
     {
         const unsigned low4 = 4u * (unsigned) rev4<3>(lane);
-        const unsigned off_a = low4 * (F16_A ? 2u : 4u), off_b = low4 * (F16_B ? 2u : 4u);
-        const char* base_a = static_cast<const char*>(s.a) + 2 * w * (F16_A ? 2 : 4);
-        const char* base_b = static_cast<const char*>(s.b) + 2 * w * (F16_B ? 2 : 4);
+        const unsigned off_a = low4 * (unsigned) sample_bytes(FMT_A), off_b = low4 * (unsigned) sample_bytes(FMT_B);
+        const char* base_a = static_cast<const char*>(s.a) + 2 * w * sample_bytes(FMT_A);
+        const char* base_b = static_cast<const char*>(s.b) + 2 * w * sample_bytes(FMT_B);
 #pragma unroll
         for (int d = 0; d < 2; d++) {
 #pragma unroll
@@ -224,9 +197,8 @@ FX_MARK("p_load");
                 const int r = rj(j);
                 const bool second = r >= RA / 2;                               // low < 256 <= N/2
                 const int k = d + 256 * (second ? r - RA / 2 : r);            // compile-time part of the sample index
-                const bool f16 = second ? F16_B : F16_A;
-                const char* at = (second ? base_b : base_a) + (second ? off_b : off_a) + k * (f16 ? 2 : 4);
-                x[d * RA + j] = f16 ? __half2float(*reinterpret_cast<const __half*>(at)) : *reinterpret_cast<const float*>(at);
+                const char* at = (second ? base_b : base_a) + (second ? off_b : off_a) + k * sample_bytes(second ? FMT_B : FMT_A);
+                x[d * RA + j] = second ? widen_one<FMT_B>(at) : widen_one<FMT_A>(at);
             }
         }
         if (s.gain_a != 1.0f || s.gain_b != 1.0f) {                           // ref AudioDataCollector.h:88 (wave-uniform)
@@ -256,9 +228,7 @@ FX_MARK("p_load");
     {
         asm volatile("" ::: "memory");
         const Sources s = sources();
-        if (s.f16_a && s.f16_b) inputs_from_global_t<WINDOWED, true,  true >(lane, x, s);
-        else if (s.f16_b)       inputs_from_global_t<WINDOWED, false, true >(lane, x, s);
-        else                    inputs_from_global_t<WINDOWED, false, false>(lane, x, s);
+        FX_FORMATS(s.fmt_a, s.fmt_b, (inputs_from_global_t<WINDOWED, FA, FB>(lane, x, s)));
     }
 
     // ---- the transform ---------------------------------------------------------------------------------------------
@@ -497,9 +467,6 @@ FX_MARK("p_lag");
         if (w == 0) {
             LagSearch<N> ls;
             ls.begin();
-#if (FX_EXP_PAIR_SKIP_MORE + 0) & 1
-            ls.done = true; ls.lag = 100.0f;
-#endif
             for (int blk = 0; blk < N / 64 && !ls.done; blk++) ls.block(lane, blk, rbuf[64 * blk + lane]);
             lag = ls.finish(lane, v_end);
             if (lane == 0) { *reinterpret_cast<float*>(slot(0, 0)) = lag; fpl->lag = lag; }
@@ -965,18 +932,10 @@ fx_pair_kernel(const FrameParams p_arg)
 
     const double nyquist = p.nyquist;
     PairWave<N> pw{p, tw, prev, turn2, cbuf, reinterpret_cast<float*>(cbuf), mbox, flags, nullptr,
-                   nyquist, 1.0 / nyquist, nyquist / (double) M, 1.0f / (float) N, c, T, 0, w, 0u, 0u
-#ifdef FX_PAIR_STAMPS
-                   , 0
-#endif
-    };
+                   nyquist, 1.0 / nyquist, nyquist / (double) M, 1.0f / (float) N, c, T, 0, w, 0u, 0u};
     for (int t = live ? t_begin + slot : t_end; t < t_end; t += K) {
         const int ln = opaque<N>(lane);
         pw.t = t;
-#ifdef FX_PAIR_STAMPS
-        pw.stamp_i = 0;
-        pw.stamp(ln);
-#endif
         pw.fpl = p.part + ((size_t) c * T + t);
         if (w == 0 && ln == 0) pw.fpl->flags = 0;
         // a1 + a2: the window into the real image, the sum of its squares
@@ -987,18 +946,10 @@ fx_pair_kernel(const FrameParams p_arg)
         pw.next_exchange();
         if (w == 0 && ln == 0) pw.fpl->sum_sq = sum_sq;
         // the harmonic analyser's pitch estimate first: its low-pass reads the raw frame's image
-        // (FX_EXP_PAIR_SKIP: costing by omission -- bit 0 pitch, 1 spectral, 2 harmonic; results are wrong by construction)
-#ifndef FX_EXP_PAIR_SKIP
-#define FX_EXP_PAIR_SKIP 0
-#endif
-        float lag = 100.0f;
-        if (!(FX_EXP_PAIR_SKIP & 1)) lag = pw.pitch(ln);
+        const float lag = pw.pitch(ln);
         const double f0 = (nyquist * 2.0) / (double) lag;                      // ref PitchAnalyser.h:57
-        if (!(FX_EXP_PAIR_SKIP & 2)) pw.spectral(opaque<N>(ln), sum_sq);
-        if (!(FX_EXP_PAIR_SKIP & 4)) { typename PairWave<N>::HarmonicSpectrum hs; pw.harmonic_spectrum(opaque<N>(ln), hs); pw.harmonic_tail(opaque<N>(ln), hs, f0); }
-#ifdef FX_PAIR_STAMPS
-        pw.stamp(ln);
-#endif
+        pw.spectral(opaque<N>(ln), sum_sq);
+        { typename PairWave<N>::HarmonicSpectrum hs; pw.harmonic_spectrum(opaque<N>(ln), hs); pw.harmonic_tail(opaque<N>(ln), hs, f0); }
     }
 
     __syncthreads();

@@ -10,6 +10,7 @@ __device__ __forceinline__ EpilogueParams with_dyn(const EpilogueParams& in)
     if (p.dyn) {
         p.nyquist = p.dyn->nyquist;
         p.frames_before = p.dyn->frames_before;
+        p.hist_base = p.dyn->hist_base;
         p.onset_reset_frame = p.dyn->onset_reset_frame;
         p.onset_window = p.dyn->onset_window;
         p.onset_type = p.dyn->onset_type;
@@ -155,14 +156,20 @@ fx_finalise_kernel(const EpilogueParams p_arg)
 // oldest first, padded on the left with the zeros it was created with; getTotal() adds them left to
 // right in fp32.  Every smoothed value and every onset decision of frame t is therefore a pure
 // function of the raw values of frames t-HLEN+1 .. t, and all (channel, frame) pairs are evaluated
-// in parallel: thread = (channel, frame).  Frames before this call come from hist_in.
+// in parallel: thread = (channel, frame).  Frames before this call come from `hist`, a ring of HLEN rows per channel
+// (row of the frame with global index g = g mod HLEN; EpilogueParams::hist_base = the row of this call's first frame).
 // ---------------------------------------------------------------------------------------------
-// Rows of raw values around a frame: from global memory (this call's rows in `raw`, the HLEN rows before the call in
-// `hist`), or from an LDS tile holding rows tile_first .. of one channel with TILE_STRIDE floats per row (13: odd, so
-// that threads one row apart fall on different banks).
+// Rows of raw values around a frame: this call's rows in `raw`, the rows before the call in the channel's ring `hist`
+// (global memory or an LDS copy of the ring, same row positions), or an LDS tile holding rows tile_first .. of one
+// channel with TILE_STRIDE floats per row (13: odd, so that threads one row apart fall on different banks).
 constexpr int TILE_STRIDE = 13;
+// ring row of the frame tau frames from this call's first one, -HLEN <= tau < 0 (hist_base in [0, HLEN))
+__device__ __forceinline__ int hist_row_before(int hist_base, int tau) { const int r = hist_base + tau; return r < 0 ? r + HLEN : r; }
+// rows before a frame that its smoothed values and its onset decision read: nine for the 10-deep slots (RealTimeAnalyser.h:73); the
+// detector's L candidates each want an RMS mean that reaches nine frames back with one insert per hop, five with two
+__device__ __forceinline__ int hist_rows_read(int onset_window) { const int n = onset_window + 8; return n < 9 ? 9 : (n > HLEN ? HLEN : n); }
 struct RawView {
-    const float* raw; const float* hist; int T; long long frames_before;
+    const float* raw; const float* hist; int T; long long frames_before; int hist_base;
     const float* tile = nullptr; int tile_first = 0;
     // raw value of slot s at frame index tau relative to this call (tau may be negative);
     // frames before the stream began read as "not recorded"
@@ -170,7 +177,7 @@ struct RawView {
     __device__ __forceinline__ float get(int tau, int s) const
     {
         if (tile) return tile[(tau - tile_first) * TILE_STRIDE + s];
-        return tau >= 0 ? raw[(size_t) tau * FX_NUM_FEATURES + s] : hist[(size_t) (HLEN + tau) * FX_NUM_FEATURES + s];
+        return tau >= 0 ? raw[(size_t) tau * FX_NUM_FEATURES + s] : hist[hist_row_before(hist_base, tau) * FX_NUM_FEATURES + s];
     }
 };
 
@@ -255,9 +262,10 @@ __device__ __forceinline__ void epilogue_frame(const EpilogueParams& p, int c, i
 {
     RawView v;
     v.raw = p.raw + (size_t) c * p.T * FX_NUM_FEATURES;
-    v.hist = p.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES;
+    v.hist = p.hist + (size_t) c * HLEN * FX_NUM_FEATURES;
     v.T = p.T;
     v.frames_before = p.frames_before;
+    v.hist_base = p.hist_base;
     v.tile = tile;
     v.tile_first = tile_first;
 
@@ -355,26 +363,21 @@ __device__ __forceinline__ bool detect_onset_wave(const EpilogueParams& p, const
 // The same for the single frame of a one-hop call (T == 1) with the twelve slots spread over twelve lanes: lane s
 // evaluates slot s (the onset lane the detector, the RMS lane the double-insert mean), so the hop's tail takes the time
 // of its longest slot instead of the sum of all.  Same expressions, same order of the fp32 additions as epilogue_frame.
-// `slots`: bit s set = this call finishes slot s.  The one-hop kernels finish the spectral analyser's slots (and the onset, which reads
-// flux and RMS only) as soon as that analyser is done -- while the pitch estimate is still running -- and the harmonic analyser's four
-// at the end.  All 64 lanes of the calling wavefront must take part when the onset slot is among them.
-constexpr unsigned SLOTS_ALL = (1u << FX_NUM_FEATURES) - 1u;
-constexpr unsigned SLOTS_HARMONIC = (1u << FX_F0) | (1u << FX_HER) | (1u << FX_OER) | (1u << FX_INHARM);
-constexpr unsigned SLOTS_SPECTRAL = SLOTS_ALL & ~SLOTS_HARMONIC;
-__device__ __forceinline__ void epilogue_hop(const EpilogueParams& p, int c, int lane, float* scratch, unsigned slots = SLOTS_ALL)
+// All 64 lanes of the calling wavefront must take part (the onset detector's candidates are spread over them).
+__device__ __forceinline__ void epilogue_hop(const EpilogueParams& p, int c, int lane, float* scratch)
 {
     RawView v;
     v.raw = p.raw + (size_t) c * p.T * FX_NUM_FEATURES;
-    v.hist = p.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES;
+    v.hist = p.hist + (size_t) c * HLEN * FX_NUM_FEATURES;
     v.T = p.T;
     v.frames_before = p.frames_before;
+    v.hist_base = p.hist_base;
     const int t = 0, s = lane;
     const bool spec = p.analysers & 1, harm = p.analysers & 2;
     const int order_mode = (spec && harm) ? p.order_mode : FX_ORDER_ISOLATED;
     const float never = __int_as_float(0x7fc00000);
-    bool onset = false;
-    if (slots & (1u << FX_ONSET)) onset = detect_onset_wave(p, v, t, order_mode, spec, lane, scratch);       // all 64 lanes
-    const bool mine = lane < FX_NUM_FEATURES && ((slots >> lane) & 1u);
+    const bool onset = detect_onset_wave(p, v, t, order_mode, spec, lane, scratch);       // all 64 lanes
+    const bool mine = lane < FX_NUM_FEATURES;
     float rw = 0.0f, sm = 0.0f;
     if (mine) {
         rw = v.get(t, s);
@@ -418,12 +421,12 @@ fx_epilogue_kernel(const EpilogueParams p_arg)
     const int first = t0 - HLEN;                                     // first row of the tile (may be before the call)
     const int rows = (p.T - t0 < EPI_TILE ? p.T - t0 : EPI_TILE) + HLEN;
     const float* raw = p.raw + (size_t) c * p.T * FX_NUM_FEATURES;
-    const float* hist = p.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES;
+    const float* hist = p.hist + (size_t) c * HLEN * FX_NUM_FEATURES;
     for (int i = threadIdx.x; i < rows * FX_NUM_FEATURES; i += EPI_TILE) {
         const int r = i / FX_NUM_FEATURES, s = i % FX_NUM_FEATURES, tau = first + r;
         // rows more than HLEN before the call do not exist (and are never read: RawView::valid)
         tile[r * TILE_STRIDE + s] = tau >= 0 ? raw[(size_t) tau * FX_NUM_FEATURES + s]
-                                             : (tau >= -HLEN ? hist[(size_t) (HLEN + tau) * FX_NUM_FEATURES + s] : 0.0f);
+                                             : (tau >= -HLEN ? hist[hist_row_before(p.hist_base, tau) * FX_NUM_FEATURES + s] : 0.0f);
     }
     __syncthreads();
     // The detector of frame t compares the RMS means of frames t - L + 1 .. t as they stood at each frame's own
@@ -432,7 +435,7 @@ fx_epilogue_kernel(const EpilogueParams p_arg)
     // before them.
     {
         RawView v;
-        v.raw = raw; v.hist = hist; v.T = p.T; v.frames_before = p.frames_before; v.tile = tile; v.tile_first = first;
+        v.raw = raw; v.hist = hist; v.T = p.T; v.frames_before = p.frames_before; v.hist_base = p.hist_base; v.tile = tile; v.tile_first = first;
         const bool both = (p.analysers & 1) && (p.analysers & 2);
         const int order_mode = both ? p.order_mode : FX_ORDER_ISOLATED;
         const int pushes = (order_mode == FX_ORDER_HARMONIC_THEN_SPECTRAL) ? 2 : 1;
@@ -447,34 +450,36 @@ fx_epilogue_kernel(const EpilogueParams p_arg)
 }
 #endif
 
-// carry the newest HLEN frames of raw values over to the next call
-__device__ __forceinline__ void history_value(const EpilogueParams& p, long long idx)
+// The call's newest min(T, HLEN) frames go to their rows of the channel's ring: row (hist_base + tau) mod HLEN for the frame
+// tau of this call.  Nothing else moves -- a one-hop call writes ONE row per channel (until round 4 the whole table was
+// copied from a `hist_in` to a `hist_out` to shift it by the call's frames: 33 of a live 8192-channel call's 107 us).
+__device__ __forceinline__ int hist_rows_written(int T) { return T < HLEN ? T : HLEN; }
+__device__ __forceinline__ void history_value(const EpilogueParams& p, int c, int h, int s)
 {
-    const int s = (int) (idx % FX_NUM_FEATURES);
-    const int h = (int) ((idx / FX_NUM_FEATURES) % HLEN);
-    const int c = (int) (idx / ((long long) FX_NUM_FEATURES * HLEN));
-    const int tau = p.T - HLEN + h;                                  // frame relative to this call
-    float val;
-    if (tau >= 0) val = p.raw[((size_t) c * p.T + tau) * FX_NUM_FEATURES + s];
-    else          val = p.hist_in[((size_t) c * HLEN + (HLEN + tau)) * FX_NUM_FEATURES + s];
-    p.hist_out[idx] = val;
+    const int tau = p.T - hist_rows_written(p.T) + h;                // frame relative to this call, 0 <= h < hist_rows_written
+    p.hist[((size_t) c * HLEN + (size_t) ((p.hist_base + tau) % HLEN)) * FX_NUM_FEATURES + s] = p.raw[((size_t) c * p.T + tau) * FX_NUM_FEATURES + s];
 }
 
 #ifdef FX_WITH_TAIL_KERNELS
 __global__ void __launch_bounds__(256)
-fx_history_kernel(const EpilogueParams p)
+fx_history_kernel(const EpilogueParams p_arg)
 {
+    const EpilogueParams p = with_dyn(p_arg);
+    const int rows = hist_rows_written(p.T);
     const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long) p.C * HLEN * FX_NUM_FEATURES) return;
-    history_value(p, idx);
+    if (idx >= (long long) p.C * rows * FX_NUM_FEATURES) return;
+    const int s = (int) (idx % FX_NUM_FEATURES);
+    const int h = (int) ((idx / FX_NUM_FEATURES) % rows);
+    const int c = (int) (idx / ((long long) FX_NUM_FEATURES * rows));
+    history_value(p, c, h, s);
 }
 #endif
 
 // The three kernels above in one launch for calls of a few frames per channel (the streaming ring at one hop per call),
 // where two kernel boundaries cost more than the work: one wavefront per channel.  Lane t finalises frame t; the raw
-// values of the HLEN frames before the call and of the call's own frames are staged in LDS (one round trip to memory
-// instead of the ~70 dependent ones of the smoothing / onset loops), lane t smooths frame t from there, then all 64
-// lanes carry the history over.
+// values of the frames before the call that the smoothing reads (hist_rows_read: 13 of the ring's 48 rows with the default
+// onset window) and of the call's own frames are staged in LDS (one round trip to memory instead of the ~70 dependent
+// ones of the smoothing / onset loops), lane t smooths frame t from there, then the call's own rows go to the ring.
 #ifdef FX_WITH_TAIL_KERNELS
 __global__ void __launch_bounds__(64)
 fx_tail_fused_kernel(const EpilogueParams p_arg)
@@ -484,9 +489,14 @@ fx_tail_fused_kernel(const EpilogueParams p_arg)
     __shared__ float s_scratch[64];
     EpilogueParams p = with_dyn(p_arg);
     const int c = blockIdx.x, lane = threadIdx.x;
+    float* ring = p.hist + (size_t) c * HLEN * FX_NUM_FEATURES;
     {
-        const uint4* h4 = reinterpret_cast<const uint4*>(p.hist_in + (size_t) c * HLEN * FX_NUM_FEATURES);
-        for (int i = lane; i < HLEN * FX_NUM_FEATURES / 4; i += 64) reinterpret_cast<uint4*>(s_hist)[i] = h4[i];
+        // the LDS copy keeps the ring's row positions; rows nobody reads are not fetched (a row is 48 bytes: three 16-byte pieces)
+        const int need = hist_rows_read(p.onset_window);            // what the call's FIRST frame reaches back; later frames less
+        for (int i = lane; i < need * 3; i += 64) {
+            const int r = hist_row_before(p.hist_base, -need + i / 3), q = i % 3;
+            reinterpret_cast<uint4*>(s_hist)[r * 3 + q] = reinterpret_cast<const uint4*>(ring)[r * 3 + q];
+        }
     }
     if (p.T == 1) {
         // one hop: the scalar tail by the whole wavefront (its logarithms side by side), straight into the LDS row -- the
@@ -508,11 +518,15 @@ fx_tail_fused_kernel(const EpilogueParams p_arg)
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_s_barrier();
-    // the smoothing and the history rows read channel c's rows through (raw + c*T*12, hist_in + c*HLEN*12): point those at the LDS copies
-    p.raw = s_raw - (size_t) c * p.T * FX_NUM_FEATURES;
-    p.hist_in = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
-    if (p.T == 1) epilogue_hop(p, c, lane, s_scratch);                // one hop: a lane per slot, the onset detector's candidates side by side
-    else if (lane < p.T) epilogue_frame(p, c, lane);
-    for (int i = lane; i < HLEN * FX_NUM_FEATURES; i += 64) history_value(p, (long long) c * HLEN * FX_NUM_FEATURES + i);
+    // the smoothing reads channel c's rows through (raw + c*T*12, hist + c*HLEN*12): point those at the LDS copies
+    EpilogueParams q = p;
+    q.raw = s_raw - (size_t) c * p.T * FX_NUM_FEATURES;
+    q.hist = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
+    if (p.T == 1) epilogue_hop(q, c, lane, s_scratch);                // one hop: a lane per slot, the onset detector's candidates side by side
+    else if (lane < p.T) epilogue_frame(q, c, lane);
+    // this call's rows of the ring: T <= FUSED_TAIL_MAX_FRAMES different rows, which held frames HLEN before these -- further back
+    // than anything reads (hist_rows_read <= 40), and what was read went through the LDS copy above in any case
+    q.hist = p.hist;
+    for (int i = lane; i < p.T * FX_NUM_FEATURES; i += 64) history_value(q, c, i / FX_NUM_FEATURES, i % FX_NUM_FEATURES);
 }
 #endif

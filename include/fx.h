@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 3
+#define FX_ABI_VERSION 4
 
 typedef int fx_status;
 enum {
@@ -55,8 +55,11 @@ enum { FX_ONSET_SPECTRAL = 0, FX_ONSET_AMPLITUDE = 1, FX_ONSET_COMBINATION = 2 }
 /* Where a caller buffer lives. */
 enum { FX_MEM_HOST = 0, FX_MEM_DEVICE = 1 };
 
-/* Sample formats accepted for audio input. */
-enum { FX_SAMPLE_F32 = 0, FX_SAMPLE_F16 = 1 };
+/* Sample formats accepted for audio input.  FX_SAMPLE_S16 is 16-bit signed PCM, little endian as the host has it: the load
+ * stage of the kernels turns a sample v into the float v / 32768 -- exactly what JUCE's WAV reader (and include/fx_wav.hpp)
+ * makes of a 16-bit file before AudioDataCollector sees it (AudioFilePlayer.h:41-61, AudioDataCollector.h:42-64) -- so an
+ * integer source crosses PCIe at two bytes per sample and every result is bit for bit that of the decoded floats. */
+enum { FX_SAMPLE_F32 = 0, FX_SAMPLE_F16 = 1, FX_SAMPLE_S16 = 2 };
 
 /* fx_create flags.  The first three fix the order in which the reference's two
  * analysis threads write the ONE shared AudioFeatures object per hop
@@ -70,6 +73,14 @@ enum { FX_SAMPLE_F32 = 0, FX_SAMPLE_F16 = 1 };
  * AudioFeatures::getValue returns before any insert, RealTimeAnalyser.h:84-88). */
 #define FX_SPECTRAL_ONLY                4u   /* RealTimeSpectralAnalyser only: RMS, centroid..slope, onset */
 #define FX_HARMONIC_ONLY                8u   /* RealTimeHarmonicAnalyser only: RMS, F0, HER, OER, inharmonicity */
+/* The low-latency kernel family, for hosts that run the reference's own cadence -- one analysis per hop as it arrives
+ * (AudioDataCollector.h:66-94) -- and care about the round trip of that one hop rather than about frames per second.
+ * Windows of 2048 and 4096 points (both analysers): every analysis frame is spread over a PAIR of wavefronts, which halves the
+ * arithmetic on a hop's critical path (4096-point hop 35 -> 31 us) and costs throughput on long calls (2048 points: -25 %).
+ * Results: every discrete decision (onset, pitch lag, peaks, gates) is identical to the default family's; the continuous slots
+ * may differ from it in the last bit (sums over bins are added in another order).  One family per context, from fx_create to
+ * fx_destroy, so a channel's smoothing history never mixes the two.  No effect on other window sizes or with one analyser. */
+#define FX_LOW_LATENCY                  16u
 
 typedef struct fx_context fx_context;
 
@@ -165,8 +176,10 @@ fx_status fx_stream_collect(fx_stream* s, float* out_raw, float* out_smoothed);
 int fx_stream_in_flight(fx_stream* s);
 
 /* ---- launch-shape knobs (experiments, tests) ----
- * None of these changes a result bit (tests/test_gpu_parity.py pins that); they choose workgroup shapes,
- * how long calls are cut into work units, and which of the equivalent streaming paths runs.  A context
+ * Within a kernel family none of these changes a result bit (tests/test_gpu_parity.py pins that); they choose workgroup
+ * shapes, how long calls are cut into work units, and which of the equivalent streaming paths runs.  The one knob that
+ * selects a FAMILY is waves_per_frame (see FX_LOW_LATENCY): fx_set_tuning refuses to change it once the context has
+ * analysed frames (FX_ERR_INVALID_ARGUMENT until fx_reset_state), so the two are never mixed in one history.  A context
  * takes its knobs ONCE, in fx_create, from the FX_* environment variables named below (later changes of
  * the environment have no effect: no entry point on the analysis path reads the environment);
  * fx_set_tuning replaces them explicitly.  A stream takes the stream_* knobs in fx_stream_create. */
@@ -174,8 +187,8 @@ int fx_stream_in_flight(fx_stream* s);
 typedef struct fx_tuning {
     int waves_per_channel;       /* FX_WAVES: frames of one channel in flight in a workgroup; 0 = measured best */
     int channels_per_workgroup;  /* FX_CHANNELS_PER_WG; 0 = measured best */
-    int waves_per_frame;         /* FX_WAVES_PER_FRAME: 1 = a frame lives in one wavefront, 2 = in a pair of wavefronts
-                                    (windows >= 2048 only); 0 = measured best */
+    int waves_per_frame;         /* FX_WAVES_PER_FRAME: kernel family -- 1 = a frame lives in one wavefront, 2 = in a pair of wavefronts
+                                    (windows >= 2048 only); 0 = as the create flags say (pairs with FX_LOW_LATENCY, else one) */
     int frames_per_unit;         /* FX_FRAMES_PER_CHUNK: work-unit length of a call cut in time; 0 = never cut; -1 = measured best */
     int unit_plan_len;           /* FX_CHUNK_PLAN=a,b,...: explicit unit lengths (used when they add up to the call's frames) */
     int unit_plan[FX_MAX_UNITS];
@@ -190,15 +203,12 @@ typedef struct fx_tuning {
                                     Calls between fx_profile_begin / fx_profile_end are timed regardless */
     int handover_spin_limit;     /* FX_HANDOVER_SPINS: polls a work unit spends waiting for its predecessor's flux state
                                     before it gives up and the call is reported failed (FX_ERR_HIP); 0 = default (1 << 22) */
-    int debug_flags;             /* FX_DEBUG_FLAGS: bit 0 = work units do not publish their hand-over (forces the time-out; tests);
-                                    bit 1 = keep a buffer for the cycle stamps of diagnostic kernel builds (fx_debug_read_stamps) */
+    int debug_flags;             /* FX_DEBUG_FLAGS: bit 0 = work units do not publish their hand-over (forces the time-out; tests) */
 } fx_tuning;
 void fx_tuning_defaults(fx_tuning* t);     /* every knob "measured best" */
 void fx_tuning_from_env(fx_tuning* t);     /* defaults overridden by the FX_* variables set right now */
 fx_status fx_get_tuning(fx_context* ctx, fx_tuning* out);
 fx_status fx_set_tuning(fx_context* ctx, const fx_tuning* t);
-/* Diagnostic (tools/pair_stamps.py): 128 shader-clock stamps left by a library built with -DFX_PAIR_STAMPS; zeros otherwise. */
-fx_status fx_debug_read_stamps(fx_context* ctx, unsigned long long* out128);
 
 /* Host-only arithmetic, exposed for testing: how a call of `num_frames` frames per channel is cut into
  * work units for the frame kernel (several workgroups per channel, each analysing a run of consecutive
