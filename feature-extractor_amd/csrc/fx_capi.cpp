@@ -252,7 +252,10 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     st->pair = st->hop_pairs = uses_pairs(c, c->tuning.waves_per_frame);
     {
         const int kcap = st->pair ? fxk::pair_kernel_max_pairs(c->N) : fxk::frame_kernel_max_waves(c->N);
-        auto lds_bytes = [&](int ch_, int k_) { return st->pair ? fxk::pair_kernel_lds_bytes(c->N, ch_, k_) : fxk::frame_kernel_lds_bytes(c->N, ch_, k_); };
+        // one frame per call through the batch kernels (both analysers): the flux state stays in global memory (FrameParams::direct_state)
+        const bool direct = T == 1 && !st->pair && st->analysers == 3;
+        fp.direct_state = direct ? 1 : 0;
+        auto lds_bytes = [&](int ch_, int k_) { return st->pair ? fxk::pair_kernel_lds_bytes(c->N, ch_, k_) : fxk::frame_kernel_lds_bytes(c->N, ch_, k_, direct); };
         int ch = 1, k = 1;
         if (st->pair) { ch = 1; k = kcap; }
         else fxk::frame_kernel_preferred_shape(c->N, &ch, &k);
@@ -260,9 +263,11 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
         if (c->tuning.channels_per_workgroup >= 1) ch = c->tuning.channels_per_workgroup;
         if (k > T) k = T;
         if (k > kcap) k = kcap;
-        // one frame per call through the batch kernels: one wavefront per channel, so let four channels share a workgroup's
-        // twiddle table (measured: 2048 points, 4096 channels x 1 hop 152 us against 193 us; no difference at 1024 points)
-        if (T == 1 && !st->pair && c->tuning.channels_per_workgroup < 1) ch = 4;
+        // one frame per call through the batch kernels: one wavefront per channel, so channels share a workgroup's twiddle table:
+        // as many as a workgroup may hold when the flux state stays in global memory (1024 points: 8 channels = 76 KB, two workgroups
+        // and 16 wavefronts per CU -- what the LDS holds of the batch shape too), else four (measured: 2048 points, 4096 channels x 1 hop
+        // 152 us against 193 us)
+        if (T == 1 && !st->pair && c->tuning.channels_per_workgroup < 1) ch = direct ? kcap : 4;
         if (ch > c->C) ch = c->C;
         while (ch > 1 && (ch * k > kcap || lds_bytes(ch, k) > lds_cu)) ch--;
         while (k > 1 && lds_bytes(ch, k) > lds_cu) k--;

@@ -289,7 +289,10 @@ template <int N> struct Occ {
 // One wavefront's view of the frame it is analysing: where its buffers are and the constants every section
 // uses.  The member functions are the sections of the reference's two run() loops in the order the kernel
 // calls them; all of them are inlined into fx_frame_kernel.
-template <int N> struct FrameWave {
+// DIRECT: a call of ONE frame per channel reads and replaces the channel's flux state where it lives, in global memory: every
+// element is read once and written once, there is no next frame in this launch to hand it to, and without the LDS copy a
+// workgroup is eight channels with nothing but a transform buffer each -- 16 wavefronts per CU at 1024 points instead of 12.
+template <int N, bool DIRECT = false> struct FrameWave {
     typedef Geo<N> G;
     static constexpr int M = G::M, P = G::P, U = G::U, HALF = N / 2;
 
@@ -580,16 +583,21 @@ FX_MARK("flux");
             // ---- flux against the previous accepted frame; hand-off between waves ----
             double flux = 0.0;
             {
-#ifndef FX_EXP_NOWAIT
-                while (__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t)
-                    __builtin_amdgcn_s_sleep(1);
-#endif
-                // the turn is held for two LDS reads and two writes only: the next frame's wave is usually waiting for it
                 float pvf[U];
-                lds_load_block<U>(prev + bimg<N>(U * lane), pvf);
-                if (accepted) lds_store_block<U>(prev + bimg<N>(U * lane), re);         // :138 (only on the accepted path)
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) __hip_atomic_store(turn, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if constexpr (DIRECT) {
+                    float* state = p.prev_re + (size_t) c * M + U * lane;              // the lane's U bins, coalesced (16-byte pieces from 512 points on)
+                    lds_load_block<U>(state, pvf);                                      // (plain wide loads / stores: global memory here)
+                    if (accepted) lds_store_block<U>(state, re);                        // :138 (only on the accepted path)
+                } else {
+                    // (the hand-over costs 2 % of the kernel, and not because of the length of this section: round 2)
+                    while (__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t)
+                        __builtin_amdgcn_s_sleep(1);
+                    // the turn is held for two LDS reads and two writes only: the next frame's wave is usually waiting for it
+                    lds_load_block<U>(prev + bimg<N>(U * lane), pvf);
+                    if (accepted) lds_store_block<U>(prev + bimg<N>(U * lane), re);     // :138 (only on the accepted path)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) __hip_atomic_store(turn, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
 #pragma unroll
                 for (int j = 0; j < U; j++) {
                     const double pv = (double) pvf[j];
@@ -1018,7 +1026,9 @@ FX_MARK("harm2");
 
 // SPEC / HARM: which of the reference's two analysers run (RealTimeSpectralAnalyser,
 // RealTimeHarmonicAnalyser -- both by default, as AnalyserTrackController constructs them)
-template <int N, bool SPEC, bool HARM>
+// DIRECT: calls of one frame per channel (FrameWave): p.T == 1, p.waves_per_ch == 1, a workgroup is p.ch_per_wg channels, no flux
+// state in LDS.
+template <int N, bool SPEC, bool HARM, bool DIRECT = false>
 __global__ void __launch_bounds__(Occ<N>::MAX_THREADS, Occ<N>::WAVES_PER_SIMD)
 fx_frame_kernel(const FrameParams p_arg)
 {
@@ -1034,7 +1044,7 @@ fx_frame_kernel(const FrameParams p_arg)
     // One workgroup = CH channels x K waves (K frames of a channel in flight), sharing one twiddle table.  LDS:
     //   twiddles [N] | CH x { bins image of the channel's flux state (+ its hand-over counter) } | one buffer per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int PREV_FLOATS = G::BIMG + (G::BQ ? 0 : 4);
+    constexpr int PREV_FLOATS = DIRECT ? 0 : G::BIMG + (G::BQ ? 0 : 4);
     constexpr size_t WAVE_BYTES = G::BUF_BYTES;
     const int CH = p.ch_per_wg, K = p.waves_per_ch;
 #ifdef FX_EXP_TW_GLOBAL
@@ -1097,7 +1107,7 @@ fx_frame_kernel(const FrameParams p_arg)
         }
         __syncthreads();
     }
-    if (live) {
+    if (live && !DIRECT) {
         for (int i = lane0 + 64 * slot; i < M; i += 64 * K) prev[bimg<N>(i)] = p.prev_re[(size_t) c * M + i];
         if (lane0 == 0 && slot == 0) turn[0] = t_begin;
     }
@@ -1117,7 +1127,7 @@ fx_frame_kernel(const FrameParams p_arg)
         // in every lane for the whole frame
         FramePart* fpl = p.part + ((size_t) c * T + t);
         if (lane == 0) fpl->flags = 0;            // the harmonic tail sets it; the other fields are read only where written
-        const FrameWave<N> w{p, tw, &twr, prev, turn, cbuf, rbuf, fpl, nyquist, rnyq, frpb, scale, c, T, t};
+        const FrameWave<N, DIRECT> w{p, tw, &twr, prev, turn, cbuf, rbuf, fpl, nyquist, rnyq, frpb, scale, c, T, t};
 
         const double ssq_lane = w.load_frame(lane);
         float xr[P];
@@ -1144,7 +1154,7 @@ fx_frame_kernel(const FrameParams p_arg)
         }
         FX_STOP(6, continue); FX_STOP(7, continue); FX_STOP(8, continue); FX_STOP(9, continue); FX_STOP(10, continue);
         if constexpr (HARM) {
-            typename FrameWave<N>::HarmonicSpectrum hs;
+            typename FrameWave<N, DIRECT>::HarmonicSpectrum hs;
             if constexpr (G::SPLIT) w.load_raw(lane, xr);
             w.harmonic_spectrum(lane, xr, hs);
             FX_STOP(11, FX_KEEP(hs.sum); FX_KEEP(hs.max); FX_KEEP(hs.left2); FX_KEEP(hs.left1); FX_KEEP(hs.right1); for (int j = 0; j < G::U; j++) FX_KEEP(hs.hre[j]); continue);
@@ -1152,6 +1162,7 @@ fx_frame_kernel(const FrameParams p_arg)
         }
     }
 
+    if constexpr (DIRECT) return;                       // (the flux state was replaced in place)
     __syncthreads();
     if (live)
         for (int i = lane0 + 64 * slot; i < M; i += 64 * K) p.prev_re[(size_t) c * M + i] = prev[bimg<N>(i)];

@@ -12,7 +12,7 @@ namespace fxk {
 // evaluated without any sequential state: 32 + 9 rounded up.
 constexpr int HLEN = 48;
 constexpr int MAX_ONSET_WINDOW = 32;
-// calls of at most this many frames per channel run finalise + smoothing/onset + history as one kernel (wavefront = channel)
+// calls of at most this many frames per channel run finalise + smoothing/onset + history as one kernel (a quarter wavefront per channel)
 constexpr int FUSED_TAIL_MAX_FRAMES = 8;
 
 // What the frame kernel leaves per frame: every reduction over samples / bins / lags is done, the
@@ -64,6 +64,8 @@ struct FrameParams {
     int          C;
     int          ch_per_wg;     // channels per workgroup (they share the twiddle table in LDS)
     int          waves_per_ch;  // wavefronts per channel = frames of a channel in flight
+    int          direct_state;  // 1: a call of ONE frame per channel with both analysers -- the flux state is read and replaced in global
+                                // memory (no LDS copy, no hand-over): T == 1, waves_per_ch == 1, num_chunks == 1
     // A long call over few channels is cut in time as well: num_chunks workgroups per channel group, each analysing
     // frames_per_chunk consecutive frames (many small work units keep every CU busy to the end of the launch; one
     // workgroup per channel is two rounds of 512 at the bench shape, and 8 % slower).  The one thing a chunk needs from
@@ -139,7 +141,7 @@ void build_pass_twiddles(int window_size, const float* canonical, float* out);
 void fill_first_pass_twiddles(int window_size, const float* pass_ordered, float* out18);
 bool first_pass_twiddles_hermitian(int window_size, const float* first18);   // must hold before any launch
 
-size_t frame_kernel_lds_bytes(int window_size, int channels_per_wg, int waves_per_channel);
+size_t frame_kernel_lds_bytes(int window_size, int channels_per_wg, int waves_per_channel, bool direct_state = false);
 int frame_kernel_max_waves(int window_size);     // the frame kernel's launch bound, in wavefronts per workgroup
 // measured-best workgroup shape for a window size: channels per workgroup x wavefronts per channel
 void frame_kernel_preferred_shape(int window_size, int* channels_per_wg, int* waves_per_channel);

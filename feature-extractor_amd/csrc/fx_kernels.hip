@@ -96,10 +96,10 @@ hipError_t launch_hop_kernel(int n, const FrameParams& p, const EpilogueParams& 
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-template <int N> static size_t lds_bytes_t(int ch, int k)
+template <int N> static size_t lds_bytes_t(int ch, int k, bool direct = false)
 {
     typedef Geo<N> G;
-    return sizeof(f2) * N + (size_t) ch * sizeof(float) * (G::BIMG + (G::BQ ? 0 : 4)) + (size_t) ch * k * G::BUF_BYTES;
+    return sizeof(f2) * N + (direct ? 0 : (size_t) ch * sizeof(float) * (G::BIMG + (G::BQ ? 0 : 4))) + (size_t) ch * k * G::BUF_BYTES;
 }
 
 
@@ -113,16 +113,23 @@ template <int N> hipError_t prepare_t()
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, true, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, false, true>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, false, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, true, true, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 template <int N> hipError_t launch_t(const FrameParams& p, int analysers, hipStream_t stream)
 {
-    const size_t lds = lds_bytes_t<N>(p.ch_per_wg, p.waves_per_ch);
+    const size_t lds = lds_bytes_t<N>(p.ch_per_wg, p.waves_per_ch, p.direct_state != 0);
     const dim3 grid((unsigned) ((p.C + p.ch_per_wg - 1) / p.ch_per_wg) * (unsigned) (p.num_chunks > 1 ? p.num_chunks : 1)),
                block((unsigned) (p.ch_per_wg * p.waves_per_ch) * 64);
-    if (analysers == 3)      hipLaunchKernelGGL((fx_frame_kernel<N, true, true>), grid, block, lds, stream, p);
+    if (p.direct_state) {
+        if (analysers != 3 || p.T != 1 || p.waves_per_ch != 1 || p.num_chunks > 1) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((fx_frame_kernel<N, true, true, true>), grid, block, lds, stream, p);
+    }
+    else if (analysers == 3) hipLaunchKernelGGL((fx_frame_kernel<N, true, true>), grid, block, lds, stream, p);
     else if (analysers == 1) hipLaunchKernelGGL((fx_frame_kernel<N, true, false>), grid, block, lds, stream, p);
     else if (analysers == 2) hipLaunchKernelGGL((fx_frame_kernel<N, false, true>), grid, block, lds, stream, p);
     else return hipErrorInvalidValue;
@@ -270,14 +277,14 @@ void frame_kernel_preferred_shape(int n, int* ch, int* k)
     else                { *ch = 1; *k = 7; }
 }
 
-size_t frame_kernel_lds_bytes(int n, int ch, int k)
+size_t frame_kernel_lds_bytes(int n, int ch, int k, bool direct_state)
 {
     switch (n) {
-        case 256:  return lds_bytes_t<256>(ch, k);
-        case 512:  return lds_bytes_t<512>(ch, k);
-        case 1024: return lds_bytes_t<1024>(ch, k);
-        case 2048: return lds_bytes_t<2048>(ch, k);
-        case 4096: return lds_bytes_t<4096>(ch, k);
+        case 256:  return lds_bytes_t<256>(ch, k, direct_state);
+        case 512:  return lds_bytes_t<512>(ch, k, direct_state);
+        case 1024: return lds_bytes_t<1024>(ch, k, direct_state);
+        case 2048: return lds_bytes_t<2048>(ch, k, direct_state);
+        case 4096: return lds_bytes_t<4096>(ch, k, direct_state);
         default:   return 0;
     }
 }
@@ -316,7 +323,7 @@ hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t stream)
 {
     if (p.C <= 0 || p.T <= 0) return hipSuccess;
     if (p.T <= FUSED_TAIL_MAX_FRAMES) {
-        hipLaunchKernelGGL(fx_tail_fused_kernel, dim3((unsigned) p.C), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL(fx_tail_fused_kernel, dim3((unsigned) ((p.C + TAIL_CHANNELS - 1) / TAIL_CHANNELS)), dim3(64), 0, stream, p);
         return hipGetLastError();
     }
     const long long n1 = (long long) p.C * p.T;

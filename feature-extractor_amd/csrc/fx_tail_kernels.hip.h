@@ -105,24 +105,41 @@ __device__ __forceinline__ void finalise_logs(const float (&y)[NUM_LOGS], float 
     out[FX_INHARM] = y[LOG_INHARM];
 }
 
-__device__ __forceinline__ void finalise_frame(const EpilogueParams& p, long long idx)
+// one thread, one frame: the twelve raw values (onset slot still 0)
+__device__ __forceinline__ void finalise_thread(const EpilogueParams& p, const FramePart& f, float (&out)[FX_NUM_FEATURES])
 {
-    const FramePart f = p.part[idx];
-    float out[FX_NUM_FEATURES];
     double logs[NUM_LOGS];
     float y[NUM_LOGS];
     finalise_values(p, f, out, logs);
 #pragma unroll
     for (int i = 0; i < NUM_LOGS; i++) y[i] = (float) log10(logs[i]);
     finalise_logs(y, out);
+}
+
+__device__ __forceinline__ void finalise_frame(const EpilogueParams& p, long long idx)
+{
+    const FramePart f = p.part[idx];
+    float out[FX_NUM_FEATURES];
+    finalise_thread(p, f, out);
     f4* dst = reinterpret_cast<f4*>(p.raw + idx * FX_NUM_FEATURES);
     dst[0] = f4{out[0], out[1], out[2], out[3]};
     dst[1] = f4{out[4], out[5], out[6], out[7]};
     dst[2] = f4{out[8], out[9], out[10], out[11]};
 }
 
-// The same for the one frame of a one-hop call, by a whole wavefront: every lane forms the values (they are uniform), lanes
-// 0..4 take one logarithm each; `out` is the full vector in every lane.  Bit for bit what finalise_frame writes.
+// A GROUP of lanes that works on one channel's hop together: the whole wavefront (the one-hop kernels: a workgroup is a channel)
+// or a quarter of one (fx_tail_fused_kernel: four channels per wavefront).  `lane` is the lane in the wavefront throughout;
+// group_lane() its index in the group, group_get() the value lane i of the caller's group holds.
+template <int GROUP> __device__ __forceinline__ int group_lane(int lane) { return lane & (GROUP - 1); }
+template <int GROUP> __device__ __forceinline__ float group_get(float v, int lane, int i)
+{
+    if (GROUP == 64) return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i));
+    return __shfl(v, (lane & ~(GROUP - 1)) + i, 64);
+}
+
+// The same for the one frame of a one-hop call, by a group of lanes: every lane forms the values (they are uniform in the group),
+// lanes 0..4 take one logarithm each; `out` is the full vector in every lane.  Bit for bit what finalise_frame writes.
+template <int GROUP = 64>
 __device__ __forceinline__ void finalise_wave(const EpilogueParams& p, const FramePart& f, int lane, float (&out)[FX_NUM_FEATURES])
 {
     double logs[NUM_LOGS];
@@ -130,10 +147,10 @@ __device__ __forceinline__ void finalise_wave(const EpilogueParams& p, const Fra
     finalise_values(p, f, out, logs);
     double mine = logs[0];
 #pragma unroll
-    for (int i = 1; i < NUM_LOGS; i++) mine = lane == i ? logs[i] : mine;
+    for (int i = 1; i < NUM_LOGS; i++) mine = group_lane<GROUP>(lane) == i ? logs[i] : mine;
     const float ym = (float) log10(mine);
 #pragma unroll
-    for (int i = 0; i < NUM_LOGS; i++) y[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ym), i));
+    for (int i = 0; i < NUM_LOGS; i++) y[i] = group_get<GROUP>(ym, lane, i);
     finalise_logs(y, out);
 }
 #ifdef FX_WITH_TAIL_KERNELS
@@ -170,13 +187,13 @@ __device__ __forceinline__ int hist_row_before(int hist_base, int tau) { const i
 __device__ __forceinline__ int hist_rows_read(int onset_window) { const int n = onset_window + 8; return n < 9 ? 9 : (n > HLEN ? HLEN : n); }
 struct RawView {
     const float* raw; const float* hist; int T; long long frames_before; int hist_base;
-    const float* tile = nullptr; int tile_first = 0;
+    const float* tile = nullptr; int tile_first = 0; bool tiled = false;     // (a flag, not `tile != nullptr`: a dynamic-LDS tile may sit at LDS address 0)
     // raw value of slot s at frame index tau relative to this call (tau may be negative);
     // frames before the stream began read as "not recorded"
     __device__ __forceinline__ bool valid(int tau) const { return frames_before + (long long) tau >= 0 && tau > -HLEN - 1; }
     __device__ __forceinline__ float get(int tau, int s) const
     {
-        if (tile) return tile[(tau - tile_first) * TILE_STRIDE + s];
+        if (tiled) return tile[(tau - tile_first) * TILE_STRIDE + s];
         return tau >= 0 ? raw[(size_t) tau * FX_NUM_FEATURES + s] : hist[hist_row_before(hist_base, tau) * FX_NUM_FEATURES + s];
     }
 };
@@ -257,6 +274,7 @@ __device__ __forceinline__ bool detect_onset(const EpilogueParams& p, const RawV
     return onset;
 }
 
+template <bool TILED = false>
 __device__ __forceinline__ void epilogue_frame(const EpilogueParams& p, int c, int t, const float* tile = nullptr, int tile_first = 0,
                                                const float* amp = nullptr, int amp_first = 0)
 {
@@ -268,6 +286,7 @@ __device__ __forceinline__ void epilogue_frame(const EpilogueParams& p, int c, i
     v.hist_base = p.hist_base;
     v.tile = tile;
     v.tile_first = tile_first;
+    v.tiled = TILED;
 
     float sm[FX_NUM_FEATURES];
     float rw[FX_NUM_FEATURES];
@@ -312,10 +331,11 @@ __device__ __forceinline__ void epilogue_frame(const EpilogueParams& p, int c, i
     }
 }
 
-// detect_onset for a whole wavefront: the L <= 32 candidates' (RMS mean, flux) pairs -- each RMS mean is ten history
-// reads and the index arithmetic of the double insert -- are evaluated by L lanes side by side into `scratch` ([64]
-// floats of LDS); the detector's serial loop then only reads them back.  Same values, same order of additions; the
-// result is wave-uniform.
+// detect_onset for a group of lanes: the L <= 32 candidates' (RMS mean, flux) pairs -- each RMS mean is ten history
+// reads and the index arithmetic of the double insert -- are evaluated by the group's lanes side by side into `scratch` (the
+// group's own [64] floats of LDS); the detector's serial loop then only reads them back.  Same values, same order of
+// additions; the result is uniform in the group.
+template <int GROUP = 64>
 __device__ __forceinline__ bool detect_onset_wave(const EpilogueParams& p, const RawView& v, int t, int order_mode, bool spec, int lane, float* scratch)
 {
     const int L = p.onset_window;
@@ -324,10 +344,10 @@ __device__ __forceinline__ bool detect_onset_wave(const EpilogueParams& p, const
     long long recorded = g - p.onset_reset_frame + 1;
     if (recorded > L) recorded = L;
     if (!(spec && recorded >= L && L > 0)) return false;            // :253-258 both histories full
-    if (lane < L) {
-        const int f = t - L + 1 + lane;
-        scratch[lane] = rms_value(v, f, order_mode, rms_pushes_at_detect);
-        scratch[32 + lane] = (0.0f + v.get(f, FX_FLUX)) / 1.0f;
+    for (int k = group_lane<GROUP>(lane); k < L; k += GROUP) {
+        const int f = t - L + 1 + k;
+        scratch[k] = rms_value(v, f, order_mode, rms_pushes_at_detect);
+        scratch[32 + k] = (0.0f + v.get(f, FX_FLUX)) / 1.0f;
     }
     wave_fence();
     int cand = L - 1;                                               // :263-266
@@ -363,8 +383,10 @@ __device__ __forceinline__ bool detect_onset_wave(const EpilogueParams& p, const
 // The same for the single frame of a one-hop call (T == 1) with the twelve slots spread over twelve lanes: lane s
 // evaluates slot s (the onset lane the detector, the RMS lane the double-insert mean), so the hop's tail takes the time
 // of its longest slot instead of the sum of all.  Same expressions, same order of the fp32 additions as epilogue_frame.
-// All 64 lanes of the calling wavefront must take part (the onset detector's candidates are spread over them).
-__device__ __forceinline__ void epilogue_hop(const EpilogueParams& p, int c, int lane, float* scratch)
+// All lanes of the calling wavefront must take part (the onset detector's candidates are spread over the group's lanes);
+// `live` = false: a group beyond the last channel, which keeps in step and stores nothing.
+template <int GROUP = 64>
+__device__ __forceinline__ void epilogue_hop(const EpilogueParams& p, int c, int lane, float* scratch, bool live = true)
 {
     RawView v;
     v.raw = p.raw + (size_t) c * p.T * FX_NUM_FEATURES;
@@ -372,12 +394,12 @@ __device__ __forceinline__ void epilogue_hop(const EpilogueParams& p, int c, int
     v.T = p.T;
     v.frames_before = p.frames_before;
     v.hist_base = p.hist_base;
-    const int t = 0, s = lane;
+    const int t = 0, s = group_lane<GROUP>(lane);
     const bool spec = p.analysers & 1, harm = p.analysers & 2;
     const int order_mode = (spec && harm) ? p.order_mode : FX_ORDER_ISOLATED;
     const float never = __int_as_float(0x7fc00000);
-    const bool onset = detect_onset_wave(p, v, t, order_mode, spec, lane, scratch);       // all 64 lanes
-    const bool mine = lane < FX_NUM_FEATURES;
+    const bool onset = detect_onset_wave<GROUP>(p, v, t, order_mode, spec, lane, scratch);       // all lanes
+    const bool mine = s < FX_NUM_FEATURES;
     float rw = 0.0f, sm = 0.0f;
     if (mine) {
         rw = v.get(t, s);
@@ -400,7 +422,7 @@ __device__ __forceinline__ void epilogue_hop(const EpilogueParams& p, int c, int
     const size_t o = ((size_t) c * p.T + t) * FX_NUM_FEATURES;
     // (Round 3 also tried the twelve slots as three 16-byte stores per vector -- a one-hop call's results go to a pinned host slot,
     // every store a transaction across PCIe: no measurable difference in the hop's round trip, not kept.)
-    if (!mine) return;
+    if (!mine || !live) return;
     if (p.out_raw) p.out_raw[o + s] = rw;
     if (p.out_smoothed) p.out_smoothed[o + s] = sm;
     p.latest[(size_t) c * FX_NUM_FEATURES + s] = sm;
@@ -435,7 +457,7 @@ fx_epilogue_kernel(const EpilogueParams p_arg)
     // before them.
     {
         RawView v;
-        v.raw = raw; v.hist = hist; v.T = p.T; v.frames_before = p.frames_before; v.hist_base = p.hist_base; v.tile = tile; v.tile_first = first;
+        v.raw = raw; v.hist = hist; v.T = p.T; v.frames_before = p.frames_before; v.hist_base = p.hist_base; v.tile = tile; v.tile_first = first; v.tiled = true;
         const bool both = (p.analysers & 1) && (p.analysers & 2);
         const int order_mode = both ? p.order_mode : FX_ORDER_ISOLATED;
         const int pushes = (order_mode == FX_ORDER_HARMONIC_THEN_SPECTRAL) ? 2 : 1;
@@ -446,7 +468,7 @@ fx_epilogue_kernel(const EpilogueParams p_arg)
     }
     __syncthreads();
     const int t = t0 + (int) threadIdx.x;
-    if (t < p.T) epilogue_frame(p, c, t, tile, first, amp, t0 - MAX_ONSET_WINDOW);
+    if (t < p.T) epilogue_frame<true>(p, c, t, tile, first, amp, t0 - MAX_ONSET_WINDOW);
 }
 #endif
 
@@ -475,58 +497,70 @@ fx_history_kernel(const EpilogueParams p_arg)
 }
 #endif
 
-// The three kernels above in one launch for calls of a few frames per channel (the streaming ring at one hop per call),
-// where two kernel boundaries cost more than the work: one wavefront per channel.  Lane t finalises frame t; the raw
-// values of the frames before the call that the smoothing reads (hist_rows_read: 13 of the ring's 48 rows with the default
-// onset window) and of the call's own frames are staged in LDS (one round trip to memory instead of the ~70 dependent
-// ones of the smoothing / onset loops), lane t smooths frame t from there, then the call's own rows go to the ring.
+// The three kernels above in one launch for calls of a few frames per channel (one hop per call: the reference's own cadence,
+// AudioDataCollector.h:66-94), where two kernel boundaries cost more than the work.  A QUARTER of a wavefront per channel: the
+// tail of a hop has 12 slots, 5 logarithms and (by default) 5 onset candidates to spread over lanes, which 16 lanes hold as well
+// as 64 -- and a call over thousands of channels then issues a quarter of the instructions.  (Measured at 8192 channels x one
+// 1024-pt hop: a wavefront per channel 24.6 us; a THREAD per channel -- the other extreme, 64 channels per instruction --
+// 33 us, all of it the latency of one lane's chain of ~5 000 dependent fp64 instructions; profiles/r04_live_cadence.txt.)
+// Lanes 0..T-1 of a group finalise the call's frames; the raw values of the frames before the call that the smoothing reads
+// (hist_rows_read: 13 of the ring's 48 rows with the default onset window) and of the call's own frames are staged in LDS (one
+// round trip to memory instead of the ~70 dependent ones of the smoothing / onset loops), then a lane per slot (one hop) or a
+// lane per frame smooths from there, and the call's own rows go to the ring.
+constexpr int TAIL_GROUP = 16;                          // lanes per channel
+constexpr int TAIL_CHANNELS = 64 / TAIL_GROUP;          // channels per wavefront = per workgroup
+static_assert(FUSED_TAIL_MAX_FRAMES <= TAIL_GROUP && FX_NUM_FEATURES <= TAIL_GROUP && NUM_LOGS <= TAIL_GROUP, "a lane per frame / slot / logarithm");
 #ifdef FX_WITH_TAIL_KERNELS
 __global__ void __launch_bounds__(64)
 fx_tail_fused_kernel(const EpilogueParams p_arg)
 {
-    __shared__ __attribute__((aligned(16))) float s_hist[HLEN * FX_NUM_FEATURES];
-    __shared__ float s_raw[FUSED_TAIL_MAX_FRAMES * FX_NUM_FEATURES];
-    __shared__ float s_scratch[64];
-    EpilogueParams p = with_dyn(p_arg);
-    const int c = blockIdx.x, lane = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) float s_hist[TAIL_CHANNELS][HLEN * FX_NUM_FEATURES];
+    __shared__ float s_raw[TAIL_CHANNELS][FUSED_TAIL_MAX_FRAMES * FX_NUM_FEATURES];
+    __shared__ float s_scratch[TAIL_CHANNELS][64];
+    const EpilogueParams p = with_dyn(p_arg);
+    const int lane = threadIdx.x, g = lane / TAIL_GROUP, gl = lane % TAIL_GROUP;
+    const int c_mine = blockIdx.x * TAIL_CHANNELS + g;
+    const bool live = c_mine < p.C;
+    const int c = live ? c_mine : p.C - 1;                // a group beyond the last channel keeps in step on the last one and stores nothing
     float* ring = p.hist + (size_t) c * HLEN * FX_NUM_FEATURES;
     {
         // the LDS copy keeps the ring's row positions; rows nobody reads are not fetched (a row is 48 bytes: three 16-byte pieces)
         const int need = hist_rows_read(p.onset_window);            // what the call's FIRST frame reaches back; later frames less
-        for (int i = lane; i < need * 3; i += 64) {
+        for (int i = gl; i < need * 3; i += TAIL_GROUP) {
             const int r = hist_row_before(p.hist_base, -need + i / 3), q = i % 3;
-            reinterpret_cast<uint4*>(s_hist)[r * 3 + q] = reinterpret_cast<const uint4*>(ring)[r * 3 + q];
+            reinterpret_cast<uint4*>(s_hist[g])[r * 3 + q] = reinterpret_cast<const uint4*>(ring)[r * 3 + q];
         }
     }
     if (p.T == 1) {
-        // one hop: the scalar tail by the whole wavefront (its logarithms side by side), straight into the LDS row -- the
+        // one hop: the scalar tail by the whole group (its logarithms side by side), straight into the LDS row -- the
         // raw vector never makes the trip through global memory
         const FramePart f = p.part[c];
         float out[FX_NUM_FEATURES];
-        finalise_wave(p, f, lane, out);
-        if (lane < FX_NUM_FEATURES) {
+        finalise_wave<TAIL_GROUP>(p, f, lane, out);
+        if (gl < FX_NUM_FEATURES) {
             float mine = out[0];
 #pragma unroll
-            for (int k = 1; k < FX_NUM_FEATURES; k++) mine = lane == k ? out[k] : mine;
-            s_raw[lane] = mine;
+            for (int k = 1; k < FX_NUM_FEATURES; k++) mine = gl == k ? out[k] : mine;
+            s_raw[g][gl] = mine;
         }
     } else {
-        if (lane < p.T) finalise_frame(p, (long long) c * p.T + lane);
+        if (gl < p.T && live) finalise_frame(p, (long long) c * p.T + gl);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // the wave's raw values are written before any lane reads them back
         __builtin_amdgcn_s_barrier();
-        for (int i = lane; i < p.T * FX_NUM_FEATURES; i += 64) s_raw[i] = p.raw[(size_t) c * p.T * FX_NUM_FEATURES + i];
+        for (int i = gl; i < p.T * FX_NUM_FEATURES; i += TAIL_GROUP) s_raw[g][i] = p.raw[(size_t) c * p.T * FX_NUM_FEATURES + i];
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_s_barrier();
     // the smoothing reads channel c's rows through (raw + c*T*12, hist + c*HLEN*12): point those at the LDS copies
     EpilogueParams q = p;
-    q.raw = s_raw - (size_t) c * p.T * FX_NUM_FEATURES;
-    q.hist = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
-    if (p.T == 1) epilogue_hop(q, c, lane, s_scratch);                // one hop: a lane per slot, the onset detector's candidates side by side
-    else if (lane < p.T) epilogue_frame(q, c, lane);
+    q.raw = s_raw[g] - (size_t) c * p.T * FX_NUM_FEATURES;
+    q.hist = s_hist[g] - (size_t) c * HLEN * FX_NUM_FEATURES;
+    if (p.T == 1) epilogue_hop<TAIL_GROUP>(q, c, lane, s_scratch[g], live);      // one hop: a lane per slot, the onset detector's candidates side by side
+    else if (gl < p.T && live) epilogue_frame(q, c, gl);
     // this call's rows of the ring: T <= FUSED_TAIL_MAX_FRAMES different rows, which held frames HLEN before these -- further back
     // than anything reads (hist_rows_read <= 40), and what was read went through the LDS copy above in any case
     q.hist = p.hist;
-    for (int i = lane; i < p.T * FX_NUM_FEATURES; i += 64) history_value(q, c, i / FX_NUM_FEATURES, i % FX_NUM_FEATURES);
+    if (live)
+        for (int i = gl; i < p.T * FX_NUM_FEATURES; i += TAIL_GROUP) history_value(q, c, i / FX_NUM_FEATURES, i % FX_NUM_FEATURES);
 }
 #endif

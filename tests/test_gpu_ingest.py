@@ -240,3 +240,32 @@ def test_config2_bench_shape_two_calls_state_carried(gpu_fx, oracle):
     oraw, osm = oracle.push_hops(np.concatenate(held, axis=1), N)
     close(np.concatenate([o[0] for o in outs], 1), oraw, "configs[2] raw")
     close(np.concatenate([o[1] for o in outs], 1), osm, "configs[2] smoothed")
+
+
+@pytest.mark.parametrize("N,C", [(512, 700), (1024, 1100), (2048, 600), (4096, 520)])
+def test_short_calls_over_many_channels_equal_one_long_call_bitwise(gpu_fx, oracle, N, C):
+    """Calls of 1..8 frames per channel over >= 512 channels: one-frame calls run the frame kernel with the flux state left in
+    global memory (FrameParams::direct_state), and the scalar tails, smoothing and onset run with a THREAD per channel
+    (fx_tail_block_kernel) instead of a wavefront per channel.  Same bits as one long call (uncut frame kernel + the
+    three-kernel tail), and as the oracle on a sample of channels, across a wrap of the history ring."""
+    sizes = [1, 1, 3, 1, 8, 2, 1, 1, 7, 1, 5, 1, 1, 8, 8, 1, 4, 1, 1, 6]
+    T = sum(sizes)
+    hops = np.tile(signals.bursts(20, T, N, seed=N), (C // 20, 1, 1))
+    hops[::7] *= 0.5
+    one = gpu_fx.BatchAnalyser(C, N)
+    one.set_onset_window_length(9)
+    want = one.push_hops(hops)
+    an = gpu_fx.BatchAnalyser(C, N)
+    an.set_onset_window_length(9)
+    an.set_tuning(one_hop_kernel=0)
+    parts, at = [], 0
+    for n in sizes:
+        parts.append(an.push_hops(hops[:, at:at + n]))
+        at += n
+    got = (np.concatenate([p[0] for p in parts], 1), np.concatenate([p[1] for p in parts], 1))
+    same(got, want, "many channels N=%d" % N)
+    assert np.array_equal(an.get_features(), one.get_features(), equal_nan=True)
+    pick = [0, 7, C - 1]
+    oraw, osm = oracle.push_hops(hops[pick], N, onset_window=9)
+    close(got[0][pick], oraw, "many channels raw")
+    close(got[1][pick], osm, "many channels smoothed")
