@@ -285,7 +285,7 @@ def pmc_child(args):
     torch.cuda.set_device(0)
     frames = torch.from_numpy(np.load(args.input_file)).cuda(0)
     C, T = frames.shape[0], frames.shape[1]
-    an = fx.BatchAnalyser(C, args.window, device=0)
+    an = fx.BatchAnalyser(C, args.window, device=0, analysers=args.analysers)
     raw = torch.empty((C, T, 12), dtype=torch.float32, device=frames.device)
     sm = torch.empty_like(raw)
     for _ in range(args.warmup + args.steps):
@@ -437,6 +437,8 @@ def build_parser():
                     help="with --gpus 1: create a one-rank RCCL communicator and run the N>1 code path (gather included), "
                          "then check the gathered block against the local one")
     ap.add_argument("--rank-timeout", type=int, default=600, help="seconds a rank may spend joining the group / communicator or in one barrier before it gives up")
+    ap.add_argument("--analysers", default="both", choices=["both", "spectral", "harmonic"],
+                    help="--pmc-child only (tools/pmc_quick.py): which of the reference's two analysers the profiled context constructs")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--input-file", default=None, help=argparse.SUPPRESS)
     return ap
@@ -806,13 +808,12 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
         # The path a caller with HOST audio stands on (ref AudioDataCollector.h:36-94, AudioFilePlayer.h:41-61): hops in
         # host memory -> the pinned ring (fx_stream_*) -> H2D on a side stream || analysis || vectors back on a third queue -> host.
         # PCIe-inclusive by construction, never `value`.  Its roofline is the H2D link: `peak` = what hipMemcpyAsync from pinned
-        # memory reaches for the same bytes in this run, `achieved` = sample bytes per second the ring really moved.  The producer
-        # writes every slot IN PLACE from `fill_threads` threads (one block of channels each, as the reference's per-channel
-        # collectors would); the same loop with the slots left as they are (producer excluded) is reported beside it.
-        from concurrent.futures import ThreadPoolExecutor
+        # memory reaches for the same bytes in this run, `achieved` = sample bytes per second the ring really moved.  The producer's
+        # batch sits in ordinary memory and is copied into the slot by `fill_threads` threads (fx_stream_push: a thread pool inside
+        # the library; the reference's per-channel collectors write their own channel's samples); the same loop with the slots left
+        # as they are (producer excluded) is reported beside it.
         cores = usable_cores()
-        fill_threads = max(4, min(16, cores))
-        pool = ThreadPoolExecutor(fill_threads)
+        fill_threads = max(4, min(12, cores - 2))               # (the caller's thread and the runtime's need a core too)
         res = {"fill_threads": fill_threads, "slots": 3,
                "note": "frames/s with host-resident hops, PCIe-inclusive (never `value`); roofline.bound = pcie: achieved = sample bytes/s through the "
                        "ring with the producer filling slots in place, peak = pinned hipMemcpyAsync H2D of the same bytes measured in this run"}
@@ -839,7 +840,6 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
                 peak = memcpy_rate(src.nbytes)
                 an5 = fx.BatchAnalyser(c2, n2, device=dev)
                 st5 = fx.HopStream(an5, t2, slots=3, dtype=src.dtype)
-                bounds = [(k * c2 // fill_threads, (k + 1) * c2 // fill_threads) for k in range(fill_threads)]
 
                 def run(fill, steps, warm=4):
                     for k in range(steps + warm):
@@ -849,10 +849,11 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
                             t0 = time.perf_counter()
                         if st5.in_flight() == 3:
                             st5.collect(want_raw=False)
-                        slot = st5.slot()
                         if fill or k < 3:
-                            list(pool.map(lambda ab: np.copyto(slot[ab[0]:ab[1]], src[ab[0]:ab[1]]), bounds))
-                        st5.submit()
+                            st5.push(src, fill_threads=fill_threads)
+                        else:
+                            st5.slot()
+                            st5.submit()
                     while st5.in_flight():
                         st5.collect(want_raw=False)
                     return time.perf_counter() - t0
@@ -871,7 +872,6 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
                 del src
             res[str(n2)] = shape
             del src32
-        pool.shutdown()
         return res
 
     guarded("spectral_only", spectral_only)

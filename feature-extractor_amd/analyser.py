@@ -301,9 +301,17 @@ class HopStream:
     def submit(self):
         capi.check(self._lib.fx_stream_submit(self._h))
 
-    def push(self, hops):
-        """Copy one batch into the next slot and submit it."""
-        self.slot()[...] = np.asarray(hops, self.dtype).reshape(self._shape)
+    def push(self, hops, fill_threads=1):
+        """Copy one batch into the next slot and submit it.  fill_threads > 1: the copy is made by that many host threads inside
+        the library (fx_stream_push) -- for batches of many megabytes, where one thread's memcpy is several times slower than PCIe."""
+        hops = np.asarray(hops, self.dtype)
+        if hops.size != int(np.prod(self._shape)):
+            raise ValueError("a batch is %r samples" % (self._shape,))
+        if fill_threads > 1:
+            hops = np.ascontiguousarray(hops)
+            capi.check(self._lib.fx_stream_push(self._h, hops.ctypes.data_as(ctypes.c_void_p), int(fill_threads)))
+            return
+        self.slot()[...] = hops.reshape(self._shape)
         self.submit()
 
     def collect(self, want_raw=True, want_smoothed=True):

@@ -21,7 +21,7 @@ FX_OK, FX_ERR_INVALID_ARGUMENT, FX_ERR_NO_DEVICE, FX_ERR_HIP, FX_ERR_OUT_OF_MEMO
 EXPORTS = ["fx_create", "fx_destroy", "fx_reset_state", "fx_set_sample_rate", "fx_set_onset_sensitivity",
            "fx_set_onset_window", "fx_set_onset_type", "fx_set_gain", "fx_push_hops", "fx_process_frames",
            "fx_get_smoothed", "fx_sync", "fx_get_stream", "fx_last_kernel_ms", "fx_profile_begin", "fx_profile_end",
-           "fx_stream_create", "fx_stream_destroy", "fx_stream_acquire", "fx_stream_submit", "fx_stream_collect", "fx_stream_in_flight", "fx_pack_osc12",
+           "fx_stream_create", "fx_stream_destroy", "fx_stream_acquire", "fx_stream_submit", "fx_stream_push", "fx_stream_collect", "fx_stream_in_flight", "fx_pack_osc12",
            "fx_pack_osc10", "fx_osc_encode", "fx_last_error", "fx_abi_version",
            "fx_comm_unique_id", "fx_comm_create", "fx_comm_destroy", "fx_comm_layout", "fx_gather_smoothed", "fx_comm_sync",
            "fx_plan_units", "fx_tuning_defaults", "fx_tuning_from_env", "fx_get_tuning", "fx_set_tuning",
@@ -109,6 +109,7 @@ def load_library(build_if_missing=True):
     L.fx_stream_destroy.argtypes = [vp]
     L.fx_stream_acquire.argtypes = [vp, ctypes.POINTER(vp)]
     L.fx_stream_submit.argtypes = [vp]
+    L.fx_stream_push.argtypes = [vp, vp, i]
     L.fx_stream_collect.argtypes = [vp, vp, vp]
     L.fx_stream_in_flight.argtypes = [vp]
     L.fx_profile_begin.argtypes = [vp]

@@ -4,12 +4,15 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fx_kernels.h"
@@ -694,8 +697,73 @@ fx_status fx_profile_end(fx_context* c, double* frame_ms, double* epi_ms, int* c
 // ---------------------------------------------------------------------------------------------
 } // extern "C"
 
+// The producer's copy into a pinned slot, by several host threads (fx_stream_push): a caller whose audio sits in ordinary memory
+// has to move every sample once more before PCIe sees it, and one memcpy thread moves ~12 GB/s where the link takes 55.  A small
+// persistent pool: workers sleep on a generation counter, each copies its share of the bytes, the last one wakes the caller.
+class FillPool {
+public:
+    ~FillPool() { resize(0); }
+    void copy(void* dst, const void* src, size_t bytes, int threads)
+    {
+        if (threads <= 1 || bytes < (1u << 20)) { memcpy(dst, src, bytes); return; }
+        if ((int) workers_.size() != threads - 1) resize(threads - 1);
+        const size_t piece = ((bytes + (size_t) threads - 1) / (size_t) threads + 4095) & ~(size_t) 4095;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            dst_ = static_cast<unsigned char*>(dst); src_ = static_cast<const unsigned char*>(src); bytes_ = bytes; piece_ = piece;
+            pending_ = (int) workers_.size();
+            generation_++;
+        }
+        wake_.notify_all();
+        slice(threads - 1);                                   // the caller copies the last piece itself
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [&] { return pending_ == 0; });
+    }
+private:
+    void slice(int k)
+    {
+        const size_t at = piece_ * (size_t) k;
+        if (at < bytes_) memcpy(dst_ + at, src_ + at, bytes_ - at < piece_ ? bytes_ - at : piece_);
+    }
+    void resize(int n)
+    {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            quit_ = true;
+        }
+        wake_.notify_all();
+        for (auto& t : workers_) t.join();
+        workers_.clear();
+        quit_ = false;
+        const unsigned long long born = generation_;           // (read here, by the caller: a worker that starts late must not miss the first job)
+        for (int k = 0; k < n; k++)
+            workers_.emplace_back([this, k, born] {
+                unsigned long long seen = born;
+                for (;;) {
+                    std::unique_lock<std::mutex> g(m_);
+                    wake_.wait(g, [&] { return quit_ || generation_ != seen; });
+                    if (quit_) return;
+                    seen = generation_;
+                    g.unlock();
+                    slice(k);
+                    g.lock();
+                    if (--pending_ == 0) done_.notify_one();
+                }
+            });
+    }
+    std::mutex m_;
+    std::condition_variable wake_, done_;
+    std::vector<std::thread> workers_;
+    unsigned char* dst_ = nullptr; const unsigned char* src_ = nullptr;
+    size_t bytes_ = 0, piece_ = 0;
+    unsigned long long generation_ = 0;
+    int pending_ = 0;
+    bool quit_ = false;
+};
+
 struct fx_stream {
     fx_context* ctx = nullptr;
+    FillPool fill;
     int hops = 0, slots = 0, fmt = FX_SAMPLE_F32;
     size_t in_bytes = 0, out_bytes = 0;
     // Large batches: three queues, so that PCIe runs in both directions while the kernels run -- `copy` carries batch k+1's samples
@@ -955,6 +1023,17 @@ fx_status fx_stream_submit(fx_stream* s)
     s->in_flight++;
     s->acquired = false;
     return FX_OK;
+}
+
+fx_status fx_stream_push(fx_stream* s, const void* hops, int fill_threads)
+{
+    if (!s || !hops) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    if (fill_threads < 1 || fill_threads > 64) return fx_fail(FX_ERR_INVALID_ARGUMENT, "fill_threads must be in [1, 64]");
+    void* slot = nullptr;
+    const fx_status st = fx_stream_acquire(s, &slot);
+    if (st != FX_OK) return st;
+    s->fill.copy(slot, hops, s->in_bytes, fill_threads);
+    return fx_stream_submit(s);
 }
 
 fx_status fx_stream_collect(fx_stream* s, float* out_raw, float* out_smoothed)

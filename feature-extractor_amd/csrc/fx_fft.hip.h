@@ -2,14 +2,9 @@
 // Included by fx_kernels.hip inside namespace fxk (one translation unit: every kernel sees the same
 // inlined helpers); not a stand-alone header.
 
-// The un-split transforms (N <= 1024) let the compiler hoist their few lane-derived addresses out of the frame loop
-// (+1 %, 126 VGPRs); everywhere else lane-derived values are re-materialised per frame (opaque(): hoisting them all
-// spills 85 registers at 1024 points).
-#ifdef FX_EXP_FFT_NO_HOIST
-#define FFT_OPAQUE(x) opaque<N>(x)
-#else
-#define FFT_OPAQUE(x) (x)
-#endif
+// (The un-split transforms (N <= 1024) let the compiler hoist their few lane-derived addresses out of the frame loop: +1 %, 126
+// VGPRs.  Everywhere else lane-derived values are re-materialised per frame -- opaque(): hoisting them all spills 85 registers at
+// 1024 points.)
 
 // ---------------------------------------------------------------------------------------------
 // LDS images
@@ -33,11 +28,7 @@ template <int N> struct Geo {
     static constexpr int RQ     = P > 16 ? P : 16;
     static constexpr int RIMG   = N + 4 * (N / RQ);                       // floats
     // bins image (re of bins < M, one run of U bins per lane): the same idea, 4 floats per U bins (U >= 8)
-#ifdef FX_EXP_NO_BPAD
-    static constexpr int BQ     = 0;
-#else
     static constexpr int BQ     = U >= 8 ? U : 0;
-#endif
     static constexpr int BIMG   = M + (BQ ? 4 * (M / U) : 0);             // floats
     // ONE LDS buffer per wavefront, reused as: real image of the frame, complex image of each transform (the whole
     // image, or one half at a time), v array of the lag scan, harmonic scratch (bins image + 16-bit peak list).
@@ -163,13 +154,9 @@ __device__ __forceinline__ void bfly4_core(f2& d0, f2& d1, f2& d2, f2& d3, f2 s0
 // output 0 when D0Y (getMagnitude's raw floats, imag[0] of the inverse transform).  Every value that is formed has the
 // operands, the order and the roundings of twmul + bfly4_core; what no consumer reads is not computed: s1 needs its real
 // part only (three plain instructions instead of three packed ones), s3 / s4 one half each (one packed add for both).
-// -DFX_EXP_FULL_LAST restores the full butterfly (A/B).
 template <bool INV, bool ALL4, bool D0Y>
 __device__ __forceinline__ void bfly4_re(f2& d0, f2& d1, f2& d2, f2& d3, f2 w1, f2 w2, f2 w3)
 {
-#ifdef FX_EXP_FULL_LAST
-    bfly4_core<INV>(d0, d1, d2, d3, twmul<INV>(d1, w1), twmul<INV>(d2, w2), twmul<INV>(d3, w3));
-#else
     const f2 s0 = twmul<INV>(d1, w1);
     const f2 s2 = twmul<INV>(d3, w3);
     float s1x, s1y = 0.0f;
@@ -185,7 +172,6 @@ __device__ __forceinline__ void bfly4_re(f2& d0, f2& d1, f2& d2, f2& d3, f2 w1, 
         d2 = f2{ax - t.x, 0.0f};
         d3 = f2{INV ? s5x + t.y : s5x - t.y, 0.0f};
     }
-#endif
 }
 // Real part of output 0 alone: (d0.x + s1.x) + (s0.x + s2.x), each s a twiddle product's real part (one packed
 // multiply + one add / subtract each) -- what the head of the lag search reads of an inverse transform.
@@ -237,18 +223,10 @@ __host__ __device__ constexpr int item_off(int L0, int i) { return L0 * i + (L0 
 // Layout: [item][11] float2, no padding (rows of 88 B: the 16 lanes of a ds_write_b64 group and the 32 of a ds_read_b64 group fall
 // on distinct banks; lanes that want the same element of the same item read one address).
 template <int N> struct RealExchange {
-#ifdef FX_EXP_FULL_FIRST_EXCHANGE
-    static constexpr bool USE = false;
-#else
     // 1024 (un-split, one item per lane) and 4096 (split, two per half): 16-element items, next pass at stride 16.
     // 2048 (split) has 8-element items (a radix-2 and a radix-4 stage) of which only e[6] = conj(e[2]) is exact: 7 stores of 8 are
-    // the same four store instructions and the sign flips cost 1 % (measured, FX_EXP_REAL_EXCHANGE_2048): not used there.
-#ifdef FX_EXP_REAL_EXCHANGE_2048
-    static constexpr bool USE = N == 1024 || N == 2048 || N == 4096;
-#else
+    // the same four store instructions and the sign flips cost 1 % (measured, profiles/r03_variants.txt): not used there.
     static constexpr bool USE = N == 1024 || N == 4096;
-#endif
-#endif
     static constexpr int RA = Geo<N>::RA;
     static constexpr int SLOTS = RA == 16 ? 11 : 7;
     // float2 of padding behind every 16 items: 7-slot rows need it to keep the 32 lanes of a read group on distinct banks
@@ -273,7 +251,6 @@ template <int N> struct RealExchange {
 template <int N, int R, int L0, int TWOFF, bool INV, bool FROM_REAL = false>
 __device__ __forceinline__ void fft_pass(f2* cbuf, const f2* tw, int lane)
 {
-    lane = FFT_OPAQUE(lane);
     constexpr int ITEMS = N / R;
     for (int it = lane; it < ITEMS; it += 64) {
         f2 e[R];
@@ -405,7 +382,6 @@ __device__ __forceinline__ void fft_first_pass(const float (&xin)[Geo<N>::P], f2
 {
     typedef Geo<N> G;
     constexpr int R = G::RA;
-    lane = FFT_OPAQUE(lane);
     f2 ta[9];                      // wave-uniform: kernel arguments, not LDS
 #pragma unroll
     for (int i = 0; i < 9; i++) ta[i] = f2{ftw[2 * i], ftw[2 * i + 1]};
@@ -495,16 +471,8 @@ __device__ __forceinline__ void item16_last(f2 (&e)[16], W w, bool first_item)
 // pipe are co-limiting, so the 180 twiddle reads per frame -- a fifth of its LDS instructions -- are worth removing).
 // The second pass's twiddles depend on it % L1 only, which is the same for all of a lane's items.
 template <int N> struct TwRegs {
-#ifdef FX_EXP_2048_LDS_TW
-    static constexpr bool USE = false;
-#else
     static constexpr bool USE = N == 2048;
-#endif
-#ifdef FX_EXP_2048_TW_PARTIAL
-    static constexpr bool USE_C = false;            // experiment: only the second pass's 15 twiddles in registers (<= 168 VGPRs, 3 waves per SIMD)
-#else
     static constexpr bool USE_C = USE;
-#endif
     static constexpr int GB = USE_C ? (N / 16) / 64 : 1;
     f2 b[15];
     f2 c[GB][15];
@@ -597,7 +565,6 @@ __device__ __forceinline__ float fft_last_pass_fused(f2* cbuf, const f2* tw, int
 {
     typedef Plan<N> PL;
     constexpr int R = PL::R2, L0 = PL::L2, GI = (N / R) / 64;
-    lane = FFT_OPAQUE(lane);
     f2 e[GI][R];
 #pragma unroll
     for (int g = 0; g < GI; g++) {
@@ -645,7 +612,7 @@ template <int N> struct LazyLag {
     {
         fft_first_pass<N, true>(xin, cbuf, ftw, lane_);
         fft_pass<N, PL::R1, PL::L1, PL::OFF1, true, RealExchange<N>::USE>(cbuf, tw, lane_);
-        lane = FFT_OPAQUE(lane_);
+        lane = lane_;
         scale = scale_;
         t1 = tw + PL::OFF2 + lane;
 #pragma unroll

@@ -1,9 +1,6 @@
-// Re-materialisation points of lane-derived values (see opaque()); FX_HOIST_MASK bit n lets the compiler hoist at point n
-// (experiments: tools/variants.sh "-DFX_HOIST_MASK=0x..").
-#ifndef FX_HOIST_MASK
-#define FX_HOIST_MASK 0
-#endif
-#define FX_OPQ(n, x) (((FX_HOIST_MASK) >> (n)) & 1 ? (x) : opaque<N>(x))
+// Re-materialisation points of lane-derived values (see opaque()).  (Letting the compiler hoist at some of them took 5 % of the
+// instructions out at 1024 points and not a microsecond: round 3, profiles/r03_variants.txt (e).)
+#define FX_OPQ(n, x) opaque<N>(x)
 // Costing builds only (-DFX_EXP_STOP_AT=k, tools/section_costs.sh): the frame's work ends at stop point k, the values it has
 // formed so far kept alive; the differences of the instruction counters between consecutive k are the sections' dynamic
 // costs.  Results are garbage and nothing waits for a frame that stopped early (the flux turn is taken at stop 8, which every
@@ -257,12 +254,6 @@ template <int N> struct LagSearch {
 };
 
 // waves per SIMD the register allocator must leave room for (LDS bounds residency as well)
-#ifndef FX_OCC_SMALL
-#define FX_OCC_SMALL 4
-#endif
-#ifndef FX_OCC_TINY
-#define FX_OCC_TINY 6
-#endif
 template <int N> struct Occ {
     // Residency is set by the LDS; the waves of a CU should spread evenly over its four SIMDs (a workgroup's waves go
     // round the SIMDs, so 6 waves are 2+2+1+1 and two such workgroups in the same rotation leave two SIMDs with 4 waves
@@ -274,16 +265,8 @@ template <int N> struct Occ {
     //   2048 points   : 3 x 4 = 12 waves, one workgroup   -> 3 per SIMD, <= 168 VGPRs
     //   4096 points   : 1 x 7 (the 160 KB to the byte)    -> 2 per SIMD at most, <= 256 VGPRs (the split transform keeps a
     //                   lane's 64 second-pass results in registers)
-#if defined(FX_EXP_2048_LDS_TW) || defined(FX_EXP_2048_TW_PARTIAL)
-    static constexpr int WAVES_PER_SIMD = N <= 1024 ? FX_OCC_SMALL : (N == 2048 ? 3 : 2);
-#else
-    static constexpr int WAVES_PER_SIMD = N <= 512 ? FX_OCC_TINY : (N <= 1024 ? FX_OCC_SMALL : 2);
-#endif
-#if defined(FX_EXP_2048_LDS_TW) || defined(FX_EXP_2048_TW_PARTIAL)
-    static constexpr int MAX_THREADS = N <= 1024 ? 512 : (N == 2048 ? 768 : 448);
-#else
+    static constexpr int WAVES_PER_SIMD = N <= 512 ? 8 : (N <= 1024 ? 4 : 2);
     static constexpr int MAX_THREADS = N <= 2048 ? 512 : 448;
-#endif
 };
 
 // One wavefront's view of the frame it is analysing: where its buffers are and the constants every section
@@ -440,7 +423,6 @@ FX_MARK("rms");
     {
         loc = FlatProd{0.5, 1};                                            // 1.0
         emin = 1; emax = 1;                                                // exponents of the lane's own prefixes (1 = the empty one)
-#ifndef FX_EXP_SKIP_FLATPROD
 #pragma unroll
         for (int j = 0; j < U; j++) {
             const double v = (double) re[j];
@@ -451,15 +433,11 @@ FX_MARK("rms");
                 emax = loc.exp > emax ? loc.exp : emax;
             }
         }
-#endif
     }
     // part 2: across the lanes
     __device__ __forceinline__ double flatness_product(int lane, const float (&re)[U], float tg, FlatProd loc, int emin, int emax) const
     {
 FX_MARK("flatprod");
-#ifdef FX_EXP_SKIP_FLATPROD
-        return 1.0;
-#endif
         // inclusive / exclusive scan of lane totals in lane (= bin) order; identity = 1.0 = (0.5, 1)
         FlatProd inc = loc;
 #define FX_FP_STEP(CTRL, ROW_MASK) { FlatProd nb; nb.mant = dpp_d<CTRL, ROW_MASK>(0.5, inc.mant); nb.exp = dpp_i<CTRL, ROW_MASK>(1, inc.exp); inc = fp_mul2(nb, inc); }
@@ -807,7 +785,6 @@ FX_MARK("scan");
         lane = FX_OPQ(4, lane);
         LagSearch<N> ls;
         ls.begin();
-#ifndef FX_EXP_SKIP_SCAN
         ls.block(lane, 0, vreg[0]);
         if (!ls.done && P > 1) ls.block(lane, 1, vreg[1]);
         if (!ls.done && P > 2) {
@@ -833,7 +810,6 @@ FX_MARK("scan");
                 for (int blk = 2; blk < P && !ls.done; blk++) ls.block(lane, blk, vbuf[64 * blk + lane]);
             }
         }
-#endif
         return ls.finish(lane, v_end);
     }
 
@@ -870,7 +846,6 @@ FX_MARK("power");
 FX_MARK("ifft");
         float vreg[P];
         float lag;
-#ifndef FX_EXP_NO_LAZY_LAG
         if constexpr (N == 1024) {
             LazyLag<N> lz;                                                 // a12 inverse, ref :110-121, its last pass on demand
             lz.load(xf, cbuf, tw, p.first_tw, lane, scale);
@@ -879,7 +854,6 @@ FX_MARK("ifft");
             FX_STOP(4, FX_KEEP(vreg[0]); FX_KEEP(vreg[1]); return 1.0);
             lag = lag_search<true>(lane, vreg, 0.0f, &lz);
         } else
-#endif
         {
             const float v_end = fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, p.first_tw, lane, scale, vreg, twr);   // a12 inverse, ref :110-121
             lag = lag_search<false>(lane, vreg, v_end, nullptr);
@@ -898,11 +872,7 @@ FX_MARK("ifft");
 FX_MARK("harm2");
         // ---------------- harmonic analyser, part 2 (ref HarmonicCharacteristics.h:71-105) ----------
         lane = FX_OPQ(8, lane);
-#ifdef FX_EXP_SKIP_HARM2
-        if (h_sum < -1.0) {
-#else
         if (!(h_sum < 0.005)) {                                                // :88-89
-#endif
             float* normed = reinterpret_cast<float*>(cbuf);                    // bins image: re of every bin (normalised on demand)
             unsigned short* peaks = reinterpret_cast<unsigned short*>(normed + G::BIMG);   // [<= M] peak bins (< 2048: 16 bits)
             double mean_mag = h_sum / (double) M;                              // :86
@@ -1032,12 +1002,8 @@ template <int N, bool SPEC, bool HARM, bool DIRECT = false>
 __global__ void __launch_bounds__(Occ<N>::MAX_THREADS, Occ<N>::WAVES_PER_SIMD)
 fx_frame_kernel(const FrameParams p_arg)
 {
-#ifdef FX_EXP_NO_DYN
-    const FrameParams& p = p_arg;
-#else
     FrameParams p = p_arg;
     if (p.dyn) { p.gain = p.dyn->gain; p.nyquist = p.dyn->nyquist; }         // captured step (hipGraph): per-call scalars
-#endif
     typedef Geo<N> G;
     constexpr int M = G::M, P = G::P;
 
@@ -1047,17 +1013,15 @@ fx_frame_kernel(const FrameParams p_arg)
     constexpr int PREV_FLOATS = DIRECT ? 0 : G::BIMG + (G::BQ ? 0 : 4);
     constexpr size_t WAVE_BYTES = G::BUF_BYTES;
     const int CH = p.ch_per_wg, K = p.waves_per_ch;
-#ifdef FX_EXP_TW_GLOBAL
-    const f2* tw = reinterpret_cast<const f2*>(p.tw);                     // experiment: twiddles through the vector cache
-    f2*    tw_lds = reinterpret_cast<f2*>(smem);
-#else
     f2*    tw    = reinterpret_cast<f2*>(smem);                             // [N]
     f2*    tw_lds = tw;
-#endif
     float* prev0 = reinterpret_cast<float*>(tw_lds + N);
     unsigned char* per_wave = reinterpret_cast<unsigned char*>(prev0 + (size_t) CH * PREV_FLOATS);
 
-    const int wave = threadIdx.x >> 6;
+    // (the wavefront's index is wave-uniform by construction; saying so keeps everything derived from it -- channel, frame index,
+    // buffer and record addresses, the frame loop itself -- in scalar registers: 126 -> 106 VGPRs at 1024 points, 256 + 60 B of
+    // scratch -> 245 at 4096, 80 + 16 B -> 64 at 512)
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     const int lane0 = threadIdx.x & 63;
     const int chl = wave / K, slot = wave % K;          // channel within the workgroup, frame slot within the channel
     const int T = p.T;
@@ -1086,9 +1050,7 @@ fx_frame_kernel(const FrameParams p_arg)
     float* rbuf = reinterpret_cast<float*>(cbuf);      // the same memory viewed as the real image
 
     // workgroup prologue: twiddle table + the channels' flux state into LDS
-#ifndef FX_EXP_TW_GLOBAL
     for (int i = threadIdx.x; i < N; i += blockDim.x) tw_lds[i] = reinterpret_cast<const f2*>(p.tw)[i];
-#endif
     if (chunk > 0) {
         // the flux state comes from the chunk before, written by another workgroup (another CU): its count, then an
         // agent-scope acquire, then the barrier (MI355X guide: one relaxed poll -> one acquire -> vmcnt(0) -> barrier ->

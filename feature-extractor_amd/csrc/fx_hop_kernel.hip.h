@@ -45,7 +45,7 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
     float* s_raw  = reinterpret_cast<float*>(smem + HG::OFF_RAW);
     float* s_onset = reinterpret_cast<float*>(smem + HG::OFF_ONSET);
 
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));     // wave-uniform: scalar registers for all that follows from it
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x;
     f2*    cbuf = reinterpret_cast<f2*>(smem + HG::OFF_WAVES + (size_t) G::BUF_BYTES * wave);
@@ -194,7 +194,7 @@ fx_hop_pair_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const H
     float* s_onset = reinterpret_cast<float*>(smem + HG::OFF_ONSET);
     unsigned* s_ready = reinterpret_cast<unsigned*>(smem + HG::OFF_READY);
 
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));     // wave-uniform: scalar registers for all that follows from it
     const int lane = threadIdx.x & 63;
     const int pair = wave >> 1, w = wave & 1;
     const int c = blockIdx.x;

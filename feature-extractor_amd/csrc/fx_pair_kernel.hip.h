@@ -882,7 +882,7 @@ fx_pair_kernel(const FrameParams p_arg)
     unsigned char* per_pair = reinterpret_cast<unsigned char*>(prev0 + (size_t) CH * PG::PREV_FLOATS);
     constexpr size_t PAIR_BYTES = PG::BUF_BYTES + PG::PAIR_EXTRA;
 
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));     // wave-uniform: scalar registers for all that follows from it
     const int lane = threadIdx.x & 63;
     const int pair = wave >> 1, w = wave & 1;
     const int chl = pair / K, slot = pair % K;

@@ -22,21 +22,13 @@ __device__ __forceinline__ void wave_fence()
 // Re-materialise a lane-derived value so that nothing computed from it is hoisted out of the frame
 // loop (loop-invariant code motion would otherwise keep hundreds of addresses, window gains and
 // shuffle indices live across the whole loop and spill them).
-#ifdef FX_EXP_NO_OPAQUE
-template <int N = 0> __device__ __forceinline__ int opaque(int v) { return v; }
-#else
 // (a lane index: saying so lets the compiler drop the sign handling of its divisions and the trip tests of per-lane item loops)
-// FX_LANE_RANGE_MAX: largest window whose kernels are told so (experiments)
-#ifndef FX_LANE_RANGE_MAX
-#define FX_LANE_RANGE_MAX 4096
-#endif
 template <int N = 0> __device__ __forceinline__ int opaque(int v)
 {
     asm volatile("" : "+v"(v));
-    if constexpr (N <= FX_LANE_RANGE_MAX) __builtin_assume((unsigned) v < 64u);
+    __builtin_assume((unsigned) v < 64u);
     return v;
 }
-#endif
 
 // ---------------------------------------------------------------------------------------------
 // wavefront reductions (all lanes receive the result, as a wave-uniform value).

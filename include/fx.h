@@ -168,6 +168,11 @@ fx_status fx_stream_destroy(fx_stream* s);
 fx_status fx_stream_acquire(fx_stream* s, void** host_slot);
 /* Hand the acquired slot to the GPU (asynchronous). */
 fx_status fx_stream_submit(fx_stream* s);
+/* acquire + copy + submit for a producer whose batch sits in ordinary host memory: `hops` ([num_channels][hops_per_batch]
+ * [window_size/2] samples of the stream's format) is copied into the next pinned slot by `fill_threads` host threads (1..64; a
+ * persistent pool inside the stream: one memcpy thread moves ~12 GB/s, PCIe Gen5 takes 55) and the slot is submitted.  A
+ * producer that can write its samples into the slot directly (fx_stream_acquire) saves that copy altogether. */
+fx_status fx_stream_push(fx_stream* s, const void* hops, int fill_threads);
 /* Wait for the OLDEST submitted batch and copy its results out: raw / smoothed
  * [num_channels][hops_per_batch][12] host floats (either may be NULL).  FX_ERR_INVALID_ARGUMENT
  * if nothing is in flight. */
