@@ -566,7 +566,19 @@ def rank_main(args, engine, rank, world):
     dt = time.perf_counter() - t0
     frame_ms, epi_ms, calls = an.profile_end()
 
+    per_rank = None
     if collective:
+        # every rank's own clock, kernel time and view of the exchange, so that a sub-linear scaling result can be read off one run:
+        # a slow rank, a slow gather or a communicator of the wrong size each show up in their own column
+        mine = {"rank": rank, "device": getattr(engine, "device", None), "channels": count, "seconds": dt,
+                "frames_per_s": count * T * args.steps / dt, "frame_kernel_ms_per_step": frame_ms / max(calls, 1),
+                "tail_kernels_ms_per_step": epi_ms / max(calls, 1)}
+        if rccl:
+            an.comm_sync()
+            mine["exchange"] = an.comm_stats()
+        gathered_records = [None] * world
+        dist.all_gather_object(gathered_records, mine)
+        per_rank = gathered_records
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -656,6 +668,8 @@ def rank_main(args, engine, rank, world):
                                    if collective else "single GPU"},
             "roofline": roof,
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
         if world == 1 and not args.no_extra and not args.debug_collective and engine.name == "gpu":
             extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes, avg_launch_s)
         if not args.no_cpu_baseline and world == 1 and not args.debug_collective:

@@ -255,6 +255,14 @@ class BatchAnalyser:
     def comm_sync(self):
         capi.check(self._lib.fx_comm_sync(self._h))
 
+    def comm_stats(self):
+        """fx_comm_stats: RCCL's rank count, gathers issued / timed, their summed and longest device time (ms) on the side stream."""
+        n, g, t = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        tot, mx = ctypes.c_double(), ctypes.c_double()
+        capi.check(self._lib.fx_comm_stats(self._h, ctypes.byref(n), ctypes.byref(g), ctypes.byref(t), ctypes.byref(tot), ctypes.byref(mx)))
+        return {"rccl_ranks": n.value, "gathers": g.value, "gathers_timed": t.value, "gather_ms_total": tot.value, "gather_ms_max": mx.value,
+                "gather_ms_mean": tot.value / t.value if t.value else None}
+
 
 class HopStream:
     """Streaming ingest on top of a BatchAnalyser: the stand-in for AudioDataCollector's ring

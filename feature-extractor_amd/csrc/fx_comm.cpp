@@ -81,12 +81,34 @@ struct fx_comm {
     float*      stage[2] = {nullptr, nullptr};   // [C][12] snapshots of `latest`
     hipEvent_t  snap[2] = {nullptr, nullptr};    // snapshot taken (context stream)
     hipEvent_t  sent[2] = {nullptr, nullptr};    // gather that read stage[i] finished (side stream)
+    hipEvent_t  began[2] = {nullptr, nullptr};   // ... and started (side stream, behind the snapshot): began -> sent is the gather's device time
     bool        sent_valid[2] = {false, false};
+    bool        timed_pending[2] = {false, false};   // a (began, sent) pair not yet read
+    int         rccl_ranks = 0;                  // ncclCommCount at creation
+    int         gathers = 0, gathers_timed = 0;
+    double      gather_ms_total = 0.0, gather_ms_max = 0.0;
     float*      d_out = nullptr;                 // sink-side device buffer for FX_MEM_HOST destinations
     float*      h_out = nullptr;                 // pinned bounce buffer for FX_MEM_HOST destinations
     float*      h_dst = nullptr;                 // caller's host buffer of the gather in flight, copied at fx_comm_sync
     unsigned    slot = 0;
 };
+
+// Device time of the gather that used staging slot s (events on the side stream), if it has finished (`finished`: the caller has
+// synchronised the stream; otherwise the event is queried and an unfinished gather is simply not counted).
+static void harvest(fx_comm* m, int s, bool finished)
+{
+    if (!m->timed_pending[s]) return;
+    if (!finished && hipEventQuery(m->sent[s]) != hipSuccess) { (void) hipGetLastError(); return; }
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, m->began[s], m->sent[s]) == hipSuccess) {
+        m->gathers_timed++;
+        m->gather_ms_total += ms;
+        if (ms > m->gather_ms_max) m->gather_ms_max = ms;
+    } else {
+        (void) hipGetLastError();
+    }
+    m->timed_pending[s] = false;
+}
 
 #define NCCL_TRY(expr)                                                                          \
     do {                                                                                        \
@@ -106,6 +128,7 @@ void fx_comm_release(fx_context* c)
         if (m->stage[i]) (void) hipFree(m->stage[i]);
         if (m->snap[i]) (void) hipEventDestroy(m->snap[i]);
         if (m->sent[i]) (void) hipEventDestroy(m->sent[i]);
+        if (m->began[i]) (void) hipEventDestroy(m->began[i]);
     }
     if (m->d_out) (void) hipFree(m->d_out);
     if (m->h_out) (void) hipHostFree(m->h_out);
@@ -152,6 +175,7 @@ fx_status fx_comm_create(fx_context* c, int rank, int world, const void* unique_
         int count = -1;
         M_NCCL(rccl()->CommCount(m->comm, &count));
         fprintf(stderr, "[fx_comm] rank %d of %d: RCCL communicator of %d rank(s) on device %d\n", rank, world, count, c->device);
+        m->rccl_ranks = count;
         if (count != world) return bail(fx_fail(FX_ERR_HIP, "RCCL reports %d ranks in the communicator, expected %d", count, world));
     }
     M_HIP(hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking));
@@ -159,7 +183,8 @@ fx_status fx_comm_create(fx_context* c, int rank, int world, const void* unique_
     for (int i = 0; i < 2; i++) {
         M_HIP(hipMalloc((void**) &m->stage[i], bytes));
         M_HIP(hipEventCreateWithFlags(&m->snap[i], hipEventDisableTiming));
-        M_HIP(hipEventCreateWithFlags(&m->sent[i], hipEventDisableTiming));
+        M_HIP(hipEventCreate(&m->sent[i]));
+        M_HIP(hipEventCreate(&m->began[i]));
     }
     // every rank's channel count (shards may differ by a remainder block)
     {
@@ -224,10 +249,12 @@ fx_status fx_gather_smoothed(fx_context* c, int dst, float* out, int mem_kind)
     m->slot++;
     // the gather that last read this staging slot must be over before the snapshot overwrites it
     if (m->sent_valid[s]) HIP_TRY(hipStreamWaitEvent(c->stream, m->sent[s], 0));
+    harvest(m, s, false);                        // (its timing, if it has finished: the events are about to be recorded again)
     const size_t bytes = (size_t) c->C * FX_NUM_FEATURES * sizeof(float);
     HIP_TRY(hipMemcpyAsync(m->stage[s], c->d_latest, bytes, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipEventRecord(m->snap[s], c->stream));
     HIP_TRY(hipStreamWaitEvent(m->side, m->snap[s], 0));
+    HIP_TRY(hipEventRecord(m->began[s], m->side));
     NCCL_TRY(rccl()->GroupStart());
     ncclResult_t r = rccl()->Send(m->stage[s], (size_t) c->C * FX_NUM_FEATURES, ncclFloat32, dst, m->comm, m->side);
     if (r == ncclSuccess && sink) {
@@ -240,6 +267,8 @@ fx_status fx_gather_smoothed(fx_context* c, int dst, float* out, int mem_kind)
     if (re != ncclSuccess) return fx_fail(FX_ERR_HIP, "ncclGroupEnd failed: %s", rccl()->GetErrorString(re));
     HIP_TRY(hipEventRecord(m->sent[s], m->side));
     m->sent_valid[s] = true;
+    m->timed_pending[s] = true;
+    m->gathers++;
     if (sink && mem_kind == FX_MEM_HOST) {
         HIP_TRY(hipMemcpyAsync(m->h_out, m->d_out, total_bytes, hipMemcpyDeviceToHost, m->side));
         m->h_dst = out;
@@ -253,10 +282,24 @@ fx_status fx_comm_sync(fx_context* c)
     fx_comm* m = c->comm;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(m->side));
+    harvest(m, 0, true);
+    harvest(m, 1, true);
     if (m->h_dst) {
         memcpy(m->h_dst, m->h_out, (size_t) m->total * FX_NUM_FEATURES * sizeof(float));
         m->h_dst = nullptr;
     }
+    return FX_OK;
+}
+
+fx_status fx_comm_stats(fx_context* c, int* rccl_ranks, int* gathers, int* gathers_timed, double* total_ms, double* max_ms)
+{
+    if (!c || !c->comm) return fx_fail(FX_ERR_INVALID_ARGUMENT, "context has no communicator");
+    const fx_comm* m = c->comm;
+    if (rccl_ranks) *rccl_ranks = m->rccl_ranks;
+    if (gathers) *gathers = m->gathers;
+    if (gathers_timed) *gathers_timed = m->gathers_timed;
+    if (total_ms) *total_ms = m->gather_ms_total;
+    if (max_ms) *max_ms = m->gather_ms_max;
     return FX_OK;
 }
 

@@ -262,6 +262,10 @@ fx_status fx_comm_layout(fx_context* ctx, int* total_channels, int* first_channe
 fx_status fx_gather_smoothed(fx_context* ctx, int dst_rank, float* out, int mem_kind);
 /* Wait for every gather issued so far on this context. */
 fx_status fx_comm_sync(fx_context* ctx);
+/* What a scaling run wants to see of the exchange: RCCL's own rank count of the communicator (ncclCommCount), the gathers issued, how many
+ * of them were timed (HIP events around the send / receive group on the side stream; a gather still running when its staging slot comes
+ * round again is not counted), and their summed and longest device time in milliseconds.  Any pointer may be NULL. */
+fx_status fx_comm_stats(fx_context* ctx, int* rccl_ranks, int* gathers, int* gathers_timed, double* total_ms, double* max_ms);
 
 /* ---- the reference's LEGACY offline analyser: struct AudioAnalyser (AudioAnalysis.h), SURVEY.md 8(f) rank 4 ----
  * Never instantiated by the reference application (AudioAnalysis.h:221-246 is commented out); provided for hosts that

@@ -13,6 +13,7 @@
 
 #include <cstddef>
 #include <cstdlib>
+#include <cstdint>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -119,6 +120,12 @@ public:
     {
         check (fx_push_hops (ctx, hops, numHops, FX_SAMPLE_F32, FX_MEM_HOST, raw, smoothed));
     }
+    // the same hops as 16-bit PCM (FX_SAMPLE_S16: v / 32768 in the kernels' load stage -- what JUCE's WAV reader makes of a 16-bit
+    // file before AudioDataCollector sees it, ref AudioFilePlayer.h:41-61): half the bytes across PCIe, the same bits out
+    void pushHopsPCM16 (const std::int16_t* hops, int numHops, float* raw, float* smoothed)
+    {
+        check (fx_push_hops (ctx, hops, numHops, FX_SAMPLE_S16, FX_MEM_HOST, raw, smoothed));
+    }
     void processFrames (const float* frames, int numFrames, float* raw, float* smoothed)
     {
         check (fx_process_frames (ctx, frames, numFrames, FX_SAMPLE_F32, FX_MEM_HOST, raw, smoothed));
@@ -140,8 +147,8 @@ public:
     }
     float getValue (int channel, AudioFeatures::eAudioFeature f) { return getValues (channel)[(std::size_t) f]; }
 
-    // launch-shape knobs (struct fx_tuning of fx.h; e.g. waves_per_frame = 2: every frame on a pair of wavefronts, the lower
-    // one-hop latency at 2048 / 4096 points).  No knob changes a result bit within a kernel family.
+    // launch-shape knobs (struct fx_tuning of fx.h).  No knob changes a result bit within a kernel family; the family itself is a
+    // constructor flag (FX_LOW_LATENCY: every frame on a pair of wavefronts, the lower one-hop latency at 2048 / 4096 points).
     fx_tuning getTuning()                  { fx_tuning t; check (fx_get_tuning (ctx, &t)); return t; }
     void setTuning (const fx_tuning& t)    { check (fx_set_tuning (ctx, &t)); }
 

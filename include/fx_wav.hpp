@@ -32,6 +32,8 @@ struct WavData
     int    bitsPerSample = 0;
     bool   isFloat = false;
     std::vector<float> interleaved;     // [frame][channel]
+    std::vector<std::int16_t> pcm16;    // 16-bit PCM files only: the samples as the file holds them, [frame][channel] -- what
+                                        // FX_SAMPLE_S16 ingests (the kernels make v / 2^15 of them, exactly as `interleaved` holds)
 
     std::size_t numFrames() const { return numChannels > 0 ? interleaved.size() / (std::size_t) numChannels : 0; }
 
@@ -113,6 +115,8 @@ inline bool readWav (const std::string& path, WavData& out, std::string& error)
 
     const std::size_t total = dataBytes / (std::size_t) blockAlign * (std::size_t) out.numChannels;
     out.interleaved.resize (total);
+    out.pcm16.clear();
+    if (format == 1 && bits == 16) out.pcm16.resize (total);
     const float scale = 1.0f / (float) 0x7fffffff;                  // == 2^-31
     for (std::size_t i = 0; i < total; ++i)
     {
@@ -127,7 +131,7 @@ inline bool readWav (const std::string& path, WavData& out, std::string& error)
         {
             std::int32_t wide;
             if (bits == 8)       wide = (std::int32_t) (((std::uint32_t) p[0] - 128u) << 24);
-            else if (bits == 16) wide = (std::int32_t) ((std::uint32_t) u16 (p) << 16);
+            else if (bits == 16) { wide = (std::int32_t) ((std::uint32_t) u16 (p) << 16); out.pcm16[i] = (std::int16_t) u16 (p); }
             else if (bits == 24) wide = (std::int32_t) (((std::uint32_t) p[0] << 8) | ((std::uint32_t) p[1] << 16) | ((std::uint32_t) p[2] << 24));
             else                 wide = (std::int32_t) u32 (p);
             v = (float) wide * scale;
@@ -146,6 +150,18 @@ inline std::vector<float> hopsOfChannel (const WavData& wav, int channel, int wi
     std::vector<float> mono = wav.channel (channel);
     numHops = (int) (mono.size() / hop);
     mono.resize ((std::size_t) numHops * hop);
+    return mono;
+}
+// The same hop stream as 16-bit PCM, untouched (16-bit files only; empty otherwise): two bytes per sample across PCIe.
+inline std::vector<std::int16_t> hopsOfChannelPCM16 (const WavData& wav, int channel, int windowSize, int& numHops)
+{
+    std::vector<std::int16_t> mono;
+    numHops = 0;
+    if (wav.pcm16.empty()) return mono;
+    const std::size_t hop = (std::size_t) windowSize / 2, frames = wav.numFrames();
+    numHops = (int) (frames / hop);
+    mono.resize ((std::size_t) numHops * hop);
+    for (std::size_t i = 0; i < mono.size(); ++i) mono[i] = wav.pcm16[i * (std::size_t) wav.numChannels + (std::size_t) channel];
     return mono;
 }
 } // namespace fx

@@ -85,6 +85,16 @@ def test_wav_to_osc_matches_oracle(gpu_fx, oracle, tmp_path, fmt, window, gain):
     got = _records(dump)
     assert len(got) == len(want) == (48000 + 333) // (window // 2)
     assert got == want
+    if fmt == "pcm16":
+        # the 16-bit samples as the file holds them, widened in the kernels' load stage (FX_SAMPLE_S16): the same datagrams
+        dump16 = str(tmp_path / "o16.bin")
+        out = subprocess.run([exe, wav, "--window", str(window), "--channel", "1", "--gain", str(gain), "--address", "/Audio/A1",
+                              "--dump", dump16, "--batch", "7", "--pcm16-direct"], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert _records(dump16) == want
+    else:
+        out = subprocess.run([exe, wav, "--window", str(window), "--pcm16-direct"], capture_output=True, text=True)
+        assert out.returncode == 1 and "16-bit PCM" in out.stderr
 
     # the 60 Hz timer view: tick k reads the values after the last hop completed by k/60 s
     dump60 = str(tmp_path / "o60.bin")

@@ -192,3 +192,33 @@ def test_bench_rank_path_two_ranks_gloo_cpu(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["total_channels"] == 6 and d["config"]["channels_per_gpu"] == 3
     assert d["value"] > 0 and d["steps"] == 2 and "gloo" in d["config"]["sharding"]
     assert d["roofline"]["bound"] == "valu" and d["roofline"]["compute"]["flops_per_frame"] > 2e5
+
+
+def test_first_multigpu_report_shape_from_a_two_rank_gloo_run(tmp_path):
+    """tools/first_multigpu_run.py (the one-command kit for the day a multi-GPU node runs this): its report is assembled from bench
+    lines with per-rank records.  Dry run on CPU: a real two-rank gloo line from bench.rank_main (oracle stand-in engine) plus a
+    made-up one-rank line go through assemble(); the JSON has every rank's rate and kernel times, the scaling table and findings."""
+    import importlib.util
+    import json
+    out = str(tmp_path / "line.json")
+    mp.spawn(_bench_rank, args=(2, _free_port(), out), nprocs=2, join=True)
+    two = json.load(open(out))
+    assert [r["rank"] for r in two["per_rank"]] == [0, 1]
+    for r in two["per_rank"]:
+        assert r["channels"] == 3 and r["frames_per_s"] > 0 and r["frame_kernel_ms_per_step"] > 0 and "seconds" in r
+    spec = importlib.util.spec_from_file_location("first_multigpu_run", os.path.join(ROOT, "tools", "first_multigpu_run.py"))
+    kit = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kit)
+    one = dict(two, n_gpus=1, value=two["value"] / 1.9, per_rank=None)
+    rep = kit.assemble(2, {2: {"rc": 0, "skipped": False, "tail": "ok"}}, {1: one, 2: two})
+    assert set(rep) >= {"visible_gpus", "comm_ranks", "bench", "scaling", "findings"}
+    assert abs(rep["scaling"]["2"]["speedup_vs_1"] - 1.9) < 1e-9 and abs(rep["scaling"]["2"]["efficiency"] - 0.95) < 1e-9
+    assert rep["bench"]["2"]["per_rank"][1]["rank"] == 1 and isinstance(rep["findings"], list) and rep["findings"]
+    # what the findings are for: a slow rank, a communicator of the wrong size, a gather that takes a third of the step
+    bad = json.loads(json.dumps(two))
+    bad["per_rank"][1]["frames_per_s"] *= 0.5
+    bad["per_rank"][0]["exchange"] = {"rccl_ranks": 1, "gathers": 3, "gathers_timed": 3, "gather_ms_total": 3.0, "gather_ms_max": 1.5,
+                                      "gather_ms_mean": 0.4 * bad["ms_per_step"]}
+    text = " ".join(kit.findings(2, bad))
+    assert "slower than the fastest rank" in text and "RCCL counts 1 ranks" in text and "may no longer hide" in text
+    json.dumps(rep)
