@@ -26,7 +26,8 @@ EXPORTS = ["fx_create", "fx_destroy", "fx_reset_state", "fx_set_sample_rate", "f
            "fx_comm_unique_id", "fx_comm_create", "fx_comm_destroy", "fx_comm_layout", "fx_gather_smoothed", "fx_comm_sync", "fx_comm_stats",
            "fx_plan_units", "fx_tuning_defaults", "fx_tuning_from_env", "fx_get_tuning", "fx_set_tuning",
            "fx_offline_create", "fx_offline_destroy", "fx_offline_reset", "fx_offline_sync", "fx_offline_get_previous_f0", "fx_offline_zero_crosses",
-           "fx_offline_log_attack_time", "fx_offline_fft_lbp", "fx_offline_harmonic_characteristics"]
+           "fx_offline_log_attack_time", "fx_offline_fft_lbp", "fx_offline_harmonic_characteristics", "fx_offline_spectral_characteristics",
+           "fx_offline_get_previous_bins", "fx_offline_spectral_slope", "fx_offline_auto_correlation"]
 COMM_ID_BYTES = 128
 ABI_VERSION = 4
 MAX_UNITS = 24
@@ -137,6 +138,10 @@ def load_library(build_if_missing=True):
     L.fx_offline_log_attack_time.argtypes = [vp, vp, i, i, i, i, vp, i]
     L.fx_offline_fft_lbp.argtypes = [vp, vp, vp, i, vp, vp, vp, i]
     L.fx_offline_harmonic_characteristics.argtypes = [vp, vp, i, vp, i]
+    L.fx_offline_spectral_characteristics.argtypes = [vp, vp, i, vp, i]
+    L.fx_offline_get_previous_bins.argtypes = [vp, ctypes.POINTER(d), i]
+    L.fx_offline_spectral_slope.argtypes = [vp, vp, i, vp, i]
+    L.fx_offline_auto_correlation.argtypes = [vp, vp, i, vp, vp, i]
     L.fx_pack_osc12.argtypes = [fp, fp]
     L.fx_pack_osc12.restype = None
     L.fx_pack_osc10.argtypes = [fp, fp]

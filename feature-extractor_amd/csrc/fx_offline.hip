@@ -1,6 +1,6 @@
 // fx_offline.hip -- the reference's LEGACY offline analyser (struct AudioAnalyser, ref AudioAnalysis.h) on
-// gfx950: zero crossings, log attack time, FFT-LBP and the histogram F0 / harmonic energy ratio / inharmonicity, behind the
-// fx_offline_* entries of include/fx.h.  "ref:" citations are relative to the reference's Source/.
+// gfx950: zero crossings, log attack time, FFT-LBP, the histogram F0 / harmonic energy ratio / inharmonicity and (round 4) the
+// full-spectrum characteristics, the legacy slope and the auto-correlation peak, behind the fx_offline_* entries of include/fx.h.  "ref:" citations are relative to the reference's Source/.
 //
 // None of this is on the real-time path (the reference never instantiates AudioAnalyser); the kernels are written for exact
 // agreement with the reference's arithmetic -- integer counts, fp32 comparisons as written, fp64 sums in the reference's own
@@ -21,6 +21,8 @@ struct fx_offline {
     double nyquist = 24000.0;
     hipStream_t stream = nullptr;
     double* d_prev_f0 = nullptr;        // [C] previousF0 of each channel's analyser (ref AudioAnalysis.h:109,293,697)
+    double* d_prev_bins = nullptr;      // [C][prev_bins] previousBinMagnitudes of each channel's analyser (ref :120-121,510,700); null until first used
+    int     prev_bins = 0;
     void*   d_in = nullptr;  size_t in_cap = 0;      // staging for host buffers
     void*   d_out = nullptr; size_t out_cap = 0;
 };
@@ -278,6 +280,128 @@ fx_status check_args(fx_offline* o, const void* in, const void* out, int mem_kin
     return FX_OK;
 }
 
+// ---- ref AudioAnalysis.h:463-515 calculateSpectralCharacteristics: block = channel.  Every sum of the reference is a serial double
+// sum in bin order, and the product a serial IEEE product (inf / 0 sticky): the block stages the frame and the state in LDS,
+// ONE thread runs the reference's two loops as written, the block writes the state back.  (An offline function: exactness over speed.)
+__global__ void __launch_bounds__(NT) spectral_characteristics_kernel(const float* mags, int num_bins, double nyquist, double* prev_bins, float* out4)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* prev = reinterpret_cast<double*>(smem);                         // [num_bins]
+    float* mag = reinterpret_cast<float*>(prev + num_bins);                 // [num_bins]
+    __shared__ int s_accepted;
+    const int c = blockIdx.x;
+    double* gprev = prev_bins + (size_t) c * num_bins;
+    for (int i = threadIdx.x; i < num_bins; i += NT) { mag[i] = mags[(size_t) c * num_bins + i]; prev[i] = gprev[i]; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const size_t n = (size_t) num_bins;
+        const double frpb = nyquist / n;                                    // :466
+        double weighted = 0.0, var = 0.0, sum = 0.0, product = 1.0, flux = 0.0;
+        for (size_t i = 0; i < n; ++i) {                                    // :479-496
+            const double fc = (double) i * frpb + (frpb / 2.0);
+            const double m = (double) mag[i];
+            const double diff = fabs(m) - fabs(prev[i]);
+            const double rectified = (diff + fabs(diff)) / 2.0;
+            if (diff > 0.0) flux += rectified;
+            sum += m;
+            product *= m;
+            weighted += fc * m;
+        }
+        float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, r3 = 0.0f;
+        const bool accepted = sum > 0.001;                                  // :498-500
+        if (accepted) {
+            const float centroid = (float) (weighted / sum);
+            const double inv = 1.0 / n;
+            const float flatness = (float) (pow(product, inv) / (inv * sum));        // :505
+            for (size_t i = 0; i < n; ++i) {
+                const double fc = (double) i * frpb + (frpb / 2.0);         // binCentreFrequencies[i], the same expression
+                var += pow((fc / nyquist) - (centroid / nyquist), 2.0) * (double) mag[i];   // :509
+            }
+            const float max_spread = (float) ((centroid / nyquist) * (1.0 - (centroid / nyquist)));
+            r0 = centroid / (float) nyquist; r1 = (float) ((var / sum) / max_spread); r2 = flatness; r3 = (float) flux;
+        }
+        out4[4 * c] = r0; out4[4 * c + 1] = r1; out4[4 * c + 2] = r2; out4[4 * c + 3] = r3;
+        s_accepted = accepted ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_accepted)
+        for (int i = threadIdx.x; i < num_bins; i += NT) gprev[i] = (double) mag[i];          // :510
+}
+
+// ---- ref AudioAnalysis.h:566-609 calculateNormalisedSpectralSlope: block = channel; the maximum in parallel (order does not matter),
+// the double sums by one thread in the reference's order ----
+__global__ void __launch_bounds__(NT) spectral_slope_kernel(const float* mags, int num_bins, float* out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* mag = reinterpret_cast<float*>(smem);
+    __shared__ float s_max[NT];
+    const int c = blockIdx.x;
+    float peak = 0.0f;
+    for (int i = threadIdx.x; i < num_bins; i += NT) { const float v = mags[(size_t) c * num_bins + i]; mag[i] = v; const float a = fabsf(v); if (a > peak) peak = a; }
+    s_max[threadIdx.x] = peak;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < NT; k++) if (s_max[k] > peak) peak = s_max[k];
+        const double bins = (double) num_bins, mean_bin = 0.5, magnitude = (double) peak;      // getMagnitude, :573
+        float result = 0.0f;
+        if (magnitude > 0.0001) {
+            double mean_energy = 0.0, prod_sum = 0.0;
+            for (int i = 0; i < (int) bins; i++) {
+                const double e = mag[i] / magnitude;
+                mean_energy += e;
+                prod_sum += (double) i * e;
+            }
+            mean_energy /= bins;
+            double bin_var = 0.0, energy_var = 0.0;
+            for (double i = 0.0; i < bins; i++) {
+                const double ni = i / bins;
+                bin_var += (ni - mean_bin) * (ni - mean_bin);
+                const double e = mag[(int) i] / magnitude;
+                energy_var += (e - mean_energy) * (e - mean_energy);
+            }
+            bin_var /= bins;
+            energy_var /= bins;
+            const double bin_std = sqrt(bin_var), energy_std = sqrt(energy_var);
+            const double r = (prod_sum - (bins * mean_energy * mean_bin)) / (bins - 1.0f) * energy_std * bin_std;      // :602
+            result = (float) (r * (bin_std / energy_std));
+        }
+        out[c] = result;
+    }
+}
+
+// ---- ref AudioAnalysis.h:623-633 getConjugateComplexMultiplicationInPlace: thread = item ----
+__global__ void __launch_bounds__(NT) conjugate_multiplication_kernel(float* data, long long items)
+{
+    const long long k = (long long) blockIdx.x * NT + threadIdx.x;
+    if (k >= items) return;
+    const float r = data[2 * k], i = data[2 * k + 1];
+    const float cr = r, ci = -i;
+    data[2 * k] = (r * cr) - (i * ci);
+    data[2 * k + 1] = (r * ci) + (cr * i);
+}
+
+// ---- ref AudioAnalysis.h:636-665 analyseAutoCorrelation + getMaxIndex: block = channel; the FIRST bin holding the largest real part ----
+__global__ void __launch_bounds__(NT) auto_correlation_kernel(const float* data, int num_items, double nyquist, int* peak_bin, double* frequency)
+{
+    __shared__ float s_val[NT];
+    __shared__ int s_idx[NT];
+    const int c = blockIdx.x;
+    const float* d = data + (size_t) c * num_items * 2;
+    float best = 0.0f; int at = -1;
+    for (int i = threadIdx.x; i < num_items; i += NT) { const float v = d[2 * i]; if (at < 0 || v > best) { best = v; at = i; } }      // ascending i: the first on ties
+    s_val[threadIdx.x] = best; s_idx[threadIdx.x] = at;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // getMaxIndex starts from data[0] and moves on `data[i] > currentMax` only: a NaN at 0 keeps bin 0, NaNs elsewhere never win
+        int peak = 0; float current = d[0];
+        for (int k = 0; k < NT; k++)
+            if (s_idx[k] >= 0 && (s_val[k] > current || (s_val[k] == current && s_idx[k] < peak))) { current = s_val[k]; peak = s_idx[k]; }
+        const double frpb = nyquist / (double) num_items;
+        peak_bin[c] = peak;
+        frequency[c] = (peak * frpb) + (frpb / 2.0);
+    }
+}
+
 } // namespace
 
 extern "C" {
@@ -302,6 +426,8 @@ fx_status fx_offline_create(fx_offline** out, int device_id, int num_channels, d
     if (e == hipSuccess) e = hipMemsetAsync(o->d_prev_f0, 0, sizeof(double) * (size_t) num_channels, o->stream);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&harmonic_characteristics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int) harmonic_lds_bytes(MAX_BINS));      // (beside ~9 KB of static LDS)
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectral_characteristics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int) ((sizeof(double) + sizeof(float)) * MAX_BINS));
     if (e == hipSuccess) e = hipStreamSynchronize(o->stream);
     if (e != hipSuccess) { fx_offline_destroy(o); return fx_fail(FX_ERR_HIP, "setting up the offline analyser failed: %s", hipGetErrorString(e)); }
     *out = o;
@@ -314,6 +440,7 @@ fx_status fx_offline_destroy(fx_offline* o)
     (void) hipSetDevice(o->device);
     if (o->stream) (void) hipStreamSynchronize(o->stream);
     if (o->d_prev_f0) (void) hipFree(o->d_prev_f0);
+    if (o->d_prev_bins) (void) hipFree(o->d_prev_bins);
     if (o->d_in) (void) hipFree(o->d_in);
     if (o->d_out) (void) hipFree(o->d_out);
     if (o->stream) (void) hipStreamDestroy(o->stream);
@@ -327,6 +454,7 @@ fx_status fx_offline_reset(fx_offline* o)
     HIP_TRY(hipSetDevice(o->device));
     HIP_TRY(hipMemsetAsync(o->d_prev_f0, 0, sizeof(double) * (size_t) o->C, o->stream));
     HIP_TRY(hipStreamSynchronize(o->stream));
+    if (o->d_prev_bins) { HIP_TRY(hipFree(o->d_prev_bins)); o->d_prev_bins = nullptr; o->prev_bins = 0; }      // a new analyser: any frame size again
     return FX_OK;
 }
 
@@ -413,6 +541,86 @@ fx_status fx_offline_harmonic_characteristics(fx_offline* o, const float* magnit
                        static_cast<const float*>(da), num_bins, o->nyquist, o->d_prev_f0, d_out);
     HIP_TRY(hipGetLastError());
     if (mem_kind == FX_MEM_HOST) { HIP_TRY(hipMemcpyAsync(out3, d_out, out_bytes, hipMemcpyDeviceToHost, o->stream)); HIP_TRY(hipStreamSynchronize(o->stream)); }
+    return FX_OK;
+}
+
+fx_status fx_offline_spectral_characteristics(fx_offline* o, const float* magnitudes, int num_bins, float* out4, int mem_kind)
+{
+    fx_status st = check_args(o, magnitudes, out4, mem_kind);
+    if (st != FX_OK) return st;
+    if (num_bins < 1 || num_bins > MAX_BINS) return fx_fail(FX_ERR_INVALID_ARGUMENT, "num_bins must be in [1, %d]", MAX_BINS);
+    if (o->d_prev_bins && o->prev_bins != num_bins)
+        return fx_fail(FX_ERR_INVALID_ARGUMENT, "this analyser's previousBinMagnitudes holds %d bins (fixed by its window size, ref AudioAnalysis.h:120-121); "
+                                                "fx_offline_reset before frames of %d", o->prev_bins, num_bins);
+    if (!o->d_prev_bins) {
+        HIP_TRY(hipMalloc((void**) &o->d_prev_bins, sizeof(double) * (size_t) o->C * num_bins));
+        HIP_TRY(hipMemsetAsync(o->d_prev_bins, 0, sizeof(double) * (size_t) o->C * num_bins, o->stream));
+        o->prev_bins = num_bins;
+    }
+    const size_t in_bytes = sizeof(float) * (size_t) o->C * num_bins, out_bytes = sizeof(float) * 4 * (size_t) o->C;
+    const void *da, *db;
+    if ((st = stage_in(o, mem_kind, magnitudes, in_bytes, nullptr, 0, &da, &db)) != FX_OK) return st;
+    float* d_out = out4;
+    if (mem_kind == FX_MEM_HOST) { if ((st = grow_bytes(&o->d_out, &o->out_cap, out_bytes)) != FX_OK) return st; d_out = static_cast<float*>(o->d_out); }
+    hipLaunchKernelGGL(spectral_characteristics_kernel, dim3((unsigned) o->C), dim3(NT), (sizeof(double) + sizeof(float)) * (size_t) num_bins, o->stream,
+                       static_cast<const float*>(da), num_bins, o->nyquist, o->d_prev_bins, d_out);
+    HIP_TRY(hipGetLastError());
+    if (mem_kind == FX_MEM_HOST) { HIP_TRY(hipMemcpyAsync(out4, d_out, out_bytes, hipMemcpyDeviceToHost, o->stream)); HIP_TRY(hipStreamSynchronize(o->stream)); }
+    return FX_OK;
+}
+
+fx_status fx_offline_get_previous_bins(fx_offline* o, double* out, int num_bins)
+{
+    if (!o || !out) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    if (!o->d_prev_bins || o->prev_bins != num_bins) return fx_fail(FX_ERR_INVALID_ARGUMENT, "previousBinMagnitudes holds %d bins", o->prev_bins);
+    HIP_TRY(hipSetDevice(o->device));
+    HIP_TRY(hipMemcpyAsync(out, o->d_prev_bins, sizeof(double) * (size_t) o->C * num_bins, hipMemcpyDeviceToHost, o->stream));
+    HIP_TRY(hipStreamSynchronize(o->stream));
+    return FX_OK;
+}
+
+fx_status fx_offline_spectral_slope(fx_offline* o, const float* magnitudes, int num_bins, float* out, int mem_kind)
+{
+    fx_status st = check_args(o, magnitudes, out, mem_kind);
+    if (st != FX_OK) return st;
+    if (num_bins < 1 || num_bins > MAX_BINS) return fx_fail(FX_ERR_INVALID_ARGUMENT, "num_bins must be in [1, %d]", MAX_BINS);
+    const size_t in_bytes = sizeof(float) * (size_t) o->C * num_bins, out_bytes = sizeof(float) * (size_t) o->C;
+    const void *da, *db;
+    if ((st = stage_in(o, mem_kind, magnitudes, in_bytes, nullptr, 0, &da, &db)) != FX_OK) return st;
+    float* d_out = out;
+    if (mem_kind == FX_MEM_HOST) { if ((st = grow_bytes(&o->d_out, &o->out_cap, out_bytes)) != FX_OK) return st; d_out = static_cast<float*>(o->d_out); }
+    hipLaunchKernelGGL(spectral_slope_kernel, dim3((unsigned) o->C), dim3(NT), sizeof(float) * (size_t) num_bins, o->stream, static_cast<const float*>(da), num_bins, d_out);
+    HIP_TRY(hipGetLastError());
+    if (mem_kind == FX_MEM_HOST) { HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, o->stream)); HIP_TRY(hipStreamSynchronize(o->stream)); }
+    return FX_OK;
+}
+
+fx_status fx_offline_auto_correlation(fx_offline* o, float* data, int num_items, int* peak_bin, double* frequency, int mem_kind)
+{
+    fx_status st = check_args(o, data, peak_bin, mem_kind);
+    if (st != FX_OK) return st;
+    if (!frequency || num_items < 1) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument or num_items < 1");
+    const size_t in_bytes = sizeof(float) * 2 * (size_t) o->C * num_items;
+    const void *da, *db;
+    if ((st = stage_in(o, mem_kind, data, in_bytes, nullptr, 0, &da, &db)) != FX_OK) return st;
+    float* d_data = const_cast<float*>(static_cast<const float*>(da));
+    int* d_peak = peak_bin; double* d_freq = frequency;
+    if (mem_kind == FX_MEM_HOST) {
+        if ((st = grow_bytes(&o->d_out, &o->out_cap, (sizeof(double) + sizeof(double)) * (size_t) o->C)) != FX_OK) return st;
+        d_freq = static_cast<double*>(o->d_out);
+        d_peak = reinterpret_cast<int*>(d_freq + o->C);
+    }
+    const long long items = (long long) o->C * num_items;
+    hipLaunchKernelGGL(conjugate_multiplication_kernel, dim3((unsigned) ((items + NT - 1) / NT)), dim3(NT), 0, o->stream, d_data, items);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(auto_correlation_kernel, dim3((unsigned) o->C), dim3(NT), 0, o->stream, d_data, num_items, o->nyquist, d_peak, d_freq);
+    HIP_TRY(hipGetLastError());
+    if (mem_kind == FX_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(data, d_data, in_bytes, hipMemcpyDeviceToHost, o->stream));
+        HIP_TRY(hipMemcpyAsync(peak_bin, d_peak, sizeof(int) * (size_t) o->C, hipMemcpyDeviceToHost, o->stream));
+        HIP_TRY(hipMemcpyAsync(frequency, d_freq, sizeof(double) * (size_t) o->C, hipMemcpyDeviceToHost, o->stream));
+        HIP_TRY(hipStreamSynchronize(o->stream));
+    }
     return FX_OK;
 }
 

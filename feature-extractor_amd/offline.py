@@ -72,3 +72,36 @@ class AudioAnalyser:
         capi.check(self._lib.fx_offline_harmonic_characteristics(self._h, mags.ctypes.data_as(ctypes.c_void_p), mags.shape[1],
                                                                  out.ctypes.data_as(ctypes.c_void_p), capi.MEM_HOST))
         return out
+
+    def calculate_spectral_characteristics(self, fft_results):                              # ref :463-515
+        """magnitudes [C][num_bins] of one frame -> [C][4] = centroid / nyquist, spread, flatness, flux; previousBinMagnitudes is kept."""
+        mags = self._rows(fft_results)
+        out = np.empty((self.num_channels, 4), np.float32)
+        capi.check(self._lib.fx_offline_spectral_characteristics(self._h, mags.ctypes.data_as(ctypes.c_void_p), mags.shape[1],
+                                                                 out.ctypes.data_as(ctypes.c_void_p), capi.MEM_HOST))
+        self._bins = mags.shape[1]
+        return out
+
+    @property
+    def previous_bin_magnitudes(self):                                                      # ref :700
+        out = np.empty((self.num_channels, self._bins), np.float64)
+        capi.check(self._lib.fx_offline_get_previous_bins(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), self._bins))
+        return out
+
+    def calculate_normalised_spectral_slope(self, fft_results):                             # ref :566-609
+        mags = self._rows(fft_results)
+        out = np.empty(self.num_channels, np.float32)
+        capi.check(self._lib.fx_offline_spectral_slope(self._h, mags.ctypes.data_as(ctypes.c_void_p), mags.shape[1],
+                                                       out.ctypes.data_as(ctypes.c_void_p), capi.MEM_HOST))
+        return out
+
+    def analyse_auto_correlation(self, data):                                               # ref :623-665
+        """data [C][num_items][2] (r, i) -> (products [C][num_items][2] of getConjugateComplexMultiplicationInPlace, peak bin [C],
+        frequency [C] float64 as analyseAutoCorrelation prints it)."""
+        data = np.array(data, np.float32, order="C")
+        if data.ndim != 3 or data.shape[0] != self.num_channels or data.shape[2] != 2:
+            raise ValueError("expected [%d][num_items][2] float32" % self.num_channels)
+        peaks, freqs = np.empty(self.num_channels, np.int32), np.empty(self.num_channels, np.float64)
+        capi.check(self._lib.fx_offline_auto_correlation(self._h, data.ctypes.data_as(ctypes.c_void_p), data.shape[1],
+                                                         peaks.ctypes.data_as(ctypes.c_void_p), freqs.ctypes.data_as(ctypes.c_void_p), capi.MEM_HOST))
+        return data, peaks, freqs

@@ -294,6 +294,19 @@ fx_status fx_offline_fft_lbp(fx_offline* o, const float* cur, const float* prev,
  * estimateF0AndHERFromFrequencyHistogram :419-441, the octave rule :273-291, calculateInharmonicity :305-336):
  * magnitudes [C][num_bins] of one frame -> out3 [C][3] = f0, harmonicEnergyRatio, inharmonicity; 4 <= num_bins <= 4097 */
 fx_status fx_offline_harmonic_characteristics(fx_offline* o, const float* magnitudes, int num_bins, float* out3, int mem_kind);
+/* AudioAnalyser::calculateSpectralCharacteristics, AudioAnalysis.h:463-515 (the legacy full-spectrum form): magnitudes [C][num_bins] of one
+ * frame -> out4 [C][4] = centroid / nyquist, spread, flatness, flux (AudioAnalysis.h:17-29).  Each channel's previousBinMagnitudes
+ * (:120-121, :510, :700) is kept across calls and replaced only by frames that pass the 0.001 gate (:498-500); its length is fixed by
+ * the first call (an analyser's window size) until fx_offline_reset.  1 <= num_bins <= 4097 */
+fx_status fx_offline_spectral_characteristics(fx_offline* o, const float* magnitudes, int num_bins, float* out4, int mem_kind);
+fx_status fx_offline_get_previous_bins(fx_offline* o, double* out /*[num_channels][num_bins]*/, int num_bins);
+/* AudioAnalyser::calculateNormalisedSpectralSlope, AudioAnalysis.h:566-609: magnitudes [C][num_bins] -> out [C] */
+fx_status fx_offline_spectral_slope(fx_offline* o, const float* magnitudes, int num_bins, float* out, int mem_kind);
+/* AudioAnalyser::getConjugateComplexMultiplicationInPlace + analyseAutoCorrelation (+ getMaxIndex), AudioAnalysis.h:623-665:
+ * data [C][num_items][2] interleaved (r, i) is replaced IN PLACE by each item times its conjugate; peak_bin [C] = the first item holding
+ * the largest real part of the products, frequency [C] (doubles) = the estimate the reference prints for it,
+ * peak_bin * (nyquist / num_items) + half a bin */
+fx_status fx_offline_auto_correlation(fx_offline* o, float* data, int num_items, int* peak_bin, double* frequency, int mem_kind);
 
 /* ---- OSC sink helpers (host side, no GPU) ---- */
 /* Re-order one 12-slot vector into the wire order of

@@ -205,6 +205,33 @@ public:
         for (int c = 0; c < channels; c++) out[(std::size_t) c] = { raw[3 * (std::size_t) c], raw[3 * (std::size_t) c + 1], raw[3 * (std::size_t) c + 2] };
         return out;
     }
+    // ref :463-515 (legacy full-spectrum form): magnitudes [channels][numBins] -> per channel centroid / nyquist, spread, flatness, flux;
+    // previousBinMagnitudes is kept per channel across calls
+    struct SpectralCharacteristics { float centroid, spread, flatness, flux; };             // ref AudioAnalysis.h:17-29
+    std::vector<SpectralCharacteristics> calculateSpectralCharacteristics (const float* fftResults, int numBins)
+    {
+        std::vector<float> raw ((std::size_t) channels * 4);
+        check (fx_offline_spectral_characteristics (off, fftResults, numBins, raw.data(), FX_MEM_HOST));
+        std::vector<SpectralCharacteristics> out ((std::size_t) channels);
+        for (int c = 0; c < channels; c++) out[(std::size_t) c] = { raw[4 * (std::size_t) c], raw[4 * (std::size_t) c + 1], raw[4 * (std::size_t) c + 2], raw[4 * (std::size_t) c + 3] };
+        return out;
+    }
+    // ref :566-609
+    std::vector<float> calculateNormalisedSpectralSlope (const float* fftResults, int numBins)
+    {
+        std::vector<float> out ((std::size_t) channels);
+        check (fx_offline_spectral_slope (off, fftResults, numBins, out.data(), FX_MEM_HOST));
+        return out;
+    }
+    // ref :623-665: data [channels][numItems] (r, i) pairs, replaced in place by item x conjugate; returns the frequency estimates the reference prints
+    std::vector<double> analyseAutoCorrelation (float* data, int numItems, std::vector<int>* peakBins = nullptr)
+    {
+        std::vector<int> peaks ((std::size_t) channels);
+        std::vector<double> freqs ((std::size_t) channels);
+        check (fx_offline_auto_correlation (off, data, numItems, peaks.data(), freqs.data(), FX_MEM_HOST));
+        if (peakBins != nullptr) *peakBins = peaks;
+        return freqs;
+    }
     fx_offline* handle() { return off; }
 
 private:

@@ -156,3 +156,100 @@ void fxo_offline_harmonic_characteristics(const float* mag, int num_bins, double
     out3[0] = (float) f0; out3[1] = (float) her; out3[2] = (float) inh;
     free(peaks); free(hist);
 }
+
+/* ref: AudioAnalysis.h:463-515 calculateSpectralCharacteristics (the legacy, full-spectrum form: magnitudes as they are, no gate on
+ * single bins).  mags [num_bins] of one channel; prev [num_bins] = previousBinMagnitudes (:700; zeros in a new analyser, :120-121),
+ * replaced by this frame's magnitudes only when the frame passes the 0.001 gate (:498-500, :510).  out4 = centroid / nyquist,
+ * spread, flatness, flux -- the struct's four floats in constructor order (:19-29, :514).
+ * Every sum runs in double in bin order (:479-496); flux adds the rectified difference of |magnitude| (:486-489: (diff + |diff|) / 2
+ * where diff > 0); the product is the plain serial IEEE product (:494: inf and 0 are sticky); frequencyRangePerBin = nyquist /
+ * numBins with numBins a size_t (:465-466); invNumBins = 1.0 / numBins (:504); pow (x, 2.0) as the reference writes it (:509). */
+void fxo_offline_spectral_characteristics(const float* mags, int num_bins, double nyquist, double* prev, float* out4)
+{
+    const size_t n = (size_t) num_bins;
+    const double frpb = nyquist / n;
+    double weighted = 0.0, var = 0.0, sum = 0.0, product = 1.0, flux = 0.0;
+    double* centre = (double*) malloc(sizeof(double) * n);
+    for (size_t i = 0; i < n; ++i) {
+        const double fc = (double) i * frpb + (frpb / 2.0);
+        centre[i] = fc;
+        const double m = (double) mags[i];
+        const double diff = fabs(m) - fabs(prev[i]);
+        const double rectified = (diff + fabs(diff)) / 2.0;
+        if (diff > 0.0) flux += rectified;
+        sum += m;
+        product *= m;
+        weighted += fc * m;
+    }
+    out4[0] = out4[1] = out4[2] = out4[3] = 0.0f;
+    const double eps = 0.001;
+    if (sum > eps) {
+        const float centroid = (float) (weighted / sum);
+        const double inv = 1.0 / n;
+        const float flatness = (float) (pow(product, inv) / (inv * sum));
+        for (size_t i = 0; i < n; ++i) {
+            var += pow((centre[i] / nyquist) - (centroid / nyquist), 2.0) * (double) mags[i];
+            prev[i] = (double) mags[i];
+        }
+        const float max_spread = (float) ((centroid / nyquist) * (1.0 - (centroid / nyquist)));
+        const float spread = (float) ((var / sum) / max_spread);
+        out4[0] = centroid / (float) nyquist; out4[1] = spread; out4[2] = flatness; out4[3] = (float) flux;
+    }
+    free(centre);
+}
+
+/* ref: AudioAnalysis.h:566-609 calculateNormalisedSpectralSlope (legacy form: the magnitudes themselves, normalised by
+ * AudioSampleBuffer::getMagnitude = max |x| of the frame, :573).  The loops and the final expression are those of
+ * SpectralCharacteristics.h:145-200, which descends from this function: `(numBins - 1.0f)` with numBins a double (:602). */
+float fxo_offline_spectral_slope(const float* mags, int num_bins)
+{
+    const double bins = (double) num_bins, mean_bin = 0.5;
+    float peak = 0.0f;
+    for (int i = 0; i < num_bins; i++) { const float a = fabsf(mags[i]); if (a > peak) peak = a; }
+    const double magnitude = (double) peak;
+    if (!(magnitude > 0.0001)) return 0.0f;
+    double mean_energy = 0.0, prod_sum = 0.0;
+    for (int i = 0; i < (int) bins; i++) {
+        const double e = mags[i] / magnitude;
+        mean_energy += e;
+        prod_sum += (double) i * e;
+    }
+    mean_energy /= bins;
+    double bin_var = 0.0, energy_var = 0.0;
+    for (double i = 0.0; i < bins; i++) {
+        const double ni = i / bins;
+        bin_var += (ni - mean_bin) * (ni - mean_bin);
+        const double e = mags[(int) i] / magnitude;
+        energy_var += (e - mean_energy) * (e - mean_energy);
+    }
+    bin_var /= bins;
+    energy_var /= bins;
+    const double bin_std = sqrt(bin_var), energy_std = sqrt(energy_var);
+    const double r = (prod_sum - (bins * mean_energy * mean_bin)) / (bins - 1.0f) * energy_std * bin_std;
+    return (float) (r * (bin_std / energy_std));
+}
+
+/* ref: AudioAnalysis.h:623-633 getConjugateComplexMultiplicationInPlace: data [num_items] interleaved (r, i), each item times its own
+ * conjugate in float arithmetic exactly as written: ((r * r) - (i * (-i)), (r * (-i)) + (r * i)). */
+void fxo_offline_conjugate_multiplication(float* data, int num_items)
+{
+    for (int k = 0; k < num_items; k++) {
+        const float r = data[2 * k], i = data[2 * k + 1];
+        const float cr = r, ci = -i;
+        data[2 * k] = (r * cr) - (i * ci);
+        data[2 * k + 1] = (r * ci) + (cr * i);
+    }
+}
+
+/* ref: AudioAnalysis.h:636-648 analyseAutoCorrelation (+ getMaxIndex, :650-665): the bin of the largest real part -- the first one on
+ * ties, `data[i] > currentMax` -- and the frequency the reference prints for it: peakBin * (nyquist / numItems) + half a bin. */
+int fxo_offline_auto_correlation(const float* data, int num_items, double nyquist, double* frequency)
+{
+    int peak = 0;
+    float current = data[0];
+    for (int i = 0; i < num_items; i++)
+        if (data[2 * i] > current) { peak = i; current = data[2 * i]; }
+    const double frpb = nyquist / (double) num_items;
+    *frequency = (peak * frpb) + (frpb / 2.0);
+    return peak;
+}

@@ -75,6 +75,12 @@ def lib():
         L.fxo_offline_log_attack_time.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         L.fxo_offline_fft_lbp.argtypes = [fp, fp, ctypes.c_int, ctypes.POINTER(ctypes.c_ubyte), fp, fp]
         L.fxo_offline_harmonic_characteristics.argtypes = [fp, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double), fp]
+        L.fxo_offline_spectral_characteristics.argtypes = [fp, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double), fp]
+        L.fxo_offline_spectral_slope.restype = ctypes.c_float
+        L.fxo_offline_spectral_slope.argtypes = [fp, ctypes.c_int]
+        L.fxo_offline_conjugate_multiplication.argtypes = [fp, ctypes.c_int]
+        L.fxo_offline_auto_correlation.restype = ctypes.c_int
+        L.fxo_offline_auto_correlation.argtypes = [fp, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
         L.fxo_osc_message.restype = ctypes.c_int
         L.fxo_osc_message.argtypes = [ctypes.c_char_p, fp, ctypes.POINTER(ctypes.c_ubyte), ctypes.c_int]
         _lib = L
@@ -299,3 +305,39 @@ def offline_harmonic_characteristics(mags, nyquist, previous_f0):
         lib().fxo_offline_harmonic_characteristics(_fp(mags[c]), B, float(nyquist), ctypes.byref(pf), _fp(out[c]))
         previous_f0[c] = pf.value
     return out
+
+
+def offline_spectral_characteristics(mags, nyquist, previous_bins):
+    """mags [C][num_bins], previous_bins [C][num_bins] float64 (previousBinMagnitudes, updated in place) -> [C][4] = centroid / nyquist,
+    spread, flatness, flux (ref AudioAnalysis.h:463-515)."""
+    mags = _f32(mags)
+    C, B = mags.shape
+    out = np.empty((C, 4), np.float32)
+    for c in range(C):
+        lib().fxo_offline_spectral_characteristics(_fp(mags[c]), B, float(nyquist), previous_bins[c].ctypes.data_as(ctypes.POINTER(ctypes.c_double)), _fp(out[c]))
+    return out
+
+
+def offline_spectral_slope(mags):
+    """mags [C][num_bins] -> [C] (ref AudioAnalysis.h:566-609)."""
+    mags = _f32(mags)
+    return np.array([lib().fxo_offline_spectral_slope(_fp(mags[c]), mags.shape[1]) for c in range(mags.shape[0])], np.float32)
+
+
+def offline_conjugate_multiplication(data):
+    """data [C][num_items][2] (r, i) -> each item times its conjugate, as the reference's float arithmetic writes it (ref AudioAnalysis.h:623-633)."""
+    out = _f32(data).copy()
+    for c in range(out.shape[0]):
+        lib().fxo_offline_conjugate_multiplication(_fp(out[c]), out.shape[1])
+    return out
+
+
+def offline_auto_correlation(data, nyquist):
+    """data [C][num_items][2] -> (peak bin [C] int32, frequency [C] float64) (ref AudioAnalysis.h:636-665)."""
+    data = _f32(data)
+    peaks, freqs = np.empty(data.shape[0], np.int32), np.empty(data.shape[0], np.float64)
+    for c in range(data.shape[0]):
+        f = ctypes.c_double()
+        peaks[c] = lib().fxo_offline_auto_correlation(_fp(data[c]), data.shape[1], float(nyquist), ctypes.byref(f))
+        freqs[c] = f.value
+    return peaks, freqs

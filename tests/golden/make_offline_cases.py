@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools", "refdiff"))
 
 
 def offline_inputs():
-    """Seeded inputs for the four functions: [(name, kwargs)]."""
+    """Seeded inputs for the functions: {name: [case, ...]}."""
     rng = np.random.default_rng(20260403)
     cases = {}
     # zero crossings: noise, a sine with exact zeros, silence, DC, a ragged length
@@ -45,6 +45,29 @@ def offline_inputs():
         frames.append(np.stack([comb(1025, sp0, 8.0), comb(1025, sp1, 3.0), np.abs(rng.normal(0, 1.0, 1025)),
                                 np.full(1025, 1e-7), comb(1025, sp0 * 3 if t % 2 else sp0, 5.0, 0.9)]))
     cases["hc"] = [(np.stack(frames).astype(np.float32), 24000.0), (np.stack(frames)[:, :, :513].astype(np.float32), 22050.0)]
+    # (round 4) the legacy full-spectrum characteristics: T frames x C channels x B magnitudes through one analyser per channel -- a comb, noise,
+    # a frame under the 0.001 gate in the middle (previousBinMagnitudes must survive it), loud magnitudes (the product overflows to inf),
+    # tiny ones (it underflows to 0), and a channel with a negative magnitude (the function takes whatever the buffer holds)
+    rng2 = np.random.default_rng(20260404)
+    sc = []
+    for t in range(5):
+        loud = np.abs(rng2.normal(0, 1, 513)) * 1e3 + 10.0
+        tiny = np.abs(rng2.normal(0, 1, 513)) * 1e-3 + 1e-5
+        quiet = np.full(513, 1e-7) if t == 2 else np.abs(rng2.normal(0, 0.5, 513))
+        neg = np.abs(rng2.normal(0, 1, 513)); neg[100] = -0.5
+        sc.append(np.stack([comb(513, 16 + t, 6.0), np.abs(rng2.normal(0, 1.0, 513)), quiet, loud, tiny, neg]))
+    cases["sc"] = [(np.stack(sc).astype(np.float32), 24000.0), (np.stack(sc)[:3, :2, :65].astype(np.float32), 11025.0)]
+    # the legacy slope: decaying, rising, flat (energy variance 0: NaN), silent (under 0.0001: 0), one with a negative peak
+    k = np.arange(1025)
+    falling, rising = np.exp(-k / 200.0), k / 1024.0
+    negpeak = np.abs(rng2.normal(0, 0.1, 1025)); negpeak[7] = -3.0
+    cases["slope"] = [np.stack([falling, rising, np.full(1025, 0.3), np.full(1025, 1e-5), negpeak, np.abs(rng2.normal(0, 1, 1025))]).astype(np.float32),
+                      np.abs(rng2.normal(0, 1, (3, 17))).astype(np.float32)]
+    # auto-correlation: complex items; a tie for the largest product (the first wins), the maximum at item 0, ordinary noise
+    ac = rng2.normal(0, 1, (4, 512, 2)).astype(np.float32)
+    ac[0, 40] = [3.0, 4.0]; ac[0, 300] = [5.0, 0.0]            # both products are 25
+    ac[1, 0] = [9.0, 9.0]
+    cases["ac"] = [(ac, 24000.0), (ac[:2, :16].copy(), 8000.0)]
     return cases
 
 
@@ -63,6 +86,14 @@ def main():
     for k, (mags, nyq) in enumerate(cases["hc"]):
         o, pf = refdiff.legacy_harmonic_characteristics(mags, nyq)
         out["hc_%d_out" % k], out["hc_%d_prev" % k] = o, pf
+    for k, (mags, nyq) in enumerate(cases["sc"]):
+        o, pb = refdiff.legacy_spectral_characteristics(mags, nyq)
+        out["sc_%d_out" % k], out["sc_%d_prev" % k] = o, pb
+    for k, mags in enumerate(cases["slope"]):
+        out["slope_%d" % k] = refdiff.legacy_spectral_slope(mags)
+    for k, (data, nyq) in enumerate(cases["ac"]):
+        prod, freq = refdiff.legacy_auto_correlation(data, nyq)
+        out["ac_%d_prod" % k], out["ac_%d_freq" % k] = prod, freq
     path = os.path.join(ROOT, "tests", "golden", "offline", "cases.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")

@@ -39,6 +39,25 @@ def test_oracle_equals_the_reference_headers_vectors(oracle):
     # the cases exercise what they are meant to: the octave rule keeps the previous F0 (frame 2, channel 0), silence returns zeros
     o = g["hc_0_out"]
     assert o[2, 0, 0] == o[1, 0, 0] and o[3, 0, 0] == o[1, 0, 0] and not o[:, 3].any() and (o[:, :3, 0] > 0).all()
+    # round 4: the legacy full-spectrum characteristics, slope and auto-correlation
+    for k, (mags, nyq) in enumerate(cases["sc"]):
+        pb = np.zeros(mags.shape[1:], np.float64)
+        for t in range(mags.shape[0]):
+            assert same(oracle.offline_spectral_characteristics(mags[t], nyq, pb), g["sc_%d_out" % k][t]), (k, t)
+        assert same(pb, g["sc_%d_prev" % k]), k
+    o = g["sc_0_out"]
+    assert not o[2, 2].any() and o[3, 2].any()                      # the frame under the gate returns zeros ...
+    assert np.isinf(o[:, 3, 2]).all() and not o[:, 4, 2].any()      # the product overflows to inf / underflows to 0, as in the reference
+    for k, mags in enumerate(cases["slope"]):
+        assert same(oracle.offline_spectral_slope(mags), g["slope_%d" % k]), k
+    s = g["slope_0"]
+    assert np.isnan(s[2]) and s[3] == 0.0 and s[1] > s[0] > 0        # flat: energy variance 0 -> NaN; under 0.0001: 0 (as the reference returns them)
+    for k, (data, nyq) in enumerate(cases["ac"]):
+        prod = oracle.offline_conjugate_multiplication(data)
+        assert same(prod, g["ac_%d_prod" % k]), k
+        peaks, freqs = oracle.offline_auto_correlation(prod, nyq)
+        assert same(freqs, g["ac_%d_freq" % k]), k
+    assert g["ac_0_freq"][0] == 40 * (24000.0 / 512) + 24000.0 / 1024 and g["ac_0_freq"][1] == 24000.0 / 1024      # the first of a tie; item 0
 
 
 @pytest.mark.gpu
@@ -61,6 +80,45 @@ def test_offline_kernels_equal_the_reference_headers_vectors(gpu_fx, oracle):
             assert same(an.previous_f0, g["hc_%d_prev" % k][t]), (k, t)
         an.reset()
         assert not an.previous_f0.any()
+
+
+@pytest.mark.gpu
+def test_offline_round4_kernels_equal_the_reference_headers_vectors(gpu_fx, oracle):
+    """The legacy full-spectrum characteristics (AudioAnalysis.h:463-515), slope (:566-609) and auto-correlation peak (:623-665) on the GPU
+    against what the reference's own header produced, bit for bit, and against the oracle on shapes beyond the fixture (bit for bit
+    where no libm function is involved; flatness and spread go through pow(), which the device and glibc round independently)."""
+    g, cases = np.load(GOLDEN), offline_inputs()
+    for k, (mags, nyq) in enumerate(cases["sc"]):
+        an = gpu_fx.offline.AudioAnalyser(mags.shape[1], nyq)
+        for t in range(mags.shape[0]):
+            got = an.calculate_spectral_characteristics(mags[t])
+            assert same(got, g["sc_%d_out" % k][t]), (k, t, got, g["sc_%d_out" % k][t])
+        assert same(an.previous_bin_magnitudes, g["sc_%d_prev" % k]), k
+        with pytest.raises(gpu_fx.FxError):
+            an.calculate_spectral_characteristics(mags[0][:, :-1])             # previousBinMagnitudes has the analyser's size
+        an.reset()
+        assert same(an.calculate_spectral_characteristics(mags[0]), g["sc_%d_out" % k][0])
+    for k, mags in enumerate(cases["slope"]):
+        assert same(gpu_fx.offline.AudioAnalyser(mags.shape[0]).calculate_normalised_spectral_slope(mags), g["slope_%d" % k]), k
+    for k, (data, nyq) in enumerate(cases["ac"]):
+        prod, peaks, freqs = gpu_fx.offline.AudioAnalyser(data.shape[0], nyq).analyse_auto_correlation(data)
+        assert same(prod, g["ac_%d_prod" % k]) and same(freqs, g["ac_%d_freq" % k]), k
+    rng = np.random.default_rng(11)
+    for C, B, nyq in ((9, 4097, 24000.0), (3, 1, 100.0), (40, 1025, 22050.0)):
+        an = gpu_fx.offline.AudioAnalyser(C, nyq)
+        pb = np.zeros((C, B))
+        for t in range(3):
+            mags = np.abs(rng.normal(0, 1.0, (C, B))).astype(np.float32) * (10.0 ** rng.integers(-3, 3))
+            got, want = an.calculate_spectral_characteristics(mags), oracle.offline_spectral_characteristics(mags, nyq, pb)
+            assert same(got[:, [0, 3]], want[:, [0, 3]]), (C, B, t)                                # centroid, flux: sums only
+            np.testing.assert_allclose(got[:, [1, 2]], want[:, [1, 2]], rtol=2e-7, atol=0)            # spread, flatness: pow()
+            assert same(an.previous_bin_magnitudes, pb)
+            assert same(an.calculate_normalised_spectral_slope(mags), oracle.offline_spectral_slope(mags)), (C, B, t)
+        data = rng.normal(0, 1, (C, max(B // 2, 1), 2)).astype(np.float32)
+        prod, peaks, freqs = an.analyse_auto_correlation(data)
+        want_prod = oracle.offline_conjugate_multiplication(data)
+        wp, wf = oracle.offline_auto_correlation(want_prod, nyq)
+        assert same(prod, want_prod) and same(peaks, wp) and same(freqs, wf), (C, B)
 
 
 @pytest.mark.gpu

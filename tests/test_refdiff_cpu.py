@@ -114,3 +114,22 @@ def test_legacy_offline_analyser_oracle_equals_the_reference_header():
     pf = np.zeros(3)
     for t in range(4):
         assert fo.offline_harmonic_characteristics(m2[t], 11025.0, pf).tobytes() == ro[t].tobytes() and pf.tobytes() == rp[t].tobytes()
+    # round 4: the legacy full-spectrum characteristics, slope and auto-correlation -- the fixture is what the header produces now, and
+    # the oracle equals the header on fresh random frames (same glibc on both sides: pow() included)
+    mags, nyq = cases["sc"][0]
+    ro, rp = refdiff.legacy_spectral_characteristics(mags, nyq)
+    assert ro.tobytes() == g["sc_0_out"].tobytes() and rp.tobytes() == g["sc_0_prev"].tobytes()
+    assert refdiff.legacy_spectral_slope(cases["slope"][0]).tobytes() == g["slope_0"].tobytes()
+    prod, freq = refdiff.legacy_auto_correlation(*cases["ac"][0])
+    assert prod.tobytes() == g["ac_0_prod"].tobytes() and freq.tobytes() == g["ac_0_freq"].tobytes()
+    m3 = np.abs(rng.normal(0, 1.0, (5, 4, 257))).astype(np.float32) * np.float32(3.0)
+    m3[2, 1] = 1e-8
+    ro, rp = refdiff.legacy_spectral_characteristics(m3, 8000.0)
+    pb = np.zeros((4, 257))
+    for t in range(5):
+        assert fo.offline_spectral_characteristics(m3[t], 8000.0, pb).tobytes() == ro[t].tobytes(), t
+    assert pb.tobytes() == rp.tobytes()
+    assert fo.offline_spectral_slope(m3[0]).tobytes() == refdiff.legacy_spectral_slope(m3[0]).tobytes()
+    d3 = rng.normal(0, 2.0, (3, 100, 2)).astype(np.float32)
+    prod, freq = refdiff.legacy_auto_correlation(d3, 8000.0)
+    assert fo.offline_conjugate_multiplication(d3).tobytes() == prod.tobytes() and fo.offline_auto_correlation(prod, 8000.0)[1].tobytes() == freq.tobytes()

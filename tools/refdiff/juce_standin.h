@@ -43,7 +43,9 @@ const double double_Pi = 3.14159265358979323846;
 
 #define jassert(x)      ((void) 0)
 #define jassertfalse    ((void) 0)
+#ifndef DBG
 #define DBG(x)          ((void) 0)
+#endif
 #define JUCE_DECLARE_NON_COPYABLE_WITH_LEAK_DETECTOR(T) T (const T&) = delete; T& operator= (const T&) = delete;
 template <typename... A> void ignoreUnused (A&&...) {}
 #define JUCE_LIVE_CONSTANT(x) (x)

@@ -118,3 +118,27 @@ def legacy_harmonic_characteristics(mags, nyquist):
     out = _legacy(4, C, B, T, 0, float(nyquist), mags)
     n = T * C * 3 * 4
     return np.frombuffer(out[:n], np.float32).reshape(T, C, 3).copy(), np.frombuffer(out[n:], np.float64).reshape(T, C).copy()
+
+
+def legacy_spectral_characteristics(mags, nyquist):
+    """mags [T][C][B]: T successive frames through one AudioAnalyser per channel -> (out [T][C][4] = centroid / nyquist, spread, flatness,
+    flux; previousBinMagnitudes [C][B] after the last frame)."""
+    mags = np.ascontiguousarray(mags, np.float32)
+    T, C, B = mags.shape
+    out = _legacy(5, C, B, T, 0, float(nyquist), mags)
+    n = T * C * 4 * 4
+    return np.frombuffer(out[:n], np.float32).reshape(T, C, 4).copy(), np.frombuffer(out[n:], np.float64).reshape(C, B).copy()
+
+
+def legacy_spectral_slope(mags):
+    mags = np.ascontiguousarray(mags, np.float32)
+    return np.frombuffer(_legacy(6, mags.shape[0], mags.shape[1], 0, 0, 0.0, mags), np.float32).copy()
+
+
+def legacy_auto_correlation(data, nyquist):
+    """data [C][B][2] -> (products [C][B][2] of getConjugateComplexMultiplicationInPlace, frequency [C] analyseAutoCorrelation prints for them)."""
+    data = np.ascontiguousarray(data, np.float32)
+    C, B = data.shape[0], data.shape[1]
+    out = _legacy(7, C, B, 0, 0, float(nyquist), data)
+    n = C * B * 2 * 4
+    return np.frombuffer(out[:n], np.float32).reshape(C, B, 2).copy(), np.frombuffer(out[n:], np.float64).copy()

@@ -9,6 +9,15 @@
 //   op 2 log attack time : a = envelope length, b = input samples, c = downsamples, d = sample rate; payload envelope[a] -> float32 out[1]
 //   op 3 FFT-LBP         : a = channels, b = bins; payload cur[a][b], prev[a][b]                  -> per channel: float32 bits[b], highest ratio, activity ratio
 //   op 4 histogram F0    : a = channels, b = bins, c = frames, x = nyquist; payload mags[c][a][b]   -> float32 out[c][a][3], float64 previousF0 after each frame [c][a]
+//   op 5 spectral chars  : a = channels, b = bins, c = frames, x = nyquist; payload mags[c][a][b]   -> float32 out[c][a][4], then float64 previousBinMagnitudes after the last frame [a][b]
+//   op 6 spectral slope  : a = channels, b = bins; payload mags[a][b]                               -> float32 out[a]
+//   op 7 auto-correlation: a = channels, b = items, x = nyquist; payload data[a][b][2] (r, i)       -> float32 products[a][b][2] (getConjugateComplexMultiplicationInPlace),
+//                                                                                                     then float64 frequency[a] as analyseAutoCorrelation prints it for the products
+// The reference's DBG output is captured (analyseAutoCorrelation only prints its estimate): DBG streams into g_dbg at full precision.
+#include <iomanip>
+#include <sstream>
+static std::ostringstream g_dbg;
+#define DBG(x) do { g_dbg.str (""); g_dbg << std::setprecision (17) << x; } while (0)
 #include "juce_standin.h"
 
 #include <cstdint>
@@ -85,6 +94,36 @@ int main (int argc, char** argv)
             }
         }
         fwrite (prevs.data(), 8, prevs.size(), o);
+    } else if (h.op == 5) {
+        std::vector<AudioAnalyser*> ans;                       // one analyser per channel: previousBinMagnitudes is per analyser (:700); window 2 (b - 1) -> b bins
+        for (int ch = 0; ch < h.a; ch++) ans.push_back (new AudioAnalyser (2 * (h.b - 1), h.a, h.x, true, true));
+        for (int fr = 0; fr < h.c; fr++) {
+            AudioSampleBuffer mags (h.a, h.b);
+            for (int ch = 0; ch < h.a; ch++) mags.copyFrom (ch, 0, in.data() + ((size_t) fr * h.a + ch) * h.b, h.b);
+            for (int ch = 0; ch < h.a; ch++) {
+                AudioAnalyser::SpectralCharacteristics sc = ans[(size_t) ch]->calculateSpectralCharacteristics (mags, ch);
+                fwrite (&sc.centroid, 4, 1, o); fwrite (&sc.spread, 4, 1, o); fwrite (&sc.flatness, 4, 1, o); fwrite (&sc.flux, 4, 1, o);
+            }
+        }
+        for (int ch = 0; ch < h.a; ch++) fwrite (ans[(size_t) ch]->previousBinMagnitudes.data(), 8, (size_t) h.b, o);
+    } else if (h.op == 6) {
+        AudioSampleBuffer mags (h.a, h.b);
+        for (int ch = 0; ch < h.a; ch++) mags.copyFrom (ch, 0, in.data() + (size_t) ch * h.b, h.b);
+        AudioAnalyser an (1024, h.a, 24000.0, true, true);
+        for (int ch = 0; ch < h.a; ch++) { const float v = an.calculateNormalisedSpectralSlope (mags, ch); fwrite (&v, 4, 1, o); }
+    } else if (h.op == 7) {
+        AudioAnalyser an (1024, h.a, h.x, true, true);
+        std::vector<double> freqs;
+        for (int ch = 0; ch < h.a; ch++) {
+            std::vector<FFT::Complex> data ((size_t) h.b);
+            for (int k = 0; k < h.b; k++) data[(size_t) k] = { in[((size_t) ch * h.b + k) * 2], in[((size_t) ch * h.b + k) * 2 + 1] };
+            AudioAnalyser::getConjugateComplexMultiplicationInPlace (data.data(), h.b);
+            for (int k = 0; k < h.b; k++) { fwrite (&data[(size_t) k].r, 4, 1, o); fwrite (&data[(size_t) k].i, 4, 1, o); }
+            an.analyseAutoCorrelation (data.data(), h.b);
+            const std::string s = g_dbg.str();                  // "Frequency estimation: <value>"
+            freqs.push_back (std::strtod (s.c_str() + s.rfind (' ') + 1, nullptr));
+        }
+        fwrite (freqs.data(), 8, freqs.size(), o);
     } else return 2;
     fclose (o);
     return 0;
