@@ -301,12 +301,12 @@ def stream_bench(fx, args, C, T, N, device):
     hops = fx.synth.hops(C, T, N).astype(dtype)
     an = fx.BatchAnalyser(C, N, device=device)
     st = fx.HopStream(an, T, slots=3, dtype=dtype)
+    fill_threads = max(1, min(12, usable_cores() - 2))
 
     def step():
         if st.in_flight() == 3:
             st.collect(want_raw=False)
-        st.slot()[...] = hops                       # the producer's copy into pinned memory is part of the path
-        st.submit()
+        st.push(hops, fill_threads=fill_threads)    # the producer's copy into pinned memory (fx_stream_push's thread pool) is part of the path
 
     for _ in range(args.warmup):
         step()

@@ -58,8 +58,21 @@ def _run(cmd):
         raise subprocess.CalledProcessError(proc.returncode, cmd)
 
 
+FLAGS_STAMP = os.path.join(LIB_DIR, ".build.flags")
+
+
+def _flags_stamp():
+    return " ".join(HIPCC_FLAGS) + " | " + " ; ".join("%s:%s" % (o, " ".join(x)) for _, o, x in UNITS)
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
+        return True
+    # a library built with other options (FX_EXTRA_HIPCC_FLAGS experiments) is not the library these sources describe
+    try:
+        if open(FLAGS_STAMP).read() != _flags_stamp():
+            return True
+    except OSError:
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
@@ -101,6 +114,8 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
             os.replace(LIB_PATH + tag, LIB_PATH)
+            with open(FLAGS_STAMP, "w") as f:
+                f.write(_flags_stamp())
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH

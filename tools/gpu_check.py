@@ -37,6 +37,7 @@ def main():
     mode = sys.argv[4] if len(sys.argv) > 4 else "hops"
     x = fx.synth.hops(C, T, N) if mode == "hops" else fx.synth.frames(C, T, N)
     an = fx.BatchAnalyser(C, N)
+    an.set_tuning(call_timing=1)          # (one-frame calls record no timing events by default: fx_last_kernel_ms would refuse)
     t0 = time.time()
     if mode == "hops":
         raw, sm = an.push_hops(x)

@@ -7,6 +7,7 @@ N=${1:-1024}; C=${2:-1024}; T=${3:-512}
 L=feature-extractor_amd/lib
 names=(- load+rms lpf pitch_fft ifft scan spec_fft spec_sums flux flatprod spec_pass2 harm1 harm2)
 cp $L/libfx_hip.so $L/variants/shipped.so
+trap 'cp $L/variants/shipped.so $L/libfx_hip.so' EXIT        # stop builds produce garbage by construction: never leave one in place
 for k in 1 2 3 4 5 6 7 8 9 10 11 12; do
   if [ $k = 12 ]; then cp $L/variants/shipped.so $L/libfx_hip.so; else cp $L/variants/stop$k.so $L/libfx_hip.so || continue; fi
   timeout -k 10 120 python3 tools/pmc_quick.py $N $C $T "[through ${names[$k]}]" 2>&1 | tail -1

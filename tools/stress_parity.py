@@ -30,6 +30,7 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
     ring_cases = [0]
     pair_cases = [0]
     hop_cases = [0]
+    pcm_cases = [0]
     last_note = time.time()
     while time.time() < t_end and (max_cases is None or cases < max_cases):
         N = int(rng.choice([256, 512, 1024, 1024, 2048, 2048, 4096]))
@@ -46,6 +47,12 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
         which = str(rng.choice(["both", "both", "both", "spectral", "harmonic"]))
         mask = {"both": 3, "spectral": 1, "harmonic": 2}[which]
         hops = make_signal(rng, C, T, N)
+        feed = hops
+        if rng.random() < 0.2:
+            # 16-bit PCM ingest (FX_SAMPLE_S16): the kernels widen v to v / 32768 in their load stage; the oracle analyses the decoded floats
+            feed = np.clip(np.round(hops * 32768.0), -32768, 32767).astype(np.int16)
+            hops = feed.astype(np.float32) / np.float32(32768.0)
+            pcm_cases[0] += 1
         an = fx.BatchAnalyser(C, N, order=order, analysers=which)
         an.set_onset_detection_type(otype); an.set_onset_window_length(owin)
         an.set_onset_detection_sensitivity(sens); an.set_gain(gain)
@@ -57,12 +64,12 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
         ring = which == "both" and N >= 1024 and T <= 24 and rng.random() < 0.25
         if ring:
             # one hop per call through the pinned ring: fx_hop_kernel (three wavefronts per channel, one launch per hop)
-            st = fx.HopStream(an, 1, slots=3)
+            st = fx.HopStream(an, 1, slots=3, dtype=feed.dtype)
             parts = []
             for t in range(T):
                 if st.in_flight() == 3:
                     parts.append(st.collect())
-                st.push(hops[:, t:t + 1])
+                st.push(feed[:, t:t + 1])
             while st.in_flight():
                 parts.append(st.collect())
             st.close()
@@ -73,9 +80,9 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
             if hop_cases[0] % 2:
                 an.set_tuning(one_hop_kernel=0)          # (keyword form: changes this field of the context's current knobs)
             hop_cases[0] += 1
-            parts = [an.push_hops(hops[:, t:t + 1]) for t in range(T)]
+            parts = [an.push_hops(feed[:, t:t + 1]) for t in range(T)]
         else:
-            parts = [an.push_hops(hops[:, :split]), an.push_hops(hops[:, split:])]
+            parts = [an.push_hops(feed[:, :split]), an.push_hops(feed[:, split:])]
         raw = np.concatenate([p[0] for p in parts], 1); sm = np.concatenate([p[1] for p in parts], 1)
         oraw, osm = fo.batch_hops(hops, N, order=order, threads=THREADS, onset_type=otype, onset_window=owin, onset_sensitivity=sens, gain=gain, analysers=mask)
         cases += 1; frames += C * T
@@ -105,7 +112,8 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
                           % (name, N, C, T, order, otype, owin, len(bad), c, t, fx.FEATURE_NAMES[f], g[c, t, f], w[c, t, f]), flush=True)
     if verbose:
         print("cases run one hop per call through the ring (fx_hop_kernel / fx_hop_pair_kernel): %d; cases on wavefront pairs (fx_pair_kernel): %d; "
-              "cases hop by hop through fx_push_hops (half of them on the batch kernels + one-frame fused tail): %d" % (ring_cases[0], pair_cases[0], hop_cases[0]), flush=True)
+              "cases hop by hop through fx_push_hops (half of them on the batch kernels + one-frame fused tail): %d; cases fed as 16-bit PCM: %d"
+              % (ring_cases[0], pair_cases[0], hop_cases[0], pcm_cases[0]), flush=True)
     if verbose and inexact.any():
         print("raw values not bit-identical (within tolerance), per slot:", dict((fx.FEATURE_NAMES[i], int(n)) for i, n in enumerate(inexact) if n), flush=True)
     return cases, frames, bad_cases, worst
