@@ -1,6 +1,11 @@
 // Re-materialisation points of lane-derived values (see opaque()).  (Letting the compiler hoist at some of them took 5 % of the
 // instructions out at 1024 points and not a microsecond: round 3, profiles/r03_variants.txt (e).)
-#define FX_OPQ(n, x) opaque<N>(x)
+// A kernel with registers to spare (HOIST: the spectral analyser alone at 1024 points, 77 of the 128 VGPRs four wavefronts per SIMD allow) is
+// transparent at the top of the frame loop (point 15) and at the start of the spectral section (point 0), so that the frame's addresses and the
+// sixteen window gains of a lane are formed once per wavefront instead of once per frame: that kernel is bound by VALU issue (round 4:
+// SQ_ACTIVE_INST_VALU x 4 waves = 1.01), so instructions are time -- 1.031 -> 0.981 ms per 524 288 frames (+5 %), 117 VGPRs, no scratch.
+// (All points transparent: 128 VGPRs + 16 B of scratch, 1.014 ms; points 15 alone 1.010-1.025; 15 + 1: 1.017.  profiles/r04_variants.txt.)
+#define FX_OPQ(n, x) ((HOIST && ((n) == 15 || (n) == 0)) ? (x) : opaque<N>(x))
 // Costing builds only (-DFX_EXP_STOP_AT=k, tools/section_costs.sh): the frame's work ends at stop point k, the values it has
 // formed so far kept alive; the differences of the instruction counters between consecutive k are the sections' dynamic
 // costs.  Results are garbage and nothing waits for a frame that stopped early (the flux turn is taken at stop 8, which every
@@ -275,7 +280,8 @@ template <int N> struct Occ {
 // DIRECT: a call of ONE frame per channel reads and replaces the channel's flux state where it lives, in global memory: every
 // element is read once and written once, there is no next frame in this launch to hand it to, and without the LDS copy a
 // workgroup is eight channels with nothing but a transform buffer each -- 16 wavefronts per CU at 1024 points instead of 12.
-template <int N, bool DIRECT = false> struct FrameWave {
+// HOIST: two of the re-materialisation points are transparent (FX_OPQ).
+template <int N, bool DIRECT = false, bool HOIST = false> struct FrameWave {
     typedef Geo<N> G;
     static constexpr int M = G::M, P = G::P, U = G::U, HALF = N / 2;
 
@@ -1097,12 +1103,13 @@ fx_frame_kernel(const FrameParams p_arg)
         return __builtin_amdgcn_readfirstlane(v);
     };
     for (int t = live ? (CLAIM ? next_frame(0) : t_begin + slot) : t_end; t < t_end; t = next_frame(t)) {
+        constexpr bool HOIST = SPEC && !HARM && N == 1024;       // (see FX_OPQ)
         const int lane = FX_OPQ(15, lane0);
         // uniform per-frame results go to LDS as soon as they exist instead of occupying ~28 VGPRs
         // in every lane for the whole frame
         FramePart* fpl = p.part + ((size_t) c * T + t);
         if (lane == 0) fpl->flags = 0;            // the harmonic tail sets it; the other fields are read only where written
-        const FrameWave<N, DIRECT> w{p, tw, &twr, prev, turn, cbuf, rbuf, fpl, nyquist, rnyq, frpb, scale, c, T, t};
+        const FrameWave<N, DIRECT, HOIST> w{p, tw, &twr, prev, turn, cbuf, rbuf, fpl, nyquist, rnyq, frpb, scale, c, T, t};
 
         const double ssq_lane = w.load_frame(lane);
         float xr[P];
@@ -1129,7 +1136,7 @@ fx_frame_kernel(const FrameParams p_arg)
         }
         FX_STOP(6, continue); FX_STOP(7, continue); FX_STOP(8, continue); FX_STOP(9, continue); FX_STOP(10, continue);
         if constexpr (HARM) {
-            typename FrameWave<N, DIRECT>::HarmonicSpectrum hs;
+            typename FrameWave<N, DIRECT, HOIST>::HarmonicSpectrum hs;
             if constexpr (G::SPLIT) w.load_raw(lane, xr);
             w.harmonic_spectrum(lane, xr, hs);
             FX_STOP(11, FX_KEEP(hs.sum); FX_KEEP(hs.max); FX_KEEP(hs.left2); FX_KEEP(hs.left1); FX_KEEP(hs.right1); for (int j = 0; j < G::U; j++) FX_KEEP(hs.hre[j]); continue);
