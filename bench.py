@@ -864,8 +864,11 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
             base = fx.synth.hops(128, t2, n2)
             src32 = np.ascontiguousarray(np.tile(base, (c2 // 128, 1, 1)))
             shape = {"workload": "%d channels x %d hops per batch x %d-pt windows (%d new samples per frame)" % (c2, t2, n2, n2 // 2)}
-            for fmt in ("f32", "f16", "s16"):
-                src = src32 if fmt == "f32" else (src32.astype(np.float16) if fmt == "f16" else np.round(src32 * 32767.0).astype(np.int16))
+            for fmt in ("f32", "f16", "s16", "s24"):
+                if fmt == "s24":          # packed 24-bit PCM: three bytes per sample, [C][T][3 N/2] bytes
+                    src = fx.pack_s24(np.round(src32.astype(np.float64) * 8388607.0).astype(np.int32))
+                else:
+                    src = src32 if fmt == "f32" else (src32.astype(np.float16) if fmt == "f16" else np.round(src32 * 32767.0).astype(np.int16))
                 peak = memcpy_rate(src.nbytes)
                 an5 = fx.BatchAnalyser(c2, n2, device=dev)
                 st5 = fx.HopStream(an5, t2, slots=3, dtype=src.dtype)

@@ -8,10 +8,10 @@
 // datagrams are written to a UDP target and/or a dump file (each record: u32 little-endian length + bytes).
 //
 //   wav_to_osc in.wav [--window 1024] [--channel 0] [--gain 1.0] [--address /Audio/A0]
-//                     [--target 127.0.0.1:9000] [--dump out.bin] [--rate 0] [--batch 64] [--device 0] [--pcm16-direct]
+//                     [--target 127.0.0.1:9000] [--dump out.bin] [--rate 0] [--batch 64] [--device 0] [--pcm16-direct | --pcm24-direct]
 //
-// --pcm16-direct (16-bit PCM files): the samples go to the GPU as the file holds them (FX_SAMPLE_S16, two bytes each) and are
-// widened to v / 32768 in the kernels' load stage -- the same datagrams, byte for byte, as with the decoded floats.
+// --pcm16-direct / --pcm24-direct (16- / 24-bit PCM files): the samples go to the GPU as the file holds them (FX_SAMPLE_S16 / _S24, two /
+// three bytes each) and are widened to v / 2^15 / v / 2^23 in the kernels' load stage -- the same datagrams, byte for byte, as with the decoded floats.
 //
 // --rate 0 (default) emits one message per hop.  --rate 60 emits what the reference's timer would read if
 // the file played in real time: at t = k/60 s, the smoothed values after the last hop completed by t.
@@ -30,7 +30,7 @@ int main (int argc, char** argv)
     int window = 1024, channel = 0, batch = 64, device = 0;
     double rate = 0.0;
     float gain = 1.0f;
-    bool pcm16Direct = false;
+    bool pcm16Direct = false, pcm24Direct = false;
     for (int i = 1; i < argc; ++i)
     {
         const std::string a = argv[i];
@@ -45,6 +45,7 @@ int main (int argc, char** argv)
         else if (a == "--batch")   batch = std::atoi (next());
         else if (a == "--device")  device = std::atoi (next());
         else if (a == "--pcm16-direct") pcm16Direct = true;
+        else if (a == "--pcm24-direct") pcm24Direct = true;
         else if (a[0] != '-')      path = a;
         else { std::fprintf (stderr, "unknown option %s\n", a.c_str()); return 2; }
     }
@@ -65,6 +66,13 @@ int main (int argc, char** argv)
         int n16 = 0;
         hops16 = fx::hopsOfChannelPCM16 (wav, channel, window, n16);
         if (wav.pcm16.empty() || n16 != numHops) { std::fprintf (stderr, "--pcm16-direct needs a 16-bit PCM file (this one: %d-bit%s)\n", wav.bitsPerSample, wav.isFloat ? " float" : ""); return 1; }
+    }
+    std::vector<unsigned char> hops24;
+    if (pcm24Direct)
+    {
+        int n24 = 0;
+        hops24 = fx::hopsOfChannelPCM24 (wav, channel, window, n24);
+        if (wav.pcm24.empty() || n24 != numHops) { std::fprintf (stderr, "--pcm24-direct needs a 24-bit PCM file (this one: %d-bit%s)\n", wav.bitsPerSample, wav.isFloat ? " float" : ""); return 1; }
     }
 
     std::FILE* out = nullptr;
@@ -96,8 +104,9 @@ int main (int argc, char** argv)
         for (int done = 0; done < numHops; done += batch)
         {
             const int n = numHops - done < batch ? numHops - done : batch;
-            if (pcm16Direct) analyser.pushHopsPCM16 (hops16.data() + (std::size_t) done * hop, n, raw.data(), smoothed.data());
-            else             analyser.pushHops (hops.data() + (std::size_t) done * hop, n, raw.data(), smoothed.data());
+            if (pcm16Direct)      analyser.pushHopsPCM16 (hops16.data() + (std::size_t) done * hop, n, raw.data(), smoothed.data());
+            else if (pcm24Direct) analyser.pushHopsPCM24 (hops24.data() + (std::size_t) done * hop * 3, n, raw.data(), smoothed.data());
+            else                  analyser.pushHops (hops.data() + (std::size_t) done * hop, n, raw.data(), smoothed.data());
             for (int t = 0; t < n; ++t)
             {
                 const float* v = smoothed.data() + (std::size_t) t * FX_NUM_FEATURES;

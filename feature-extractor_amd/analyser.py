@@ -16,6 +16,13 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+def pack_s24(values):
+    """int32 samples in [-2^23, 2^23) -> packed 24-bit PCM, little endian, three bytes per sample along a new last axis folded into the
+    last one: [...][n] -> uint8 [...][3 n] (the layout of a 24-bit WAV file's data chunk, FX_SAMPLE_S24)."""
+    v = np.ascontiguousarray(values, "<i4")
+    return np.ascontiguousarray(v.view(np.uint8).reshape(v.shape + (4,))[..., :3]).reshape(v.shape[:-1] + (3 * v.shape[-1],))
+
+
 class BatchAnalyser:
     def __init__(self, num_channels, window_size=2048, sample_rate=48000.0, device=0,
                  order=capi.ORDER_SPECTRAL_THEN_HARMONIC, analysers="both", low_latency=False):
@@ -108,6 +115,8 @@ class BatchAnalyser:
 
     # ---- analysis ----
     def _run(self, fn, x, per_frame, want_raw, want_smoothed, out_raw=None, out_smoothed=None):
+        """Sample formats by dtype: float32, float16, int16 (16-bit PCM) and uint8 = packed 24-bit PCM, three bytes per sample
+        (pack_s24): the integer formats are widened in the kernels' load stage to exactly the floats a WAV reader would produce."""
         C = self.num_channels
         if _is_torch(x):
             import torch
@@ -121,8 +130,11 @@ class BatchAnalyser:
                 fmt = capi.SAMPLE_F16
             elif x.dtype == torch.int16:
                 fmt = capi.SAMPLE_S16            # 16-bit PCM: v / 32768 in the kernels' load stage (include/fx_wav.hpp's scaling)
+            elif x.dtype == torch.uint8:
+                fmt = capi.SAMPLE_S24            # packed 24-bit PCM: three bytes per sample
+                per_frame = 3 * per_frame
             else:
-                raise ValueError("samples must be float32, float16 or int16 (PCM)")
+                raise ValueError("samples must be float32, float16, int16 (16-bit PCM) or uint8 (packed 24-bit PCM)")
             if x.numel() % (C * per_frame):
                 raise ValueError("input size is not a multiple of channels x samples per frame")
             T = x.numel() // (C * per_frame)
@@ -157,6 +169,9 @@ class BatchAnalyser:
             fmt = capi.SAMPLE_F16
         elif x.dtype == np.int16:
             fmt = capi.SAMPLE_S16
+        elif x.dtype == np.uint8:
+            fmt = capi.SAMPLE_S24
+            per_frame = 3 * per_frame
         else:
             x = np.ascontiguousarray(x, np.float32)
             fmt = capi.SAMPLE_F32
@@ -276,13 +291,13 @@ class HopStream:
         self.hops = int(hops_per_batch)
         self.slots = int(slots)
         self.dtype = np.dtype(dtype)
-        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float16), np.dtype(np.int16)):
-            raise ValueError("HopStream samples are float32, float16 or int16 (PCM)")
-        fmt = {np.dtype(np.float16): capi.SAMPLE_F16, np.dtype(np.int16): capi.SAMPLE_S16}.get(self.dtype, capi.SAMPLE_F32)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float16), np.dtype(np.int16), np.dtype(np.uint8)):
+            raise ValueError("HopStream samples are float32, float16, int16 (16-bit PCM) or uint8 (packed 24-bit PCM, three bytes per sample)")
+        fmt = {np.dtype(np.float16): capi.SAMPLE_F16, np.dtype(np.int16): capi.SAMPLE_S16, np.dtype(np.uint8): capi.SAMPLE_S24}.get(self.dtype, capi.SAMPLE_F32)
         h = ctypes.c_void_p()
         capi.check(self._lib.fx_stream_create(analyser._h, self.hops, self.slots, fmt, ctypes.byref(h)))
         self._h = h
-        self._shape = (analyser.num_channels, self.hops, analyser.window_size // 2)
+        self._shape = (analyser.num_channels, self.hops, (analyser.window_size // 2) * (3 if self.dtype == np.uint8 else 1))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -14,7 +14,7 @@ ONSET_SPECTRAL, ONSET_AMPLITUDE, ONSET_COMBINATION = 0, 1, 2
 ORDER_SPECTRAL_THEN_HARMONIC, ORDER_HARMONIC_THEN_SPECTRAL, ORDER_ISOLATED = 0, 1, 2
 SPECTRAL_ONLY, HARMONIC_ONLY, LOW_LATENCY = 4, 8, 16
 MEM_HOST, MEM_DEVICE = 0, 1
-SAMPLE_F32, SAMPLE_F16, SAMPLE_S16 = 0, 1, 2
+SAMPLE_F32, SAMPLE_F16, SAMPLE_S16, SAMPLE_S24 = 0, 1, 2, 3
 FX_OK, FX_ERR_INVALID_ARGUMENT, FX_ERR_NO_DEVICE, FX_ERR_HIP, FX_ERR_OUT_OF_MEMORY, FX_ERR_UNSUPPORTED = range(6)
 
 # every symbol include/fx.h declares

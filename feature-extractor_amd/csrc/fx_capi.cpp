@@ -42,8 +42,8 @@ bool uses_pairs(const fx_context* c, int waves_per_frame)
     if (!fxk::pair_kernel_available(c->N) || (c->flags & (FX_SPECTRAL_ONLY | FX_HARMONIC_ONLY))) return false;
     return waves_per_frame == 2 || (waves_per_frame == 0 && (c->flags & FX_LOW_LATENCY));
 }
-bool known_format(int f) { return f == FX_SAMPLE_F32 || f == FX_SAMPLE_F16 || f == FX_SAMPLE_S16; }
-size_t sample_size(int f) { return f == FX_SAMPLE_F32 ? 4 : 2; }
+bool known_format(int f) { return f == FX_SAMPLE_F32 || f == FX_SAMPLE_F16 || f == FX_SAMPLE_S16 || f == FX_SAMPLE_S24; }
+size_t sample_size(int f) { return f == FX_SAMPLE_F32 ? 4 : (f == FX_SAMPLE_S24 ? 3 : 2); }
 
 } // namespace
 

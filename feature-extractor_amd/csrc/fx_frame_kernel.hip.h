@@ -23,19 +23,31 @@
 // ---------------------------------------------------------------------------------------------
 // frame load: global -> real LDS image, 16 B per lane, coalesced
 // ---------------------------------------------------------------------------------------------
-// Sample formats on the wire (FX_SAMPLE_*, include/fx.h): fp32, fp16, or 16-bit signed PCM, which becomes v / 2^15 -- exactly
-// what the WAV reader makes of a 16-bit file (include/fx_wav.hpp, JUCE's int -> float scaling), so integer audio crosses PCIe
-// at two bytes a sample and loses nothing.  The carried-over window tail is always fp32.
-__device__ __forceinline__ constexpr int sample_bytes(int fmt) { return fmt == FX_SAMPLE_F32 ? 4 : 2; }
+// Sample formats on the wire (FX_SAMPLE_*, include/fx.h): fp32, fp16, or signed PCM of 16 bits (v / 2^15) or 24 bits packed in three
+// bytes, little endian (v / 2^23) -- exactly what the WAV reader makes of such files (include/fx_wav.hpp, JUCE's int -> float scaling:
+// the sample left-justified in an int32, times 2^-31), so integer audio crosses PCIe at two / three bytes a sample and loses
+// nothing.  The carried-over window tail is always fp32.
+__device__ __forceinline__ constexpr int sample_bytes(int fmt) { return fmt == FX_SAMPLE_F32 ? 4 : (fmt == FX_SAMPLE_S24 ? 3 : 2); }
+// a 24-bit sample left-justified in 32 bits -> float: 24 significant bits, so the conversion and the power-of-two scaling are exact
+__device__ __forceinline__ float from_left_justified(unsigned w) { return (float) (int) w * (1.0f / 2147483648.0f); }
 template <int FMT> __device__ __forceinline__ float widen_one(const void* at)
 {
     if (FMT == FX_SAMPLE_F16) return __half2float(*static_cast<const __half*>(at));
     if (FMT == FX_SAMPLE_S16) return (float) (int) *static_cast<const short*>(at) * (1.0f / 32768.0f);
+    if (FMT == FX_SAMPLE_S24) {
+        // (three byte loads: a packed sample starts at any byte, and a wider load at the last sample of a buffer would read past its end)
+        const unsigned char* b = static_cast<const unsigned char*>(at);
+        return from_left_justified(((unsigned) b[0] << 8) | ((unsigned) b[1] << 16) | ((unsigned) b[2] << 24));
+    }
     return *static_cast<const float*>(at);
 }
-// four consecutive samples: r = the 16 bytes of four floats, or (r.x, r.y) = the 8 bytes of four 16-bit samples
+// four consecutive samples: r = the 16 bytes of four floats, (r.x, r.y) = the 8 bytes of four 16-bit samples, or (r.x, r.y, r.z) = the
+// 12 bytes of four packed 24-bit samples
 template <int FMT> __device__ __forceinline__ f4 widen_four(uint4 r)
 {
+    if (FMT == FX_SAMPLE_S24)
+        return f4{from_left_justified(r.x << 8), from_left_justified((r.y << 16) | ((r.x >> 16) & 0xff00u)),
+                  from_left_justified((r.z << 24) | ((r.y >> 8) & 0xffff00u)), from_left_justified(r.z & 0xffffff00u)};
     if (FMT == FX_SAMPLE_F16) {
         const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&r.x));
         const float2 b = __half22float2(*reinterpret_cast<const __half2*>(&r.y));
@@ -50,6 +62,10 @@ template <int FMT> __device__ __forceinline__ f4 widen_four(uint4 r)
 template <int FMT> __device__ __forceinline__ uint4 fetch_four(const void* src, int i)       // samples i .. i + 3 of src
 {
     if (FMT == FX_SAMPLE_F32) return *reinterpret_cast<const uint4*>(static_cast<const float*>(src) + i);
+    if (FMT == FX_SAMPLE_S24) {             // i is a multiple of 4: twelve bytes from a 4-byte boundary
+        const uint3 v = *reinterpret_cast<const uint3*>(static_cast<const unsigned char*>(src) + 3 * i);
+        return uint4{v.x, v.y, v.z, 0u};
+    }
     const uint2 v = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(src) + i);
     return uint4{v.x, v.y, 0u, 0u};
 }
@@ -60,6 +76,8 @@ template <int FMT> __device__ __forceinline__ uint4 fetch_four(const void* src, 
                                           else                       { constexpr int FA = FX_SAMPLE_F32, FB = FX_SAMPLE_F16; CALL; } } \
         else if ((fb) == FX_SAMPLE_S16) { if ((fa) == FX_SAMPLE_S16) { constexpr int FA = FX_SAMPLE_S16, FB = FX_SAMPLE_S16; CALL; }   \
                                           else                       { constexpr int FA = FX_SAMPLE_F32, FB = FX_SAMPLE_S16; CALL; } } \
+        else if ((fb) == FX_SAMPLE_S24) { if ((fa) == FX_SAMPLE_S24) { constexpr int FA = FX_SAMPLE_S24, FB = FX_SAMPLE_S24; CALL; }   \
+                                          else                       { constexpr int FA = FX_SAMPLE_F32, FB = FX_SAMPLE_S24; CALL; } } \
         else                            { constexpr int FA = FX_SAMPLE_F32, FB = FX_SAMPLE_F32; CALL; }                                \
     } while (0)
 
@@ -72,6 +90,7 @@ __device__ __forceinline__ void load_half(const void* src, int sample_format, fl
         f4 v;
         if (sample_format == FX_SAMPLE_F16)      v = widen_four<FX_SAMPLE_F16>(fetch_four<FX_SAMPLE_F16>(src, i));
         else if (sample_format == FX_SAMPLE_S16) v = widen_four<FX_SAMPLE_S16>(fetch_four<FX_SAMPLE_S16>(src, i));
+        else if (sample_format == FX_SAMPLE_S24) v = widen_four<FX_SAMPLE_S24>(fetch_four<FX_SAMPLE_S24>(src, i));
         else                                     v = widen_four<FX_SAMPLE_F32>(fetch_four<FX_SAMPLE_F32>(src, i));
         if (apply_gain) v *= gain;                       // ref AudioDataCollector.h:88
         *reinterpret_cast<f4*>(&rbuf[rimg<N>(dst_off + i)]) = v;

@@ -58,7 +58,7 @@ constexpr int FX_MAX_CHUNKS = FX_MAX_UNITS;
 
 struct FrameParams {
     const void*  in;            // frames [C][T][N] or hops [C][T][N/2]
-    int          sample_format; // FX_SAMPLE_F32 / FX_SAMPLE_F16 / FX_SAMPLE_S16
+    int          sample_format; // FX_SAMPLE_F32 / FX_SAMPLE_F16 / FX_SAMPLE_S16 / FX_SAMPLE_S24
     int          hop_mode;      // 1: `in` holds hops, windows are assembled from tail + hops
     int          T;             // frames (= hops) per channel in this call
     int          C;

@@ -160,6 +160,7 @@ FX_MARK("p_load");
         float* tail_dst = (w == 1 && t == T - 1) ? p.tail_out + (size_t) c * HALF : nullptr;
         if (fmt == FX_SAMPLE_F16) return load_half_window_t<FX_SAMPLE_F16>(lane, src, gain, tail_dst);
         if (fmt == FX_SAMPLE_S16) return load_half_window_t<FX_SAMPLE_S16>(lane, src, gain, tail_dst);
+        if (fmt == FX_SAMPLE_S24) return load_half_window_t<FX_SAMPLE_S24>(lane, src, gain, tail_dst);
         return load_half_window_t<FX_SAMPLE_F32>(lane, src, gain, tail_dst);
     }
 

@@ -58,8 +58,10 @@ enum { FX_MEM_HOST = 0, FX_MEM_DEVICE = 1 };
 /* Sample formats accepted for audio input.  FX_SAMPLE_S16 is 16-bit signed PCM, little endian as the host has it: the load
  * stage of the kernels turns a sample v into the float v / 32768 -- exactly what JUCE's WAV reader (and include/fx_wav.hpp)
  * makes of a 16-bit file before AudioDataCollector sees it (AudioFilePlayer.h:41-61, AudioDataCollector.h:42-64) -- so an
- * integer source crosses PCIe at two bytes per sample and every result is bit for bit that of the decoded floats. */
-enum { FX_SAMPLE_F32 = 0, FX_SAMPLE_F16 = 1, FX_SAMPLE_S16 = 2 };
+ * integer source crosses PCIe at two bytes per sample and every result is bit for bit that of the decoded floats.
+ * FX_SAMPLE_S24 is 24-bit signed PCM PACKED in three bytes per sample, little endian (the layout of a 24-bit WAV file's data
+ * chunk): v / 8388608, again the reader's float exactly; a hop of window_size/2 samples is window_size/2 * 3 bytes. */
+enum { FX_SAMPLE_F32 = 0, FX_SAMPLE_F16 = 1, FX_SAMPLE_S16 = 2, FX_SAMPLE_S24 = 3 };
 
 /* fx_create flags.  The first three fix the order in which the reference's two
  * analysis threads write the ONE shared AudioFeatures object per hop

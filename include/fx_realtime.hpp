@@ -126,6 +126,11 @@ public:
     {
         check (fx_push_hops (ctx, hops, numHops, FX_SAMPLE_S16, FX_MEM_HOST, raw, smoothed));
     }
+    // ... and as packed 24-bit PCM, three bytes per sample, little endian (FX_SAMPLE_S24: v / 8388608)
+    void pushHopsPCM24 (const unsigned char* hops, int numHops, float* raw, float* smoothed)
+    {
+        check (fx_push_hops (ctx, hops, numHops, FX_SAMPLE_S24, FX_MEM_HOST, raw, smoothed));
+    }
     void processFrames (const float* frames, int numFrames, float* raw, float* smoothed)
     {
         check (fx_process_frames (ctx, frames, numFrames, FX_SAMPLE_F32, FX_MEM_HOST, raw, smoothed));

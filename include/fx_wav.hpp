@@ -34,6 +34,7 @@ struct WavData
     std::vector<float> interleaved;     // [frame][channel]
     std::vector<std::int16_t> pcm16;    // 16-bit PCM files only: the samples as the file holds them, [frame][channel] -- what
                                         // FX_SAMPLE_S16 ingests (the kernels make v / 2^15 of them, exactly as `interleaved` holds)
+    std::vector<unsigned char> pcm24;   // 24-bit PCM files only: the data chunk as it is, three bytes per sample (FX_SAMPLE_S24: v / 2^23)
 
     std::size_t numFrames() const { return numChannels > 0 ? interleaved.size() / (std::size_t) numChannels : 0; }
 
@@ -116,7 +117,9 @@ inline bool readWav (const std::string& path, WavData& out, std::string& error)
     const std::size_t total = dataBytes / (std::size_t) blockAlign * (std::size_t) out.numChannels;
     out.interleaved.resize (total);
     out.pcm16.clear();
+    out.pcm24.clear();
     if (format == 1 && bits == 16) out.pcm16.resize (total);
+    if (format == 1 && bits == 24) out.pcm24.assign (data, data + total * 3);
     const float scale = 1.0f / (float) 0x7fffffff;                  // == 2^-31
     for (std::size_t i = 0; i < total; ++i)
     {
@@ -162,6 +165,19 @@ inline std::vector<std::int16_t> hopsOfChannelPCM16 (const WavData& wav, int cha
     numHops = (int) (frames / hop);
     mono.resize ((std::size_t) numHops * hop);
     for (std::size_t i = 0; i < mono.size(); ++i) mono[i] = wav.pcm16[i * (std::size_t) wav.numChannels + (std::size_t) channel];
+    return mono;
+}
+// ... and as packed 24-bit PCM (24-bit files only): numHops * windowSize/2 * 3 bytes of the chosen channel.
+inline std::vector<unsigned char> hopsOfChannelPCM24 (const WavData& wav, int channel, int windowSize, int& numHops)
+{
+    std::vector<unsigned char> mono;
+    numHops = 0;
+    if (wav.pcm24.empty()) return mono;
+    const std::size_t hop = (std::size_t) windowSize / 2, frames = wav.numFrames();
+    numHops = (int) (frames / hop);
+    mono.resize ((std::size_t) numHops * hop * 3);
+    for (std::size_t i = 0; i < (std::size_t) numHops * hop; ++i)
+        for (int b = 0; b < 3; ++b) mono[3 * i + (std::size_t) b] = wav.pcm24[(i * (std::size_t) wav.numChannels + (std::size_t) channel) * 3 + (std::size_t) b];
     return mono;
 }
 } // namespace fx

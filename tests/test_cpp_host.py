@@ -95,6 +95,12 @@ def test_wav_to_osc_matches_oracle(gpu_fx, oracle, tmp_path, fmt, window, gain):
     else:
         out = subprocess.run([exe, wav, "--window", str(window), "--pcm16-direct"], capture_output=True, text=True)
         assert out.returncode == 1 and "16-bit PCM" in out.stderr
+    if fmt == "pcm24":
+        dump24 = str(tmp_path / "o24.bin")
+        out = subprocess.run([exe, wav, "--window", str(window), "--channel", "1", "--gain", str(gain), "--address", "/Audio/A1",
+                              "--dump", dump24, "--batch", "7", "--pcm24-direct"], capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert _records(dump24) == want
 
     # the 60 Hz timer view: tick k reads the values after the last hop completed by k/60 s
     dump60 = str(tmp_path / "o60.bin")

@@ -269,3 +269,60 @@ def test_short_calls_over_many_channels_equal_one_long_call_bitwise(gpu_fx, orac
     oraw, osm = oracle.push_hops(hops[pick], N, onset_window=9)
     close(got[0][pick], oraw, "many channels raw")
     close(got[1][pick], osm, "many channels smoothed")
+
+
+# ---- packed 24-bit PCM (FX_SAMPLE_S24) ----
+def pcm24(C, T, N, seed):
+    """(packed bytes [C][T][3 N/2] uint8, the floats a WAV reader decodes them to [C][T][N/2])"""
+    f = signals.bursts(C, T, N, seed=seed) * 0.8
+    f[0] += signals.tone_vibrato_noise(1, T, N, seed=seed + 1)[0] * 0.2
+    v = np.clip(np.round(f * 8388608.0), -8388608, 8388607).astype(np.int32)
+    v[-1, 0, :4] = [-8388608, 8388607, 0, -1]
+    return None, v
+
+
+@pytest.mark.parametrize("N", [256, 512, 1024, 2048, 4096])
+def test_pcm24_hops_equal_the_decoded_floats_bitwise_and_match_the_oracle(gpu_fx, oracle, N):
+    C, T = 4, 19
+    _, v = pcm24(C, T, N, seed=2 * N)
+    packed = gpu_fx.pack_s24(v)                               # [C][T][3 N/2] bytes, little endian
+    assert packed.shape == (C, T, 3 * (N // 2)) and packed.dtype == np.uint8
+    floats = v.astype(np.float32) / np.float32(8388608.0)      # include/fx_wav.hpp: the sample left-justified in an int32, times 2^-31
+    an, ref = gpu_fx.BatchAnalyser(C, N), gpu_fx.BatchAnalyser(C, N)
+    an.set_gain(1.5); ref.set_gain(1.5)
+    got = [an.push_hops(packed[:, a:b]) for a, b in ((0, 1), (1, 8), (8, 9), (9, 19))]
+    got = (np.concatenate([g[0] for g in got], 1), np.concatenate([g[1] for g in got], 1))
+    same(got, ref.push_hops(floats), "s24 vs f32, N=%d" % N)
+    oraw, osm = oracle.push_hops(floats, N, gain=1.5)
+    close(got[0], oraw, "s24 raw N=%d" % N)
+    close(got[1], osm, "s24 smoothed N=%d" % N)
+
+
+@pytest.mark.parametrize("N,C,B,low", [(1024, 3, 1, False), (4096, 2, 1, True), (2048, 5, 3, False), (1024, 200, 16, False)])
+def test_pcm24_through_the_ring_frames_and_pairs(gpu_fx, N, C, B, low):
+    """one hop per call (the one-launch hop kernels read the packed hop out of the pinned slot), small and large batches through the
+    ring, the low-latency family, and pre-assembled frames from device memory"""
+    import torch
+    nb = 6
+    _, v = pcm24(C, B * nb, N, seed=31 + B)
+    packed, floats = gpu_fx.pack_s24(v), v.astype(np.float32) / np.float32(8388608.0)
+    want = gpu_fx.BatchAnalyser(C, N, low_latency=low).push_hops(floats)
+    an = gpu_fx.BatchAnalyser(C, N, low_latency=low)
+    st = gpu_fx.HopStream(an, B, slots=3, dtype=np.uint8)
+    got = []
+    for b in range(nb):
+        if st.in_flight() == 3:
+            got.append(st.collect())
+        st.push(packed[:, b * B:(b + 1) * B], fill_threads=2 if B == 16 else 1)
+    while st.in_flight():
+        got.append(st.collect())
+    st.close()
+    same((np.concatenate([g[0] for g in got], 1), np.concatenate([g[1] for g in got], 1)), want, "ring s24")
+    # frames [C][T][N] assembled from the same samples, packed, in device memory
+    T = B * nb - 1
+    flat = v.reshape(C, -1)
+    frames = np.stack([flat[:, t * (N // 2): t * (N // 2) + N] for t in range(T)], axis=1)
+    an2 = gpu_fx.BatchAnalyser(C, N, low_latency=low)
+    raw, sm = an2.process_frames(torch.from_numpy(gpu_fx.pack_s24(frames)).cuda())
+    an2.sync()
+    same((raw.cpu().numpy(), sm.cpu().numpy()), gpu_fx.BatchAnalyser(C, N, low_latency=low).process_frames(frames.astype(np.float32) / np.float32(8388608.0)), "s24 frames")

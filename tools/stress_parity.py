@@ -48,10 +48,17 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
         mask = {"both": 3, "spectral": 1, "harmonic": 2}[which]
         hops = make_signal(rng, C, T, N)
         feed = hops
-        if rng.random() < 0.2:
+        pick = rng.random()
+        if pick < 0.2:
             # 16-bit PCM ingest (FX_SAMPLE_S16): the kernels widen v to v / 32768 in their load stage; the oracle analyses the decoded floats
             feed = np.clip(np.round(hops * 32768.0), -32768, 32767).astype(np.int16)
             hops = feed.astype(np.float32) / np.float32(32768.0)
+            pcm_cases[0] += 1
+        elif pick < 0.3:
+            # packed 24-bit PCM (FX_SAMPLE_S24): three bytes per sample, v / 8388608
+            v24 = np.clip(np.round(hops.astype(np.float64) * 8388608.0), -8388608, 8388607).astype(np.int32)
+            feed = fx.pack_s24(v24)
+            hops = v24.astype(np.float32) / np.float32(8388608.0)
             pcm_cases[0] += 1
         an = fx.BatchAnalyser(C, N, order=order, analysers=which)
         an.set_onset_detection_type(otype); an.set_onset_window_length(owin)
@@ -112,7 +119,7 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
                           % (name, N, C, T, order, otype, owin, len(bad), c, t, fx.FEATURE_NAMES[f], g[c, t, f], w[c, t, f]), flush=True)
     if verbose:
         print("cases run one hop per call through the ring (fx_hop_kernel / fx_hop_pair_kernel): %d; cases on wavefront pairs (fx_pair_kernel): %d; "
-              "cases hop by hop through fx_push_hops (half of them on the batch kernels + one-frame fused tail): %d; cases fed as 16-bit PCM: %d"
+              "cases hop by hop through fx_push_hops (half of them on the batch kernels + one-frame fused tail): %d; cases fed as 16- or 24-bit PCM: %d"
               % (ring_cases[0], pair_cases[0], hop_cases[0], pcm_cases[0]), flush=True)
     if verbose and inexact.any():
         print("raw values not bit-identical (within tolerance), per slot:", dict((fx.FEATURE_NAMES[i], int(n)) for i, n in enumerate(inexact) if n), flush=True)
