@@ -301,7 +301,7 @@ def stream_bench(fx, args, C, T, N, device):
     hops = fx.synth.hops(C, T, N).astype(dtype)
     an = fx.BatchAnalyser(C, N, device=device)
     st = fx.HopStream(an, T, slots=3, dtype=dtype)
-    fill_threads = max(1, min(12, usable_cores() - 2))
+    fill_threads = max(1, min(8, usable_cores() // 2))
 
     def step():
         if st.in_flight() == 3:
@@ -842,8 +842,11 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
         # the library; the reference's per-channel collectors write their own channel's samples); the same loop with the slots left
         # as they are (producer excluded) is reported beside it.
         cores = usable_cores()
-        fill_threads = max(4, min(12, cores - 2))               # (the caller's thread and the runtime's need a core too)
-        res = {"fill_threads": fill_threads, "slots": 3,
+        # (measured on the 16-CPU quota of these boxes, fp32, 1024 ch x 64 hops: 3 slots x 12 fill threads 0.78-0.79 of the memcpy rate, 3 x 8 0.96,
+        # 4 x 6 0.96, 4 x 12 0.92-0.93, 5 x 12 0.95: the fill pool must leave cores to the caller's thread and to the runtime's own)
+        fill_threads = max(4, min(8, cores // 2))
+        ring_slots = 4
+        res = {"fill_threads": fill_threads, "slots": ring_slots,
                "note": "frames/s with host-resident hops, PCIe-inclusive (never `value`); roofline.bound = pcie: achieved = sample bytes/s through the "
                        "ring with the producer filling slots in place, peak = pinned hipMemcpyAsync H2D of the same bytes measured in this run"}
 
@@ -871,7 +874,7 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
                     src = src32 if fmt == "f32" else (src32.astype(np.float16) if fmt == "f16" else np.round(src32 * 32767.0).astype(np.int16))
                 peak = memcpy_rate(src.nbytes)
                 an5 = fx.BatchAnalyser(c2, n2, device=dev)
-                st5 = fx.HopStream(an5, t2, slots=3, dtype=src.dtype)
+                st5 = fx.HopStream(an5, t2, slots=ring_slots, dtype=src.dtype)
 
                 def run(fill, steps, warm=4):
                     for k in range(steps + warm):
@@ -879,9 +882,9 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
                             while st5.in_flight():
                                 st5.collect(want_raw=False)
                             t0 = time.perf_counter()
-                        if st5.in_flight() == 3:
+                        if st5.in_flight() == ring_slots:
                             st5.collect(want_raw=False)
-                        if fill or k < 3:
+                        if fill or k < ring_slots:
                             st5.push(src, fill_threads=fill_threads)
                         else:
                             st5.slot()
