@@ -266,11 +266,18 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
         if (c->tuning.channels_per_workgroup >= 1) ch = c->tuning.channels_per_workgroup;
         if (k > T) k = T;
         if (k > kcap) k = kcap;
-        // one frame per call through the batch kernels: one wavefront per channel, so channels share a workgroup's twiddle table:
-        // as many as a workgroup may hold when the flux state stays in global memory (1024 points: 8 channels = 76 KB, two workgroups
-        // and 16 wavefronts per CU -- what the LDS holds of the batch shape too), else four (measured: 2048 points, 4096 channels x 1 hop
-        // 152 us against 193 us)
-        if (T == 1 && !st->pair && c->tuning.channels_per_workgroup < 1) ch = direct ? kcap : 4;
+        // one frame per call through the batch kernels: one wavefront per channel, so channels share a workgroup's twiddle table.
+        // With the flux state in global memory (direct), up to 1024 points as many as a workgroup may hold (1024 points: 8 channels =
+        // 76 KB, two workgroups and 16 wavefronts per CU -- what the LDS holds of the batch shape too); at the split sizes the registers
+        // allow 8 wavefronts per CU whatever the shape, and a CU does better with two workgroups of four (staggered) than with one of
+        // eight in lockstep, until there are so many channels that the workgroup count stops mattering.  Measured, us per call of one hop
+        // per channel, channels per workgroup 4 / 8 (7 at 4096 points) -- profiles/r04_live_cadence.txt:
+        //   1024 points  4096 ch 43.4 / 39.1   8192 ch 66.6 / 63.3   16384 ch 116.8 / 111.1
+        //   2048 points  2048 ch 44.8 / 43.2   4096 ch 72.0 / 73.0    8192 ch 125.4 / 133.6
+        //   4096 points  1024 ch 58.5 / 67.2   2048 ch 102.5 / 117.7  4096 ch 195.0 / 176.4
+        // Without the direct form (one analyser only): four (2048 points, 4096 channels x 1 hop 152 us against 193 us with one).
+        if (T == 1 && !st->pair && c->tuning.channels_per_workgroup < 1)
+            ch = !direct ? 4 : (c->N <= 1024 ? kcap : (c->N == 2048 ? 4 : (c->C >= 4096 ? kcap : 4)));
         if (ch > c->C) ch = c->C;
         while (ch > 1 && (ch * k > kcap || lds_bytes(ch, k) > lds_cu)) ch--;
         while (k > 1 && lds_bytes(ch, k) > lds_cu) k--;
