@@ -417,10 +417,10 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     // ONE frame per channel -- the reference's own cadence, an analysis per hop as it arrives (AudioDataCollector.h:66-94,
     // RealTimeAnalyser.h:201-234) -- is one launch of fx_hop_kernel: three wavefronts per channel (pitch / spectral /
     // harmonic) and the hop's tail, instead of one wavefront per channel and a second launch.
-    // (measured, tools/live_cadence.py, profiles/r03_variants.txt (c): once the call holds more than ~a million samples -- 1024 channels of
-    // 1024 points, 512 of 2048, 256 of 4096 -- the chip is full either way and the batch kernels take over: one wavefront per channel
-    // with four channels sharing a twiddle table, then the fused tail with a lane per slot: 153 against 176 us at 8192 channels x
-    // 1024-pt, 103 against 140 us at 1024 channels x 4096-pt)
+    // (measured, tools/live_cadence.py, profiles/r04_live_cadence.txt: once the call holds more than ~a million samples -- 1024 channels of
+    // 1024 points, 512 of 2048, 256 of 4096 -- the chip is full either way and the batch kernels take over: one wavefront per channel with
+    // the flux state left in global memory (prepare_step), then the fused tail on a quarter wavefront per channel: 63 against 120 us at
+    // 8192 channels x 1024-pt, 58 against 95 us at 1024 channels x 4096-pt; below it the hop kernel wins, 19.9 against 22.9 us at 1024 x 1024-pt)
     const bool one_hop = T == 1 && step.analysers == 3 && fxk::hop_kernel_available(c->N) &&
                          (c->tuning.one_hop_kernel == 1 || (c->tuning.one_hop_kernel < 0 && (long long) c->C * c->N <= (1ll << 20)));
     if (one_hop) {
