@@ -167,6 +167,37 @@ private:
     std::vector<float> latest;
 };
 
+// The stand-in for AudioDataCollector's ring (ref Source/AudioDataCollector.h:24,36-94: the audio thread writes a ring, the analysis thread
+// spins until a hop is there): a ring of pinned host batches of `hopsPerBatch` hops per channel (fx_stream_*).  The producer writes into
+// nextSlot() and submit()s it -- or push()es a batch from ordinary memory, copied by `fillThreads` host threads inside the library --
+// and collect()s the results in submission order; samples in, kernels and results back overlap.  One hop per batch is the reference's
+// own cadence: a submit is then ONE kernel launch and collect() polls a flag (34 us round trip for a 4096-point window on MI355X).
+// Destroy the ring before its analyser.
+class HopRing
+{
+public:
+    HopRing (RealTimeBatchAnalyser& analyser, int hopsPerBatch, int slots = 3, int sampleFormat = FX_SAMPLE_F32)
+        : values ((std::size_t) analyser.getNumChannels() * (std::size_t) hopsPerBatch * FX_NUM_FEATURES)
+    {
+        check (fx_stream_create (analyser.handle(), hopsPerBatch, slots, sampleFormat, &ring));
+    }
+    ~HopRing() { fx_stream_destroy (ring); }
+    HopRing (const HopRing&) = delete;
+    HopRing& operator= (const HopRing&) = delete;
+
+    void* nextSlot()                                   { void* p = nullptr; check (fx_stream_acquire (ring, &p)); return p; }
+    void submit()                                      { check (fx_stream_submit (ring)); }
+    void push (const void* hops, int fillThreads = 1)  { check (fx_stream_push (ring, hops, fillThreads)); }
+    int  inFlight() const                              { return fx_stream_in_flight (ring); }
+    // the oldest batch's values: raw / smoothed [channels][hopsPerBatch][12], either may be null
+    void collect (float* raw, float* smoothed)         { check (fx_stream_collect (ring, raw, smoothed)); }
+    std::size_t valuesPerBatch() const                 { return values; }
+
+private:
+    fx_stream* ring = nullptr;
+    std::size_t values;
+};
+
 // The reference's LEGACY offline analyser (struct AudioAnalyser, ref Source/AudioAnalysis.h), one per channel, on the GPU: the
 // members a host would have called, with the reference's names.  Buffers are host memory, [numChannels][...] row-major.
 class AudioAnalyser

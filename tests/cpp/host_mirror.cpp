@@ -126,6 +126,98 @@ int main (int argc, char** argv)
         two.pushHops (h2.data(), T2, rb.data(), sb.data());
         for (size_t i = 0; i < ra.size(); i += 12) { EXPECT (ra[i] == rb[i]); EXPECT (ra[i + FX_F0] == rb[i + FX_F0]); }
     }
+    // round 4: the low-latency family as a constructor flag, 16- and 24-bit PCM hops, the ring (fx::HopRing) one hop per call and in
+    // batches filled by the library's thread pool -- each must reproduce pushHops on the decoded floats bit for bit
+    {
+        const int C4 = 2, T4 = 24, N4 = 2048, H4 = N4 / 2;
+        std::vector<std::int16_t> pcm ((size_t) C4 * T4 * H4);
+        std::vector<unsigned char> pcm24 (pcm.size() * 3);
+        std::vector<float> dec (pcm.size()), dec24 (pcm.size());
+        unsigned r = 777;
+        for (size_t i = 0; i < pcm.size(); i++)
+        {
+            r = r * 1664525u + 1013904223u;
+            const float x = ((i / H4) % 6 < 4 ? 0.6f : 0.01f) * std::sin (0.011f * (float) (i % 5000)) + 0.02f * ((r >> 8) / 16777216.0f - 0.5f);
+            pcm[i] = (std::int16_t) std::lrint (x * 32767.0f);
+            dec[i] = (float) pcm[i] / 32768.0f;
+            const int v24 = (int) std::lrint ((double) x * 8388607.0);
+            pcm24[3 * i] = (unsigned char) v24; pcm24[3 * i + 1] = (unsigned char) (v24 >> 8); pcm24[3 * i + 2] = (unsigned char) (v24 >> 16);
+            dec24[i] = (float) v24 / 8388608.0f;
+        }
+        std::vector<float> wr ((size_t) C4 * T4 * 12), ws (wr.size()), gr (wr.size()), gs (wr.size());
+        auto sameBits = [&] (const std::vector<float>& a, const std::vector<float>& b) { return std::memcmp (a.data(), b.data(), a.size() * sizeof (float)) == 0; };
+        for (int low = 0; low < 2; low++)
+        {
+            const unsigned flags = low ? FX_LOW_LATENCY : 0u;
+            fx::RealTimeBatchAnalyser ref (C4, N4, 48000.0, 0, flags), a16 (C4, N4, 48000.0, 0, flags), a24 (C4, N4, 48000.0, 0, flags), ring1 (C4, N4, 48000.0, 0, flags),
+                                      ring8 (C4, N4, 48000.0, 0, flags);
+            ref.pushHops (dec.data(), T4, wr.data(), ws.data());
+            a16.pushHopsPCM16 (pcm.data(), T4, gr.data(), gs.data());
+            EXPECT (sameBits (gr, wr) && sameBits (gs, ws));
+            {   // 24-bit: its own decoded floats
+                std::vector<float> w24r (wr.size()), w24s (wr.size());
+                fx::RealTimeBatchAnalyser ref24 (C4, N4, 48000.0, 0, flags);
+                ref24.pushHops (dec24.data(), T4, w24r.data(), w24s.data());
+                a24.pushHopsPCM24 (pcm24.data(), T4, gr.data(), gs.data());
+                EXPECT (sameBits (gr, w24r) && sameBits (gs, w24s));
+            }
+            // one hop per call through the ring, up to three in flight: the hop is [channels][1][H4] -- gather it from the [C][T][H] layout
+            {
+                fx::HopRing ring (ring1, 1, 3, FX_SAMPLE_S16);
+                std::vector<float> one ((size_t) C4 * 12), onesm ((size_t) C4 * 12);
+                int collected = 0;
+                auto take = [&] {
+                    ring.collect (one.data(), onesm.data());
+                    for (int c = 0; c < C4; c++)
+                        for (int k = 0; k < 12; k++) { gr[((size_t) c * T4 + collected) * 12 + k] = one[(size_t) c * 12 + k]; gs[((size_t) c * T4 + collected) * 12 + k] = onesm[(size_t) c * 12 + k]; }
+                    collected++;
+                };
+                for (int t = 0; t < T4; t++)
+                {
+                    if (ring.inFlight() == 3) take();
+                    std::int16_t* slot = static_cast<std::int16_t*> (ring.nextSlot());
+                    for (int c = 0; c < C4; c++) std::memcpy (slot + (size_t) c * H4, pcm.data() + ((size_t) c * T4 + t) * H4, (size_t) H4 * sizeof (std::int16_t));
+                    ring.submit();
+                }
+                while (ring.inFlight()) take();
+                EXPECT (collected == T4 && sameBits (gr, wr) && sameBits (gs, ws));
+            }
+            // batches of 8 hops pushed from ordinary memory with two fill threads
+            {
+                const int B = 8;
+                fx::HopRing ring (ring8, B, 2, FX_SAMPLE_S16);
+                std::vector<std::int16_t> batch ((size_t) C4 * B * H4);
+                std::vector<float> br (ring.valuesPerBatch()), bs (ring.valuesPerBatch());
+                int done = 0;
+                auto take = [&] {
+                    ring.collect (br.data(), bs.data());
+                    for (int c = 0; c < C4; c++)
+                        std::memcpy (&gr[((size_t) c * T4 + (size_t) done * B) * 12], &br[(size_t) c * B * 12], (size_t) B * 12 * sizeof (float)),
+                        std::memcpy (&gs[((size_t) c * T4 + (size_t) done * B) * 12], &bs[(size_t) c * B * 12], (size_t) B * 12 * sizeof (float));
+                    done++;
+                };
+                for (int b = 0; b < T4 / B; b++)
+                {
+                    if (ring.inFlight() == 2) take();
+                    for (int c = 0; c < C4; c++) std::memcpy (&batch[(size_t) c * B * H4], pcm.data() + ((size_t) c * T4 + (size_t) b * B) * H4, (size_t) B * H4 * sizeof (std::int16_t));
+                    ring.push (batch.data(), 2);
+                }
+                while (ring.inFlight()) take();
+                EXPECT (done == T4 / B && sameBits (gr, wr) && sameBits (gs, ws));
+            }
+        }
+        // the family cannot change under a history
+        fx::RealTimeBatchAnalyser fam (C4, N4);
+        fam.pushHops (dec.data(), 2, gr.data(), gs.data());
+        fx_tuning tf = fam.getTuning();
+        tf.waves_per_frame = 2;
+        bool refused = false;
+        try { fam.setTuning (tf); } catch (const fx::Error& e) { refused = e.code == FX_ERR_INVALID_ARGUMENT; }
+        EXPECT (refused && fam.getTuning().waves_per_frame == 0);
+        fam.reset();
+        fam.setTuning (tf);
+        EXPECT (fam.getTuning().waves_per_frame == 2);
+    }
     // the legacy offline analyser's mirror (ref AudioAnalysis.h)
     {
         const int C3 = 2, S = 4000, B = 513;
@@ -137,6 +229,18 @@ int main (int argc, char** argv)
         EXPECT (zc.size() == 8 && zc[0] > 0.28f && zc[0] < 0.36f);                   // a sine of 0.5 rad per sample changes sign every ~6.3 samples: 2 / 6.3
         const std::vector<fx::AudioAnalyser::HarmonicCharacteristics> hc = legacy.calculateHarmonicCharacteristics (mags.data(), B);
         EXPECT (hc.size() == 2 && hc[0].f0 == hc[1].f0 && std::fabs (hc[0].f0 - 25.0f * 24000.0f / 513.0f) < 1.0f);   // the comb's spacing
+        // round 4: full-spectrum characteristics (state kept: the second call's flux is 0), slope, auto-correlation peak
+        const std::vector<fx::AudioAnalyser::SpectralCharacteristics> sc1 = legacy.calculateSpectralCharacteristics (mags.data(), B);
+        const std::vector<fx::AudioAnalyser::SpectralCharacteristics> sc2 = legacy.calculateSpectralCharacteristics (mags.data(), B);
+        EXPECT (sc1.size() == 2 && sc1[0].flux > 0.0f && sc2[0].flux == 0.0f && sc1[0].centroid == sc2[0].centroid && sc1[0].centroid > 0.4f && sc1[0].centroid < 0.6f);
+        const std::vector<float> slope = legacy.calculateNormalisedSpectralSlope (mags.data(), B);
+        EXPECT (slope.size() == 2 && slope[0] == slope[1] && std::isfinite (slope[0]));
+        std::vector<float> items ((size_t) C3 * 64 * 2, 0.1f);
+        items[2 * 9] = 3.0f; items[2 * 9 + 1] = 4.0f;                                 // channel 0: item 9 -> 25
+        items[(size_t) 64 * 2 + 2 * 30] = -2.0f;                                      // channel 1: item 30 -> 4.01
+        std::vector<int> peaks;
+        const std::vector<double> freq = legacy.analyseAutoCorrelation (items.data(), 64, &peaks);
+        EXPECT (peaks[0] == 9 && peaks[1] == 30 && items[2 * 9] == 25.0f && items[2 * 9 + 1] == 0.0f && freq[0] == 9 * (24000.0 / 64) + 24000.0 / 128);
     }
     std::printf (failures ? "host_mirror --gpu: %d failure(s)\n" : "host_mirror --gpu: ok\n", failures);
     return failures ? 1 : 0;
