@@ -241,6 +241,7 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     fp.lpf_b = c->lpf_b;
     fp.dyn = dyn;
     for (int i = 0; i < 18; i++) fp.first_tw[i] = c->first_tw[i];
+    fp.tw_quarter_turn = (c->tw_quarter_turn && !(c->tuning.debug_flags & 2)) ? 1 : 0;
 
     // Workgroup shape: channels per workgroup x wavefronts per channel (= frames of one channel in flight): the
     // measured-best shape for this window size, fewer waves when the call has fewer frames, fewer channels when the
@@ -526,6 +527,7 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
         fxk::fill_first_pass_twiddles(window_size, ordered.data(), c->first_tw);
         if (!fxk::first_pass_twiddles_hermitian(window_size, c->first_tw))
             return cleanup(fx_fail(FX_ERR_UNSUPPORTED, "this host's cos/sin produce a twiddle table without the mirror symmetry the kernels rely on"));
+        c->tw_quarter_turn = fxk::twiddles_have_quarter_turn(window_size, tw.data());     // (false only costs the 4096-point kernel two global reads per item)
         TRY_OR_CLEAN(hipMemcpy(c->d_tw, ordered.data(), ordered.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     // ref SpectralCharacteristics.h:180-189: binVar does not depend on the signal

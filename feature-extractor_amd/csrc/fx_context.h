@@ -65,6 +65,7 @@ struct fx_context {
     double bin_var = 0.0;
     float  lpf_a = 0.0f, lpf_b = 0.0f;
     float  first_tw[18] = {0};
+    bool   tw_quarter_turn = false;     // FrameParams::tw_quarter_turn
 
     fx_comm* comm = nullptr;      // fx_comm_create (fx_comm.cpp); null for a single-GPU context
 };

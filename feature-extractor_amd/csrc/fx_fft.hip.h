@@ -211,6 +211,43 @@ template <int N> struct Plan {
     static constexpr int OFFA = OFF2 + (R2 == 16 ? 15 : 3) * L2;
 };
 
+// COMPACT twiddle image (the 4096-point frame kernel): 24 KB instead of the pass-ordered table's 32, which together with the flux
+// state left in global memory is what an EIGHTH wavefront's transform buffer needs (160 KB = 24 KB + 8 x 17 KB).  The last pass's
+// fifteen rows of L2 = 256 entries (row i of item k: i < 3 the first stage tw[4*k*(i+1)], i = 3 + 3*jin + (q-1) the second stage
+// tw[(k + 256*jin) * q]) shrink to eleven because the q = 1 rows of the four jin are one contiguous run -- tw[0 .. 1023], the first
+// quarter of the reference's table -- and the q = 2 rows are the same run's even entries (2*k + 512*jin) for jin < 2 and a QUARTER
+// TURN of those for jin = 2, 3: tw[j + N/4] = (y, -x) of tw[j] = (x, y) -- IF the float table has that symmetry.  The host checks the
+// entries concerned (FrameParams::tw_quarter_turn); should it ever not hold, those two rows are read from the whole table in global
+// memory instead (slower, same values).  The run is stored even entries first, odd entries behind them and 16 entries (32 banks)
+// further on: the q = 2 rows then read consecutive entries, and of the q = 1 rows' 32 lanes per LDS pass the even ones fall on one
+// half of the banks and the odd ones on the other.  The 16-entry gap holds the workgroup's hand-over counters (FrameLds).
+//   [0, 240)      the second pass's 15 * L1 entries, as in the pass-ordered table
+//   [240, 1008)   S : rows 0, 1, 2
+//   [1008, 2048)  Q1: tw[j] at q1_pos(j) = j/2 + (j odd ? 528 : 0), j < 1024; [1008 + 512, 1008 + 528) free
+//   [2048, 3072)  R3: the q = 3 rows, tw[3*k + 768*jin]
+struct TwGlobal { const f2* table; bool quarter_turn; };       // the pass-ordered table in global memory
+template <int N> struct CompactTw {
+    typedef Plan<N> PL;
+    static constexpr int L2 = PL::L2;
+    static constexpr int Q1_GAP = 16;
+    static constexpr int OFF_S = 15 * PL::L1, OFF_Q1 = OFF_S + 3 * L2, OFF_GAP = OFF_Q1 + 2 * L2, OFF_R3 = OFF_Q1 + 4 * L2 + Q1_GAP, ENTRIES = OFF_R3 + 4 * L2;
+    __host__ __device__ static constexpr int q1_pos(int j) { return (j >> 1) + ((j & 1) ? 2 * L2 + Q1_GAP : 0); }
+    // where entry e of the image comes from in the pass-ordered table (the kernel's prologue copies it from there)
+    __host__ __device__ static constexpr int source(int e)
+    {
+        if (e < OFF_S)  return PL::OFF1 + e;
+        if (e < OFF_Q1) return PL::OFF2 + (e - OFF_S);                                               // rows 0..2 are contiguous
+        if (e < OFF_R3) {
+            const int pos = e - OFF_Q1;
+            if (pos >= 2 * L2 && pos < 2 * L2 + Q1_GAP) return -1;                                   // the gap: not a twiddle
+            const int j = pos < 2 * L2 ? 2 * pos : 2 * (pos - 2 * L2 - Q1_GAP) + 1;                  // tw[j]: row 3 + 3*(j / 256) of the table
+            return PL::OFF2 + (3 + 3 * (j / L2)) * L2 + j % L2;
+        }
+        return PL::OFF2 + (5 + 3 * ((e - OFF_R3) / L2)) * L2 + (e - OFF_R3) % L2;
+    }
+};
+static_assert(CompactTw<4096>::ENTRIES == 3072 && CompactTw<4096>::OFF_S == 240 && CompactTw<4096>::q1_pos(1) == 528 && CompactTw<4096>::q1_pos(1022) == 511, "compact twiddle image");
+
 // offset of element i of an item inside the padded complex image, relative to cpad(base):
 // cpad(base + L0*i) - cpad(base) is a compile-time constant because base = blk*(R*L0) + k, k < L0
 __host__ __device__ constexpr int item_off(int L0, int i) { return L0 * i + (L0 >= 16 ? (L0 / 16) * i : ((L0 * i) >> 4)); }
@@ -655,9 +692,10 @@ template <int N> struct LazyLag {
 //   last pass   : 16-element items at stride L2 = N/16, GB items per lane: item k = lane + 64*g reads positions
 //                 k + L2*i, produced as element i' of second-pass items with (k'' + L1*i') mod L2 = k, i.e. by
 //                 elements i' < 8 for the first half of the g's and i' >= 8 for the second half.
-template <int N, bool INV, int OUT>
+// CTW: `tw` is the compact image (CompactTw<N>), `tg` the whole table in global memory.
+template <int N, bool INV, int OUT, bool CTW = false>
 __device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, const float (&ftw)[18],
-                                           int lane, float scale, float* regs_out, const TwRegs<N>* twr)
+                                           int lane, float scale, float* regs_out, const TwRegs<N>* twr, TwGlobal tg = TwGlobal{nullptr, false})
 {
     typedef Geo<N> G;
     typedef Plan<N> PL;
@@ -746,6 +784,24 @@ __device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cb
         for (int gl = 0; gl < HB; gl++) {
             const int g = h * HB + gl, k = lane + 64 * g;
             if constexpr (TwRegs<N>::USE_C) { const f2 (&wr)[15] = twr->c[g]; item16_last<INV, OUT>(ec[gl], [&](int i) { return wr[i]; }, g == 0); }
+            else if constexpr (CTW) {
+                static_assert(!TwRegs<N>::USE, "compact image: twiddles from LDS");
+                typedef CompactTw<N> CT;
+                const f2* ts = tw + CT::OFF_S + k;
+                const f2* q1 = tw + CT::OFF_Q1 + CT::q1_pos(k);           // tw[k + 256*jin] sits 128 entries further per jin (256 is even)
+                const f2* q2 = tw + CT::OFF_Q1 + k;                        // tw[2*k + 512*jin]: entry k + 256*jin of the even half
+                const f2* r3 = tw + CT::OFF_R3 + k;
+                item16_last<INV, OUT>(ec[gl], [&](int i) -> f2 {
+                    if (i < 3) return ts[i * L2];
+                    const int jin = (i - 3) / 3, q = (i - 3) % 3 + 1;
+                    if (q == 1) return q1[jin * (L2 / 2)];
+                    if (q == 3) return r3[jin * L2];
+                    if (jin < 2) return q2[jin * L2];
+                    if (!tg.quarter_turn) return tg.table[PL::OFF2 + k + i * L2];
+                    const f2 t = q2[(jin - 2) * L2];
+                    return f2{t.y, -t.x};
+                }, g == 0);
+            }
             else { const f2* t2 = tw + PL::OFF2 + k; item16_last<INV, OUT>(ec[gl], [&](int i) { return t2[i * L2]; }, g == 0); }
             last_item_reduce<N, OUT>(ec[gl], k, scale, res[g], aux);
             if (OUT == OUT_LAG && g == 0) { const float d = ec[0][0].y * scale; aux = d * d * (float) N; }
@@ -767,13 +823,15 @@ __device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cb
 }
 
 // Whole transform of one wavefront: P real inputs per lane (first-pass order) -> OUT (see above).
-template <int N, bool INV, int OUT>
+template <int N, bool INV, int OUT, bool CTW = false>
 __device__ __forceinline__ float fft_from_regs(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, const float (&ftw)[18],
-                                               int lane, float scale = 0.0f, float* regs_out = nullptr, const TwRegs<N>* twr = nullptr)
+                                               int lane, float scale = 0.0f, float* regs_out = nullptr, const TwRegs<N>* twr = nullptr,
+                                               TwGlobal tg = TwGlobal{nullptr, false})
 {
     typedef Plan<N> PL;
+    static_assert(!CTW || Geo<N>::SPLIT, "the compact twiddle image belongs to a split transform");
     if constexpr (Geo<N>::SPLIT) {
-        return fft_split<N, INV, OUT>(xin, cbuf, tw, ftw, lane, scale, regs_out, twr);
+        return fft_split<N, INV, OUT, CTW>(xin, cbuf, tw, ftw, lane, scale, regs_out, twr, tg);
     } else {
         fft_first_pass<N, INV>(xin, cbuf, ftw, lane);
         fft_pass<N, PL::R1, PL::L1, PL::OFF1, INV, RealExchange<N>::USE>(cbuf, tw, lane);

@@ -290,8 +290,21 @@ template <int N> struct Occ {
     //   4096 points   : 1 x 7 (the 160 KB to the byte)    -> 2 per SIMD at most, <= 256 VGPRs (the split transform keeps a
     //                   lane's 64 second-pass results in registers)
     static constexpr int WAVES_PER_SIMD = N <= 512 ? 8 : (N <= 1024 ? 4 : 2);
-    static constexpr int MAX_THREADS = N <= 2048 ? 512 : 448;
+    static constexpr int MAX_THREADS = 512;
 };
+
+// The frame kernel's LDS, shared with the host's size computation (fx_kernels.hip, lds_bytes_t).
+template <int N> struct FrameLds {
+    static constexpr bool WIDE = N == 4096;
+    static constexpr int TW_ENTRIES = WIDE ? CompactTw<N>::ENTRIES : N;
+    static constexpr int WIDE_TURN_ENTRY = WIDE ? CompactTw<N>::OFF_GAP : 0;      // [channels <= 8][2] ints in the image's 128-byte gap
+    __host__ __device__ static constexpr int prev_floats(bool direct) { return (direct || WIDE) ? 0 : Geo<N>::BIMG + (Geo<N>::BQ ? 0 : 4); }
+    __host__ __device__ static constexpr size_t bytes(int ch, int k, bool direct)
+    {
+        return sizeof(f2) * TW_ENTRIES + (size_t) ch * sizeof(float) * prev_floats(direct) + (size_t) ch * k * Geo<N>::BUF_BYTES;
+    }
+};
+static_assert(FrameLds<4096>::bytes(1, 8, false) <= 160 * 1024 && FrameLds<4096>::bytes(8, 1, true) <= 160 * 1024, "eight 4096-point wavefronts per CU");
 
 // One wavefront's view of the frame it is analysing: where its buffers are and the constants every section
 // uses.  The member functions are the sections of the reference's two run() loops in the order the kernel
@@ -300,12 +313,16 @@ template <int N> struct Occ {
 // element is read once and written once, there is no next frame in this launch to hand it to, and without the LDS copy a
 // workgroup is eight channels with nothing but a transform buffer each -- 16 wavefronts per CU at 1024 points instead of 12.
 // HOIST: two of the re-materialisation points are transparent (FX_OPQ).
-template <int N, bool DIRECT = false, bool HOIST = false> struct FrameWave {
+// WIDE: the frame kernel's 4096-point layout -- the flux state stays in global memory for calls of any length (handed from frame to
+// frame through the `turn` counter, as the LDS image is elsewhere) and `tw` is the compact twiddle image (CompactTw): what it takes
+// to give a CU an eighth wavefront at this size.
+template <int N, bool DIRECT = false, bool HOIST = false, bool WIDE = false> struct FrameWave {
     typedef Geo<N> G;
     static constexpr int M = G::M, P = G::P, U = G::U, HALF = N / 2;
 
     const FrameParams& p;
-    const f2* tw;       // [N] pass-ordered twiddles (workgroup LDS)
+    const f2* tw;       // [N] pass-ordered twiddles (workgroup LDS); WIDE: the compact image
+    __device__ __forceinline__ TwGlobal tw_global() const { return TwGlobal{reinterpret_cast<const f2*>(p.tw), p.tw_quarter_turn != 0}; }
     const TwRegs<N>* twr;   // the lane's second- / last-pass twiddles in registers (2048 points), else unused
     float* prev;        // [M] re of the channel's last accepted spectral frame (workgroup LDS)
     int*   turn;        // index of the frame whose turn it is to read / replace `prev`
@@ -527,7 +544,7 @@ FX_MARK("spec_fft");
                     xw[g * G::RA + j] = xr[g * G::RA + j] * gain;
                 }
             }
-            spec_aux = fft_from_regs<N, false, OUT_RE_LOW_MAXABS>(xw, cbuf, tw, p.first_tw, lane, 0.0f, nullptr, twr);   // a4
+            spec_aux = fft_from_regs<N, false, OUT_RE_LOW_MAXABS, WIDE>(xw, cbuf, tw, p.first_tw, lane, 0.0f, nullptr, twr, tw_global());   // a4
         }
         FX_STOP(6, FX_KEEP(spec_aux); return);
 FX_MARK("spec_sums");
@@ -591,6 +608,16 @@ FX_MARK("flux");
                     float* state = p.prev_re + (size_t) c * M + U * lane;              // the lane's U bins, coalesced (16-byte pieces from 512 points on)
                     lds_load_block<U>(state, pvf);                                      // (plain wide loads / stores: global memory here)
                     if (accepted) lds_store_block<U>(state, re);                        // :138 (only on the accepted path)
+                } else if constexpr (WIDE) {
+                    // the same in global memory, in turn: the wavefronts of a workgroup share their CU's vector cache, so workgroup-scope
+                    // acquire / release order the state's loads and stores between them (the release waits for the stores)
+                    while (__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t)
+                        __builtin_amdgcn_s_sleep(1);
+                    float* state = p.prev_re + (size_t) c * M + U * lane;
+                    lds_load_block<U>(state, pvf);
+                    if (accepted) lds_store_block<U>(state, re);                        // :138
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) __hip_atomic_store(turn, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
                     // (the hand-over costs 2 % of the kernel, and not because of the length of this section: round 2)
                     while (__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t)
@@ -671,7 +698,7 @@ FX_MARK("harm1");
         // ---------------- harmonic analyser, part 1: raw (un-windowed) spectrum ---------------------
         // ref RealTimeAnalyser.h:161
         lane = FX_OPQ(2, lane);
-        fft_from_regs<N, false, OUT_RE_LOW>(xr, cbuf, tw, p.first_tw, lane, 0.0f, nullptr, twr);
+        fft_from_regs<N, false, OUT_RE_LOW, WIDE>(xr, cbuf, tw, p.first_tw, lane, 0.0f, nullptr, twr, tw_global());
         {
             const int b0 = U * lane;
             const float* relin = reinterpret_cast<const float*>(cbuf);
@@ -854,7 +881,7 @@ FX_MARK("pitch_fft");
         // a11 getComplexConjugateMultiplication, ref PitchAnalyser.h:83-108: re*re, imag := 0, delivered in the order the
         // inverse transform's first pass wants it
         float xp[P];
-        fft_from_regs<N, false, OUT_POWER>(xf, cbuf, tw, p.first_tw, lane, 0.0f, xp, twr);  // ref RealTimeAnalyser.h:160
+        fft_from_regs<N, false, OUT_POWER, WIDE>(xf, cbuf, tw, p.first_tw, lane, 0.0f, xp, twr, tw_global());  // ref RealTimeAnalyser.h:160
         FX_STOP(3, for (int j = 0; j < P; j++) FX_KEEP(xp[j]); return 1.0);
 FX_MARK("power");
         lane = FX_OPQ(7, lane);
@@ -880,7 +907,7 @@ FX_MARK("ifft");
             lag = lag_search<true>(lane, vreg, 0.0f, &lz);
         } else
         {
-            const float v_end = fft_from_regs<N, true, OUT_LAG>(xf, cbuf, tw, p.first_tw, lane, scale, vreg, twr);   // a12 inverse, ref :110-121
+            const float v_end = fft_from_regs<N, true, OUT_LAG, WIDE>(xf, cbuf, tw, p.first_tw, lane, scale, vreg, twr, tw_global());   // a12 inverse, ref :110-121
             lag = lag_search<false>(lane, vreg, v_end, nullptr);
         }
         if (lane == 0) fpl->lag = lag;
@@ -1035,12 +1062,14 @@ fx_frame_kernel(const FrameParams p_arg)
     // One workgroup = CH channels x K waves (K frames of a channel in flight), sharing one twiddle table.  LDS:
     //   twiddles [N] | CH x { bins image of the channel's flux state (+ its hand-over counter) } | one buffer per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int PREV_FLOATS = DIRECT ? 0 : G::BIMG + (G::BQ ? 0 : 4);
+    //   WIDE (4096 points): compact twiddle image, the hand-over counters (8 bytes per channel) in its gap | one buffer per wave
+    constexpr bool WIDE = FrameLds<N>::WIDE;
+    constexpr int PREV_FLOATS = FrameLds<N>::prev_floats(DIRECT);
     constexpr size_t WAVE_BYTES = G::BUF_BYTES;
     const int CH = p.ch_per_wg, K = p.waves_per_ch;
-    f2*    tw    = reinterpret_cast<f2*>(smem);                             // [N]
+    f2*    tw    = reinterpret_cast<f2*>(smem);                             // [N], or the compact image
     f2*    tw_lds = tw;
-    float* prev0 = reinterpret_cast<float*>(tw_lds + N);
+    float* prev0 = reinterpret_cast<float*>(tw_lds + FrameLds<N>::TW_ENTRIES);
     unsigned char* per_wave = reinterpret_cast<unsigned char*>(prev0 + (size_t) CH * PREV_FLOATS);
 
     // (the wavefront's index is wave-uniform by construction; saying so keeps everything derived from it -- channel, frame index,
@@ -1070,12 +1099,18 @@ fx_frame_kernel(const FrameParams p_arg)
     float* prev = prev0 + (size_t) chl * PREV_FLOATS;   // bins image: re of the channel's last accepted frame
     // the hand-over counter lives in the first padding gap of the bins image when there is one (4096 points fills the
     // 160 KB to the byte with 7 waves), else behind it
-    int*   turn = reinterpret_cast<int*>(G::BQ ? prev + G::U : prev + G::BIMG);
+    int*   turn = WIDE ? reinterpret_cast<int*>(tw_lds + FrameLds<N>::WIDE_TURN_ENTRY) + 2 * chl : reinterpret_cast<int*>(G::BQ ? prev + G::U : prev + G::BIMG);
     f2*    cbuf = reinterpret_cast<f2*>(per_wave + WAVE_BYTES * wave);
     float* rbuf = reinterpret_cast<float*>(cbuf);      // the same memory viewed as the real image
 
     // workgroup prologue: twiddle table + the channels' flux state into LDS
-    for (int i = threadIdx.x; i < N; i += blockDim.x) tw_lds[i] = reinterpret_cast<const f2*>(p.tw)[i];
+    if constexpr (WIDE) {
+        typedef CompactTw<N> CT;
+        const f2* table = reinterpret_cast<const f2*>(p.tw);
+        for (int i = threadIdx.x; i < CT::ENTRIES; i += blockDim.x) { const int from = CT::source(i); if (from >= 0) tw_lds[i] = table[from]; }
+    } else {
+        for (int i = threadIdx.x; i < N; i += blockDim.x) tw_lds[i] = reinterpret_cast<const f2*>(p.tw)[i];
+    }
     if (chunk > 0) {
         // the flux state comes from the chunk before, written by another workgroup (another CU): its count, then an
         // agent-scope acquire, then the barrier (MI355X guide: one relaxed poll -> one acquire -> vmcnt(0) -> barrier ->
@@ -1095,7 +1130,8 @@ fx_frame_kernel(const FrameParams p_arg)
         __syncthreads();
     }
     if (live && !DIRECT) {
-        for (int i = lane0 + 64 * slot; i < M; i += 64 * K) prev[bimg<N>(i)] = p.prev_re[(size_t) c * M + i];
+        if constexpr (!WIDE)
+            for (int i = lane0 + 64 * slot; i < M; i += 64 * K) prev[bimg<N>(i)] = p.prev_re[(size_t) c * M + i];
         if (lane0 == 0 && slot == 0) { turn[0] = t_begin; turn[1] = t_begin; }
     }
     __syncthreads();
@@ -1128,7 +1164,7 @@ fx_frame_kernel(const FrameParams p_arg)
         // in every lane for the whole frame
         FramePart* fpl = p.part + ((size_t) c * T + t);
         if (lane == 0) fpl->flags = 0;            // the harmonic tail sets it; the other fields are read only where written
-        const FrameWave<N, DIRECT, HOIST> w{p, tw, &twr, prev, turn, cbuf, rbuf, fpl, nyquist, rnyq, frpb, scale, c, T, t};
+        const FrameWave<N, DIRECT, HOIST, WIDE> w{p, tw, &twr, prev, turn, cbuf, rbuf, fpl, nyquist, rnyq, frpb, scale, c, T, t};
 
         const double ssq_lane = w.load_frame(lane);
         float xr[P];
@@ -1155,7 +1191,7 @@ fx_frame_kernel(const FrameParams p_arg)
         }
         FX_STOP(6, continue); FX_STOP(7, continue); FX_STOP(8, continue); FX_STOP(9, continue); FX_STOP(10, continue);
         if constexpr (HARM) {
-            typename FrameWave<N, DIRECT, HOIST>::HarmonicSpectrum hs;
+            typename FrameWave<N, DIRECT, HOIST, WIDE>::HarmonicSpectrum hs;
             if constexpr (G::SPLIT) w.load_raw(lane, xr);
             w.harmonic_spectrum(lane, xr, hs);
             FX_STOP(11, FX_KEEP(hs.sum); FX_KEEP(hs.max); FX_KEEP(hs.left2); FX_KEEP(hs.left1); FX_KEEP(hs.right1); for (int j = 0; j < G::U; j++) FX_KEEP(hs.hre[j]); continue);
@@ -1165,8 +1201,9 @@ fx_frame_kernel(const FrameParams p_arg)
 
     if constexpr (DIRECT) return;                       // (the flux state was replaced in place)
     __syncthreads();
-    if (live)
-        for (int i = lane0 + 64 * slot; i < M; i += 64 * K) p.prev_re[(size_t) c * M + i] = prev[bimg<N>(i)];
+    if constexpr (!WIDE)                                // (WIDE: in place as well)
+        if (live)
+            for (int i = lane0 + 64 * slot; i < M; i += 64 * K) p.prev_re[(size_t) c * M + i] = prev[bimg<N>(i)];
     if (chunk + 1 < p.num_chunks) {
         // hand the flux state to the next chunk's workgroup: every storing wave's stores done, the barrier, one lane's
         // agent-scope release, then the count (MI355X guide, producer form)

@@ -98,8 +98,7 @@ hipError_t launch_hop_kernel(int n, const FrameParams& p, const EpilogueParams& 
 // ---------------------------------------------------------------------------------------------
 template <int N> static size_t lds_bytes_t(int ch, int k, bool direct = false)
 {
-    typedef Geo<N> G;
-    return sizeof(f2) * N + (direct ? 0 : (size_t) ch * sizeof(float) * (G::BIMG + (G::BQ ? 0 : 4))) + (size_t) ch * k * G::BUF_BYTES;
+    return FrameLds<N>::bytes(ch, k, direct);
 }
 
 
@@ -230,6 +229,18 @@ bool first_pass_twiddles_hermitian(int n, const float* t)
         && t[16] == t[5] && t[17] == t[4];              // W^9 = i * conj(W^3)
 }
 
+// The 4096-point frame kernel's compact twiddle image forms last-pass rows 10 and 13 -- tw[2*k + 1024] and tw[2*k + 1536], k < 256 --
+// as quarter turns of rows 4 and 7, tw[2*k] and tw[2*k + 512] (fx_fft.hip.h, CompactTw).  Exact cosines have that symmetry; the
+// float table has it wherever libm's cos and sin round consistently, which is checked here entry by entry, not assumed.
+bool twiddles_have_quarter_turn(int n, const float* canonical)
+{
+    if (n != 4096) return true;
+    const f2* c = reinterpret_cast<const f2*>(canonical);
+    for (int j = 0; j < 1024; j += 2)
+        if (!(c[j + 1024].x == c[j].y && c[j + 1024].y == -c[j].x)) return false;
+    return true;
+}
+
 void fill_first_pass_twiddles(int n, const float* ordered, float* out18)
 {
     switch (n) {
@@ -274,7 +285,7 @@ void frame_kernel_preferred_shape(int n, int* ch, int* k)
 {
     if (n <= 1024)      { *ch = 1; *k = 8; }
     else if (n == 2048) { *ch = 1; *k = 4; }
-    else                { *ch = 1; *k = 7; }
+    else                { *ch = 1; *k = 8; }
 }
 
 size_t frame_kernel_lds_bytes(int n, int ch, int k, bool direct_state)

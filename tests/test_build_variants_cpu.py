@@ -57,5 +57,5 @@ def test_public_header_is_free_of_diagnostics():
     text = open(os.path.join(ROOT, "include", "fx.h")).read()
     for word in ("stamp", "FX_PAIR_STAMPS", "fx_debug_"):
         assert word not in text, word
-    # the one debug bit that stays is the forced hand-over time-out the tests use
+    # what stays is one field with two test bits: the forced hand-over time-out and the 4096-point kernel's twiddle fallback
     assert text.count("debug_flags") == 1

@@ -82,6 +82,28 @@ def test_failed_handover_between_work_units_is_reported(gpu_fx):
         assert np.array_equal(got[k], good[k], equal_nan=True)
 
 
+def test_4096_twiddle_fallback_gives_the_same_bits(gpu_fx):
+    """The 4096-point frame kernel keeps 24 KB of its 32 KB of twiddles in LDS and forms two rows of the last pass as quarter
+    turns of two others, which the float table allows on this host (fx_create checks it entry by entry).  A host where it
+    does not reads those rows from the whole table in global memory: forced here (fx_tuning::debug_flags bit 1), batch calls
+    and one-frame calls (the kernel that leaves the flux state in global memory) -- same values, so the same bits."""
+    import torch
+    C, T, N = 20, 19, 4096
+    hops = np.concatenate([signals.bursts(C, 10, N, seed=5), signals.low_tones(C, T - 10, N)], axis=1)
+    a, b = gpu_fx.BatchAnalyser(C, N), gpu_fx.BatchAnalyser(C, N)
+    b.set_tuning(debug_flags=2)
+    for an in (a, b):
+        an.set_tuning(one_hop_kernel=0)
+    ra, rb = a.push_hops(hops[:, :12]), b.push_hops(hops[:, :12])
+    for k in (0, 1):
+        assert np.array_equal(ra[k], rb[k], equal_nan=True)
+    for t in range(12, T):                               # one frame per call through the batch kernels
+        ra, rb = a.push_hops(hops[:, t:t + 1]), b.push_hops(hops[:, t:t + 1])
+        for k in (0, 1):
+            assert np.array_equal(ra[k], rb[k], equal_nan=True)
+    assert ra[0][:, 0, 2].max() > 0                      # (F0 slot: the analysers did run)
+
+
 @pytest.mark.parametrize("N,C", [(1024, 300), (2048, 130), (4096, 40)])
 def test_one_frame_calls_run_the_hop_kernel_and_equal_the_batch_kernels(gpu_fx, oracle, N, C):
     """One frame per channel per call -- the reference's own cadence (ref AudioDataCollector.h:66-94, RealTimeAnalyser.h:
