@@ -234,6 +234,7 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     fp.tail_out = c->d_tail[c->cur ^ 1];
     fp.prev_re = c->d_prev;
     fp.tw = c->d_tw;
+    fp.tw_image = c->d_tw + 2 * (size_t) c->N;
     fp.part = part;
     fp.nyquist = c->sample_rate / 2.0;          // ref RealTimeAudioAnalysis.h:251, RealTimeAnalyser.h:113
     fp.bin_var = c->bin_var;
@@ -271,14 +272,15 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
         // With the flux state in global memory (direct), up to 1024 points as many as a workgroup may hold (1024 points: 8 channels =
         // 76 KB, two workgroups and 16 wavefronts per CU -- what the LDS holds of the batch shape too); at the split sizes the registers
         // allow 8 wavefronts per CU whatever the shape, and a CU does better with two workgroups of four (staggered) than with one of
-        // eight in lockstep, until there are so many channels that the workgroup count stops mattering.  Measured, us per call of one hop
-        // per channel, channels per workgroup 4 / 8 (7 at 4096 points) -- profiles/r04_live_cadence.txt:
+        // eight in lockstep (2048 points), or with one workgroup of eight from the channel count at which every CU has one (4096 points,
+        // whose eight wavefronts are all a CU holds).  Measured, us per call of one hop per channel, channels per workgroup 4 / 8 --
+        // profiles/r04_live_cadence.txt:
         //   1024 points  4096 ch 43.4 / 39.1   8192 ch 66.6 / 63.3   16384 ch 116.8 / 111.1
         //   2048 points  2048 ch 44.8 / 43.2   4096 ch 72.0 / 73.0    8192 ch 125.4 / 133.6
-        //   4096 points  1024 ch 58.5 / 67.2   2048 ch 102.5 / 117.7  4096 ch 195.0 / 176.4
+        //   4096 points  1024 ch 61.7 / 71.0   2048 ch 108.7 / 75.7   4096 ch 205.4 / 139.6
         // Without the direct form (one analyser only): four (2048 points, 4096 channels x 1 hop 152 us against 193 us with one).
         if (T == 1 && !st->pair && c->tuning.channels_per_workgroup < 1)
-            ch = !direct ? 4 : (c->N <= 1024 ? kcap : (c->N == 2048 ? 4 : (c->C >= 4096 ? kcap : 4)));
+            ch = !direct ? 4 : (c->N <= 1024 ? kcap : (c->N == 2048 ? 4 : (c->C >= 2048 ? kcap : 4)));
         if (ch > c->C) ch = c->C;
         while (ch > 1 && (ch * k > kcap || lds_bytes(ch, k) > lds_cu)) ch--;
         while (k > 1 && lds_bytes(ch, k) > lds_cu) k--;
@@ -503,7 +505,7 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
     TRY_OR_CLEAN(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (int i = 0; i < 3; i++) TRY_OR_CLEAN(hipEventCreate(&c->ev[i]));
     const size_t half = (size_t) num_channels * (window_size / 2);
-    TRY_OR_CLEAN(hipMalloc((void**) &c->d_tw, sizeof(float) * 2 * window_size));
+    TRY_OR_CLEAN(hipMalloc((void**) &c->d_tw, sizeof(float) * 4 * window_size));      // the pass-ordered table, then the frame kernel's LDS image of it
     TRY_OR_CLEAN(hipMalloc((void**) &c->d_prev, sizeof(float) * half));
     for (int i = 0; i < 2; i++) TRY_OR_CLEAN(hipMalloc((void**) &c->d_tail[i], sizeof(float) * half));
     TRY_OR_CLEAN(hipMalloc((void**) &c->d_hist, sizeof(float) * (size_t) num_channels * fxk::HLEN * FX_NUM_FEATURES));
@@ -529,6 +531,9 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
             return cleanup(fx_fail(FX_ERR_UNSUPPORTED, "this host's cos/sin produce a twiddle table without the mirror symmetry the kernels rely on"));
         c->tw_quarter_turn = fxk::twiddles_have_quarter_turn(window_size, tw.data());     // (false only costs the 4096-point kernel two global reads per item)
         TRY_OR_CLEAN(hipMemcpy(c->d_tw, ordered.data(), ordered.size() * sizeof(float), hipMemcpyHostToDevice));
+        std::vector<float> image(ordered.size(), 0.0f);
+        fxk::build_twiddle_image(window_size, ordered.data(), image.data());
+        TRY_OR_CLEAN(hipMemcpy(c->d_tw + ordered.size(), image.data(), image.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     // ref SpectralCharacteristics.h:180-189: binVar does not depend on the signal
     {

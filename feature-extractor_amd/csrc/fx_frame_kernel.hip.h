@@ -287,8 +287,9 @@ template <int N> struct Occ {
     //                   +6 % at 512 points over 4 waves per SIMD, round 3: the kernels are bound by latency, not by issue)
     //   1024 points   : 1 x 8, two workgroups per CU      -> 4 waves per SIMD, <= 128 VGPRs (all the LDS holds)
     //   2048 points   : 3 x 4 = 12 waves, one workgroup   -> 3 per SIMD, <= 168 VGPRs
-    //   4096 points   : 1 x 7 (the 160 KB to the byte)    -> 2 per SIMD at most, <= 256 VGPRs (the split transform keeps a
-    //                   lane's 64 second-pass results in registers)
+    //   4096 points   : 1 x 8 (the 160 KB to the byte: 24 KB of twiddles -- CompactTw -- and eight 17 KB buffers, the flux state
+    //                   in global memory; until round 4 seven wavefronts beside the whole 32 KB table and the state's LDS image)
+    //                   -> 2 per SIMD, <= 256 VGPRs (the split transform keeps a lane's 64 second-pass results in registers)
     static constexpr int WAVES_PER_SIMD = N <= 512 ? 8 : (N <= 1024 ? 4 : 2);
     static constexpr int MAX_THREADS = 512;
 };
@@ -1097,17 +1098,19 @@ fx_frame_kernel(const FrameParams p_arg)
     const int t_end = p.num_chunks > 1 ? p_arg.chunk_begin[chunk + 1] : T;
 
     float* prev = prev0 + (size_t) chl * PREV_FLOATS;   // bins image: re of the channel's last accepted frame
-    // the hand-over counter lives in the first padding gap of the bins image when there is one (4096 points fills the
-    // 160 KB to the byte with 7 waves), else behind it
+    // the hand-over counter lives in the first padding gap of the bins image when there is one, else behind it; 4096 points, which
+    // has no state image (WIDE), keeps its counters in the gap of the compact twiddle image
     int*   turn = WIDE ? reinterpret_cast<int*>(tw_lds + FrameLds<N>::WIDE_TURN_ENTRY) + 2 * chl : reinterpret_cast<int*>(G::BQ ? prev + G::U : prev + G::BIMG);
     f2*    cbuf = reinterpret_cast<f2*>(per_wave + WAVE_BYTES * wave);
     float* rbuf = reinterpret_cast<float*>(cbuf);      // the same memory viewed as the real image
 
     // workgroup prologue: twiddle table + the channels' flux state into LDS
     if constexpr (WIDE) {
+        // (the image as the host laid it out -- build_twiddle_image; its gap holds the hand-over counters, set below)
         typedef CompactTw<N> CT;
-        const f2* table = reinterpret_cast<const f2*>(p.tw);
-        for (int i = threadIdx.x; i < CT::ENTRIES; i += blockDim.x) { const int from = CT::source(i); if (from >= 0) tw_lds[i] = table[from]; }
+        const f2* image = reinterpret_cast<const f2*>(p.tw_image);
+        for (int i = threadIdx.x; i < CT::ENTRIES; i += blockDim.x)
+            if (i < CT::OFF_GAP || i >= CT::OFF_GAP + CT::Q1_GAP) tw_lds[i] = image[i];
     } else {
         for (int i = threadIdx.x; i < N; i += blockDim.x) tw_lds[i] = reinterpret_cast<const f2*>(p.tw)[i];
     }
@@ -1144,12 +1147,13 @@ fx_frame_kernel(const FrameParams p_arg)
     const double frpb = nyquist / (double) M;          // ref SpectralCharacteristics.h:64,105
     const float  scale = 1.0f / (float) N;             // JUCE inverse scale
 
-    // Which frame a wavefront takes next.  Round robin (frame slot, slot + K, ...) where the workgroup's wavefronts are spread evenly
-    // over the SIMDs.  At 4096 points a CU holds SEVEN wavefronts -- 2 + 2 + 2 + 1 -- and the one that has a SIMD to itself runs
-    // ahead of the six that share: there the wavefronts CLAIM frames, in order, from a counter beside the hand-over counter (`turn[1]`;
-    // the frame before any claimed frame has been claimed by a wavefront that is running, so the flux hand-over cannot deadlock).
-    // Which wavefront analyses a frame changes no arithmetic.  Measured (profiles/r04_4096.txt): 1024 channels x 64 frames 1.785 -> 1.652 ms
-    // (+7.8 %); at 2048 / 1024 points, whose 8 / 16 wavefronts per CU sit evenly on the SIMDs, -0.3 % / +0.5 %: not used there.
+    // Which frame a wavefront takes next.  Round robin (frame slot, slot + K, ...) at most sizes.  At 4096 points the wavefronts CLAIM
+    // frames, in order, from a counter beside the hand-over counter (`turn[1]`; the frame before any claimed frame has been claimed by
+    // a wavefront that is running, so the flux hand-over cannot deadlock): a frame's time depends on its data (the lag search), a
+    // wavefront gets through eight frames or fewer per call at the bench shape, and with two wavefronts per SIMD nothing else evens a
+    // slow one out.  Which wavefront analyses a frame changes no arithmetic.  Measured (profiles/r04_4096.txt), 1024 channels x 64 frames:
+    // seven wavefronts per CU (2 + 2 + 2 + 1 on the SIMDs) 1.785 -> 1.652 ms, eight 1.718 -> 1.593 ms; at 2048 / 1024 points, with 8 / 16
+    // wavefronts per CU and more frames each, -0.3 % / +0.5 %: not used there.
     constexpr bool CLAIM = (N == 4096) && !DIRECT;
     auto next_frame = [&](int t_now) -> int {
         if constexpr (!CLAIM) return t_now + K;

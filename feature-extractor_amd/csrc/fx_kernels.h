@@ -93,6 +93,7 @@ struct FrameParams {
     double       bin_var;       // sum_i (i/M - 0.5)^2 / M, summed serially on the host (ref SpectralCharacteristics.h:182-189)
     float        lpf_a, lpf_b;  // ref RealTimeAudioAnalysis.h:122
     const DynParams* dyn;       // non-null in a captured step: overrides gain and nyquist
+    const float* tw_image;      // 4096 points: the frame kernel's compact LDS image of `tw` (build_twiddle_image), copied as it is
     int          tw_quarter_turn;   // 4096 points: canonical[j + N/4] == (canonical[j].y, -canonical[j].x) bit for bit for the entries the
                                 // frame kernel's compact twiddle image derives that way (twiddles_have_quarter_turn); 0: it reads them from `tw`
     float        first_tw[18];  // the <= 9 twiddles of the first FFT pass (re, im pairs): wave-uniform, so they travel as
@@ -142,6 +143,9 @@ void build_pass_twiddles(int window_size, const float* canonical, float* out);
 // the first pass's constants, taken from the same pass-ordered table
 void fill_first_pass_twiddles(int window_size, const float* pass_ordered, float* out18);
 bool first_pass_twiddles_hermitian(int window_size, const float* first18);   // must hold before any launch
+// FrameParams::tw_image: the frame kernel's LDS twiddle image where it is not the pass-ordered table itself (4096 points: CompactTw,
+// fx_fft.hip.h).  Returns the number of complex entries written to `out` (room for window_size), 0 where the kernel copies `tw`.
+int build_twiddle_image(int window_size, const float* pass_ordered, float* out);
 // FrameParams::tw_quarter_turn for this table (the reference's N-entry table, canonical order); true where the kernel does not ask
 bool twiddles_have_quarter_turn(int window_size, const float* canonical);
 

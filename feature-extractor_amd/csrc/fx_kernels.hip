@@ -241,6 +241,17 @@ bool twiddles_have_quarter_turn(int n, const float* canonical)
     return true;
 }
 
+int build_twiddle_image(int n, const float* ordered, float* out)
+{
+    if (n != 4096) return 0;
+    typedef CompactTw<4096> CT;
+    static_assert(CT::ENTRIES <= 4096, "the image fits the room of a table");
+    const f2* t = reinterpret_cast<const f2*>(ordered);
+    f2* o = reinterpret_cast<f2*>(out);
+    for (int e = 0; e < CT::ENTRIES; e++) { const int from = CT::source(e); o[e] = from >= 0 ? t[from] : f2{0.0f, 0.0f}; }
+    return CT::ENTRIES;
+}
+
 void fill_first_pass_twiddles(int n, const float* ordered, float* out18)
 {
     switch (n) {
@@ -280,7 +291,7 @@ int frame_kernel_max_waves(int n)
 
 // Measured on MI355X (see Occ<N>): up to 1024 points 1 channel x 8 waves (two workgroups per CU); 2048: 1 x 4 (two
 // workgroups, 8 waves per CU: 12 waves as 3 x 4, 2 x 6 or 4 x 3 in one workgroup measured within 4 % of it, the LDS
-// pipe and VALU issue being co-limiting by then); 4096: 1 x 7.
+// pipe and VALU issue being co-limiting by then); 4096: 1 x 8 (FrameLds<4096>: all the LDS holds).
 void frame_kernel_preferred_shape(int n, int* ch, int* k)
 {
     if (n <= 1024)      { *ch = 1; *k = 8; }

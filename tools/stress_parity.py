@@ -20,7 +20,7 @@ THREADS = usable_cores()
 from stress_signals import make_signal  # noqa: E402
 
 
-def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
+def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True, windows=(256, 512, 1024, 1024, 2048, 2048, 4096)):
     """Returns (cases, frames, mismatching cases, worst finite relative error)."""
     rng = np.random.default_rng(seed)
     t_end = time.time() + seconds
@@ -33,7 +33,7 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
     pcm_cases = [0]
     last_note = time.time()
     while time.time() < t_end and (max_cases is None or cases < max_cases):
-        N = int(rng.choice([256, 512, 1024, 1024, 2048, 2048, 4096]))
+        N = int(rng.choice(list(windows)))
         C = int(rng.integers(1, 24)) if rng.random() < 0.8 else int(rng.integers(24, 200))
         rt = rng.random()
         T = int(rng.integers(1, 40)) if rt < 0.85 else (int(rng.integers(40, 130)) if rt < 0.95 else int(rng.integers(128, 330)))
@@ -129,7 +129,8 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True):
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    cases, frames, bad_cases, worst = run(seconds, seed)
+    kw = dict(windows=tuple(int(v) for v in sys.argv[3].split(","))) if len(sys.argv) > 3 else {}      # e.g. 4096  or  2048,4096
+    cases, frames, bad_cases, worst = run(seconds, seed, **kw)
     print("stress: %d cases, %d frames, %d mismatching cases, worst finite rel err %.3e" % (cases, frames, bad_cases, worst))
 
 
