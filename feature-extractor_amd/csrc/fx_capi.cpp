@@ -420,12 +420,14 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     // ONE frame per channel -- the reference's own cadence, an analysis per hop as it arrives (AudioDataCollector.h:66-94,
     // RealTimeAnalyser.h:201-234) -- is one launch of fx_hop_kernel: three wavefronts per channel (pitch / spectral /
     // harmonic) and the hop's tail, instead of one wavefront per channel and a second launch.
-    // (measured, tools/live_cadence.py, profiles/r04_live_cadence.txt: once the call holds more than ~a million samples -- 1024 channels of
-    // 1024 points, 512 of 2048, 256 of 4096 -- the chip is full either way and the batch kernels take over: one wavefront per channel with
-    // the flux state left in global memory (prepare_step), then the fused tail on a quarter wavefront per channel: 63 against 120 us at
-    // 8192 channels x 1024-pt, 58 against 95 us at 1024 channels x 4096-pt; below it the hop kernel wins, 19.9 against 22.9 us at 1024 x 1024-pt)
+    // (measured, tools/live_cadence.py, profiles/r04_live_cadence.txt: once the call holds more than the chip takes in one round of
+    // workgroups -- 1024 channels of 1024 points, 512 of 2048, and 1024 of 4096 since a 4096-point workgroup is 80 KB and a CU holds two --
+    // the batch kernels take over: one wavefront per channel with the flux state left in global memory (prepare_step), then the fused
+    // tail on a quarter wavefront per channel: 63 against 120 us at 8192 channels x 1024-pt, 76 against 186 us at 2048 channels x 4096-pt;
+    // below it the hop kernel wins, 19.9 against 22.9 us at 1024 x 1024-pt, 58.7 against 61.8 us at 1024 x 4096-pt.  The pair family's
+    // hop kernel -- six wavefronts and 100 KB per channel -- keeps 2^20 at every size)
     const bool one_hop = T == 1 && step.analysers == 3 && fxk::hop_kernel_available(c->N) &&
-                         (c->tuning.one_hop_kernel == 1 || (c->tuning.one_hop_kernel < 0 && (long long) c->C * c->N <= (1ll << 20)));
+                         (c->tuning.one_hop_kernel == 1 || (c->tuning.one_hop_kernel < 0 && (long long) c->C * c->N <= ((c->N == 4096 && !step.hop_pairs) ? (1ll << 22) : (1ll << 20))));
     if (one_hop) {
         const fxk::HopSignal none = {nullptr, nullptr, 0u, 0u, nullptr};
         FX_EV(e0);

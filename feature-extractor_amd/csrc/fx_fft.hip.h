@@ -787,10 +787,13 @@ __device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cb
             else if constexpr (CTW) {
                 static_assert(!TwRegs<N>::USE, "compact image: twiddles from LDS");
                 typedef CompactTw<N> CT;
-                const f2* ts = tw + CT::OFF_S + k;
-                const f2* q1 = tw + CT::OFF_Q1 + CT::q1_pos(k);           // tw[k + 256*jin] sits 128 entries further per jin (256 is even)
-                const f2* q2 = tw + CT::OFF_Q1 + k;                        // tw[2*k + 512*jin]: entry k + 256*jin of the even half
-                const f2* r3 = tw + CT::OFF_R3 + k;
+                // (two per-lane addresses for all of a lane's items: everything else is a compile-time offset -- item k = lane + 64*g)
+                const f2* at_lane = tw + lane;
+                const f2* at_half = tw + CT::q1_pos(lane);
+                const f2* ts = at_lane + (CT::OFF_S + 64 * g);
+                const f2* q1 = at_half + (CT::OFF_Q1 + 32 * g);           // q1_pos(lane + 64*g); tw[k + 256*jin] sits 128 entries further per jin
+                const f2* q2 = at_lane + (CT::OFF_Q1 + 64 * g);           // tw[2*k + 512*jin]: entry k + 256*jin of the even half
+                const f2* r3 = at_lane + (CT::OFF_R3 + 64 * g);
                 item16_last<INV, OUT>(ec[gl], [&](int i) -> f2 {
                     if (i < 3) return ts[i * L2];
                     const int jin = (i - 3) / 3, q = (i - 3) % 3 + 1;

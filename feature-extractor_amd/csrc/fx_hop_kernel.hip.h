@@ -15,11 +15,13 @@
 // pinned host memory, next to the results, which the kernel also writes there directly.  No second launch, no graph,
 // no event: the critical path is the pitch estimate plus the harmonic tail.
 
+// The flux state is read and replaced where it lives, in global memory, by the one wavefront that uses it (FrameWave's DIRECT
+// form, as in one-frame calls of the frame kernel), and 4096 points keeps the frame kernel's 24 KB twiddle image (WIDE / CompactTw)
+// instead of the 32 KB table: a 4096-point workgroup is 80 KB, so a CU holds TWO -- 512 channels per round of the chip instead of 256.
 template <int N> struct HopGeo {
     typedef Geo<N> G;
-    static constexpr int    PREV_FLOATS = G::BIMG + (G::BQ ? 0 : 4);
-    static constexpr size_t OFF_PREV = sizeof(f2) * N;
-    static constexpr size_t OFF_WAVES = OFF_PREV + sizeof(float) * PREV_FLOATS;
+    static constexpr bool   WIDE = FrameLds<N>::WIDE;
+    static constexpr size_t OFF_WAVES = sizeof(f2) * FrameLds<N>::TW_ENTRIES;
     static constexpr size_t OFF_PART = OFF_WAVES + 3 * (size_t) G::BUF_BYTES;
     static constexpr size_t OFF_HIST = OFF_PART + sizeof(FramePart);
     static constexpr size_t OFF_RAW = OFF_HIST + sizeof(float) * HLEN * FX_NUM_FEATURES;
@@ -29,7 +31,9 @@ template <int N> struct HopGeo {
 };
 
 template <int N>
-__global__ void __launch_bounds__(192, 1)
+// (4096 points: two workgroups per CU, so <= 256 VGPRs -- the harmonic wave, which is not the one the hop waits for, then keeps
+// six register pairs of its transform in scratch, 52 bytes per lane; measured 34.1 -> 32.6 us per hop all the same)
+__global__ void __launch_bounds__(192, HopGeo<N>::WIDE ? 2 : 1)
 fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSignal sig)
 {
     FrameParams p = p_arg;
@@ -38,8 +42,6 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
     constexpr int M = G::M, P = G::P;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     f2*    tw   = reinterpret_cast<f2*>(smem);
-    float* prev = reinterpret_cast<float*>(smem + HG::OFF_PREV);
-    int*   turn = reinterpret_cast<int*>(G::BQ ? prev + G::U : prev + G::BIMG);
     FramePart* part = reinterpret_cast<FramePart*>(smem + HG::OFF_PART);
     float* s_hist = reinterpret_cast<float*>(smem + HG::OFF_HIST);
     float* s_raw  = reinterpret_cast<float*>(smem + HG::OFF_RAW);
@@ -51,20 +53,17 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
     f2*    cbuf = reinterpret_cast<f2*>(smem + HG::OFF_WAVES + (size_t) G::BUF_BYTES * wave);
     float* rbuf = reinterpret_cast<float*>(cbuf);
 
-    // prologue: twiddle table, the channel's flux state, the history of raw values -- 16 bytes per lane per load, all
-    // of them issued before the first is used (this is one trip to memory, not twenty)
+    // prologue: twiddles and the history of raw values -- 16 bytes per lane per load, all of them issued before the first is
+    // used (this is one trip to memory, not twenty)
     {
-        const uint4* src = reinterpret_cast<const uint4*>(p.tw);
+        const uint4* src = reinterpret_cast<const uint4*>(HG::WIDE ? p.tw_image : p.tw);
         uint4* dst = reinterpret_cast<uint4*>(tw);
 #pragma unroll 4
-        for (int i = threadIdx.x; i < N / 2; i += 192) dst[i] = src[i];
-        const f4* ps = reinterpret_cast<const f4*>(p.prev_re + (size_t) c * M);
-#pragma unroll 2
-        for (int i = threadIdx.x; i < M / 4; i += 192) *reinterpret_cast<f4*>(&prev[bimg<N>(4 * i)]) = ps[i];   // 4 | U: a group stays whole
+        for (int i = threadIdx.x; i < FrameLds<N>::TW_ENTRIES / 2; i += 192) dst[i] = src[i];
         const uint4* hs4 = reinterpret_cast<const uint4*>(ep_arg.hist + (size_t) c * HLEN * FX_NUM_FEATURES);     // the channel's ring, row for row
         for (int i = threadIdx.x; i < HLEN * FX_NUM_FEATURES / 4; i += 192) reinterpret_cast<uint4*>(s_hist)[i] = hs4[i];
     }
-    if (threadIdx.x == 0) { turn[0] = 0; part->flags = 0; }
+    if (threadIdx.x == 0) part->flags = 0;
     if (sig.stage) {
         // the hop itself: out of the pinned host slot into device memory, 16 bytes per lane, once
         const size_t hop_bytes = (size_t) (N / 2) * (size_t) sample_bytes(p.sample_format);
@@ -78,12 +77,13 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
     TwRegs<N> twr;
     if constexpr (TwRegs<N>::USE) twr.load(tw, lane);
     const double nyquist = p.nyquist;
-    const FrameWave<N> w{p, tw, &twr, prev, turn, cbuf, rbuf, part, nyquist, 1.0 / nyquist, nyquist / (double) M,
-                         1.0f / (float) N, c, 1, 0};
+    typedef FrameWave<N, true, false, HG::WIDE> Wave;
+    const Wave w{p, tw, &twr, nullptr, nullptr, cbuf, rbuf, part, nyquist, 1.0 / nyquist, nyquist / (double) M,
+                 1.0f / (float) N, c, 1, 0};
 
     // every wave assembles the window in its own buffer (a1): three reads of the same 2-8 KB, two of them from L2
     const double ssq_lane = w.load_frame(lane);
-    typename FrameWave<N>::HarmonicSpectrum hs;
+    typename Wave::HarmonicSpectrum hs;
     if (wave == 0) {
         (void) w.pitch(lane);                                   // leaves the lag in the record
     } else if (wave == 1) {
@@ -133,8 +133,7 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
             s_raw[FX_F0] = out[FX_F0]; s_raw[FX_HER] = out[FX_HER]; s_raw[FX_OER] = out[FX_OER]; s_raw[FX_INHARM] = out[FX_INHARM];
         }
     }
-    __syncthreads();                                            // the record is complete, the flux state is final
-    for (int i = threadIdx.x; i < M; i += blockDim.x) p.prev_re[(size_t) c * M + i] = prev[bimg<N>(i)];
+    __syncthreads();                                            // the record is complete
     if (wave != 0) return;
 
     // the rest of the hop -- smoothing, onset, history -- as fx_tail_fused_kernel does it for T = 1, from LDS, one slot per lane

@@ -207,7 +207,7 @@ typedef struct fx_tuning {
     int stream_hop_kernel;       /* FX_STREAM_HOP_KERNEL: 0 forbids the one-launch hop kernel in the ring; -1 = when it applies */
     int stream_zero_copy;        /* FX_STREAM_ZEROCOPY: 1 / 0 force / forbid zero-copy slots in the captured step; -1 = by size */
     int one_hop_kernel;          /* FX_ONE_HOP_KERNEL: 0 / 1 = fx_push_hops / fx_process_frames of ONE frame per channel never / always run
-                                    the one-launch hop kernel; -1 = where it is the faster of the two (channels x window <= 2^20 samples) */
+                                    the one-launch hop kernel; -1 = where it is the faster of the two (channels x window <= 2^20 samples; 2^22 for 4096-point windows on the default family) */
     int call_timing;             /* FX_CALL_TIMING: whether an analysis call records the three events fx_last_kernel_ms() reads: 1 / 0 = every /
                                     no call; -1 = calls of more than one frame per channel (a one-frame call is the live, latency-critical
                                     case, and the events cost it 13 of its 27 us back to back: each is a barrier packet between launches).
