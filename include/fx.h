@@ -165,7 +165,7 @@ fx_status fx_last_kernel_ms(fx_context* ctx, float* frame_kernel_ms, float* epil
  * tens of megabytes); results return in submission order.
  * With hops_per_batch == 1 -- the reference's own cadence, one analysis per hop as it arrives -- a
  * submit is ONE kernel launch that reads the hop from the pinned slot, writes the vectors back to it
- * and raises a flag that fx_stream_collect() polls (34 us per 4096-sample window on MI355X; 29 us
+ * and raises a flag that fx_stream_collect() polls (32-33 us per 4096-sample window on MI355X; 29 us
  * with FX_LOW_LATENCY). */
 typedef struct fx_stream fx_stream;
 fx_status fx_stream_create(fx_context* ctx, int hops_per_batch, int slots, int sample_format, fx_stream** out);

@@ -171,7 +171,7 @@ private:
 // spins until a hop is there): a ring of pinned host batches of `hopsPerBatch` hops per channel (fx_stream_*).  The producer writes into
 // nextSlot() and submit()s it -- or push()es a batch from ordinary memory, copied by `fillThreads` host threads inside the library --
 // and collect()s the results in submission order; samples in, kernels and results back overlap.  One hop per batch is the reference's
-// own cadence: a submit is then ONE kernel launch and collect() polls a flag (34 us round trip for a 4096-point window on MI355X).
+// own cadence: a submit is then ONE kernel launch and collect() polls a flag (32-33 us round trip for a 4096-point window on MI355X).
 // Destroy the ring before its analyser.
 class HopRing
 {
