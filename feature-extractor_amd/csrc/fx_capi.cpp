@@ -437,9 +437,23 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     } else {
         if (step.fp.num_chunks > 1) HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned) * (1 + (size_t) c->C), c->stream));
         FX_EV(e0);
-        HIP_TRY(launch_frames(c, step));
-        FX_EV(e1);
-        HIP_TRY(fxk::launch_epilogue_kernels(step.ep, c->stream));
+        // One frame per channel through the batch kernels: frames and tails in ONE launch (fx_frame_tail_kernel) while the chip holds all
+        // of the call's workgroups at once -- two per CU at these sizes, one of eight channels at 4096 points.  Beyond that a workgroup whose
+        // first wavefronts are finishing its hops keeps the LDS the next workgroup is waiting for, and the tail is better off as a launch
+        // of its own.  Measured (us per call, one launch / two; profiles/r04_live_cadence.txt): 1024 points 2048 channels 26.8 / 28.6, 4096
+        // channels 41.0 / 41.7, 8192 channels 70.2 / 68.2; 2048 points 2048 channels 44.9 / 45.7, 4096 channels 77.5 / 73.8; windows of 512
+        // points and fewer lose either way (4096 channels 34.7 / 33.2): their frames are no longer than the tail.
+        const long long groups = ((long long) c->C + step.fp.ch_per_wg - 1) / step.fp.ch_per_wg;
+        const long long one_round = (long long) c->compute_units * ((c->N == 4096 && step.fp.ch_per_wg > 4) ? 1 : 2);
+        const bool one_launch = step.fp.direct_state && ((c->tuning.debug_flags & 8) || (!(c->tuning.debug_flags & 4) && c->N >= 1024 && groups <= one_round));
+        if (one_launch) {
+            HIP_TRY(fxk::launch_frame_tail_kernel(c->N, step.fp, step.ep, c->stream));
+            FX_EV(e1);
+        } else {
+            HIP_TRY(launch_frames(c, step));
+            FX_EV(e1);
+            HIP_TRY(fxk::launch_epilogue_kernels(step.ep, c->stream));
+        }
         FX_EV(e2);
     }
 #undef FX_EV
@@ -488,6 +502,7 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
 
     fx_context* c = new (std::nothrow) fx_context();
     if (!c) return fx_fail(FX_ERR_OUT_OF_MEMORY, "host allocation failed");
+    if (prop.multiProcessorCount > 0) c->compute_units = prop.multiProcessorCount;
     c->device = device_id;
     c->C = num_channels;
     c->N = window_size;

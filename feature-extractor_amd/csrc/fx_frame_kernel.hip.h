@@ -1051,9 +1051,9 @@ FX_MARK("harm2");
 // RealTimeHarmonicAnalyser -- both by default, as AnalyserTrackController constructs them)
 // DIRECT: calls of one frame per channel (FrameWave): p.T == 1, p.waves_per_ch == 1, a workgroup is p.ch_per_wg channels, no flux
 // state in LDS.
-template <int N, bool SPEC, bool HARM, bool DIRECT = false>
-__global__ void __launch_bounds__(Occ<N>::MAX_THREADS, Occ<N>::WAVES_PER_SIMD)
-fx_frame_kernel(const FrameParams p_arg)
+// (the kernel's body as a device function: fx_frame_tail_kernel -- fx_tail_kernels.hip.h -- runs it too and finishes the hop itself)
+template <int N, bool SPEC, bool HARM, bool DIRECT>
+__device__ __forceinline__ void frame_kernel_body(const FrameParams& p_arg)
 {
     FrameParams p = p_arg;
     if (p.dyn) { p.gain = p.dyn->gain; p.nyquist = p.dyn->nyquist; }         // captured step (hipGraph): per-call scalars
@@ -1219,4 +1219,11 @@ fx_frame_kernel(const FrameParams p_arg)
             __hip_atomic_store(p.queue + 1 + c, (unsigned) (chunk + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+}
+
+template <int N, bool SPEC, bool HARM, bool DIRECT = false>
+__global__ void __launch_bounds__(Occ<N>::MAX_THREADS, Occ<N>::WAVES_PER_SIMD)
+fx_frame_kernel(const FrameParams p_arg)
+{
+    frame_kernel_body<N, SPEC, HARM, DIRECT>(p_arg);
 }

@@ -55,9 +55,7 @@ namespace fxk {
 #if FX_PART == 0 || FX_PART == 2 || FX_PART == 3
 #include "fx_pair_kernel.hip.h"
 #endif
-#if FX_PART != 2
-#include "fx_tail_kernels.hip.h"
-#endif
+#include "fx_tail_kernels.hip.h"        // (device functions everywhere; the tail kernels themselves where FX_WITH_TAIL_KERNELS is defined)
 #if FX_PART == 0 || FX_PART == 3
 #include "fx_hop_kernel.hip.h"
 #endif
@@ -115,7 +113,10 @@ template <int N> hipError_t prepare_t()
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, false, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, true, true, true>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, true, true, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_tail_kernel<N>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -132,6 +133,19 @@ template <int N> hipError_t launch_t(const FrameParams& p, int analysers, hipStr
     else if (analysers == 1) hipLaunchKernelGGL((fx_frame_kernel<N, true, false>), grid, block, lds, stream, p);
     else if (analysers == 2) hipLaunchKernelGGL((fx_frame_kernel<N, false, true>), grid, block, lds, stream, p);
     else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// one frame per channel and the hop's tail in one launch (fx_frame_tail_kernel): p as for the DIRECT frame kernel
+template <int N> hipError_t launch_tail_t(const FrameParams& p, const EpilogueParams& ep, hipStream_t stream)
+{
+    if (!p.direct_state || p.T != 1 || ep.T != 1 || ep.analysers != 3 || p.waves_per_ch != 1 || p.num_chunks > 1) return hipErrorInvalidValue;
+    size_t lds = lds_bytes_t<N>(p.ch_per_wg, 1, true);
+    const size_t tail = sizeof(f2) * FrameLds<N>::TW_ENTRIES + (size_t) ((p.ch_per_wg + TAIL_CHANNELS - 1) / TAIL_CHANNELS) * ONE_HOP_TAIL_BYTES;
+    if (tail > lds) lds = tail;                               // (small windows: the transform buffers are smaller than a tail's ring copies)
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    const dim3 grid((unsigned) ((p.C + p.ch_per_wg - 1) / p.ch_per_wg)), block((unsigned) p.ch_per_wg * 64);
+    hipLaunchKernelGGL((fx_frame_tail_kernel<N>), grid, block, lds, stream, p, ep);
     return hipGetLastError();
 }
 
@@ -176,11 +190,15 @@ extern template hipError_t prepare_t<2048>();
 extern template hipError_t prepare_t<4096>();
 extern template hipError_t launch_t<2048>(const FrameParams&, int, hipStream_t);
 extern template hipError_t launch_t<4096>(const FrameParams&, int, hipStream_t);
+extern template hipError_t launch_tail_t<2048>(const FrameParams&, const EpilogueParams&, hipStream_t);
+extern template hipError_t launch_tail_t<4096>(const FrameParams&, const EpilogueParams&, hipStream_t);
 #elif FX_PART == 2
 template hipError_t prepare_t<2048>();
 template hipError_t prepare_t<4096>();
 template hipError_t launch_t<2048>(const FrameParams&, int, hipStream_t);
 template hipError_t launch_t<4096>(const FrameParams&, int, hipStream_t);
+template hipError_t launch_tail_t<2048>(const FrameParams&, const EpilogueParams&, hipStream_t);
+template hipError_t launch_tail_t<4096>(const FrameParams&, const EpilogueParams&, hipStream_t);
 #endif
 
 #if FX_PART != 2
@@ -337,6 +355,20 @@ hipError_t launch_frame_kernel(int n, const FrameParams& p, int analysers, hipSt
         case 1024: return launch_t<1024>(p, analysers, stream);
         case 2048: return launch_t<2048>(p, analysers, stream);
         case 4096: return launch_t<4096>(p, analysers, stream);
+        default:   return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_frame_tail_kernel(int n, const FrameParams& p, const EpilogueParams& ep, hipStream_t stream)
+{
+    if (p.C <= 0) return hipSuccess;
+    if (p.ch_per_wg < 1 || p.ch_per_wg > frame_kernel_max_waves(n)) return hipErrorInvalidValue;
+    switch (n) {
+        case 256:  return launch_tail_t<256>(p, ep, stream);
+        case 512:  return launch_tail_t<512>(p, ep, stream);
+        case 1024: return launch_tail_t<1024>(p, ep, stream);
+        case 2048: return launch_tail_t<2048>(p, ep, stream);
+        case 4096: return launch_tail_t<4096>(p, ep, stream);
         default:   return hipErrorInvalidValue;
     }
 }

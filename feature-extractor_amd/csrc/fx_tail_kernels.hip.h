@@ -510,30 +510,34 @@ fx_history_kernel(const EpilogueParams p_arg)
 constexpr int TAIL_GROUP = 16;                          // lanes per channel
 constexpr int TAIL_CHANNELS = 64 / TAIL_GROUP;          // channels per wavefront = per workgroup
 static_assert(FUSED_TAIL_MAX_FRAMES <= TAIL_GROUP && FX_NUM_FEATURES <= TAIL_GROUP && NUM_LOGS <= TAIL_GROUP, "a lane per frame / slot / logarithm");
-#ifdef FX_WITH_TAIL_KERNELS
-__global__ void __launch_bounds__(64)
-fx_tail_fused_kernel(const EpilogueParams p_arg)
+
+// ONE hop per channel, the four channels of a wavefront (first channel c_first): ring rows to LDS, the scalar tail by the whole group
+// straight into the LDS row, a lane per smoothed slot, this hop's row to the ring.  The wavefront's LDS: s_hist[4][HLEN * 12],
+// s_raw[4][16], s_scratch[4][64] floats (ONE_HOP_TAIL_BYTES).  Called by every lane of the wavefront; the two barriers are the
+// workgroup's (fx_tail_fused_kernel: a workgroup IS one wavefront; fx_frame_tail_kernel: its tail wavefronts all pass here).
+constexpr int ONE_HOP_TAIL_FLOATS = TAIL_CHANNELS * (HLEN * FX_NUM_FEATURES + 16 + 64);
+constexpr int ONE_HOP_TAIL_BYTES = 4 * ONE_HOP_TAIL_FLOATS;
+__device__ __forceinline__ void tail_one_hop(const EpilogueParams& p, int c_first, int lane, float* lds)
 {
-    __shared__ __attribute__((aligned(16))) float s_hist[TAIL_CHANNELS][HLEN * FX_NUM_FEATURES];
-    __shared__ float s_raw[TAIL_CHANNELS][FUSED_TAIL_MAX_FRAMES * FX_NUM_FEATURES];
-    __shared__ float s_scratch[TAIL_CHANNELS][64];
-    const EpilogueParams p = with_dyn(p_arg);
-    const int lane = threadIdx.x, g = lane / TAIL_GROUP, gl = lane % TAIL_GROUP;
-    const int c_mine = blockIdx.x * TAIL_CHANNELS + g;
+    const int g = lane / TAIL_GROUP, gl = lane % TAIL_GROUP;
+    float* s_hist = lds + g * (HLEN * FX_NUM_FEATURES);
+    float* s_raw = lds + TAIL_CHANNELS * (HLEN * FX_NUM_FEATURES) + g * 16;
+    float* s_scratch = lds + TAIL_CHANNELS * (HLEN * FX_NUM_FEATURES + 16) + g * 64;
+    const int c_mine = c_first + g;
     const bool live = c_mine < p.C;
     const int c = live ? c_mine : p.C - 1;                // a group beyond the last channel keeps in step on the last one and stores nothing
-    float* ring = p.hist + (size_t) c * HLEN * FX_NUM_FEATURES;
+    const float* ring = p.hist + (size_t) c * HLEN * FX_NUM_FEATURES;
     {
         // the LDS copy keeps the ring's row positions; rows nobody reads are not fetched (a row is 48 bytes: three 16-byte pieces)
-        const int need = hist_rows_read(p.onset_window);            // what the call's FIRST frame reaches back; later frames less
+        const int need = hist_rows_read(p.onset_window);
         for (int i = gl; i < need * 3; i += TAIL_GROUP) {
             const int r = hist_row_before(p.hist_base, -need + i / 3), q = i % 3;
-            reinterpret_cast<uint4*>(s_hist[g])[r * 3 + q] = reinterpret_cast<const uint4*>(ring)[r * 3 + q];
+            reinterpret_cast<uint4*>(s_hist)[r * 3 + q] = reinterpret_cast<const uint4*>(ring)[r * 3 + q];
         }
     }
-    if (p.T == 1) {
-        // one hop: the scalar tail by the whole group (its logarithms side by side), straight into the LDS row -- the
-        // raw vector never makes the trip through global memory
+    {
+        // the scalar tail by the whole group (its logarithms side by side), straight into the LDS row -- the raw vector never makes
+        // the trip through global memory
         const FramePart f = p.part[c];
         float out[FX_NUM_FEATURES];
         finalise_wave<TAIL_GROUP>(p, f, lane, out);
@@ -541,22 +545,75 @@ fx_tail_fused_kernel(const EpilogueParams p_arg)
             float mine = out[0];
 #pragma unroll
             for (int k = 1; k < FX_NUM_FEATURES; k++) mine = gl == k ? out[k] : mine;
-            s_raw[g][gl] = mine;
+            s_raw[gl] = mine;
         }
-    } else {
-        if (gl < p.T && live) finalise_frame(p, (long long) c * p.T + gl);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // the wave's raw values are written before any lane reads them back
-        __builtin_amdgcn_s_barrier();
-        for (int i = gl; i < p.T * FX_NUM_FEATURES; i += TAIL_GROUP) s_raw[g][i] = p.raw[(size_t) c * p.T * FX_NUM_FEATURES + i];
     }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    EpilogueParams q = p;                                 // the smoothing reads channel c's rows through (raw + c*12, hist + c*HLEN*12)
+    q.raw = s_raw - (size_t) c * FX_NUM_FEATURES;
+    q.hist = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
+    epilogue_hop<TAIL_GROUP>(q, c, lane, s_scratch, live);   // a lane per slot, the onset detector's candidates side by side
+    q.hist = p.hist;
+    if (live && gl < FX_NUM_FEATURES) history_value(q, c, 0, gl);
+}
+
+// fx_frame_kernel's one-frame form (DIRECT: one wavefront per channel, flux state in global memory) and the hop's tail in ONE launch:
+// when the frames are done, the first ceil(channels / 4) wavefronts of the workgroup finish its channels' hops as tail_one_hop does,
+// in the transform buffers nobody needs any more; the others leave.  What it buys a live call over thousands of channels is the
+// second launch and its ramp: the tails of the workgroups that finish first run beside the frames of those still at work.
+#if FX_PART != 3
+template <int N>
+__global__ void __launch_bounds__(Occ<N>::MAX_THREADS, Occ<N>::WAVES_PER_SIMD)
+fx_frame_tail_kernel(const FrameParams p, const EpilogueParams ep_arg)
+{
+    frame_kernel_body<N, true, true, true>(p);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // the frames' records (global memory) ...
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");            // ... are read below by other wavefronts of this workgroup
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    const int tail_waves = (p.ch_per_wg + TAIL_CHANNELS - 1) / TAIL_CHANNELS;
+    if (wave >= tail_waves) return;
+    const EpilogueParams ep = with_dyn(ep_arg);
+    float* lds = reinterpret_cast<float*>(smem + sizeof(f2) * FrameLds<N>::TW_ENTRIES) + (size_t) wave * ONE_HOP_TAIL_FLOATS;
+    tail_one_hop(ep, (int) blockIdx.x * p.ch_per_wg + TAIL_CHANNELS * wave, (int) (threadIdx.x & 63), lds);
+}
+#endif
+#ifdef FX_WITH_TAIL_KERNELS
+__global__ void __launch_bounds__(64)
+fx_tail_fused_kernel(const EpilogueParams p_arg)
+{
+    // [channels of the wavefront] ring copy | raw rows of the call's frames | onset scratch; one hop per call: tail_one_hop's layout
+    __shared__ __attribute__((aligned(16))) float s_all[TAIL_CHANNELS * (HLEN * FX_NUM_FEATURES + FUSED_TAIL_MAX_FRAMES * FX_NUM_FEATURES + 64)];
+    static_assert(FUSED_TAIL_MAX_FRAMES * FX_NUM_FEATURES >= 16, "tail_one_hop fits the same memory");
+    const EpilogueParams p = with_dyn(p_arg);
+    const int lane = threadIdx.x, g = lane / TAIL_GROUP, gl = lane % TAIL_GROUP;
+    if (p.T == 1) { tail_one_hop(p, blockIdx.x * TAIL_CHANNELS, lane, s_all); return; }
+    float* s_hist = s_all + g * (HLEN * FX_NUM_FEATURES);
+    float* s_raw = s_all + TAIL_CHANNELS * (HLEN * FX_NUM_FEATURES) + g * (FUSED_TAIL_MAX_FRAMES * FX_NUM_FEATURES);
+    const int c_mine = blockIdx.x * TAIL_CHANNELS + g;
+    const bool live = c_mine < p.C;
+    const int c = live ? c_mine : p.C - 1;                // a group beyond the last channel keeps in step on the last one and stores nothing
+    const float* ring = p.hist + (size_t) c * HLEN * FX_NUM_FEATURES;
+    {
+        const int need = hist_rows_read(p.onset_window);            // what the call's FIRST frame reaches back; later frames less
+        for (int i = gl; i < need * 3; i += TAIL_GROUP) {
+            const int r = hist_row_before(p.hist_base, -need + i / 3), q = i % 3;
+            reinterpret_cast<uint4*>(s_hist)[r * 3 + q] = reinterpret_cast<const uint4*>(ring)[r * 3 + q];
+        }
+    }
+    if (gl < p.T && live) finalise_frame(p, (long long) c * p.T + gl);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");           // the wave's raw values are written before any lane reads them back
+    __builtin_amdgcn_s_barrier();
+    for (int i = gl; i < p.T * FX_NUM_FEATURES; i += TAIL_GROUP) s_raw[i] = p.raw[(size_t) c * p.T * FX_NUM_FEATURES + i];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_s_barrier();
     // the smoothing reads channel c's rows through (raw + c*T*12, hist + c*HLEN*12): point those at the LDS copies
     EpilogueParams q = p;
-    q.raw = s_raw[g] - (size_t) c * p.T * FX_NUM_FEATURES;
-    q.hist = s_hist[g] - (size_t) c * HLEN * FX_NUM_FEATURES;
-    if (p.T == 1) epilogue_hop<TAIL_GROUP>(q, c, lane, s_scratch[g], live);      // one hop: a lane per slot, the onset detector's candidates side by side
-    else if (gl < p.T && live) epilogue_frame(q, c, gl);
+    q.raw = s_raw - (size_t) c * p.T * FX_NUM_FEATURES;
+    q.hist = s_hist - (size_t) c * HLEN * FX_NUM_FEATURES;
+    if (gl < p.T && live) epilogue_frame(q, c, gl);                  // a lane per frame
     // this call's rows of the ring: T <= FUSED_TAIL_MAX_FRAMES different rows, which held frames HLEN before these -- further back
     // than anything reads (hist_rows_read <= 40), and what was read went through the LDS copy above in any case
     q.hist = p.hist;

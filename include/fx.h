@@ -216,7 +216,9 @@ typedef struct fx_tuning {
                                     before it gives up and the call is reported failed (FX_ERR_HIP); 0 = default (1 << 22) */
     int debug_flags;             /* FX_DEBUG_FLAGS (tests): bit 0 = work units do not publish their hand-over (forces the time-out);
                                     bit 1 = the 4096-point kernel takes no twiddle from a quarter turn of another (the path of a host whose
-                                    cos / sin lack that symmetry: same values, read from the whole table) */
+                                    cos / sin lack that symmetry: same values, read from the whole table); bits 2 / 3 = one-frame calls through the batch
+                                    kernels never / always finish the hop's tail in the frame kernel (default: while the chip holds the call's
+                                    workgroups at once) */
 } fx_tuning;
 void fx_tuning_defaults(fx_tuning* t);     /* every knob "measured best" */
 void fx_tuning_from_env(fx_tuning* t);     /* defaults overridden by the FX_* variables set right now */

@@ -82,6 +82,34 @@ def test_failed_handover_between_work_units_is_reported(gpu_fx):
         assert np.array_equal(got[k], good[k], equal_nan=True)
 
 
+@pytest.mark.parametrize("N,C", [(256, 37), (512, 9), (1024, 21), (1024, 1), (2048, 7), (4096, 10)])
+def test_one_frame_calls_finish_their_tail_in_the_frame_kernel(gpu_fx, N, C):
+    """One frame per channel through the batch kernels is ONE launch while the chip holds the call's workgroups at once
+    (fx_frame_tail_kernel: the workgroup's first wavefronts finish its channels' hops when the frames are done), else the frame
+    kernel and the fused tail kernel.  fx_tuning::debug_flags bits 3 / 2 force the one and the other: the same bits, hop after hop, with an onset window that reaches far into the history ring, channel
+    counts that leave the last workgroup partly filled, and device buffers."""
+    import torch
+    T = 60
+    hops = np.concatenate([signals.bursts(C, T // 2, N, seed=N + C), signals.tone_vibrato_noise(C, T - T // 2, N, seed=C)], axis=1)
+    one, two = gpu_fx.BatchAnalyser(C, N), gpu_fx.BatchAnalyser(C, N)
+    one.set_tuning(debug_flags=8)
+    two.set_tuning(debug_flags=4)
+    for an in (one, two):
+        an.set_tuning(one_hop_kernel=0)
+        an.set_onset_window_length(21); an.set_onset_detection_type(2); an.set_onset_detection_sensitivity(0.4)
+    dev = torch.from_numpy(hops).cuda()
+    for t in range(T):
+        a = one.push_hops(dev[:, t:t + 1].contiguous())
+        b = two.push_hops(hops[:, t:t + 1])
+        for k in (0, 1):
+            assert np.array_equal(a[k].cpu().numpy(), b[k], equal_nan=True), (t, k)
+    assert np.array_equal(one.get_features(), two.get_features(), equal_nan=True)
+    whole = gpu_fx.BatchAnalyser(C, N)
+    whole.set_onset_window_length(21); whole.set_onset_detection_type(2); whole.set_onset_detection_sensitivity(0.4)
+    want = whole.push_hops(hops)
+    assert np.array_equal(one.get_features(), want[1][:, -1], equal_nan=True)
+
+
 def test_4096_twiddle_fallback_gives_the_same_bits(gpu_fx):
     """The 4096-point frame kernel keeps 24 KB of its 32 KB of twiddles in LDS and forms two rows of the last pass as quarter
     turns of two others, which the float table allows on this host (fx_create checks it entry by entry).  A host where it

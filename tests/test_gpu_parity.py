@@ -169,7 +169,8 @@ def test_cut_launch_with_many_channels_equals_the_uncut_one_bitwise(gpu_fx, monk
     assert np.array_equal(raw2, want[1][0], equal_nan=True) and np.array_equal(sm2, want[1][1], equal_nan=True)
 
 
-@pytest.mark.parametrize("N,shape", [(1024, (3, 2)), (1024, (2, 8)), (2048, (3, 4)), (2048, (2, 6)), (512, (4, 2))])
+@pytest.mark.parametrize("N,shape", [(1024, (3, 2)), (1024, (2, 8)), (2048, (3, 4)), (2048, (2, 6)), (512, (4, 2)),
+                                     (4096, (2, 4)), (4096, (8, 1)), (4096, (3, 2))])      # 4096: the hand-over counters of up to 8 channels share the twiddle image's gap
 def test_workgroup_shapes_give_the_same_bits(gpu_fx, monkeypatch, N, shape):
     """Channels per workgroup x waves per channel is a scheduling choice (several channels can share one workgroup's
     twiddle table in LDS): every shape must give the results of the default one bit for bit, including a last
