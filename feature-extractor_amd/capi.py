@@ -24,7 +24,7 @@ EXPORTS = ["fx_create", "fx_destroy", "fx_reset_state", "fx_set_sample_rate", "f
            "fx_stream_create", "fx_stream_destroy", "fx_stream_acquire", "fx_stream_submit", "fx_stream_push", "fx_stream_collect", "fx_stream_in_flight", "fx_pack_osc12",
            "fx_pack_osc10", "fx_osc_encode", "fx_last_error", "fx_abi_version",
            "fx_comm_unique_id", "fx_comm_create", "fx_comm_destroy", "fx_comm_layout", "fx_gather_smoothed", "fx_comm_sync", "fx_comm_stats",
-           "fx_plan_units", "fx_tuning_defaults", "fx_tuning_from_env", "fx_get_tuning", "fx_set_tuning",
+           "fx_plan_units", "fx_twiddle_symmetry", "fx_tuning_defaults", "fx_tuning_from_env", "fx_get_tuning", "fx_set_tuning",
            "fx_offline_create", "fx_offline_destroy", "fx_offline_reset", "fx_offline_sync", "fx_offline_get_previous_f0", "fx_offline_zero_crosses",
            "fx_offline_log_attack_time", "fx_offline_fft_lbp", "fx_offline_harmonic_characteristics", "fx_offline_spectral_characteristics",
            "fx_offline_get_previous_bins", "fx_offline_spectral_slope", "fx_offline_auto_correlation"]
@@ -123,6 +123,7 @@ def load_library(build_if_missing=True):
     L.fx_comm_sync.argtypes = [vp]
     L.fx_comm_stats.argtypes = [vp, ctypes.POINTER(i), ctypes.POINTER(i), ctypes.POINTER(i), ctypes.POINTER(d), ctypes.POINTER(d)]
     L.fx_plan_units.argtypes = [i, u, i, i, ctypes.POINTER(Tuning), ctypes.POINTER(i), i]
+    L.fx_twiddle_symmetry.argtypes = [i]
     L.fx_tuning_defaults.argtypes = [ctypes.POINTER(Tuning)]
     L.fx_tuning_defaults.restype = None
     L.fx_tuning_from_env.argtypes = [ctypes.POINTER(Tuning)]

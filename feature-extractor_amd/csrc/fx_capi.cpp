@@ -97,6 +97,29 @@ template <typename T> fx_status grow(T** ptr, size_t* cap, size_t need)
 // eight units of 64 at the bench shape).  fx_tuning::frames_per_unit overrides the unit (0 = never cut), fx_tuning::unit_plan
 // gives the lengths outright (experiments).  Host-only arithmetic, pure (no environment, no device): declared in
 // include/fx.h so that the CPU tests can hold it to its invariants.
+// the reference's table for a window size: phase in double, entries rounded to float (JUCE 4.2 FFT::FFTConfig)
+static std::vector<float> reference_twiddles(int window_size)
+{
+    std::vector<float> tw(2 * (size_t) window_size);
+    for (int i = 0; i < window_size; i++) {
+        const double phase = -2.0 * 3.14159265358979323846 * i / window_size;
+        tw[2 * i] = (float) std::cos(phase);
+        tw[2 * i + 1] = (float) std::sin(phase);
+    }
+    return tw;
+}
+
+extern "C" int fx_twiddle_symmetry(int window_size)
+{
+    if (!is_pow2(window_size) || window_size < 256 || window_size > 4096) return 0;
+    const std::vector<float> tw = reference_twiddles(window_size);
+    std::vector<float> ordered(tw.size());
+    float first[18];
+    fxk::build_pass_twiddles(window_size, tw.data(), ordered.data());
+    fxk::fill_first_pass_twiddles(window_size, ordered.data(), first);
+    return (fxk::first_pass_twiddles_hermitian(window_size, first) ? 1 : 0) | (fxk::twiddles_have_quarter_turn(window_size, tw.data()) ? 2 : 0);
+}
+
 extern "C" int fx_plan_units(int window_size, unsigned flags, int waves_per_channel, int num_frames, const fx_tuning* tuning, int* sizes, int cap)
 {
     const int k = waves_per_channel, T = num_frames;
@@ -243,6 +266,7 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     fp.dyn = dyn;
     for (int i = 0; i < 18; i++) fp.first_tw[i] = c->first_tw[i];
     fp.tw_quarter_turn = (c->tw_quarter_turn && !(c->tuning.debug_flags & 2)) ? 1 : 0;
+    fp.tw_at_quarter[0] = c->tw_at_quarter[0]; fp.tw_at_quarter[1] = c->tw_at_quarter[1];
 
     // Workgroup shape: channels per workgroup x wavefronts per channel (= frames of one channel in flight): the
     // measured-best shape for this window size, fewer waves when the call has fewer frames, fewer channels when the
@@ -535,18 +559,14 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
     // Twiddle table exactly as the reference's FFT builds it (JUCE 4.2 FFT::FFTConfig, SURVEY.md
     // App. A.1): phase in double, entries rounded to float.  The inverse table is its conjugate.
     {
-        std::vector<float> tw(2 * (size_t) window_size);
-        for (int i = 0; i < window_size; i++) {
-            const double phase = -2.0 * 3.14159265358979323846 * i / window_size;
-            tw[2 * i] = (float) std::cos(phase);
-            tw[2 * i + 1] = (float) std::sin(phase);
-        }
+        const std::vector<float> tw = reference_twiddles(window_size);
         std::vector<float> ordered(tw.size());
         fxk::build_pass_twiddles(window_size, tw.data(), ordered.data());    // same values, pass access order
         fxk::fill_first_pass_twiddles(window_size, ordered.data(), c->first_tw);
         if (!fxk::first_pass_twiddles_hermitian(window_size, c->first_tw))
             return cleanup(fx_fail(FX_ERR_UNSUPPORTED, "this host's cos/sin produce a twiddle table without the mirror symmetry the kernels rely on"));
-        c->tw_quarter_turn = fxk::twiddles_have_quarter_turn(window_size, tw.data());     // (false only costs the 4096-point kernel two global reads per item)
+        c->tw_quarter_turn = fxk::twiddles_have_quarter_turn(window_size, tw.data());
+        c->tw_at_quarter[0] = tw[2 * (size_t) (window_size / 4)]; c->tw_at_quarter[1] = tw[2 * (size_t) (window_size / 4) + 1];     // (false only costs the 4096-point kernel two global reads per item)
         TRY_OR_CLEAN(hipMemcpy(c->d_tw, ordered.data(), ordered.size() * sizeof(float), hipMemcpyHostToDevice));
         std::vector<float> image(ordered.size(), 0.0f);
         fxk::build_twiddle_image(window_size, ordered.data(), image.data());

@@ -66,6 +66,7 @@ struct fx_context {
     float  lpf_a = 0.0f, lpf_b = 0.0f;
     float  first_tw[18] = {0};
     bool   tw_quarter_turn = false;     // FrameParams::tw_quarter_turn
+    float  tw_at_quarter[2] = {0.0f, -1.0f};
     int    compute_units = 256;         // of this context's device (MI355X: 256)
 
     fx_comm* comm = nullptr;      // fx_comm_create (fx_comm.cpp); null for a single-GPU context

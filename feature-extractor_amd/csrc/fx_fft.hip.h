@@ -225,7 +225,9 @@ template <int N> struct Plan {
 //   [240, 1008)   S : rows 0, 1, 2
 //   [1008, 2048)  Q1: tw[j] at q1_pos(j) = j/2 + (j odd ? 528 : 0), j < 1024; [1008 + 512, 1008 + 528) free
 //   [2048, 3072)  R3: the q = 3 rows, tw[3*k + 768*jin]
-struct TwGlobal { const f2* table; bool quarter_turn; };       // the pass-ordered table in global memory
+// (One entry never has the symmetry: tw[N/4] = ((float) cos(pi/2 in double), -1) = (6.1e-17, -1), not the quarter turn (-0, -1) of
+// tw[0] = (1, -0).  It is item 0's twiddle 10 alone and travels as a kernel argument: TwGlobal::at_quarter.)
+struct TwGlobal { const f2* table; bool quarter_turn; f2 at_quarter; };       // the pass-ordered table in global memory; tw[N/4]
 template <int N> struct CompactTw {
     typedef Plan<N> PL;
     static constexpr int L2 = PL::L2;
@@ -695,7 +697,7 @@ template <int N> struct LazyLag {
 // CTW: `tw` is the compact image (CompactTw<N>), `tg` the whole table in global memory.
 template <int N, bool INV, int OUT, bool CTW = false>
 __device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, const float (&ftw)[18],
-                                           int lane, float scale, float* regs_out, const TwRegs<N>* twr, TwGlobal tg = TwGlobal{nullptr, false})
+                                           int lane, float scale, float* regs_out, const TwRegs<N>* twr, TwGlobal tg = TwGlobal{nullptr, false, f2{0.0f, 0.0f}})
 {
     typedef Geo<N> G;
     typedef Plan<N> PL;
@@ -802,6 +804,7 @@ __device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cb
                     if (jin < 2) return q2[jin * L2];
                     if (!tg.quarter_turn) return tg.table[PL::OFF2 + k + i * L2];
                     const f2 t = q2[(jin - 2) * L2];
+                    if (jin == 2 && g == 0 && lane == 0) return tg.at_quarter;         // k == 0: tw[N/4] itself
                     return f2{t.y, -t.x};
                 }, g == 0);
             }
@@ -829,7 +832,7 @@ __device__ __forceinline__ float fft_split(const float (&xin)[Geo<N>::P], f2* cb
 template <int N, bool INV, int OUT, bool CTW = false>
 __device__ __forceinline__ float fft_from_regs(const float (&xin)[Geo<N>::P], f2* cbuf, const f2* tw, const float (&ftw)[18],
                                                int lane, float scale = 0.0f, float* regs_out = nullptr, const TwRegs<N>* twr = nullptr,
-                                               TwGlobal tg = TwGlobal{nullptr, false})
+                                               TwGlobal tg = TwGlobal{nullptr, false, f2{0.0f, 0.0f}})
 {
     typedef Plan<N> PL;
     static_assert(!CTW || Geo<N>::SPLIT, "the compact twiddle image belongs to a split transform");

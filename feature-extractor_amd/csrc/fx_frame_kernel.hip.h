@@ -323,7 +323,7 @@ template <int N, bool DIRECT = false, bool HOIST = false, bool WIDE = false> str
 
     const FrameParams& p;
     const f2* tw;       // [N] pass-ordered twiddles (workgroup LDS); WIDE: the compact image
-    __device__ __forceinline__ TwGlobal tw_global() const { return TwGlobal{reinterpret_cast<const f2*>(p.tw), p.tw_quarter_turn != 0}; }
+    __device__ __forceinline__ TwGlobal tw_global() const { return TwGlobal{reinterpret_cast<const f2*>(p.tw), p.tw_quarter_turn != 0, f2{p.tw_at_quarter[0], p.tw_at_quarter[1]}}; }
     const TwRegs<N>* twr;   // the lane's second- / last-pass twiddles in registers (2048 points), else unused
     float* prev;        // [M] re of the channel's last accepted spectral frame (workgroup LDS)
     int*   turn;        // index of the frame whose turn it is to read / replace `prev`

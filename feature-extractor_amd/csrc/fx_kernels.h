@@ -96,6 +96,7 @@ struct FrameParams {
     const float* tw_image;      // 4096 points: the frame kernel's compact LDS image of `tw` (build_twiddle_image), copied as it is
     int          tw_quarter_turn;   // 4096 points: canonical[j + N/4] == (canonical[j].y, -canonical[j].x) bit for bit for the entries the
                                 // frame kernel's compact twiddle image derives that way (twiddles_have_quarter_turn); 0: it reads them from `tw`
+    float        tw_at_quarter[2];  // canonical[N/4] = ((float) cos(pi/2), -1): the one entry of those that is never a quarter turn of another
     float        first_tw[18];  // the <= 9 twiddles of the first FFT pass (re, im pairs): wave-uniform, so they travel as
                                 // kernel arguments (SGPRs) instead of LDS reads; filled by fill_first_pass_twiddles
 };

@@ -254,7 +254,7 @@ bool twiddles_have_quarter_turn(int n, const float* canonical)
 {
     if (n != 4096) return true;
     const f2* c = reinterpret_cast<const f2*>(canonical);
-    for (int j = 0; j < 1024; j += 2)
+    for (int j = 2; j < 1024; j += 2)             // (j = 0: tw[N/4] is ((float) cos(pi/2), -1), never the quarter turn (-0, -1) of tw[0]; the kernel is handed it)
         if (!(c[j + 1024].x == c[j].y && c[j + 1024].y == -c[j].x)) return false;
     return true;
 }

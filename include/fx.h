@@ -234,6 +234,15 @@ fx_status fx_set_tuning(fx_context* ctx, const fx_tuning* t);
 int fx_plan_units(int window_size, unsigned flags, int waves_per_channel, int num_frames,
                   const fx_tuning* tuning, int* sizes, int cap);
 
+/* Host-only, exposed for testing: which symmetries THIS host's cos / sin give the reference's float twiddle table
+ * (juce::FFT's table: phase in double, entries rounded to float; ref SURVEY.md App. A.1) for a window size.
+ * bit 0: the mirror symmetry of the 16-point first pass's constants -- the kernels rely on it and fx_create refuses a
+ *        host without it (FX_ERR_UNSUPPORTED);
+ * bit 1: table[j + N/4] == (table[j].im, -table[j].re) for the entries the 4096-point kernel's compact twiddle image
+ *        forms that way -- a host without it gets them read from the whole table instead (slower, same values).
+ * Sizes that use neither report the bit as set.  Pure: no device. */
+int fx_twiddle_symmetry(int window_size);
+
 /* Kernel-time accounting over a region of calls: fx_profile_begin() starts recording a HIP event
  * triple per analysis call on the context's stream (no synchronisation, at most 4096 calls);
  * fx_profile_end() synchronises and returns the summed device time of the frame kernel and of the

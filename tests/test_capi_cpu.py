@@ -85,6 +85,16 @@ def test_synth_is_deterministic_and_frames_match_hops(fx):
     assert np.array_equal(fr[:, 2, :512], a[:, 1]) and np.array_equal(fr[:, 2, 512:], a[:, 2])
 
 
+def test_this_hosts_twiddle_table_has_the_symmetries_the_kernels_use(fx):
+    """fx_twiddle_symmetry (host arithmetic, no GPU): the reference's float twiddle table as this host's cos / sin produce it.
+    Bit 0 (the 16-point first pass's mirrored constants) is required -- fx_create refuses a host without it; bit 1 (quarter
+    turns in the 4096-point table) only selects the 4096-point kernel's fast path, but a host that loses it should be noticed."""
+    lib = fx.load_library(build_if_missing=True)
+    for n in (256, 512, 1024, 2048, 4096):
+        assert lib.fx_twiddle_symmetry(n) == 3, n
+    assert lib.fx_twiddle_symmetry(1000) == 0 and lib.fx_twiddle_symmetry(8192) == 0
+
+
 def test_work_unit_plans_cover_every_frame_once(fx, monkeypatch):
     """fx_plan_units (host arithmetic, no GPU, no environment): however a call is cut into work units for the frame kernel,
     the unit lengths are positive, add up to the call's frames per channel, fit the kernel's table, and only the last unit
