@@ -288,8 +288,12 @@ def pmc_child(args):
     an = fx.BatchAnalyser(C, args.window, device=0, analysers=args.analysers)
     raw = torch.empty((C, T, 12), dtype=torch.float32, device=frames.device)
     sm = torch.empty_like(raw)
+    hops = frames.shape[2] == args.window // 2          # (tools/pmc_quick.py --hops: the overlapper's input, half a window per frame)
     for _ in range(args.warmup + args.steps):
-        an.process_frames(frames, out_raw=raw, out_smoothed=sm)
+        if hops:
+            an.push_hops(frames, out_raw=raw, out_smoothed=sm)
+        else:
+            an.process_frames(frames, out_raw=raw, out_smoothed=sm)
     an.sync()
     an.close()
 

@@ -1,6 +1,7 @@
 """On the GPU box: rocprofv3 --pmc passes (8 SQ counters; with --traffic also FETCH_SIZE and WRITE_SIZE, each in its own pass, as
 the MI355X guide prescribes) + kernel time of the frame / pair kernel at a shape, printed per frame.
-Usage: python3 tools/pmc_quick.py [--traffic] [--analysers spectral|harmonic|both] N C T [label]
+Usage: python3 tools/pmc_quick.py [--traffic] [--hops] [--analysers spectral|harmonic|both] N C T [label]
+(--hops: the input is hops through fx_push_hops -- half a window per frame, consecutive frames of a channel overlap -- instead of whole frames)
 (tuning through the FX_* environment, e.g. FX_WAVES_PER_FRAME=2).  The library is built HERE, in the parent, before any profiler
 starts: the profiled child only loads it."""
 import importlib, os, subprocess, sys, tempfile, shutil
@@ -10,7 +11,8 @@ import numpy as np
 import bench
 argv = sys.argv[1:]
 traffic = "--traffic" in argv
-argv = [a for a in argv if a != "--traffic"]
+hops = "--hops" in argv
+argv = [a for a in argv if a not in ("--traffic", "--hops")]
 analysers = "both"
 if "--analysers" in argv:
     k = argv.index("--analysers"); analysers = argv[k + 1]; del argv[k:k + 2]
@@ -18,9 +20,9 @@ N, C, T = (int(v) for v in argv[:3])
 label = argv[3] if len(argv) > 3 else ""
 fx = importlib.import_module("feature-extractor_amd")
 importlib.import_module("feature-extractor_amd.build").build()          # never under the profiler
-inp = "/tmp/fx_pq_%d_%d_%d.npy" % (N, C, T)
+inp = "/tmp/fx_pq_%d_%d_%d%s.npy" % (N, C, T, "_hops" if hops else "")
 if not os.path.exists(inp):
-    np.save(inp, fx.synth.frames(C, T, N))
+    np.save(inp, fx.synth.hops(C, T, N) if hops else fx.synth.frames(C, T, N))
 exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
 counters = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY"]
 child = [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--window", str(N), "--channels-per-gpu", str(C), "--frames", str(T),
@@ -50,11 +52,11 @@ for name, args in passes:
     shutil.rmtree(d, ignore_errors=True)
 fr = C * T
 wc = out["SQ_WAVE_CYCLES"]
-line = ("%s %s %s N=%d C=%d T=%d: %.3f ms  %.4g frames/s | per frame: VALU %.0f SALU %.0f LDS %.0f | per wave-cycle: VALU-active %.3f wait_any %.3f wait_inst %.3f | waves %d, wave-cycles/frame %.0f"
-        % (label, out["kernel"], analysers, N, C, T, out["avg_ns"] / 1e6, fr / (out["avg_ns"] / 1e9), out["SQ_INSTS_VALU"] / fr, out["SQ_INSTS_SALU"] / fr, out["SQ_INSTS_LDS"] / fr,
+line = ("%s %s %s%s N=%d C=%d T=%d: %.3f ms  %.4g frames/s | per frame: VALU %.0f SALU %.0f LDS %.0f | per wave-cycle: VALU-active %.3f wait_any %.3f wait_inst %.3f | waves %d, wave-cycles/frame %.0f"
+        % (label, out["kernel"], analysers, " hops" if hops else "", N, C, T, out["avg_ns"] / 1e6, fr / (out["avg_ns"] / 1e9), out["SQ_INSTS_VALU"] / fr, out["SQ_INSTS_SALU"] / fr, out["SQ_INSTS_LDS"] / fr,
            out["SQ_ACTIVE_INST_VALU"] / wc, out["SQ_WAIT_ANY"] / wc, out["SQ_WAIT_INST_ANY"] / wc, out["SQ_WAVES"], 4 * wc / fr))
 if traffic:
     hbm = (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0          # gfx950: FETCH_SIZE counts half the bytes of wide streaming reads
-    alg = (4 * N + 48) * fr
+    alg = ((2 * N if hops else 4 * N) + 48) * fr              # hops: every sample is new once
     line += " | HBM %.4g B per launch = %.3f x algorithmic (read %.4g, written %.4g)" % (hbm, hbm / alg, 2048.0 * out["FETCH_SIZE"], 1024.0 * out["WRITE_SIZE"])
 print(line, flush=True)
