@@ -800,7 +800,8 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
             del hops, views
         res["note"] = ("%d-pt windows, ONE hop (%d samples) per channel per call, calls back to back on the library's stream (fx_push_hops, device-resident "
                        "hops; up to 2^20 samples per call one launch of fx_hop_kernel -- three wavefronts per channel + the hop's tail -- above "
-                       "that the frame kernel with four channels per workgroup + the fused tail with a lane per slot); real_time_factor = "
+                       "that the one-frame frame kernel -- a wavefront per channel, eight channels per workgroup, flux state in global memory -- and the hops' "
+                       "tails on a quarter wavefront per channel, in the same launch while the chip holds all workgroups at once); real_time_factor = "
                        "frames/s over the frames/s that many live 48 kHz channels produce" % (N, N // 2))
         return res
 
