@@ -30,8 +30,13 @@
 __device__ __forceinline__ constexpr int sample_bytes(int fmt) { return fmt == FX_SAMPLE_F32 ? 4 : (fmt == FX_SAMPLE_S24 ? 3 : 2); }
 // a 24-bit sample left-justified in 32 bits -> float: 24 significant bits, so the conversion and the power-of-two scaling are exact
 __device__ __forceinline__ float from_left_justified(unsigned w) { return (float) (int) w * (1.0f / 2147483648.0f); }
-template <int FMT> __device__ __forceinline__ float widen_one(const void* at)
+// LAST_USE: the frame's last read of its window (the split sizes fetch it three times): a non-temporal load, so that the L2 lets go of
+// a window nobody will ask for again before it lets go of one that is between its reads.  The windows in flight on an XCD are about
+// the size of its L2 at 4096 points; measured there (1024 channels x 64 whole frames): counter traffic 2.24 -> 1.53 x the algorithmic
+// bytes, kernel 1.557 -> 1.548 ms; on overlapping hops 1.32 -> 1.21 x; 2048 points unchanged (profiles/r04_4096.txt (8)).
+template <int FMT, bool LAST_USE = false> __device__ __forceinline__ float widen_one(const void* at)
 {
+    if (LAST_USE && FMT == FX_SAMPLE_F32) return __builtin_nontemporal_load(static_cast<const float*>(at));
     if (FMT == FX_SAMPLE_F16) return __half2float(*static_cast<const __half*>(at));
     if (FMT == FX_SAMPLE_S16) return (float) (int) *static_cast<const short*>(at) * (1.0f / 32768.0f);
     if (FMT == FX_SAMPLE_S24) {
@@ -133,7 +138,7 @@ __device__ __forceinline__ double load_window(const void* src_a, const void* src
 // The same window straight from global memory into registers in the order the first FFT pass consumes it (split
 // sizes: the raw frame is not kept in registers across the four transforms; it is fetched again -- from L2 -- when
 // the spectral and the harmonic analyser need it).  For a fixed (g, j) the 64 lanes read 64 consecutive samples.
-template <int N, int FMT_A, int FMT_B>
+template <int N, int FMT_A, int FMT_B, bool LAST_USE = false>
 __device__ __forceinline__ void load_window_first_pass_order(const void* src_a, const void* src_b, float gain_a, float gain_b,
                                                              int lane, float (&x)[Geo<N>::P])
 {
@@ -154,7 +159,7 @@ __device__ __forceinline__ void load_window_first_pass_order(const void* src_a, 
             const bool second = r >= G::RA / 2;                                // low + g < ITEMS_A <= N/2
             const int k = g + G::ITEMS_A * (second ? r - G::RA / 2 : r);       // compile-time part of the sample index
             const char* at = static_cast<const char*>(second ? src_b : src_a) + (second ? off_b : off_a) + k * sample_bytes(second ? FMT_B : FMT_A);
-            x[g * G::RA + j] = second ? widen_one<FMT_B>(at) : widen_one<FMT_A>(at);
+            x[g * G::RA + j] = second ? widen_one<FMT_B, LAST_USE>(at) : widen_one<FMT_A, LAST_USE>(at);
         }
     }
     if (gain_a != 1.0f || gain_b != 1.0f) {                                   // ref AudioDataCollector.h:88 (wave-uniform)
@@ -361,11 +366,12 @@ template <int N, bool DIRECT = false, bool HOIST = false, bool WIDE = false> str
     }
 
     // split sizes: the raw window again, from global memory (L2), in first-pass order
+    template <bool LAST_USE = false>
     __device__ __forceinline__ void load_raw(int lane, float (&x)[P]) const
     {
         asm volatile("" ::: "memory");        // a fetch of its own each time: the point is not to keep x live in between
         const Sources s = sources();
-        FX_FORMATS(s.fmt_a, s.fmt_b, (load_window_first_pass_order<N, FA, FB>(s.a, s.b, s.gain_a, s.gain_b, lane, x)));
+        FX_FORMATS(s.fmt_a, s.fmt_b, (load_window_first_pass_order<N, FA, FB, LAST_USE>(s.a, s.b, s.gain_a, s.gain_b, lane, x)));
     }
 
     // returns the lane's share of the frame's sum of squares (split sizes only; otherwise sum_squares() computes it)
@@ -1196,7 +1202,7 @@ __device__ __forceinline__ void frame_kernel_body(const FrameParams& p_arg)
         FX_STOP(6, continue); FX_STOP(7, continue); FX_STOP(8, continue); FX_STOP(9, continue); FX_STOP(10, continue);
         if constexpr (HARM) {
             typename FrameWave<N, DIRECT, HOIST, WIDE>::HarmonicSpectrum hs;
-            if constexpr (G::SPLIT) w.load_raw(lane, xr);
+            if constexpr (G::SPLIT) w.template load_raw<true>(lane, xr);
             w.harmonic_spectrum(lane, xr, hs);
             FX_STOP(11, FX_KEEP(hs.sum); FX_KEEP(hs.max); FX_KEEP(hs.left2); FX_KEEP(hs.left1); FX_KEEP(hs.right1); for (int j = 0; j < G::U; j++) FX_KEEP(hs.hre[j]); continue);
             w.harmonic_tail(lane, hs, f0);
