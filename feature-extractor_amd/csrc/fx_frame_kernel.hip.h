@@ -37,6 +37,8 @@ __device__ __forceinline__ float from_left_justified(unsigned w) { return (float
 template <int FMT, bool LAST_USE = false> __device__ __forceinline__ float widen_one(const void* at)
 {
     if (LAST_USE && FMT == FX_SAMPLE_F32) return __builtin_nontemporal_load(static_cast<const float*>(at));
+    if (LAST_USE && FMT == FX_SAMPLE_S16) return (float) (int) __builtin_nontemporal_load(static_cast<const short*>(at)) * (1.0f / 32768.0f);
+    if (LAST_USE && FMT == FX_SAMPLE_F16) return __half2float(__ushort_as_half(__builtin_nontemporal_load(static_cast<const unsigned short*>(at))));
     if (FMT == FX_SAMPLE_F16) return __half2float(*static_cast<const __half*>(at));
     if (FMT == FX_SAMPLE_S16) return (float) (int) *static_cast<const short*>(at) * (1.0f / 32768.0f);
     if (FMT == FX_SAMPLE_S24) {
