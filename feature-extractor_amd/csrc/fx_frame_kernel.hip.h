@@ -628,7 +628,7 @@ FX_MARK("flux");
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     if (lane == 0) __hip_atomic_store(turn, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
-                    // (the hand-over costs 2 % of the kernel, and not because of the length of this section: round 2)
+                    // (the hand-over costs 2 % of the kernel, and not because of the length of this section: round 2, profiles/NOTEBOOK.md (ix))
                     while (__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != t)
                         __builtin_amdgcn_s_sleep(1);
                     // the turn is held for two LDS reads and two writes only: the next frame's wave is usually waiting for it
