@@ -336,6 +336,7 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     ep.nyquist = c->sample_rate / 2.0;
     ep.bin_var = c->bin_var;
     ep.window = c->N;
+    fxk::epilogue_constants(ep);
     ep.hist = c->d_hist;
     ep.hist_base = (int) (c->frames_seen % fxk::HLEN);
     ep.out_raw = d_or;

@@ -107,6 +107,12 @@ struct EpilogueParams {
     double       nyquist;
     double       bin_var;
     int          window;
+    // what every frame's scalar tail would otherwise divide out for itself, all of it a function of the call's nyquist and window alone:
+    // IEEE divisions and a square root done once on the host (the same correctly rounded values), see epilogue_constants()
+    double       frpb;          // nyquist / (window / 2)                       (ref SpectralCharacteristics.h:64,105)
+    double       inv_nyquist;   // 1.0 / nyquist
+    double       inv_bins;      // 1.0 / (window / 2): a power of two, so x * inv_bins == x / (window / 2) exactly
+    double       bin_std;       // sqrt(bin_var)                                 (ref :191)
     float*       hist;          // [C][HLEN][12] raw values of the newest HLEN frames, a RING per channel: the row of the frame with
                                 // global index g (frames since the last state reset) is g mod HLEN, so a call only writes the rows of
                                 // its own frames -- one row per channel for a one-hop call, not the whole table
@@ -156,6 +162,15 @@ int frame_kernel_max_waves(int window_size);     // the frame kernel's launch bo
 void frame_kernel_preferred_shape(int window_size, int* channels_per_wg, int* waves_per_channel);
 // Launches ceil(C / p.ch_per_wg) workgroups of p.ch_per_wg * p.waves_per_ch wavefronts; returns hipSuccess or the launch error.
 hipError_t launch_frame_kernel(int window_size, const FrameParams& p, int analysers, hipStream_t stream);
+// fills EpilogueParams::frpb .. bin_std from nyquist, window and bin_var (host and device: a captured step re-derives them from its DynParams)
+__host__ __device__ inline void epilogue_constants(EpilogueParams& p)
+{
+    const double bins = (double) (p.window / 2);
+    p.frpb = p.nyquist / bins;
+    p.inv_nyquist = 1.0 / p.nyquist;
+    p.inv_bins = 1.0 / bins;
+    p.bin_std = sqrt(p.bin_var);
+}
 hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t stream);
 // launch_frame_kernel (p.direct_state: one frame per channel, one wavefront each) and launch_epilogue_kernels in ONE launch: the
 // workgroup's first wavefronts finish its channels' hops when the frames are done (fx_frame_tail_kernel)

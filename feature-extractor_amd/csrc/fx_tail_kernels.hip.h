@@ -15,6 +15,7 @@ __device__ __forceinline__ EpilogueParams with_dyn(const EpilogueParams& in)
         p.onset_window = p.dyn->onset_window;
         p.onset_type = p.dyn->onset_type;
         p.onset_multiplier = p.dyn->onset_multiplier;
+        epilogue_constants(p);                        // (the host's are for the nyquist it knew)
     }
     return p;
 }
@@ -38,13 +39,13 @@ __device__ __forceinline__ void finalise_values(const EpilogueParams& p, const F
     for (int i = 0; i < FX_NUM_FEATURES; i++) out[i] = 0.0f;
     // a2, ref RealTimeAnalyser.h:207-208: log10 of a float, correctly rounded -- it also gates bins through eps, so it
     // must equal the CPU oracle's to the last bit (see oracle/fx_oracle.c)
-    const float rms = (float) sqrt(f.sum_sq / (double) p.window);
+    const float rms = (float) sqrt(f.sum_sq * (0.5 * p.inv_bins));               // sum / window: a power of two, the product is the quotient
     logs[LOG_RMS] = (double) (rms * 9.0f + 1.0f);
     logs[LOG_FLATNESS] = 1.0; logs[LOG_CENTROID] = 1.0; logs[LOG_HER] = 1.0; logs[LOG_INHARM] = 1.0;
 
     const bool spec = p.analysers & 1, harm = p.analysers & 2;
     // weightedMagnitudeSum (:95) from the moments: fc[m] = (m + 1/2) * frpb (:70), so sum fc * mag = frpb * (b1 + mag_sum / 2)
-    const double wsum = (nyquist / (double) M) * (f.b1 + 0.5 * f.mag_sum);
+    const double wsum = p.frpb * (f.b1 + 0.5 * f.mag_sum);
     if (spec && f.mag_sum > 0.05) {                                            // :121-123
         const float centroid = (float) (wsum / f.mag_sum);                     // :127
         const double dcnt = (double) f.cnt;
@@ -61,7 +62,7 @@ __device__ __forceinline__ void finalise_values(const EpilogueParams& p, const F
         // where that form loses too much (the frame kernel's test) the kernel has taken the sum as the reference writes it
         double var = f.var;
         if (!f.refined) {
-            const double cm = (double) centroid * (1.0 / nyquist), rm = 1.0 / (double) M;
+            const double cm = (double) centroid * p.inv_nyquist, rm = p.inv_bins;
             var = ((f.b2 + f.b1 + 0.25 * f.mag_sum) * rm - (cm + cm) * (f.b1 + 0.5 * f.mag_sum)) * rm + (cm * cm) * f.mag_sum;
         }
         out[FX_SPREAD] = (float) ((var / f.mag_sum) / (double) max_spread);    // :141
@@ -73,12 +74,12 @@ __device__ __forceinline__ void finalise_values(const EpilogueParams& p, const F
         // normedEnergy = mag / max (ref :172): the sums over bins were taken before the division
         const double rmax = 1.0 / f.max_e;
         const double se = f.mag_sum * rmax;
-        const double frpb = nyquist / (double) M;
+        const double frpb = p.frpb;
         const double s1 = (wsum - (frpb / 2.0) * f.mag_sum) / frpb;            // sum m * mag
         const double ps = s1 * rmax;                                           // :175
-        const double mean_e = se / (double) M;                                 // :177
-        const double ev = f.vsum * rmax * rmax / (double) M;                   // :187,190
-        const double bin_std = sqrt(p.bin_var), e_std = sqrt(ev);              // :191-192
+        const double mean_e = se * p.inv_bins;                                 // :177  (/ M, a power of two)
+        const double ev = f.vsum * rmax * rmax * p.inv_bins;                   // :187,190
+        const double bin_std = p.bin_std, e_std = sqrt(ev);                    // :191-192
         const double r = (ps - ((double) M * mean_e * 0.5)) / (double) ((float) M - 1.0f) * e_std * bin_std;   // :195
         out[FX_SLOPE] = (float) (r * (bin_std / e_std));                       // :198
     }
