@@ -57,6 +57,9 @@ fx_status zero_state(fx_context* c)
     for (int i = 0; i < 2; i++) HIP_TRY(hipMemsetAsync(c->d_tail[i], 0, half * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_hist, 0, (size_t) c->C * fxk::HLEN * FX_NUM_FEATURES * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_latest, 0, (size_t) c->C * FX_NUM_FEATURES * sizeof(float), c->stream));
+    // the work units' ticket counter and hand-over counts: zero between calls (a cut call's last kernel leaves them so; a call that
+    // failed half way is followed by this reset)
+    HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned) * (1 + (size_t) c->C), c->stream));
     c->frames_seen = 0;
     c->onset_reset_frame = 0;
     return FX_OK;
@@ -352,6 +355,8 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     ep.order_mode = (int) (c->flags & FX_ORDER_MASK);
     ep.analysers = st->analysers;
     ep.dyn = dyn;
+    ep.clear_queue = fp.num_chunks > 1 ? c->d_queue : nullptr;
+    ep.clear_count = 1 + c->C;
     return FX_OK;
 }
 
@@ -460,7 +465,6 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
         FX_EV(e1);
         FX_EV(e2);
     } else {
-        if (step.fp.num_chunks > 1) HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned) * (1 + (size_t) c->C), c->stream));
         FX_EV(e0);
         // One frame per channel through the batch kernels: frames and tails in ONE launch (fx_frame_tail_kernel) while the chip holds all
         // of the call's workgroups at once -- two per CU at these sizes, one of eight channels at 4096 points.  Beyond that a workgroup whose

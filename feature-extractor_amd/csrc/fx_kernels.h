@@ -129,6 +129,8 @@ struct EpilogueParams {
     int          order_mode;    // FX_ORDER_*
     int          analysers;     // bit 0: spectral analyser runs, bit 1: harmonic analyser runs
     const DynParams* dyn;       // non-null in a captured step: overrides nyquist, frames_before, hist_base, onset_*
+    unsigned*    clear_queue;   // a call cut in time (FrameParams::num_chunks > 1): its ticket counter and hand-over counts, which the step's
+    int          clear_count;   // LAST kernel zeroes for the next call (a memset per call was two fill kernels and their gaps); else null
 };
 
 // Completion signal of a one-hop call (fx_hop_kernel): workgroups count themselves in `arrivals` (device memory, zero

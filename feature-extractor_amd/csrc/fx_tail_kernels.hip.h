@@ -490,6 +490,7 @@ fx_history_kernel(const EpilogueParams p_arg)
     const EpilogueParams p = with_dyn(p_arg);
     const int rows = hist_rows_written(p.T);
     const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (p.clear_queue && idx < p.clear_count) p.clear_queue[idx] = 0u;      // (the frame kernel that used them finished before this step's tail began)
     if (idx >= (long long) p.C * rows * FX_NUM_FEATURES) return;
     const int s = (int) (idx % FX_NUM_FEATURES);
     const int h = (int) ((idx / FX_NUM_FEATURES) % rows);
