@@ -770,6 +770,10 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
             fps_p, fms_p = max(time_steps(an2, fr2, None, None, 2 * extra_steps, warmup=5) for _ in range(2))
             an2.close()
             others[str(n2)]["pair_kernel"] = {"value": fps_p, "unit": "frames/s", "frame_kernel_ms": fms_p}
+            if n2 == 4096:
+                # which of the 4096-point kernel's two twiddle paths this host's cos / sin select (include/fx.h, fx_twiddle_symmetry): bit 1 set =
+                # two rows of the last pass formed from LDS as quarter turns; clear = read from the table in global memory (same values, ~3 % slower)
+                others[str(n2)]["twiddle_symmetry"] = int(fx.load_library(build_if_missing=False).fx_twiddle_symmetry(4096))
             del fr2
         return others
 
