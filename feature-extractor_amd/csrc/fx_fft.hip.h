@@ -234,7 +234,7 @@ template <int N> struct CompactTw {
     static constexpr int Q1_GAP = 16;
     static constexpr int OFF_S = 15 * PL::L1, OFF_Q1 = OFF_S + 3 * L2, OFF_GAP = OFF_Q1 + 2 * L2, OFF_R3 = OFF_Q1 + 4 * L2 + Q1_GAP, ENTRIES = OFF_R3 + 4 * L2;
     __host__ __device__ static constexpr int q1_pos(int j) { return (j >> 1) + ((j & 1) ? 2 * L2 + Q1_GAP : 0); }
-    // where entry e of the image comes from in the pass-ordered table (the kernel's prologue copies it from there)
+    // where entry e of the image comes from in the pass-ordered table (build_twiddle_image lays the image out on the host; the kernels copy it as it is)
     __host__ __device__ static constexpr int source(int e)
     {
         if (e < OFF_S)  return PL::OFF1 + e;
