@@ -9,6 +9,11 @@
 //
 //   wav_to_osc in.wav [--window 1024] [--channel 0] [--gain 1.0] [--address /Audio/A0]
 //                     [--target 127.0.0.1:9000] [--dump out.bin] [--rate 0] [--batch 64] [--device 0] [--pcm16-direct | --pcm24-direct]
+//                     [--device-block n]
+//
+// --device-block n: the file is played to the analysers the way an audio device would deliver it -- in blocks of n samples (441, 480, 512,
+// anything) through fx::AudioDataCollector::audioDeviceIOCallback (ref AudioDataCollector.h:36-70), which analyses the hops as they complete
+// (fx_push_samples).  The same datagrams, byte for byte, as with whole hops.
 //
 // --pcm16-direct / --pcm24-direct (16- / 24-bit PCM files): the samples go to the GPU as the file holds them (FX_SAMPLE_S16 / _S24, two /
 // three bytes each) and are widened to v / 2^15 / v / 2^23 in the kernels' load stage -- the same datagrams, byte for byte, as with the decoded floats.
@@ -27,7 +32,7 @@
 int main (int argc, char** argv)
 {
     std::string path, address = "/Audio/A0", target, dump;
-    int window = 1024, channel = 0, batch = 64, device = 0;
+    int window = 1024, channel = 0, batch = 64, device = 0, deviceBlock = 0;
     double rate = 0.0;
     float gain = 1.0f;
     bool pcm16Direct = false, pcm24Direct = false;
@@ -44,6 +49,7 @@ int main (int argc, char** argv)
         else if (a == "--rate")    rate = std::atof (next());
         else if (a == "--batch")   batch = std::atoi (next());
         else if (a == "--device")  device = std::atoi (next());
+        else if (a == "--device-block") deviceBlock = std::atoi (next());
         else if (a == "--pcm16-direct") pcm16Direct = true;
         else if (a == "--pcm24-direct") pcm24Direct = true;
         else if (a[0] != '-')      path = a;
@@ -101,15 +107,30 @@ int main (int argc, char** argv)
         analyser.setGain (gain);
         std::vector<float> raw ((std::size_t) batch * FX_NUM_FEATURES), smoothed ((std::size_t) batch * FX_NUM_FEATURES);
         long tick = 1;                                               // next timer tick (k / rate seconds)
-        for (int done = 0; done < numHops; done += batch)
+        fx::AudioDataCollector collector (analyser);
+        const std::vector<float> mono = deviceBlock > 0 ? wav.channel (channel) : std::vector<float>();
+        const std::vector<std::int16_t> mono16 = (deviceBlock > 0 && pcm16Direct) ? fx::samplesOfChannelPCM16 (wav, channel) : std::vector<std::int16_t>();
+        std::size_t played = 0;                                      // --device-block: samples handed to the collector so far
+        for (int done = 0; done < numHops; )
         {
-            const int n = numHops - done < batch ? numHops - done : batch;
-            if (pcm16Direct)      analyser.pushHopsPCM16 (hops16.data() + (std::size_t) done * hop, n, raw.data(), smoothed.data());
+            int n = numHops - done < batch ? numHops - done : batch;
+            const float* values = smoothed.data();
+            if (deviceBlock > 0)
+            {
+                // one device callback: the next deviceBlock samples of the file (the last block is what is left)
+                if (played >= mono.size()) break;
+                const int len = (int) (mono.size() - played < (std::size_t) deviceBlock ? mono.size() - played : (std::size_t) deviceBlock);
+                if (pcm16Direct) n = collector.pushBlock (mono16.data() + played, len, FX_SAMPLE_S16);
+                else { const float* one[1] = { mono.data() + played }; n = collector.audioDeviceIOCallback (one, 1, len); }
+                played += (std::size_t) len;
+                values = collector.smoothed();
+            }
+            else if (pcm16Direct) analyser.pushHopsPCM16 (hops16.data() + (std::size_t) done * hop, n, raw.data(), smoothed.data());
             else if (pcm24Direct) analyser.pushHopsPCM24 (hops24.data() + (std::size_t) done * hop * 3, n, raw.data(), smoothed.data());
             else                  analyser.pushHops (hops.data() + (std::size_t) done * hop, n, raw.data(), smoothed.data());
             for (int t = 0; t < n; ++t)
             {
-                const float* v = smoothed.data() + (std::size_t) t * FX_NUM_FEATURES;
+                const float* v = values + (std::size_t) t * FX_NUM_FEATURES;
                 if (rate <= 0.0) { emit (v); continue; }
                 // hop (done + t) is complete at sample (done + t + 1) * hop; it is what every tick in
                 // [that time, completion of the next hop) reads
@@ -118,6 +139,7 @@ int main (int argc, char** argv)
                 while ((double) tick / rate < from) ++tick;          // ticks before the first result read nothing
                 while ((double) tick / rate < to) { emit (v); ++tick; }
             }
+            done += n;
         }
     }
     catch (const fx::Error& e)

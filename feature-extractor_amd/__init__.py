@@ -9,8 +9,8 @@ from .capi import (FEATURE_NAMES, NUM_FEATURES, FxError, load_library, library_p
                    ONSET_SPECTRAL, ONSET_AMPLITUDE, ONSET_COMBINATION,
                    ORDER_SPECTRAL_THEN_HARMONIC, ORDER_HARMONIC_THEN_SPECTRAL, ORDER_ISOLATED,
                    pack_osc12, pack_osc10, osc_encode)
-from .analyser import BatchAnalyser, HopStream, pack_s24
+from .analyser import BatchAnalyser, HopStream, PackedS24, pack_s24
 from . import capi, offline, synth, wav
 
-__all__ = ["BatchAnalyser", "HopStream", "pack_s24", "FxError", "load_library", "library_path", "synth", "wav", "FEATURE_NAMES",
+__all__ = ["BatchAnalyser", "HopStream", "PackedS24", "pack_s24", "FxError", "load_library", "library_path", "synth", "wav", "FEATURE_NAMES",
            "NUM_FEATURES", "pack_osc12", "pack_osc10", "osc_encode"]

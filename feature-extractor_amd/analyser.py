@@ -16,11 +16,19 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+class PackedS24(np.ndarray):
+    """uint8 bytes that ARE packed 24-bit PCM (what pack_s24 returns): the tag by which push_hops / process_frames take a byte array
+    as FX_SAMPLE_S24.  A plain uint8 array is never taken for it -- 8-bit data would be read as samples three bytes wide."""
+
+
 def pack_s24(values):
     """int32 samples in [-2^23, 2^23) -> packed 24-bit PCM, little endian, three bytes per sample along a new last axis folded into the
-    last one: [...][n] -> uint8 [...][3 n] (the layout of a 24-bit WAV file's data chunk, FX_SAMPLE_S24)."""
+    last one: [...][n] -> PackedS24 (uint8) [...][3 n] (the layout of a 24-bit WAV file's data chunk, FX_SAMPLE_S24)."""
     v = np.ascontiguousarray(values, "<i4")
-    return np.ascontiguousarray(v.view(np.uint8).reshape(v.shape + (4,))[..., :3]).reshape(v.shape[:-1] + (3 * v.shape[-1],))
+    return np.ascontiguousarray(v.view(np.uint8).reshape(v.shape + (4,))[..., :3]).reshape(v.shape[:-1] + (3 * v.shape[-1],)).view(PackedS24)
+
+
+_FORMAT_NAMES = {"f32": capi.SAMPLE_F32, "f16": capi.SAMPLE_F16, "s16": capi.SAMPLE_S16, "s24": capi.SAMPLE_S24}
 
 
 class BatchAnalyser:
@@ -91,6 +99,12 @@ class BatchAnalyser:
         capi.check(self._lib.fx_set_tuning(self._h, ctypes.byref(t)))
         return t
 
+    def set_test_hooks(self, bits):
+        """fx_set_tuning_internal (csrc/fx_kernels.h, FX_HOOK_*): tests only, not part of include/fx.h."""
+        fn = self._lib.fx_set_tuning_internal
+        fn.argtypes, fn.restype = [ctypes.c_void_p, ctypes.c_uint], ctypes.c_int
+        capi.check(fn(self._h, int(bits)))
+
     def sync(self):
         capi.check(self._lib.fx_sync(self._h))
 
@@ -114,10 +128,16 @@ class BatchAnalyser:
         return s.value
 
     # ---- analysis ----
-    def _run(self, fn, x, per_frame, want_raw, want_smoothed, out_raw=None, out_smoothed=None):
-        """Sample formats by dtype: float32, float16, int16 (16-bit PCM) and uint8 = packed 24-bit PCM, three bytes per sample
-        (pack_s24): the integer formats are widened in the kernels' load stage to exactly the floats a WAV reader would produce."""
+    def _run(self, fn, x, per_frame, want_raw, want_smoothed, out_raw=None, out_smoothed=None, sample_format=None):
+        """Sample formats by dtype: float32, float16, int16 (16-bit PCM); packed 24-bit PCM (three bytes per sample) is a PackedS24
+        array (pack_s24) or any uint8 buffer passed with sample_format="s24" -- never inferred from dtype uint8 alone.  The integer
+        formats are widened in the kernels' load stage to exactly the floats a WAV reader would produce.  Device buffers must start
+        on a 16-byte boundary (fx.h)."""
         C = self.num_channels
+        if sample_format is not None and sample_format not in _FORMAT_NAMES:
+            raise ValueError("sample_format must be one of %s" % ", ".join(sorted(_FORMAT_NAMES)))
+        want = None if sample_format is None else _FORMAT_NAMES[sample_format]
+        s24_error = 'uint8 samples are taken as packed 24-bit PCM only with sample_format="s24" (or as a PackedS24 array from pack_s24)'
         if _is_torch(x):
             import torch
             if not x.is_cuda:
@@ -131,10 +151,16 @@ class BatchAnalyser:
             elif x.dtype == torch.int16:
                 fmt = capi.SAMPLE_S16            # 16-bit PCM: v / 32768 in the kernels' load stage (include/fx_wav.hpp's scaling)
             elif x.dtype == torch.uint8:
+                if want != capi.SAMPLE_S24:
+                    raise ValueError(s24_error)
                 fmt = capi.SAMPLE_S24            # packed 24-bit PCM: three bytes per sample
                 per_frame = 3 * per_frame
             else:
                 raise ValueError("samples must be float32, float16, int16 (16-bit PCM) or uint8 (packed 24-bit PCM)")
+            if want is not None and want != fmt:
+                raise ValueError("sample_format=%r does not describe a %s tensor" % (sample_format, x.dtype))
+            if x.data_ptr() % 16:
+                raise ValueError("device input must start on a 16-byte boundary (an offset view of a tensor may not)")
             if x.numel() % (C * per_frame):
                 raise ValueError("input size is not a multiple of channels x samples per frame")
             T = x.numel() // (C * per_frame)
@@ -164,17 +190,22 @@ class BatchAnalyser:
             if foreign:
                 cur.wait_stream(lib)
             return raw, sm
+        tagged = isinstance(x, PackedS24)
         x = np.ascontiguousarray(x)
         if x.dtype == np.float16:
             fmt = capi.SAMPLE_F16
         elif x.dtype == np.int16:
             fmt = capi.SAMPLE_S16
         elif x.dtype == np.uint8:
+            if not (tagged or want == capi.SAMPLE_S24):
+                raise ValueError(s24_error)
             fmt = capi.SAMPLE_S24
             per_frame = 3 * per_frame
         else:
             x = np.ascontiguousarray(x, np.float32)
             fmt = capi.SAMPLE_F32
+        if want is not None and want != fmt:
+            raise ValueError("sample_format=%r does not describe a %s array" % (sample_format, x.dtype))
         if x.size % (C * per_frame):
             raise ValueError("input size is not a multiple of channels x samples per frame")
         T = x.size // (C * per_frame)
@@ -204,13 +235,85 @@ class BatchAnalyser:
                 and str(o.dtype) == "torch.float32" and o.numel() == numel):
             raise ValueError("%s must be a contiguous float32 CUDA tensor on cuda:%d with %d elements" % (name, self.device, numel))
 
-    def push_hops(self, hops, want_raw=True, want_smoothed=True, out_raw=None, out_smoothed=None):
+    def push_hops(self, hops, want_raw=True, want_smoothed=True, out_raw=None, out_smoothed=None, sample_format=None):
         """hops [C][T][N/2] -> (raw [C][T][12], smoothed [C][T][12])."""
-        return self._run(self._lib.fx_push_hops, hops, self.window_size // 2, want_raw, want_smoothed, out_raw, out_smoothed)
+        return self._run(self._lib.fx_push_hops, hops, self.window_size // 2, want_raw, want_smoothed, out_raw, out_smoothed, sample_format)
 
-    def process_frames(self, frames, want_raw=True, want_smoothed=True, out_raw=None, out_smoothed=None):
+    def process_frames(self, frames, want_raw=True, want_smoothed=True, out_raw=None, out_smoothed=None, sample_format=None):
         """frames [C][T][N] -> (raw [C][T][12], smoothed [C][T][12])."""
-        return self._run(self._lib.fx_process_frames, frames, self.window_size, want_raw, want_smoothed, out_raw, out_smoothed)
+        return self._run(self._lib.fx_process_frames, frames, self.window_size, want_raw, want_smoothed, out_raw, out_smoothed, sample_format)
+
+    # ---- the collector's interface: device blocks of any length (ref AudioDataCollector.h:36-94) ----
+    def pending_samples(self):
+        """samples per channel that fx_push_samples is holding back (< window_size / 2)"""
+        return int(self._lib.fx_pending_samples(self._h))
+
+    def clear_buffer(self):                                  # AudioDataCollector::clearBuffer, AudioDataCollector.h:122
+        capi.check(self._lib.fx_clear_pending(self._h))
+
+    def push_samples(self, samples, want_raw=True, want_smoothed=True, sample_format=None):
+        """samples [C][n] for ANY n >= 0 (a device block: 441, 480, 512 ... samples per channel) -> (raw [C][frames][12], smoothed
+        [C][frames][12]) with frames = (pending + n) // (window_size / 2); what is left over stays pending in device memory.  Same bits
+        as push_hops on the same stream cut into hops.  numpy (host) or torch CUDA tensors, formats as push_hops."""
+        C, H = self.num_channels, self.window_size // 2
+        want = None if sample_format is None else _FORMAT_NAMES[sample_format]
+        frames_out = ctypes.c_int(0)
+        if _is_torch(samples):
+            import torch
+            x = samples
+            if not x.is_cuda or not x.is_contiguous() or x.device.index != self.device:
+                raise ValueError("torch input must be a contiguous tensor on cuda:%d" % self.device)
+            fmt = {torch.float32: capi.SAMPLE_F32, torch.float16: capi.SAMPLE_F16, torch.int16: capi.SAMPLE_S16, torch.uint8: capi.SAMPLE_S24}.get(x.dtype)
+            if fmt is None or (fmt == capi.SAMPLE_S24 and want != capi.SAMPLE_S24) or (want is not None and want != fmt):
+                raise ValueError("samples must be float32, float16, int16, or uint8 with sample_format=\"s24\"")
+            per = 3 if fmt == capi.SAMPLE_S24 else 1
+            if x.numel() % (C * per):
+                raise ValueError("input size is not a multiple of the channel count")
+            n = x.numel() // (C * per)
+            if x.data_ptr() % 4:
+                raise ValueError("device input must start on a 4-byte boundary")
+            frames = (self.pending_samples() + n) // H
+            raw = torch.empty((C, frames, 12), dtype=torch.float32, device=x.device) if want_raw else None
+            sm = torch.empty((C, frames, 12), dtype=torch.float32, device=x.device) if want_smoothed else None
+            cur = torch.cuda.current_stream(x.device)
+            lib = self._torch_stream(x.device)
+            foreign = cur.cuda_stream != lib.cuda_stream
+            if foreign:
+                lib.wait_stream(cur)
+            capi.check(self._lib.fx_push_samples(self._h, ctypes.c_void_p(x.data_ptr()), n, fmt, capi.MEM_DEVICE,
+                                                 ctypes.c_void_p(raw.data_ptr()) if raw is not None and frames else None,
+                                                 ctypes.c_void_p(sm.data_ptr()) if sm is not None and frames else None, ctypes.byref(frames_out)))
+            if foreign:
+                cur.wait_stream(lib)
+            assert frames_out.value == frames
+            return raw, sm
+        tagged = isinstance(samples, PackedS24)
+        x = np.ascontiguousarray(samples)
+        if x.dtype == np.float16:
+            fmt = capi.SAMPLE_F16
+        elif x.dtype == np.int16:
+            fmt = capi.SAMPLE_S16
+        elif x.dtype == np.uint8:
+            if not (tagged or want == capi.SAMPLE_S24):
+                raise ValueError('uint8 samples are packed 24-bit PCM only with sample_format="s24" (or as a PackedS24 array)')
+            fmt = capi.SAMPLE_S24
+        else:
+            x = np.ascontiguousarray(x, np.float32)
+            fmt = capi.SAMPLE_F32
+        if want is not None and want != fmt:
+            raise ValueError("sample_format=%r does not describe a %s array" % (sample_format, x.dtype))
+        per = 3 if fmt == capi.SAMPLE_S24 else 1
+        if x.size % (C * per):
+            raise ValueError("input size is not a multiple of the channel count")
+        n = x.size // (C * per)
+        frames = (self.pending_samples() + n) // H
+        raw = np.empty((C, frames, 12), np.float32) if want_raw else None
+        sm = np.empty((C, frames, 12), np.float32) if want_smoothed else None
+        capi.check(self._lib.fx_push_samples(self._h, x.ctypes.data_as(ctypes.c_void_p), n, fmt, capi.MEM_HOST,
+                                             raw.ctypes.data_as(ctypes.c_void_p) if raw is not None and frames else None,
+                                             sm.ctypes.data_as(ctypes.c_void_p) if sm is not None and frames else None, ctypes.byref(frames_out)))
+        assert frames_out.value == frames
+        return raw, sm
 
     def get_features(self, out=None):
         """Latest AudioFeatures::getValue of every slot, [C][12]: a host array, or -- with `out`, a contiguous
@@ -336,6 +439,27 @@ class HopStream:
             return
         self.slot()[...] = hops.reshape(self._shape)
         self.submit()
+
+    def push_samples(self, samples, fill_threads=1):
+        """A block of n samples per channel, [C][n] with 0 <= n <= hops_per_batch * window_size / 2 (a device callback's block), into the
+        next slot: fx_stream_push_samples.  collect_samples() returns what the context's pending samples and the block yielded."""
+        x = np.ascontiguousarray(samples, self.dtype)
+        per = 3 if self.dtype == np.uint8 else 1
+        C = self._shape[0]
+        if x.size % (C * per):
+            raise ValueError("input size is not a multiple of the channel count")
+        capi.check(self._lib.fx_stream_push_samples(self._h, x.ctypes.data_as(ctypes.c_void_p), x.size // (C * per), int(fill_threads)))
+
+    def collect_samples(self, want_raw=True, want_smoothed=True):
+        """(raw [C][frames][12], smoothed [C][frames][12]) of the oldest batch; frames may be 0 for a block that completed no hop."""
+        C = self._shape[0]
+        raw = np.empty((C, self.hops, 12), np.float32)
+        sm = np.empty((C, self.hops, 12), np.float32)
+        n = ctypes.c_int(0)
+        capi.check(self._lib.fx_stream_collect_samples(self._h, raw.ctypes.data_as(ctypes.c_void_p), sm.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)))
+        f = n.value
+        flat_r, flat_s = raw.reshape(-1)[:C * f * 12].reshape(C, f, 12), sm.reshape(-1)[:C * f * 12].reshape(C, f, 12)
+        return (flat_r.copy() if want_raw else None), (flat_s.copy() if want_smoothed else None)
 
     def collect(self, want_raw=True, want_smoothed=True):
         C = self._shape[0]

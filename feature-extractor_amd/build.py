@@ -10,13 +10,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfx_hip.so")
-SOURCES = ["fx_kernels.hip", "fx_capi.cpp", "fx_comm.cpp", "fx_offline.hip"]
+SOURCES = ["fx_kernels.hip", "fx_capi.cpp", "fx_comm.cpp", "fx_offline.hip", "fx_reblock.hip"]
 # fx_kernels.hip is compiled twice: frame kernels up to 1024 points (+ tail kernels + host helpers) with the scheduler's
 # alternative register-pressure tracker (+3.5 % at 1024 points), the 2048- / 4096-point frame kernels without (-7 % at 4096)
 UNITS = [("fx_kernels.hip", "fx_kernels_small.o", ["-DFX_PART=1", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"]),
          ("fx_kernels.hip", "fx_kernels_large.o", ["-DFX_PART=2"]),
          ("fx_kernels.hip", "fx_kernels_hop.o", ["-DFX_PART=3"]),
          ("fx_offline.hip", "fx_offline.o", []),
+         ("fx_reblock.hip", "fx_reblock.o", []),
          ("fx_capi.cpp", "fx_capi.o", []),
          ("fx_comm.cpp", "fx_comm.o", [])]
 HEADERS = ["fx_kernels.h", "fx_context.h", "fx_wave.hip.h", "fx_fft.hip.h", "fx_frame_kernel.hip.h", "fx_pair_kernel.hip.h", "fx_tail_kernels.hip.h", "fx_hop_kernel.hip.h",

@@ -20,6 +20,7 @@ FX_OK, FX_ERR_INVALID_ARGUMENT, FX_ERR_NO_DEVICE, FX_ERR_HIP, FX_ERR_OUT_OF_MEMO
 # every symbol include/fx.h declares
 EXPORTS = ["fx_create", "fx_destroy", "fx_reset_state", "fx_set_sample_rate", "fx_set_onset_sensitivity",
            "fx_set_onset_window", "fx_set_onset_type", "fx_set_gain", "fx_push_hops", "fx_process_frames",
+           "fx_push_samples", "fx_pending_samples", "fx_clear_pending", "fx_stream_submit_samples", "fx_stream_push_samples", "fx_stream_collect_samples",
            "fx_get_smoothed", "fx_sync", "fx_get_stream", "fx_last_kernel_ms", "fx_profile_begin", "fx_profile_end",
            "fx_stream_create", "fx_stream_destroy", "fx_stream_acquire", "fx_stream_submit", "fx_stream_push", "fx_stream_collect", "fx_stream_in_flight", "fx_pack_osc12",
            "fx_pack_osc10", "fx_osc_encode", "fx_last_error", "fx_abi_version",
@@ -29,7 +30,7 @@ EXPORTS = ["fx_create", "fx_destroy", "fx_reset_state", "fx_set_sample_rate", "f
            "fx_offline_log_attack_time", "fx_offline_fft_lbp", "fx_offline_harmonic_characteristics", "fx_offline_spectral_characteristics",
            "fx_offline_get_previous_bins", "fx_offline_spectral_slope", "fx_offline_auto_correlation"]
 COMM_ID_BYTES = 128
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_UNITS = 24
 
 
@@ -39,7 +40,7 @@ class Tuning(ctypes.Structure):
     _fields_ = [("waves_per_channel", ctypes.c_int), ("channels_per_workgroup", ctypes.c_int), ("waves_per_frame", ctypes.c_int),
                 ("frames_per_unit", ctypes.c_int), ("unit_plan_len", ctypes.c_int), ("unit_plan", ctypes.c_int * MAX_UNITS),
                 ("stream_graph", ctypes.c_int), ("stream_hop_kernel", ctypes.c_int), ("stream_zero_copy", ctypes.c_int),
-                ("one_hop_kernel", ctypes.c_int), ("call_timing", ctypes.c_int), ("handover_spin_limit", ctypes.c_int), ("debug_flags", ctypes.c_int)]
+                ("one_hop_kernel", ctypes.c_int), ("call_timing", ctypes.c_int), ("handover_spin_limit", ctypes.c_int)]
 
     @classmethod
     def defaults(cls):
@@ -102,6 +103,12 @@ def load_library(build_if_missing=True):
     L.fx_set_gain.argtypes = [vp, f]
     L.fx_push_hops.argtypes = [vp, vp, i, i, i, vp, vp]
     L.fx_process_frames.argtypes = [vp, vp, i, i, i, vp, vp]
+    L.fx_push_samples.argtypes = [vp, vp, i, i, i, vp, vp, ctypes.POINTER(i)]
+    L.fx_pending_samples.argtypes = [vp]
+    L.fx_clear_pending.argtypes = [vp]
+    L.fx_stream_submit_samples.argtypes = [vp, i]
+    L.fx_stream_push_samples.argtypes = [vp, vp, i, i]
+    L.fx_stream_collect_samples.argtypes = [vp, vp, vp, ctypes.POINTER(i)]
     L.fx_get_smoothed.argtypes = [vp, vp, i]
     L.fx_sync.argtypes = [vp]
     L.fx_get_stream.argtypes = [vp, ctypes.POINTER(vp)]

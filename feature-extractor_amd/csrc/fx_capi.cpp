@@ -62,6 +62,7 @@ fx_status zero_state(fx_context* c)
     HIP_TRY(hipMemsetAsync(c->d_queue, 0, sizeof(unsigned) * (1 + (size_t) c->C), c->stream));
     c->frames_seen = 0;
     c->onset_reset_frame = 0;
+    c->carry_count = 0;                     // (a freshly constructed AudioDataCollector: nothing written, nothing pending)
     return FX_OK;
 }
 
@@ -191,7 +192,6 @@ extern "C" void fx_tuning_from_env(fx_tuning* t)
     geti("FX_ONE_HOP_KERNEL", &t->one_hop_kernel, 0);
     geti("FX_CALL_TIMING", &t->call_timing, 0);
     geti("FX_HANDOVER_SPINS", &t->handover_spin_limit, 1);
-    geti("FX_DEBUG_FLAGS", &t->debug_flags, 0);
 }
 
 extern "C" fx_status fx_get_tuning(fx_context* c, fx_tuning* out)
@@ -213,6 +213,14 @@ extern "C" fx_status fx_set_tuning(fx_context* c, const fx_tuning* t)
         return fx_fail(FX_ERR_INVALID_ARGUMENT, "waves_per_frame selects the kernel family and %lld frames have been analysed with the other one; "
                                                 "fx_reset_state first", c->frames_seen);
     c->tuning = *t;              // (nothing below can fail: a refused call leaves the old knobs in place)
+    return FX_OK;
+}
+
+// tests only (csrc/fx_kernels.h; not in include/fx.h)
+extern "C" fx_status fx_set_tuning_internal(fx_context* c, unsigned test_hooks)
+{
+    if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    c->test_hooks = test_hooks;
     return FX_OK;
 }
 
@@ -268,7 +276,7 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     fp.lpf_b = c->lpf_b;
     fp.dyn = dyn;
     for (int i = 0; i < 18; i++) fp.first_tw[i] = c->first_tw[i];
-    fp.tw_quarter_turn = (c->tw_quarter_turn && !(c->tuning.debug_flags & 2)) ? 1 : 0;
+    fp.tw_quarter_turn = (c->tw_quarter_turn && !(c->test_hooks & FX_HOOK_NO_QUARTER_TURN)) ? 1 : 0;
     fp.tw_at_quarter[0] = c->tw_at_quarter[0]; fp.tw_at_quarter[1] = c->tw_at_quarter[1];
 
     // Workgroup shape: channels per workgroup x wavefronts per channel (= frames of one channel in flight): the
@@ -320,7 +328,7 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
         fp.queue = nullptr;
         fp.err = c->d_err;
         fp.spin_limit = c->tuning.handover_spin_limit > 0 ? (unsigned) c->tuning.handover_spin_limit : (1u << 22);
-        fp.debug_flags = (unsigned) c->tuning.debug_flags;
+        fp.debug_flags = c->test_hooks;
         for (int i = 0; i <= fxk::FX_MAX_CHUNKS; i++) fp.chunk_begin[i] = 0;
         if (!dyn && c->d_queue) {
             int sizes[fxk::FX_MAX_CHUNKS];
@@ -378,7 +386,9 @@ void advance(fx_context* c, int T)
     c->frames_seen += T;
 }
 
-fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_kind, int hop_mode,
+// in_kind / out_kind: where the caller's samples and result buffers live (fx_push_samples hands over hops it has assembled in device
+// memory with results that may go to the host)
+fx_status run(fx_context* c, const void* in, int T, int sample_format, int in_kind, int out_kind, int hop_mode,
               float* out_raw, float* out_smoothed)
 {
     if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
@@ -387,8 +397,8 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     if (!in) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null input buffer");
     if (!known_format(sample_format))
         return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown sample format %d", sample_format);
-    if (mem_kind != FX_MEM_HOST && mem_kind != FX_MEM_DEVICE)
-        return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown memory kind %d", mem_kind);
+    if ((in_kind != FX_MEM_HOST && in_kind != FX_MEM_DEVICE) || (out_kind != FX_MEM_HOST && out_kind != FX_MEM_DEVICE))
+        return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown memory kind %d", in_kind != FX_MEM_HOST && in_kind != FX_MEM_DEVICE ? in_kind : out_kind);
     HIP_TRY(hipSetDevice(c->device));
     { const fx_status es = fx_check_device_error(c); if (es != FX_OK) return es; }     // sticky: an earlier call's hand-over failed
 
@@ -405,8 +415,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     const void* d_in = in;
     float* d_or = out_raw;
     float* d_os = out_smoothed;
-    if (mem_kind == FX_MEM_HOST) {
-        if ((st = grow(reinterpret_cast<unsigned char**>(&c->d_in), &c->in_cap, in_bytes)) != FX_OK) return st;
+    if (out_kind == FX_MEM_HOST) {
         if (out_raw || out_smoothed) {
             // one allocation, two halves
             if (2 * raw_bytes > c->out_cap) {
@@ -419,10 +428,13 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
             }
             c->d_out_sm = c->d_out_raw + out_elems;
         }
-        HIP_TRY(hipMemcpyAsync(c->d_in, in, in_bytes, hipMemcpyHostToDevice, c->stream));
-        d_in = c->d_in;
         d_or = out_raw ? c->d_out_raw : nullptr;
         d_os = out_smoothed ? c->d_out_sm : nullptr;
+    }
+    if (in_kind == FX_MEM_HOST) {
+        if ((st = grow(reinterpret_cast<unsigned char**>(&c->d_in), &c->in_cap, in_bytes)) != FX_OK) return st;
+        HIP_TRY(hipMemcpyAsync(c->d_in, in, in_bytes, hipMemcpyHostToDevice, c->stream));
+        d_in = c->d_in;
     } else {
         if (reinterpret_cast<uintptr_t>(in) % 16 != 0)
             return fx_fail(FX_ERR_INVALID_ARGUMENT, "device input must be 16-byte aligned");
@@ -474,7 +486,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
         // points and fewer lose either way (4096 channels 34.7 / 33.2): their frames are no longer than the tail.
         const long long groups = ((long long) c->C + step.fp.ch_per_wg - 1) / step.fp.ch_per_wg;
         const long long one_round = (long long) c->compute_units * ((c->N == 4096 && step.fp.ch_per_wg > 4) ? 1 : 2);
-        const bool one_launch = step.fp.direct_state && ((c->tuning.debug_flags & 8) || (!(c->tuning.debug_flags & 4) && c->N >= 1024 && groups <= one_round));
+        const bool one_launch = step.fp.direct_state && ((c->test_hooks & FX_HOOK_TAIL_ALWAYS_FUSED) || (!(c->test_hooks & FX_HOOK_TAIL_NEVER_FUSED) && c->N >= 1024 && groups <= one_round));
         if (one_launch) {
             HIP_TRY(fxk::launch_frame_tail_kernel(c->N, step.fp, step.ep, c->stream));
             FX_EV(e1);
@@ -489,7 +501,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int mem_k
     c->ev_valid = last_valid;
     advance(c, T);
 
-    if (mem_kind == FX_MEM_HOST) {
+    if (out_kind == FX_MEM_HOST) {
         if (out_raw) HIP_TRY(hipMemcpyAsync(out_raw, c->d_out_raw, raw_bytes, hipMemcpyDeviceToHost, c->stream));
         if (out_smoothed) HIP_TRY(hipMemcpyAsync(out_smoothed, c->d_out_sm, raw_bytes, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -557,6 +569,7 @@ fx_status fx_create(fx_context** out, int device_id, int num_channels, int windo
     TRY_OR_CLEAN(hipMalloc((void**) &c->d_hist, sizeof(float) * (size_t) num_channels * fxk::HLEN * FX_NUM_FEATURES));
     TRY_OR_CLEAN(hipMalloc((void**) &c->d_latest, sizeof(float) * (size_t) num_channels * FX_NUM_FEATURES));
     TRY_OR_CLEAN(hipMalloc((void**) &c->d_queue, sizeof(unsigned) * (1 + (size_t) num_channels)));
+    for (int i = 0; i < 2; i++) TRY_OR_CLEAN(hipMalloc((void**) &c->d_carry[i], half * 4));
     TRY_OR_CLEAN(hipHostMalloc((void**) &c->h_err, 64, hipHostMallocCoherent));
     *c->h_err = 0;
     { void* q = nullptr; TRY_OR_CLEAN(hipHostGetDevicePointer(&q, c->h_err, 0)); c->d_err = static_cast<unsigned*>(q); }
@@ -607,7 +620,7 @@ fx_status fx_destroy(fx_context* c)
     fx_comm_release(c);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     void* bufs[] = {c->d_tw, c->d_prev, c->d_tail[0], c->d_tail[1], c->d_hist, c->d_latest,
-                    c->d_raw, c->d_part, c->d_in, c->d_out_raw, c->d_queue};
+                    c->d_raw, c->d_part, c->d_in, c->d_out_raw, c->d_queue, c->d_carry[0], c->d_carry[1], c->d_hops};
     for (void* b : bufs) if (b) (void) hipFree(b);
     if (c->h_err) (void) hipHostFree(c->h_err);
     for (int i = 0; i < 3; i++) if (c->ev[i]) (void) hipEventDestroy(c->ev[i]);
@@ -670,13 +683,94 @@ fx_status fx_set_gain(fx_context* c, float gain)
 fx_status fx_push_hops(fx_context* c, const void* hops, int num_hops, int sample_format, int mem_kind,
                        float* out_raw, float* out_smoothed)
 {
-    return run(c, hops, num_hops, sample_format, mem_kind, 1, out_raw, out_smoothed);
+    if (c && c->carry_count > 0)
+        return fx_fail(FX_ERR_INVALID_ARGUMENT, "%d samples per channel are pending from fx_push_samples; whole hops would overtake them "
+                                                "(finish the stream with fx_push_samples, or fx_reset_state)", c->carry_count);
+    return run(c, hops, num_hops, sample_format, mem_kind, mem_kind, 1, out_raw, out_smoothed);
+}
+
+// ---- the collector's real interface: device blocks of any length (ref AudioDataCollector.h:36-94) ----
+int fx_pending_samples(fx_context* c) { return c ? c->carry_count : 0; }
+
+fx_status fx_clear_pending(fx_context* c)
+{
+    if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(fxk::clear_carry(c->d_carry[c->carry_cur], (size_t) c->C * (c->N / 2) * 4, c->stream));
+    return FX_OK;
+}
+
+fx_status fx_push_samples(fx_context* c, const void* samples, int num_samples, int sample_format, int mem_kind,
+                          float* out_raw, float* out_smoothed, int* frames_out)
+{
+    if (frames_out) *frames_out = 0;
+    if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
+    if (num_samples < 0) return fx_fail(FX_ERR_INVALID_ARGUMENT, "negative sample count");
+    if (!known_format(sample_format)) return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown sample format %d", sample_format);
+    if (mem_kind != FX_MEM_HOST && mem_kind != FX_MEM_DEVICE) return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown memory kind %d", mem_kind);
+    if (num_samples == 0) return FX_OK;
+    if (!samples) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null input buffer");
+    if (c->carry_count > 0 && sample_format != c->carry_format)
+        return fx_fail(FX_ERR_INVALID_ARGUMENT, "%d pending samples per channel are in sample format %d, this block in %d: a stream keeps one format "
+                                                "between hop boundaries", c->carry_count, c->carry_format, sample_format);
+    const int H = c->N / 2;
+    const size_t esz = sample_size(sample_format);
+    const long long have = (long long) c->carry_count + num_samples;
+    const long long hops64 = have / H;
+    if (hops64 > (1ll << 24)) return fx_fail(FX_ERR_INVALID_ARGUMENT, "block of %d samples per channel is too long for one call", num_samples);
+    const int hops = (int) hops64, rest = (int) (have - hops64 * H);
+    HIP_TRY(hipSetDevice(c->device));
+    { const fx_status es = fx_check_device_error(c); if (es != FX_OK) return es; }
+
+    // whole hops from an aligned device buffer and nothing pending: the block IS the hop buffer
+    if (mem_kind == FX_MEM_DEVICE && c->carry_count == 0 && rest == 0 && reinterpret_cast<uintptr_t>(samples) % 16 == 0) {
+        const fx_status st = run(c, samples, hops, sample_format, FX_MEM_DEVICE, FX_MEM_DEVICE, 1, out_raw, out_smoothed);
+        if (st == FX_OK && frames_out) *frames_out = hops;
+        return st;
+    }
+    fx_status st;
+    const unsigned char* d_block = static_cast<const unsigned char*>(samples);
+    const size_t block_bytes = (size_t) c->C * (size_t) num_samples * esz;
+    if (mem_kind == FX_MEM_HOST) {
+        if ((st = grow(reinterpret_cast<unsigned char**>(&c->d_in), &c->in_cap, block_bytes)) != FX_OK) return st;
+        HIP_TRY(hipMemcpyAsync(c->d_in, samples, block_bytes, hipMemcpyHostToDevice, c->stream));
+        d_block = static_cast<const unsigned char*>(c->d_in);
+    } else if (reinterpret_cast<uintptr_t>(samples) % 4 != 0) {
+        return fx_fail(FX_ERR_INVALID_ARGUMENT, "device input must be 4-byte aligned (16-byte aligned to be analysed in place)");
+    }
+    const size_t hop_bytes = (size_t) c->C * (size_t) hops * H * esz;
+    if ((st = grow(&c->d_hops, &c->hops_cap, hop_bytes)) != FX_OK) return st;
+    fxk::ReblockParams rp;
+    rp.in = d_block;
+    rp.carry_in = c->d_carry[c->carry_cur];
+    rp.hops_out = c->d_hops;
+    rp.carry_out = c->d_carry[c->carry_cur ^ 1];
+    rp.in_row_bytes = (long long) num_samples * (long long) esz;
+    rp.out_row_bytes = (long long) hops * H * (long long) esz;
+    rp.carry_bytes = (int) ((size_t) c->carry_count * esz);
+    rp.carry_row_bytes = H * 4;
+    rp.C = c->C;
+    HIP_TRY(fxk::launch_reblock_kernel(rp, c->stream));
+    // the stream holds the new carry whatever happens to the analysis below
+    c->carry_cur ^= 1;
+    c->carry_count = rest;
+    c->carry_format = sample_format;
+    if (hops > 0) {
+        st = run(c, c->d_hops, hops, sample_format, FX_MEM_DEVICE, mem_kind, 1, out_raw, out_smoothed);
+        if (st != FX_OK) return st;
+    } else if (mem_kind == FX_MEM_HOST) {
+        HIP_TRY(hipStreamSynchronize(c->stream));            // the caller's block may be reused on return
+    }
+    if (frames_out) *frames_out = hops;
+    return FX_OK;
 }
 
 fx_status fx_process_frames(fx_context* c, const void* frames, int num_frames, int sample_format, int mem_kind,
                             float* out_raw, float* out_smoothed)
 {
-    return run(c, frames, num_frames, sample_format, mem_kind, 0, out_raw, out_smoothed);
+    if (c && c->carry_count > 0)
+        return fx_fail(FX_ERR_INVALID_ARGUMENT, "%d samples per channel are pending from fx_push_samples (finish the stream with fx_push_samples, or fx_reset_state)", c->carry_count);
+    return run(c, frames, num_frames, sample_format, mem_kind, mem_kind, 0, out_raw, out_smoothed);
 }
 
 fx_status fx_get_smoothed(fx_context* c, float* out, int mem_kind)
@@ -849,6 +943,8 @@ struct fx_stream {
         unsigned* h_flag = nullptr;       // pinned, coherent: sequence number of the last hop-kernel call that completed in this slot
         const void* dev_in = nullptr; float* dev_raw = nullptr; float* dev_sm = nullptr; unsigned* dev_flag = nullptr;   // device views of the pinned buffers
         unsigned  seq = 0;                // sequence number of the call in flight in this slot
+        int       frames = 0;             // analysis frames per channel of the batch in flight in this slot (hops_per_batch, or what fx_stream_submit_samples made of its block)
+        bool      by_event = false;       // the batch in flight completes with the `out` event (every path but the one-launch hop kernel, which raises a flag)
         fxk::DynParams* h_dyn = nullptr;  // pinned: what changes from call to call
         fxk::DynParams* d_dyn = nullptr;
         hipGraphExec_t  exec[2] = {nullptr, nullptr};     // per parity of the context's ping-pong buffers
@@ -859,6 +955,10 @@ struct fx_stream {
     int in_flight = 0;
     bool acquired = false;
 };
+
+static fx_status submit_large(fx_stream* s, fx_stream::Slot& sl, size_t in_bytes, int num_samples);
+#define HIP_TRY_OR(expr, after) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { after; \
+        return fx_fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
 
 extern "C" {
 
@@ -971,9 +1071,13 @@ fx_status fx_stream_submit(fx_stream* s)
     if (!s) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null stream");
     if (!s->acquired) return fx_fail(FX_ERR_INVALID_ARGUMENT, "no slot acquired");
     fx_context* c = s->ctx;
-    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY_OR(hipSetDevice(c->device), s->acquired = false);
     fx_stream::Slot& sl = s->ring[(size_t) s->head];
     { const fx_status es = fx_check_device_error(c); if (es != FX_OK) { s->acquired = false; return es; } }
+    if (c->carry_count > 0) {
+        s->acquired = false;
+        return fx_fail(FX_ERR_INVALID_ARGUMENT, "%d samples per channel are pending from fx_stream_submit_samples / fx_push_samples; whole hops would overtake them", c->carry_count);
+    }
     // Any failure below hands the slot back (the caller may fill and submit it again): the ring never wedges on
     // "a slot is already acquired".
 #define SUB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { s->acquired = false; \
@@ -997,6 +1101,7 @@ fx_status fx_stream_submit(fx_stream* s)
         if (e != hipSuccess) { s->acquired = false; return fx_fail(FX_ERR_HIP, "launching the hop kernel failed: %s", hipGetErrorString(e)); }
         c->ev_valid = false;
         advance(c, 1);
+        sl.frames = 1; sl.by_event = false;
         s->head = (s->head + 1) % s->slots;
         s->in_flight++;
         s->acquired = false;
@@ -1052,17 +1157,48 @@ fx_status fx_stream_submit(fx_stream* s)
         c->ev_valid = false;
         advance(c, s->hops);
         const hipError_t er = hipEventRecord(sl.out, c->stream);
+        sl.frames = s->hops; sl.by_event = true;
         s->head = (s->head + 1) % s->slots;
         s->in_flight++;
         s->acquired = false;
         if (er != hipSuccess) return fx_fail(FX_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(er));
         return FX_OK;
     }
-#undef SUB_TRY
-    HIP_TRY(hipMemcpyAsync(sl.d_in, sl.h_in, s->in_bytes, hipMemcpyHostToDevice, s->copy));
-    HIP_TRY(hipEventRecord(sl.copied, s->copy));
-    HIP_TRY(hipStreamWaitEvent(c->stream, sl.copied, 0));
-    fx_status st = run(c, sl.d_in, s->hops, s->fmt, FX_MEM_DEVICE, 1, sl.d_raw, sl.d_sm);
+    return submit_large(s, sl, s->in_bytes, -1);
+}
+
+fx_status fx_stream_submit_samples(fx_stream* s, int num_samples)
+{
+    if (!s) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null stream");
+    if (!s->acquired) return fx_fail(FX_ERR_INVALID_ARGUMENT, "no slot acquired");
+    fx_context* c = s->ctx;
+    if (num_samples < 0 || (long long) num_samples > (long long) s->hops * (c->N / 2)) {
+        s->acquired = false;
+        return fx_fail(FX_ERR_INVALID_ARGUMENT, "a slot holds 0 .. %lld samples per channel, got %d", (long long) s->hops * (c->N / 2), num_samples);
+    }
+    HIP_TRY_OR(hipSetDevice(c->device), s->acquired = false);
+    { const fx_status es = fx_check_device_error(c); if (es != FX_OK) { s->acquired = false; return es; } }
+    return submit_large(s, s->ring[(size_t) s->head], (size_t) c->C * (size_t) num_samples * sample_size(s->fmt), num_samples);
+}
+
+} // extern "C"
+
+// The large-batch form of a submit: samples in on `copy`, analysis on the context's stream behind an event, vectors back on `back`.
+// num_samples < 0: the slot holds hops_per_batch whole hops per channel; else a block of num_samples samples per channel
+// ([C][num_samples], rows back to back), which fx_push_samples cuts into hops with the context's pending samples.
+// Any failure hands the slot back (acquired = false) so the ring never wedges on "a slot is already acquired": before the
+// analysis is enqueued nothing has happened; after it the context has moved on and the batch's results are lost with the error.
+static fx_status submit_large(fx_stream* s, fx_stream::Slot& sl, size_t in_bytes, int num_samples)
+{
+    fx_context* c = s->ctx;
+#define LG_TRY(expr, after) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { after; s->acquired = false; \
+        return fx_fail(e_ == hipErrorOutOfMemory ? FX_ERR_OUT_OF_MEMORY : FX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } } while (0)
+    if (in_bytes) LG_TRY(hipMemcpyAsync(sl.d_in, sl.h_in, in_bytes, hipMemcpyHostToDevice, s->copy), (void) 0);
+    LG_TRY(hipEventRecord(sl.copied, s->copy), (void) hipStreamSynchronize(s->copy));
+    LG_TRY(hipStreamWaitEvent(c->stream, sl.copied, 0), (void) hipStreamSynchronize(s->copy));
+    int frames = s->hops;
+    const fx_status st = num_samples < 0 ? run(c, sl.d_in, s->hops, s->fmt, FX_MEM_DEVICE, FX_MEM_DEVICE, 1, sl.d_raw, sl.d_sm)
+                                         : fx_push_samples(c, sl.d_in, num_samples, s->fmt, FX_MEM_DEVICE, sl.d_raw, sl.d_sm, &frames);
     if (st != FX_OK) {
         // the copy is already enqueued: let it finish, then hand the slot back so the ring stays usable
         // (the caller may fill and submit it again)
@@ -1070,16 +1206,24 @@ fx_status fx_stream_submit(fx_stream* s)
         s->acquired = false;
         return st;
     }
-    HIP_TRY(hipEventRecord(sl.done, c->stream));
-    HIP_TRY(hipStreamWaitEvent(s->back, sl.done, 0));
-    HIP_TRY(hipMemcpyAsync(sl.h_raw, sl.d_raw, s->out_bytes, hipMemcpyDeviceToHost, s->back));
-    HIP_TRY(hipMemcpyAsync(sl.h_sm, sl.d_sm, s->out_bytes, hipMemcpyDeviceToHost, s->back));
-    HIP_TRY(hipEventRecord(sl.out, s->back));
+    const size_t out_bytes = (size_t) c->C * (size_t) frames * FX_NUM_FEATURES * sizeof(float);
+    // from here on the analysis is enqueued: a failure loses this batch's results, not the ring (wait for the kernels that read the slot)
+    LG_TRY(hipEventRecord(sl.done, c->stream), (void) hipStreamSynchronize(c->stream));
+    LG_TRY(hipStreamWaitEvent(s->back, sl.done, 0), (void) hipStreamSynchronize(c->stream));
+    if (out_bytes) {
+        LG_TRY(hipMemcpyAsync(sl.h_raw, sl.d_raw, out_bytes, hipMemcpyDeviceToHost, s->back), (void) hipStreamSynchronize(c->stream));
+        LG_TRY(hipMemcpyAsync(sl.h_sm, sl.d_sm, out_bytes, hipMemcpyDeviceToHost, s->back), ((void) hipStreamSynchronize(c->stream), (void) hipStreamSynchronize(s->back)));
+    }
+    LG_TRY(hipEventRecord(sl.out, s->back), ((void) hipStreamSynchronize(c->stream), (void) hipStreamSynchronize(s->back)));
+#undef LG_TRY
+    sl.frames = frames; sl.by_event = true;
     s->head = (s->head + 1) % s->slots;
     s->in_flight++;
     s->acquired = false;
     return FX_OK;
 }
+
+extern "C" {
 
 fx_status fx_stream_push(fx_stream* s, const void* hops, int fill_threads)
 {
@@ -1092,13 +1236,32 @@ fx_status fx_stream_push(fx_stream* s, const void* hops, int fill_threads)
     return fx_stream_submit(s);
 }
 
+fx_status fx_stream_push_samples(fx_stream* s, const void* samples, int num_samples, int fill_threads)
+{
+    if (!s || (!samples && num_samples > 0)) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    if (fill_threads < 1 || fill_threads > 64) return fx_fail(FX_ERR_INVALID_ARGUMENT, "fill_threads must be in [1, 64]");
+    if (num_samples < 0 || (long long) num_samples > (long long) s->hops * (s->ctx->N / 2))
+        return fx_fail(FX_ERR_INVALID_ARGUMENT, "a slot holds 0 .. %lld samples per channel, got %d", (long long) s->hops * (s->ctx->N / 2), num_samples);
+    void* slot = nullptr;
+    const fx_status st = fx_stream_acquire(s, &slot);
+    if (st != FX_OK) return st;
+    if (num_samples > 0) s->fill.copy(slot, samples, (size_t) s->ctx->C * (size_t) num_samples * sample_size(s->fmt), fill_threads);
+    return fx_stream_submit_samples(s, num_samples);
+}
+
 fx_status fx_stream_collect(fx_stream* s, float* out_raw, float* out_smoothed)
 {
+    return fx_stream_collect_samples(s, out_raw, out_smoothed, nullptr);
+}
+
+fx_status fx_stream_collect_samples(fx_stream* s, float* out_raw, float* out_smoothed, int* frames_out)
+{
+    if (frames_out) *frames_out = 0;
     if (!s) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null stream");
     if (s->in_flight == 0) return fx_fail(FX_ERR_INVALID_ARGUMENT, "nothing in flight");
     HIP_TRY(hipSetDevice(s->ctx->device));
     fx_stream::Slot& sl = s->ring[(size_t) s->tail];
-    if (s->use_hop_kernel) {
+    if (!sl.by_event) {
         // the kernel stores the call's sequence number after its results: poll it (a hop takes tens of microseconds,
         // an event wait costs as much again); if it does not show up soon -- a large grid, a busy device -- wait for the stream
         volatile unsigned* flag = sl.h_flag;
@@ -1114,8 +1277,10 @@ fx_status fx_stream_collect(fx_stream* s, float* out_raw, float* out_smoothed)
     } else {
         HIP_TRY(hipEventSynchronize(sl.out));
     }
-    if (out_raw) memcpy(out_raw, sl.h_raw, s->out_bytes);
-    if (out_smoothed) memcpy(out_smoothed, sl.h_sm, s->out_bytes);
+    const size_t got_bytes = (size_t) s->ctx->C * (size_t) sl.frames * FX_NUM_FEATURES * sizeof(float);
+    if (out_raw && got_bytes) memcpy(out_raw, sl.h_raw, got_bytes);
+    if (out_smoothed && got_bytes) memcpy(out_smoothed, sl.h_sm, got_bytes);
+    if (frames_out) *frames_out = sl.frames;
     s->tail = (s->tail + 1) % s->slots;
     s->in_flight--;
     return fx_check_device_error(s->ctx);

@@ -49,10 +49,20 @@ struct fx_context {
     float* d_hist = nullptr;      // [C][HLEN][12]: per channel a ring of the newest HLEN frames' raw values (row = frame index mod HLEN)
     float* d_latest = nullptr;    // [C][12]
     int    cur = 0;
+    unsigned test_hooks = 0;      // fx_set_tuning_internal (fx_kernels.h): tests only
     fx_tuning tuning;             // launch-shape knobs: taken from the environment ONCE, in fx_create (fx_set_tuning replaces them)
     unsigned* h_err = nullptr;    // pinned, coherent: a kernel stores 1 here when a work unit gave up waiting for its predecessor (sticky)
     unsigned* d_err = nullptr;    // device view of h_err
     unsigned* d_queue = nullptr;  // [1 + C]: ticket counter and per-channel chunk counts of a frame-kernel launch cut in time (FrameParams::queue)
+
+    // fx_push_samples: what a channel's device blocks have left over, < N/2 samples in `carry_format` (AudioDataCollector's ring holds
+    // them un-gained, AudioDataCollector.h:42-64,88); two buffers, the re-blocking kernel reads one and writes the other
+    unsigned char* d_carry[2] = {nullptr, nullptr};   // [C][N/2 * 4 bytes]
+    int    carry_cur = 0;
+    int    carry_count = 0;       // samples per channel pending (the same for every channel: blocks arrive for all channels at once)
+    int    carry_format = FX_SAMPLE_F32;
+    unsigned char* d_hops = nullptr;    // [C][hops][N/2] samples assembled for one fx_push_samples call
+    size_t hops_cap = 0;
 
     float* d_raw = nullptr;       // [C][T_cap][12]
     fxk::FramePart* d_part = nullptr;   // [C][T_cap]

@@ -78,7 +78,7 @@ struct FrameParams {
     unsigned*    queue;
     // A work unit that gives up waiting for its predecessor (after spin_limit polls) stores 1 here -- pinned host memory,
     // system scope -- and the host turns that into FX_ERR_HIP at the next synchronisation: a stale flux state is never
-    // handed on silently.  debug_flags bit 0 (tests): units do not publish their hand-over, which forces the time-out.
+    // handed on silently.  debug_flags bit 0 (FX_HOOK_NO_HANDOVER, tests): units do not publish their hand-over, which forces the time-out.
     unsigned*    err;
     unsigned     spin_limit;
     unsigned     debug_flags;
@@ -146,6 +146,20 @@ struct HopSignal {
                             // (coalesced) and its three wavefronts read it from there (the slot is un-cached memory across PCIe)
 };
 
+// fx_push_samples (fx_reblock.hip): per channel, the byte stream [carry_in row: carry_bytes][in row: in_row_bytes] is split into
+// out_row_bytes of whole hops (a multiple of 16) for `hops_out` and the remainder (< carry_row_bytes) for `carry_out`.
+struct ReblockParams {
+    const unsigned char* in;        // [C][in_row_bytes]: the new block, rows back to back (any alignment from the second row on)
+    const unsigned char* carry_in;  // [C][carry_row_bytes]: the pending samples of each channel, carry_bytes valid
+    unsigned char*       hops_out;  // [C][out_row_bytes]
+    unsigned char*       carry_out; // [C][carry_row_bytes]: the other of the context's two carry buffers
+    long long            in_row_bytes, out_row_bytes;
+    int                  carry_bytes, carry_row_bytes;
+    int                  C;
+};
+hipError_t launch_reblock_kernel(const ReblockParams& p, hipStream_t stream);
+hipError_t clear_carry(unsigned char* carry, size_t bytes, hipStream_t stream);
+
 // Re-order the reference's N-entry twiddle table (canonical[i] = (re, im) of e^{-2*pi*i/N} as floats)
 // into the order the FFT passes read it; `out` has room for window_size complex entries.
 void build_pass_twiddles(int window_size, const float* canonical, float* out);
@@ -193,4 +207,17 @@ bool hop_kernel_available(int window_size);
 hipError_t launch_hop_kernel(int window_size, const FrameParams& p, const EpilogueParams& ep, const HopSignal& sig, hipStream_t stream, bool pairs = false);
 
 } // namespace fxk
+
+// Test hooks, NOT part of the public ABI (include/fx.h does not declare this; the library exports it for tests/ only).  Bits:
+//   0  work units of a cut launch do not publish their hand-over (forces the time-out that FX_ERR_HIP reports)
+//   1  the 4096-point kernel takes no twiddle from a quarter turn of another (the path of a host whose cos / sin lack that
+//      symmetry: same values, read from the whole table)
+//   2 / 3  one-frame calls through the batch kernels never / always finish the hop's tail in the frame kernel (default: while the
+//      chip holds the call's workgroups at once)
+// None changes a result bit (bit 0 makes the call fail, as it must).
+#define FX_HOOK_NO_HANDOVER      1u
+#define FX_HOOK_NO_QUARTER_TURN  2u
+#define FX_HOOK_TAIL_NEVER_FUSED 4u
+#define FX_HOOK_TAIL_ALWAYS_FUSED 8u
+extern "C" fx_status fx_set_tuning_internal(fx_context* ctx, unsigned test_hooks);
 #endif

@@ -388,7 +388,9 @@ __global__ void __launch_bounds__(NT) auto_correlation_kernel(const float* data,
     const int c = blockIdx.x;
     const float* d = data + (size_t) c * num_items * 2;
     float best = 0.0f; int at = -1;
-    for (int i = threadIdx.x; i < num_items; i += NT) { const float v = d[2 * i]; if (at < 0 || v > best) { best = v; at = i; } }      // ascending i: the first on ties
+    // ascending i: the first on ties.  NaNs are skipped as getMaxIndex skips them (`data[i] > currentMax` is false for one), so a NaN early in a
+    // thread's stride cannot hide the maxima behind it; a NaN at data[0] is thread 0's business below
+    for (int i = threadIdx.x; i < num_items; i += NT) { const float v = d[2 * i]; if (v == v && (at < 0 || v > best)) { best = v; at = i; } }
     s_val[threadIdx.x] = best; s_idx[threadIdx.x] = at;
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -519,15 +519,18 @@ static_assert(FUSED_TAIL_MAX_FRAMES <= TAIL_GROUP && FX_NUM_FEATURES <= TAIL_GRO
 // workgroup's (fx_tail_fused_kernel: a workgroup IS one wavefront; fx_frame_tail_kernel: its tail wavefronts all pass here).
 constexpr int ONE_HOP_TAIL_FLOATS = TAIL_CHANNELS * (HLEN * FX_NUM_FEATURES + 16 + 64);
 constexpr int ONE_HOP_TAIL_BYTES = 4 * ONE_HOP_TAIL_FLOATS;
-__device__ __forceinline__ void tail_one_hop(const EpilogueParams& p, int c_first, int lane, float* lds)
+// `c_end`: one past the last channel this wavefront may finish -- the context's channel count, or the end of the calling workgroup's own
+// block of channels (fx_frame_tail_kernel with a channel count per workgroup that is no multiple of TAIL_CHANNELS: the group beyond
+// it belongs to the NEXT workgroup, which may still be analysing that channel's frame).
+__device__ __forceinline__ void tail_one_hop(const EpilogueParams& p, int c_first, int c_end, int lane, float* lds)
 {
     const int g = lane / TAIL_GROUP, gl = lane % TAIL_GROUP;
     float* s_hist = lds + g * (HLEN * FX_NUM_FEATURES);
     float* s_raw = lds + TAIL_CHANNELS * (HLEN * FX_NUM_FEATURES) + g * 16;
     float* s_scratch = lds + TAIL_CHANNELS * (HLEN * FX_NUM_FEATURES + 16) + g * 64;
     const int c_mine = c_first + g;
-    const bool live = c_mine < p.C;
-    const int c = live ? c_mine : p.C - 1;                // a group beyond the last channel keeps in step on the last one and stores nothing
+    const bool live = c_mine < c_end;
+    const int c = live ? c_mine : c_end - 1;              // a group beyond the last channel keeps in step on the last one and stores nothing
     const float* ring = p.hist + (size_t) c * HLEN * FX_NUM_FEATURES;
     {
         // the LDS copy keeps the ring's row positions; rows nobody reads are not fetched (a row is 48 bytes: three 16-byte pieces)
@@ -579,7 +582,8 @@ fx_frame_tail_kernel(const FrameParams p, const EpilogueParams ep_arg)
     if (wave >= tail_waves) return;
     const EpilogueParams ep = with_dyn(ep_arg);
     float* lds = reinterpret_cast<float*>(smem + sizeof(f2) * FrameLds<N>::TW_ENTRIES) + (size_t) wave * ONE_HOP_TAIL_FLOATS;
-    tail_one_hop(ep, (int) blockIdx.x * p.ch_per_wg + TAIL_CHANNELS * wave, (int) (threadIdx.x & 63), lds);
+    const int c_begin = (int) blockIdx.x * p.ch_per_wg;
+    tail_one_hop(ep, c_begin + TAIL_CHANNELS * wave, min(c_begin + p.ch_per_wg, p.C), (int) (threadIdx.x & 63), lds);
 }
 #endif
 #ifdef FX_WITH_TAIL_KERNELS
@@ -591,7 +595,13 @@ fx_tail_fused_kernel(const EpilogueParams p_arg)
     static_assert(FUSED_TAIL_MAX_FRAMES * FX_NUM_FEATURES >= 16, "tail_one_hop fits the same memory");
     const EpilogueParams p = with_dyn(p_arg);
     const int lane = threadIdx.x, g = lane / TAIL_GROUP, gl = lane % TAIL_GROUP;
-    if (p.T == 1) { tail_one_hop(p, blockIdx.x * TAIL_CHANNELS, lane, s_all); return; }
+    // a call cut into work units whose tail is this kernel (<= FUSED_TAIL_MAX_FRAMES frames, cut by an explicit plan or small units):
+    // its ticket counter and hand-over counts go back to zero here, as fx_history_kernel does for longer calls (16 threads per channel)
+    {
+        const long long idx = (long long) blockIdx.x * 64 + lane;
+        if (p.clear_queue && idx < p.clear_count) p.clear_queue[idx] = 0u;
+    }
+    if (p.T == 1) { tail_one_hop(p, blockIdx.x * TAIL_CHANNELS, p.C, lane, s_all); return; }
     float* s_hist = s_all + g * (HLEN * FX_NUM_FEATURES);
     float* s_raw = s_all + TAIL_CHANNELS * (HLEN * FX_NUM_FEATURES) + g * (FUSED_TAIL_MAX_FRAMES * FX_NUM_FEATURES);
     const int c_mine = blockIdx.x * TAIL_CHANNELS + g;

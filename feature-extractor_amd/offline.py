@@ -14,6 +14,7 @@ class AudioAnalyser:
         h = ctypes.c_void_p()
         capi.check(self._lib.fx_offline_create(ctypes.byref(h), int(device), self.num_channels, float(nyquist_frequency)))
         self._h = h
+        self._bins = 0          # length of previousBinMagnitudes: fixed by the first calculate_spectral_characteristics after construction / reset
 
     def close(self):
         if getattr(self, "_h", None):
@@ -28,6 +29,7 @@ class AudioAnalyser:
 
     def reset(self):
         capi.check(self._lib.fx_offline_reset(self._h))
+        self._bins = 0
 
     @property
     def previous_f0(self):                                                                  # ref AudioAnalysis.h:697
@@ -84,6 +86,8 @@ class AudioAnalyser:
 
     @property
     def previous_bin_magnitudes(self):                                                      # ref :700
+        if self._bins == 0:         # nothing analysed since construction / reset: the reference's vector exists, zero-filled, at its window size -- which this object learns from the first frame
+            return np.zeros((self.num_channels, 0), np.float64)
         out = np.empty((self.num_channels, self._bins), np.float64)
         capi.check(self._lib.fx_offline_get_previous_bins(self._h, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), self._bins))
         return out

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 4
+#define FX_ABI_VERSION 5
 
 typedef int fx_status;
 enum {
@@ -127,6 +127,28 @@ fx_status fx_set_gain(fx_context* ctx, float gain);
 fx_status fx_push_hops(fx_context* ctx, const void* hops, int num_hops, int sample_format,
                        int mem_kind, float* out_raw, float* out_smoothed);
 
+/* The collector's own interface: a device block of ANY length.  Replaces AudioDataCollector::audioDeviceIOCallback
+ * (AudioDataCollector.h:36-70: whatever `numberOfSamples` the audio device delivers -- 441, 480, 512 ... -- goes into the ring)
+ * together with the reader that pulls window_size/2 samples whenever they are there (getAnalysisBuffer, :72-94, called by
+ * RealTimeAudioDataOverlapper::getNextBuffer, RealTimeAudioAnalysis.h:205-219) for all channels at once.
+ *   samples      [num_channels][num_samples]  the block of every channel, rows back to back; num_samples >= 0
+ * The context keeps what a block leaves over -- fewer than window_size/2 samples per channel, un-gained, in device memory --
+ * analyses floor((pending + num_samples) / (window_size/2)) hops exactly as fx_push_hops would analyse the same samples cut
+ * into hops (bit for bit), and keeps the rest.  The gain (fx_set_gain) is applied when a hop is analysed, as getAnalysisBuffer
+ * applies it at read time (:88): a change reaches samples that are still pending.
+ *   out_raw / out_smoothed  [num_channels][frames][12] with frames = (fx_pending_samples() + num_samples) / (window_size/2),
+ *                           or NULL;  *frames_out (may be NULL) receives that count (0 is not an error)
+ * FX_MEM_DEVICE blocks must start on a 4-byte boundary (on a 16-byte boundary with whole hops and nothing pending they are
+ * analysed in place).  The sample format may change only while nothing is pending.  While samples are pending, fx_push_hops,
+ * fx_process_frames and fx_stream_submit refuse (whole hops would overtake them); fx_reset_state drops them. */
+fx_status fx_push_samples(fx_context* ctx, const void* samples, int num_samples, int sample_format, int mem_kind,
+                          float* out_raw, float* out_smoothed, int* frames_out);
+/* samples per channel held back by fx_push_samples / fx_stream_submit_samples, 0 <= n < window_size/2 */
+int fx_pending_samples(fx_context* ctx);
+/* AudioDataCollector::clearBuffer (AudioDataCollector.h:122; the transport buttons, AnalyserTrackController.h:135-137,167-171):
+ * the pending samples become zeros; their count, like the ring's indices, stays. */
+fx_status fx_clear_pending(fx_context* ctx);
+
 /* Same analysis on already assembled windows (the `audioWindow` each run()
  * loop sees, RealTimeAnalyser.h:147,206): frames [num_channels][num_frames]
  * [window_size].  Gain is not applied.  The overlap state is left holding the
@@ -170,7 +192,8 @@ fx_status fx_last_kernel_ms(fx_context* ctx, float* frame_kernel_ms, float* epil
 typedef struct fx_stream fx_stream;
 fx_status fx_stream_create(fx_context* ctx, int hops_per_batch, int slots, int sample_format, fx_stream** out);
 fx_status fx_stream_destroy(fx_stream* s);
-/* Next free slot to fill (pinned host memory); blocks while every slot is still in flight. */
+/* Next free slot to fill (pinned host memory).  Never blocks: FX_ERR_INVALID_ARGUMENT while every slot is still in flight
+ * (fx_stream_collect frees the oldest) or while an acquired slot has not been submitted. */
 fx_status fx_stream_acquire(fx_stream* s, void** host_slot);
 /* Hand the acquired slot to the GPU (asynchronous). */
 fx_status fx_stream_submit(fx_stream* s);
@@ -183,6 +206,17 @@ fx_status fx_stream_push(fx_stream* s, const void* hops, int fill_threads);
  * [num_channels][hops_per_batch][12] host floats (either may be NULL).  FX_ERR_INVALID_ARGUMENT
  * if nothing is in flight. */
 fx_status fx_stream_collect(fx_stream* s, float* out_raw, float* out_smoothed);
+/* The ring's form of fx_push_samples: the acquired slot holds a block of num_samples samples per channel, [num_channels]
+ * [num_samples] with rows back to back, 0 <= num_samples <= hops_per_batch * window_size/2 (a device callback's block, or several
+ * of them); the context's pending samples and the block are cut into hops on the device, analysed, and the rest is kept.  The
+ * batch yields frames = (pending + num_samples) / (window_size/2) vectors per channel, which fx_stream_collect_samples reports.
+ * Always the three-queue path (samples in, kernels, vectors back). */
+fx_status fx_stream_submit_samples(fx_stream* s, int num_samples);
+/* acquire + copy (fill_threads host threads) + fx_stream_submit_samples for a block in ordinary host memory */
+fx_status fx_stream_push_samples(fx_stream* s, const void* samples, int num_samples, int fill_threads);
+/* fx_stream_collect that also says how many frames per channel the batch produced: raw / smoothed [num_channels][frames][12]
+ * (room for hops_per_batch frames per channel is always enough) */
+fx_status fx_stream_collect_samples(fx_stream* s, float* out_raw, float* out_smoothed, int* frames_out);
 /* Number of submitted batches not yet collected. */
 int fx_stream_in_flight(fx_stream* s);
 
@@ -214,11 +248,6 @@ typedef struct fx_tuning {
                                     Calls between fx_profile_begin / fx_profile_end are timed regardless */
     int handover_spin_limit;     /* FX_HANDOVER_SPINS: polls a work unit spends waiting for its predecessor's flux state
                                     before it gives up and the call is reported failed (FX_ERR_HIP); 0 = default (1 << 22) */
-    int debug_flags;             /* FX_DEBUG_FLAGS (tests): bit 0 = work units do not publish their hand-over (forces the time-out);
-                                    bit 1 = the 4096-point kernel takes no twiddle from a quarter turn of another (the path of a host whose
-                                    cos / sin lack that symmetry: same values, read from the whole table); bits 2 / 3 = one-frame calls through the batch
-                                    kernels never / always finish the hop's tail in the frame kernel (default: while the chip holds the call's
-                                    workgroups at once) */
 } fx_tuning;
 void fx_tuning_defaults(fx_tuning* t);     /* every knob "measured best" */
 void fx_tuning_from_env(fx_tuning* t);     /* defaults overridden by the FX_* variables set right now */

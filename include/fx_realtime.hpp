@@ -6,6 +6,8 @@
 //   * fx::RealTimeBatchAnalyser     -- the pair RealTimeSpectralAnalyser + RealTimeHarmonicAnalyser
 //                                      (ref RealTimeAnalyser.h:133-269) for many channels on one GPU;
 //                                      setter names are the reference's.
+//   * fx::AudioDataCollector        -- ref Source/AudioDataCollector.h:18-138: audioDeviceIOCallback takes device blocks of ANY
+//                                      length for all channels; whole hops are analysed as they complete (fx_push_samples).
 //   * fx::OSCFeatureMessage         -- ref Source/OSCFeatureAnalysisOutput.h:89-113 wire format.
 // No JUCE.  Errors are thrown as fx::Error (the reference only jasserts).
 #ifndef FX_REALTIME_HPP
@@ -14,6 +16,8 @@
 #include <cstddef>
 #include <cstdlib>
 #include <cstdint>
+#include <cstring>
+#include <functional>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -167,8 +171,58 @@ private:
     std::vector<float> latest;
 };
 
+// AudioDataCollector, ref Source/AudioDataCollector.h:18-138, for every channel of a RealTimeBatchAnalyser at once.  The reference's
+// collector copies each device block -- whatever length the audio device delivers -- into a 4096-sample ring and notifies the analysis
+// thread, which reads window/2 samples (times the gain) whenever they are there (:36-94).  Here audioDeviceIOCallback hands the block of
+// all channels to fx_push_samples: the library keeps what is left over (< window/2 samples per channel, in device memory), analyses the
+// hops that completed and the frames' values are handed to the callback the analysis threads' updateFeature calls stood for.
+class AudioDataCollector
+{
+public:
+    explicit AudioDataCollector (RealTimeBatchAnalyser& analyserToFeed)
+        : analyser (analyserToFeed), channels (analyserToFeed.getNumChannels()), hop (analyserToFeed.getWindowSize() / 2) {}
+
+    // ref :36-70.  inputChannelData[c] points at `numberOfSamples` floats of channel c (JUCE's layout); returns the number of analysis
+    // frames per channel this block completed (0 is normal for blocks shorter than a hop).  Their values: raw() / smoothed(),
+    // [channel][frame][12], and the callback set below is called once per block that completed at least one frame.
+    int audioDeviceIOCallback (const float* const* inputChannelData, int numInputChannels, int numberOfSamples)
+    {
+        if (numInputChannels < channels) throw Error (FX_ERR_INVALID_ARGUMENT, "fewer input channels than the analyser has");   // jassert, :44-47
+        block.resize ((std::size_t) channels * (std::size_t) numberOfSamples);
+        for (int c = 0; c < channels; ++c)
+            if (numberOfSamples > 0) std::memcpy (block.data() + (std::size_t) c * (std::size_t) numberOfSamples, inputChannelData[c], sizeof (float) * (std::size_t) numberOfSamples);
+        return pushBlock (block.data(), numberOfSamples, FX_SAMPLE_F32);
+    }
+    // the same for a block that is already [channel][numberOfSamples] in one piece, in any sample format of fx.h
+    int pushBlock (const void* samples, int numberOfSamples, int sampleFormat = FX_SAMPLE_F32)
+    {
+        const std::size_t most = (std::size_t) ((fx_pending_samples (analyser.handle()) + numberOfSamples) / hop);
+        rawValues.resize ((std::size_t) channels * most * FX_NUM_FEATURES);
+        smoothedValues.resize (rawValues.size());
+        int frames = 0;
+        check (fx_push_samples (analyser.handle(), samples, numberOfSamples, sampleFormat, FX_MEM_HOST,
+                                most ? rawValues.data() : nullptr, most ? smoothedValues.data() : nullptr, &frames));
+        lastFrames = frames;
+        if (frames > 0 && framesAnalysed) framesAnalysed (frames);      // where the reference calls notifyAnalysisThread(), :68-69
+        return frames;
+    }
+    void setNotifyAnalysisThreadCallback (std::function<void (int)> f)  { framesAnalysed = f; }    // ref :107 (argument: frames per channel)
+    void setGain (float g)       { analyser.setGain (g); }                                          // ref :124
+    void clearBuffer()           { check (fx_clear_pending (analyser.handle())); }                  // ref :122
+    int  getNumPendingSamples()  { return fx_pending_samples (analyser.handle()); }
+    int  getNumFrames() const    { return lastFrames; }
+    const float* raw() const      { return rawValues.data(); }        // [channel][getNumFrames()][12] of the last block
+    const float* smoothed() const { return smoothedValues.data(); }
+
+private:
+    RealTimeBatchAnalyser& analyser;
+    int channels, hop, lastFrames = 0;
+    std::vector<float> block, rawValues, smoothedValues;
+    std::function<void (int)> framesAnalysed;
+};
+
 // The stand-in for AudioDataCollector's ring (ref Source/AudioDataCollector.h:24,36-94: the audio thread writes a ring, the analysis thread
-// spins until a hop is there): a ring of pinned host batches of `hopsPerBatch` hops per channel (fx_stream_*).  The producer writes into
+// spins until a hop is there) for hosts that batch: a ring of pinned host batches of `hopsPerBatch` hops per channel (fx_stream_*).  The producer writes into
 // nextSlot() and submit()s it -- or push()es a batch from ordinary memory, copied by `fillThreads` host threads inside the library --
 // and collect()s the results in submission order; samples in, kernels and results back overlap.  One hop per batch is the reference's
 // own cadence: a submit is then ONE kernel launch and collect() polls a flag (32-33 us round trip for a 4096-point window on MI355X).
@@ -188,6 +242,10 @@ public:
     void* nextSlot()                                   { void* p = nullptr; check (fx_stream_acquire (ring, &p)); return p; }
     void submit()                                      { check (fx_stream_submit (ring)); }
     void push (const void* hops, int fillThreads = 1)  { check (fx_stream_push (ring, hops, fillThreads)); }
+    // a block of ANY length up to a slot's capacity, [channels][numSamples] (fx_stream_submit_samples / fx_stream_push_samples)
+    void submitSamples (int numSamples)                { check (fx_stream_submit_samples (ring, numSamples)); }
+    void pushSamples (const void* samples, int numSamples, int fillThreads = 1) { check (fx_stream_push_samples (ring, samples, numSamples, fillThreads)); }
+    int  collectSamples (float* raw, float* smoothed)  { int frames = 0; check (fx_stream_collect_samples (ring, raw, smoothed, &frames)); return frames; }
     int  inFlight() const                              { return fx_stream_in_flight (ring); }
     // the oldest batch's values: raw / smoothed [channels][hopsPerBatch][12], either may be null
     void collect (float* raw, float* smoothed)         { check (fx_stream_collect (ring, raw, smoothed)); }

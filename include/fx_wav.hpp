@@ -167,6 +167,15 @@ inline std::vector<std::int16_t> hopsOfChannelPCM16 (const WavData& wav, int cha
     for (std::size_t i = 0; i < mono.size(); ++i) mono[i] = wav.pcm16[i * (std::size_t) wav.numChannels + (std::size_t) channel];
     return mono;
 }
+// every sample of one channel of a 16-bit file, as the file holds it (what an audio device would deliver block by block)
+inline std::vector<std::int16_t> samplesOfChannelPCM16 (const WavData& wav, int channel)
+{
+    std::vector<std::int16_t> mono;
+    if (wav.pcm16.empty()) return mono;
+    mono.resize (wav.numFrames());
+    for (std::size_t i = 0; i < mono.size(); ++i) mono[i] = wav.pcm16[i * (std::size_t) wav.numChannels + (std::size_t) channel];
+    return mono;
+}
 // ... and as packed 24-bit PCM (24-bit files only): numHops * windowSize/2 * 3 bytes of the chosen channel.
 inline std::vector<unsigned char> hopsOfChannelPCM24 (const WavData& wav, int channel, int windowSize, int& numHops)
 {

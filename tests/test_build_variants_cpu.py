@@ -55,7 +55,7 @@ def test_variant_compiles(name, flags):
 
 def test_public_header_is_free_of_diagnostics():
     text = open(os.path.join(ROOT, "include", "fx.h")).read()
-    for word in ("stamp", "FX_PAIR_STAMPS", "fx_debug_"):
+    for word in ("stamp", "FX_PAIR_STAMPS", "fx_debug_", "debug_flags", "fx_set_tuning_internal", "FX_HOOK_"):
         assert word not in text, word
-    # what stays is one field with two test bits: the forced hand-over time-out and the 4096-point kernel's twiddle fallback
-    assert text.count("debug_flags") == 1
+    # the test hooks live in csrc/fx_kernels.h (fx_set_tuning_internal), which no host includes
+    assert "fx_set_tuning_internal" in open(os.path.join(CSRC, "fx_kernels.h")).read()

@@ -28,7 +28,7 @@ def test_library_builds_loads_and_exports_every_symbol(fx):
     assert os.path.exists(fx.library_path())
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.fx_abi_version() == fx.capi.ABI_VERSION == 4
+    assert lib.fx_abi_version() == fx.capi.ABI_VERSION == 5
 
 
 def test_library_contains_gfx950_code(fx):
@@ -140,11 +140,11 @@ def test_tuning_comes_from_the_environment_once(fx, monkeypatch):
     capi = import_module("feature-extractor_amd.capi")
     fx.load_library(build_if_missing=True)
     for var in ("FX_WAVES", "FX_CHANNELS_PER_WG", "FX_WAVES_PER_FRAME", "FX_FRAMES_PER_CHUNK", "FX_CHUNK_PLAN", "FX_STREAM_GRAPH",
-                "FX_STREAM_HOP_KERNEL", "FX_STREAM_ZEROCOPY", "FX_ONE_HOP_KERNEL", "FX_CALL_TIMING", "FX_HANDOVER_SPINS", "FX_DEBUG_FLAGS"):
+                "FX_STREAM_HOP_KERNEL", "FX_STREAM_ZEROCOPY", "FX_ONE_HOP_KERNEL", "FX_CALL_TIMING", "FX_HANDOVER_SPINS"):
         monkeypatch.delenv(var, raising=False)
     d, e = capi.Tuning.defaults(), capi.Tuning.from_env()
     assert bytes(d) == bytes(e)
-    assert (d.waves_per_channel, d.frames_per_unit, d.stream_graph, d.one_hop_kernel, d.call_timing, d.handover_spin_limit, d.debug_flags) == (0, -1, -1, -1, -1, 0, 0)
+    assert (d.waves_per_channel, d.frames_per_unit, d.stream_graph, d.one_hop_kernel, d.call_timing, d.handover_spin_limit) == (0, -1, -1, -1, -1, 0)
     monkeypatch.setenv("FX_WAVES", "3")
     monkeypatch.setenv("FX_FRAMES_PER_CHUNK", "0")
     monkeypatch.setenv("FX_CHUNK_PLAN", "300,200,12")

@@ -61,12 +61,12 @@ def test_failed_handover_between_work_units_is_reported(gpu_fx):
     """A work unit that gives up waiting for its predecessor's flux state must not carry on silently (it would hand a
     stale previousBinMagnitudes down the channel, ref SpectralCharacteristics.h:76-79,203): the kernel raises an error
     word and every synchronising entry point returns FX_ERR_HIP until fx_reset_state.  Forced here by units that do
-    not publish (fx_tuning::debug_flags bit 0) and a poll bound of 8."""
+    not publish (fx_set_tuning_internal bit 0) and a poll bound of 8."""
     C, T, N = 64, 256, 1024
     hops = signals.bursts(C, T, N, seed=77)
     good = gpu_fx.BatchAnalyser(C, N).push_hops(hops)
     an = gpu_fx.BatchAnalyser(C, N)
-    an.set_tuning(handover_spin_limit=8, debug_flags=1)
+    an.set_tuning(handover_spin_limit=8); an.set_test_hooks(1)
     with pytest.raises(gpu_fx.FxError) as e:
         an.push_hops(hops)                              # host buffers: the call synchronises and must report
     assert e.value.code == 3 and "timed out" in str(e.value)
@@ -75,7 +75,7 @@ def test_failed_handover_between_work_units_is_reported(gpu_fx):
     with pytest.raises(gpu_fx.FxError):
         an.push_hops(hops[:, :4])
     an.reset_state()                                    # a fresh analyser again
-    an.set_tuning(handover_spin_limit=0, debug_flags=0)
+    an.set_tuning(handover_spin_limit=0); an.set_test_hooks(0)
     got = an.push_hops(hops)
     an.sync()
     for k in (0, 1):
@@ -86,14 +86,14 @@ def test_failed_handover_between_work_units_is_reported(gpu_fx):
 def test_one_frame_calls_finish_their_tail_in_the_frame_kernel(gpu_fx, N, C):
     """One frame per channel through the batch kernels is ONE launch while the chip holds the call's workgroups at once
     (fx_frame_tail_kernel: the workgroup's first wavefronts finish its channels' hops when the frames are done), else the frame
-    kernel and the fused tail kernel.  fx_tuning::debug_flags bits 3 / 2 force the one and the other: the same bits, hop after hop, with an onset window that reaches far into the history ring, channel
+    kernel and the fused tail kernel.  fx_set_tuning_internal bits 3 / 2 force the one and the other: the same bits, hop after hop, with an onset window that reaches far into the history ring, channel
     counts that leave the last workgroup partly filled, and device buffers."""
     import torch
     T = 60
     hops = np.concatenate([signals.bursts(C, T // 2, N, seed=N + C), signals.tone_vibrato_noise(C, T - T // 2, N, seed=C)], axis=1)
     one, two = gpu_fx.BatchAnalyser(C, N), gpu_fx.BatchAnalyser(C, N)
-    one.set_tuning(debug_flags=8)
-    two.set_tuning(debug_flags=4)
+    one.set_test_hooks(8)
+    two.set_test_hooks(4)
     for an in (one, two):
         an.set_tuning(one_hop_kernel=0)
         an.set_onset_window_length(21); an.set_onset_detection_type(2); an.set_onset_detection_sensitivity(0.4)
@@ -110,16 +110,54 @@ def test_one_frame_calls_finish_their_tail_in_the_frame_kernel(gpu_fx, N, C):
     assert np.array_equal(one.get_features(), want[1][:, -1], equal_nan=True)
 
 
+@pytest.mark.parametrize("ch_per_wg", [3, 5, 6, 7])
+def test_one_frame_calls_with_a_channel_count_per_workgroup_that_is_no_multiple_of_four(gpu_fx, ch_per_wg):
+    """fx_frame_tail_kernel's tail wavefronts take four channels each: with 3, 5, 6 or 7 channels per workgroup the last group of a
+    workgroup's last tail wavefront belongs to the NEXT workgroup and must be left alone (round-4 advisor finding: it used to read that
+    channel's record, possibly before it was written, and both workgroups wrote its history)."""
+    C, N, T = 23, 1024, 40
+    hops = np.concatenate([signals.bursts(C, T // 2, N, seed=ch_per_wg), signals.tone_vibrato_noise(C, T - T // 2, N, seed=3)], axis=1)
+    one, two = gpu_fx.BatchAnalyser(C, N), gpu_fx.BatchAnalyser(C, N)
+    one.set_test_hooks(8)                      # always finish the hop's tail in the frame kernel
+    one.set_tuning(one_hop_kernel=0, channels_per_workgroup=ch_per_wg)
+    two.set_test_hooks(4)                      # never
+    two.set_tuning(one_hop_kernel=0)
+    for t in range(T):
+        a, b = one.push_hops(hops[:, t:t + 1]), two.push_hops(hops[:, t:t + 1])
+        assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True), t
+    assert np.array_equal(one.get_features(), two.get_features(), equal_nan=True)
+
+
+def test_short_calls_cut_into_work_units_leave_the_ticket_counter_at_zero(gpu_fx):
+    """A call of <= 8 frames per channel finishes with fx_tail_fused_kernel; cut into work units by an explicit plan it must still
+    leave the units' ticket counter and hand-over counts zeroed for the next cut call (round-4 advisor finding: only fx_history_kernel
+    cleared them, so the second such call started its tickets past the plan and analysed nothing)."""
+    C, N, T = 6, 1024, 8
+    hops = signals.tone_vibrato_noise(C, 4 * T, N, seed=11)
+    cut, whole = gpu_fx.BatchAnalyser(C, N), gpu_fx.BatchAnalyser(C, N)
+    cut.set_tuning(waves_per_channel=2, unit_plan=[4, 4])
+    whole.set_tuning(frames_per_unit=0)
+    for k in range(4):
+        a, b = cut.push_hops(hops[:, k * T:(k + 1) * T]), whole.push_hops(hops[:, k * T:(k + 1) * T])
+        assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True), k
+    # ... and a long cut call right after a short one
+    more = signals.tone_vibrato_noise(C, 200, N, seed=12)
+    cut.set_tuning(waves_per_channel=0, unit_plan=[])
+    whole.set_tuning(waves_per_channel=0)
+    a, b = cut.push_hops(more), whole.push_hops(more)
+    assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1], equal_nan=True)
+
+
 def test_4096_twiddle_fallback_gives_the_same_bits(gpu_fx):
     """The 4096-point frame kernel keeps 24 KB of its 32 KB of twiddles in LDS and forms two rows of the last pass as quarter
     turns of two others, which the float table allows on this host (fx_create checks it entry by entry).  A host where it
-    does not reads those rows from the whole table in global memory: forced here (fx_tuning::debug_flags bit 1), batch calls
+    does not reads those rows from the whole table in global memory: forced here (fx_set_tuning_internal bit 1), batch calls
     and one-frame calls (the kernel that leaves the flux state in global memory) -- same values, so the same bits."""
     import torch
     C, T, N = 20, 19, 4096
     hops = np.concatenate([signals.bursts(C, 10, N, seed=5), signals.low_tones(C, T - 10, N)], axis=1)
     a, b = gpu_fx.BatchAnalyser(C, N), gpu_fx.BatchAnalyser(C, N)
-    b.set_tuning(debug_flags=2)
+    b.set_test_hooks(2)
     for an in (a, b):
         an.set_tuning(one_hop_kernel=0)
     ra, rb = a.push_hops(hops[:, :12]), b.push_hops(hops[:, :12])

@@ -323,6 +323,8 @@ def test_pcm24_through_the_ring_frames_and_pairs(gpu_fx, N, C, B, low):
     flat = v.reshape(C, -1)
     frames = np.stack([flat[:, t * (N // 2): t * (N // 2) + N] for t in range(T)], axis=1)
     an2 = gpu_fx.BatchAnalyser(C, N, low_latency=low)
-    raw, sm = an2.process_frames(torch.from_numpy(gpu_fx.pack_s24(frames)).cuda())
+    raw, sm = an2.process_frames(torch.from_numpy(np.asarray(gpu_fx.pack_s24(frames))).cuda(), sample_format="s24")
+    with pytest.raises(ValueError):                       # bytes are never taken for 24-bit PCM on their dtype alone
+        an2.process_frames(torch.from_numpy(np.asarray(gpu_fx.pack_s24(frames))).cuda())
     an2.sync()
     same((raw.cpu().numpy(), sm.cpu().numpy()), gpu_fx.BatchAnalyser(C, N, low_latency=low).process_frames(frames.astype(np.float32) / np.float32(8388608.0)), "s24 frames")

@@ -1,0 +1,188 @@
+"""fx_push_samples / fx_stream_submit_samples: the collector's real interface (ref AudioDataCollector.h:36-94,
+RealTimeAudioAnalysis.h:205-219) -- device blocks of ANY length per call.  Bar: bit for bit what fx_push_hops makes of the same
+stream cut into hops, whatever the block length, sample format or memory kind; against the oracle and the committed fixtures."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import signals
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BLOCKS = [1, 63, 441, 480, 512, 1000, 4097]
+
+
+def same(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+def feed_blocks(an, stream, block, device=False, sample_format=None):
+    """stream [C][total] through push_samples in blocks of `block` samples (the last one shorter): every vector it returned, in order"""
+    import torch
+    C, total = stream.shape[0], stream.shape[1] // (3 if sample_format == "s24" else 1)
+    per = 3 if sample_format == "s24" else 1
+    raws, sms = [], []
+    for at in range(0, total, block):
+        piece = np.ascontiguousarray(stream[:, at * per:(at + block) * per])
+        if device:
+            r, s = an.push_samples(torch.from_numpy(piece).cuda(), sample_format=sample_format)
+            r, s = r.cpu().numpy(), s.cpu().numpy()
+        else:
+            r, s = an.push_samples(piece, sample_format=sample_format)
+        assert r.shape == s.shape and r.shape[0] == C and r.shape[2] == 12
+        raws.append(r); sms.append(s)
+    return np.concatenate(raws, axis=1), np.concatenate(sms, axis=1)
+
+
+@pytest.mark.parametrize("N", [1024, 2048, 4096])
+@pytest.mark.parametrize("block", BLOCKS)
+@pytest.mark.parametrize("fmt", ["f32", "s16"])
+def test_blocks_of_any_length_equal_push_hops_bitwise(gpu_fx, oracle, N, block, fmt):
+    C, H = 3, N // 2
+    T = 3 if block == 1 else 9                                 # (a sample per call: thousands of calls per hop)
+    tail = 0 if block == 512 else 77                           # samples past the last whole hop stay pending
+    hops = np.concatenate([signals.bursts(C, T // 3, N, seed=N + block), signals.tone_vibrato_noise(C, T - T // 3, N, seed=block)], axis=1)
+    extra = signals.tone_vibrato_noise(C, 1, N, seed=5)[:, 0, :tail]
+    stream = np.concatenate([hops.reshape(C, -1), extra], axis=1)
+    if fmt == "s16":
+        stream = np.clip(np.round(stream * 32768.0), -32768, 32767).astype(np.int16)
+        hops = stream[:, :T * H].reshape(C, T, H)
+    ref = gpu_fx.BatchAnalyser(C, N)
+    ref.set_gain(0.75)
+    want = ref.push_hops(hops)
+    for device in (False, True):
+        an = gpu_fx.BatchAnalyser(C, N)
+        an.set_gain(0.75)
+        got = feed_blocks(an, stream, block, device=device)
+        assert got[0].shape == (C, T, 12), (got[0].shape, T)
+        assert same(got[0], want[0]) and same(got[1], want[1]), (N, block, fmt, device)
+        assert an.pending_samples() == tail
+        assert same(an.get_features(), ref.get_features())
+        an.close()
+    # and the oracle, on the floats the kernels widen the samples to
+    floats = hops.astype(np.float32) / np.float32(32768.0) if fmt == "s16" else hops
+    oraw, osm = oracle.push_hops(floats, N, gain=0.75)
+    signals.assert_features_close(want[0], oraw, 1e-5, oracle.FEATURE_NAMES, "raw")
+    signals.assert_features_close(want[1], osm, 1e-5, oracle.FEATURE_NAMES, "smoothed")
+
+
+@pytest.mark.parametrize("name,block", [("tone_2048", 480), ("bursts_1024_harmfirst", 441)])
+def test_committed_fixtures_through_device_blocks(gpu_fx, name, block):
+    """the reference's own outputs (tests/golden, made by the unmodified headers) met from blocks of an audio device's length"""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    hops = g["hops"]
+    C, T, H = hops.shape
+    an = gpu_fx.BatchAnalyser(C, int(g["window_size"]), float(g["sample_rate"]), order=int(g["order"]))
+    raw, sm = feed_blocks(an, hops.reshape(C, -1), block)
+    assert raw.shape == (C, T, 12)
+    from oracle import fx_oracle as fo
+    signals.assert_features_close(raw, g["raw"], 1e-5, fo.FEATURE_NAMES, "golden raw")
+    signals.assert_features_close(sm, g["smoothed"], 1e-5, fo.FEATURE_NAMES, "golden smoothed")
+
+
+def test_packed_24_bit_blocks_and_mixed_block_lengths(gpu_fx):
+    """three-byte samples at every byte alignment a block length can produce, block lengths changing from call to call, empty blocks"""
+    C, N, T = 5, 1024, 11
+    H = N // 2
+    rng = np.random.default_rng(3)
+    v = rng.integers(-2 ** 23, 2 ** 23, (C, T * H + 100), dtype=np.int64).astype(np.int32)
+    v[:, :4 * H] //= 64
+    packed = np.asarray(gpu_fx.pack_s24(v))                       # [C][3 * samples]
+    want = gpu_fx.BatchAnalyser(C, N).push_hops(gpu_fx.pack_s24(v[:, :T * H].reshape(C, T, H)))
+    an = gpu_fx.BatchAnalyser(C, N)
+    raws, sms, at = [], [], 0
+    while at < v.shape[1]:
+        n = int(rng.choice([0, 1, 2, 3, 5, 127, 333, 512, 513, 1500]))
+        n = min(n, v.shape[1] - at)
+        r, s = an.push_samples(np.ascontiguousarray(packed[:, 3 * at:3 * (at + n)]), sample_format="s24")
+        raws.append(r); sms.append(s)
+        at += n
+    assert same(np.concatenate(raws, 1), want[0]) and same(np.concatenate(sms, 1), want[1])
+    assert an.pending_samples() == 100
+    with pytest.raises(ValueError):
+        an.push_samples(packed[:, :30])                          # bytes are not 24-bit PCM on their dtype alone
+
+
+def test_gain_reaches_pending_samples_and_clear_buffer_zeroes_them(gpu_fx):
+    """getAnalysisBuffer multiplies by the gain at READ time (AudioDataCollector.h:88): a change applies to what is still pending;
+    clearBuffer (:122) turns the pending samples into zeros and keeps the indices."""
+    C, N = 2, 1024
+    H = N // 2
+    x = signals.tone_vibrato_noise(C, 6, N, seed=9).reshape(C, -1)
+    an = gpu_fx.BatchAnalyser(C, N)
+    an.set_gain(0.5)
+    a = an.push_samples(x[:, :2 * H + 200])                     # two hops at 0.5, 200 pending
+    an.set_gain(2.0)
+    b = an.push_samples(x[:, 2 * H + 200:4 * H + 50])           # hops 2, 3 wholly at 2.0 (their first 200 samples were pending)
+    an.clear_buffer()                                           # the 50 pending samples become zeros
+    c = an.push_samples(x[:, 4 * H + 50:6 * H])
+    assert an.pending_samples() == 0
+    ref = gpu_fx.BatchAnalyser(C, N)
+    ref.set_gain(0.5)
+    wa = ref.push_hops(x[:, :2 * H].reshape(C, 2, H))
+    ref.set_gain(2.0)
+    wb = ref.push_hops(x[:, 2 * H:4 * H].reshape(C, 2, H))
+    y = x.copy()
+    y[:, 4 * H:4 * H + 50] = 0.0
+    wc = ref.push_hops(y[:, 4 * H:].reshape(C, 2, H))
+    for got, want in ((a, wa), (b, wb), (c, wc)):
+        assert same(got[0], want[0]) and same(got[1], want[1])
+
+
+def test_pending_samples_guard_the_hop_interfaces(gpu_fx):
+    C, N = 2, 1024
+    an = gpu_fx.BatchAnalyser(C, N)
+    x = signals.tone_vibrato_noise(C, 2, N).reshape(C, -1)
+    r, s = an.push_samples(x[:, :100])
+    assert r.shape == (C, 0, 12) and an.pending_samples() == 100
+    with pytest.raises(gpu_fx.FxError):
+        an.push_hops(x[:, :512].reshape(C, 1, 512))             # whole hops would overtake the pending samples
+    with pytest.raises(gpu_fx.FxError):
+        an.push_samples(x[:, :10].astype(np.float16))           # one format between hop boundaries
+    an.reset_state()
+    assert an.pending_samples() == 0
+    an.push_hops(x[:, :512].reshape(C, 1, 512))
+
+
+@pytest.mark.parametrize("N,block", [(1024, 480), (2048, 441), (4096, 1000)])
+def test_ring_of_device_blocks_equals_push_hops_bitwise(gpu_fx, N, block):
+    """fx_stream_push_samples / fx_stream_collect_samples: the pinned ring fed with device blocks; several blocks in flight"""
+    C, T, H = 4, 10, N // 2
+    hops = np.concatenate([signals.bursts(C, 4, N, seed=1), signals.tone_vibrato_noise(C, T - 4, N, seed=2)], axis=1)
+    stream = np.clip(np.round(hops.reshape(C, -1) * 32768.0), -32768, 32767).astype(np.int16)
+    want = gpu_fx.BatchAnalyser(C, N).push_hops(stream.reshape(C, T, H))
+    an = gpu_fx.BatchAnalyser(C, N)
+    st = gpu_fx.HopStream(an, 2, slots=3, dtype=np.int16)     # a slot holds up to two hops' worth of samples
+    raws, sms = [], []
+    for at in range(0, stream.shape[1], block):
+        if st.in_flight() == 3:
+            r, s = st.collect_samples(); raws.append(r); sms.append(s)
+        st.push_samples(np.ascontiguousarray(stream[:, at:at + block]))
+    while st.in_flight():
+        r, s = st.collect_samples(); raws.append(r); sms.append(s)
+    assert same(np.concatenate(raws, 1), want[0]) and same(np.concatenate(sms, 1), want[1])
+    assert an.pending_samples() == 0
+    st.close()
+
+
+def test_wav_to_osc_device_blocks_give_identical_datagrams(gpu_fx, tmp_path):
+    """examples/wav_to_osc --device-block 480: the file played to fx::AudioDataCollector::audioDeviceIOCallback in blocks of 480 samples
+    (a 48 kHz device at 10 ms) -> the same datagrams, byte for byte, as whole hops; 16-bit samples direct as well"""
+    from test_cpp_host import _build_example, _records
+    exe = _build_example(gpu_fx, tmp_path)
+    wav = str(tmp_path / "in.wav")
+    x = gpu_fx.synth.samples(2, 48000 + 333, first_channel=5).T
+    gpu_fx.wav.write_wav(wav, 48000, x, "pcm16")
+    outs = {}
+    for tag, extra in (("hops", []), ("b480", ["--device-block", "480"]), ("b441", ["--device-block", "441", "--pcm16-direct"]),
+                       ("b4097", ["--device-block", "4097"])):
+        dump = str(tmp_path / (tag + ".bin"))
+        out = subprocess.run([exe, wav, "--window", "2048", "--channel", "1", "--gain", "1.5", "--address", "/Audio/A1", "--dump", dump] + extra,
+                             capture_output=True, text=True)
+        assert out.returncode == 0, out.stdout + out.stderr
+        outs[tag] = _records(dump)
+    assert len(outs["hops"]) == (48000 + 333) // 1024
+    assert outs["b480"] == outs["hops"] and outs["b441"] == outs["hops"] and outs["b4097"] == outs["hops"]

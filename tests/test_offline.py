@@ -127,6 +127,17 @@ def test_offline_round4_kernels_equal_the_reference_headers_vectors(gpu_fx, orac
         want_prod = oracle.offline_conjugate_multiplication(data)
         wp, wf = oracle.offline_auto_correlation(want_prod, nyq)
         assert same(prod, want_prod) and same(peaks, wp) and same(freqs, wf), (C, B)
+        # NaNs: getMaxIndex (ref AudioAnalysis.h:651-665) skips them -- `data[i] > currentMax` is false -- unless one sits at item 0, which
+        # then stays the maximum; a NaN early in a thread's stride must not hide the true maximum behind it
+        if data.shape[1] > 600:
+            data[:, 3, 0] = np.nan                   # item 3; the maximum is put 256 items further on (the same thread's stride)
+            data[:, 3 + 256, 0] = 50.0
+            data[0, 0, 0] = np.nan                   # channel 0: NaN at item 0
+            prod, peaks, freqs = an.analyse_auto_correlation(data)
+            want_prod = oracle.offline_conjugate_multiplication(data)
+            wp, wf = oracle.offline_auto_correlation(want_prod, nyq)
+            assert same(peaks, wp) and same(freqs, wf), (C, B, peaks, wp)
+            assert peaks[0] == 0 and (peaks[1:] == 3 + 256).all()
 
 
 @pytest.mark.gpu
