@@ -74,7 +74,12 @@ template <typename T> fx_status grow(T** ptr, size_t* cap, size_t need)
     size_t want = need;
     if (*ptr) {
         if (want < *cap + *cap / 2) want = *cap + *cap / 2;
-        HIP_TRY(hipFree(*ptr));
+        // the pointer is forgotten BEFORE the free is attempted: a free that reports a failure must not be repeated by the next call
+        // (found by tests/cpp/host_sanitize.cpp: the old order freed the block twice)
+        T* old = *ptr;
+        *ptr = nullptr;
+        *cap = 0;
+        HIP_TRY(hipFree(old));
     }
     *ptr = nullptr;
     *cap = 0;
@@ -419,8 +424,9 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int in_ki
         if (out_raw || out_smoothed) {
             // one allocation, two halves
             if (2 * raw_bytes > c->out_cap) {
-                if (c->d_out_raw) HIP_TRY(hipFree(c->d_out_raw));
-                c->d_out_raw = nullptr; c->out_cap = 0;
+                float* old = c->d_out_raw;
+                c->d_out_raw = nullptr; c->out_cap = 0;          // (forgotten first: see grow())
+                if (old) HIP_TRY(hipFree(old));
                 void* p = nullptr;
                 HIP_TRY(hipMalloc(&p, 2 * raw_bytes));
                 c->d_out_raw = static_cast<float*>(p);

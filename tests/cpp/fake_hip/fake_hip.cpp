@@ -1,0 +1,176 @@
+// fake_hip.cpp -- the malloc-backed runtime behind tests/cpp/fake_hip/hip/hip_runtime.h, and stand-ins for the kernel launchers of
+// csrc/fx_kernels.h (which only count as calls).  Everything is synchronous; every entry point is a countable, failable call.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+#include "fx_kernels.h"
+
+struct fake_stream { int capturing = 0; };
+struct fake_event { int recorded = 0; };
+struct fake_graph { int x = 0; };
+struct fake_graph_exec { int x = 0; };
+
+namespace {
+std::mutex g_m;
+std::map<void*, size_t> g_blocks;          // device and host allocations
+long g_objects = 0;                        // streams, events, graphs
+std::atomic<long> g_calls{0};
+long g_fail_at = 0;
+int g_failed = 0;
+const char* g_failed_name = "";
+hipError_t g_last = hipSuccess;
+
+// one countable call; `oom`: what an allocation reports when it is the one to fail
+hipError_t tick(const char* name, bool oom = false)
+{
+    const long k = ++g_calls;
+    if (g_fail_at && k == g_fail_at) { g_failed = 1; g_failed_name = name; g_last = oom ? hipErrorOutOfMemory : hipErrorUnknown; return g_last; }
+    return hipSuccess;
+}
+}
+
+extern "C" {
+void fake_hip_reset(void) { g_calls = 0; g_fail_at = 0; g_failed = 0; g_failed_name = ""; g_last = hipSuccess; }
+void fake_hip_fail_at(long call) { g_fail_at = call; g_failed = 0; }
+long fake_hip_calls(void) { return g_calls; }
+long fake_hip_live(void) { std::lock_guard<std::mutex> g(g_m); return (long) g_blocks.size() + g_objects; }
+long fake_hip_live_bytes(void) { std::lock_guard<std::mutex> g(g_m); long b = 0; for (auto& kv : g_blocks) b += (long) kv.second; return b; }
+int fake_hip_failed(void) { return g_failed; }
+const char* fake_hip_failed_name(void) { return g_failed_name; }
+hipError_t fake_hip_count(const char* name) { return tick(name); }
+
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : (e == hipErrorOutOfMemory ? "out of memory (fake)" : "injected failure (fake)"); }
+hipError_t hipGetLastError(void) { const hipError_t e = g_last; g_last = hipSuccess; return e; }
+hipError_t hipGetDeviceCount(int* n) { if (tick("hipGetDeviceCount") != hipSuccess) return g_last; *n = 1; return hipSuccess; }
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { if (tick("hipGetDeviceProperties") != hipSuccess) return g_last; memset(p, 0, sizeof *p); strcpy(p->gcnArchName, "gfx950:sramecc+:xnack-"); p->multiProcessorCount = 256; return hipSuccess; }
+hipError_t hipSetDevice(int) { return tick("hipSetDevice"); }
+
+static hipError_t alloc(const char* name, void** out, size_t bytes)
+{
+    *out = nullptr;
+    if (tick(name, true) != hipSuccess) return g_last;
+    void* p = malloc(bytes ? bytes : 1);
+    if (!p) return hipErrorOutOfMemory;
+    memset(p, 0xA5, bytes);               // (uninitialised "device" memory is not zero)
+    std::lock_guard<std::mutex> g(g_m);
+    g_blocks[p] = bytes;
+    *out = p;
+    return hipSuccess;
+}
+static hipError_t release(const char* name, void* p)
+{
+    // a failing free still gives the memory back: what the leak check asks is whether the SHIM let go of everything
+    const hipError_t e = tick(name);
+    if (p) {
+        std::lock_guard<std::mutex> g(g_m);
+        auto it = g_blocks.find(p);
+        if (it == g_blocks.end()) { fprintf(stderr, "fake hip: %s of a pointer that is not allocated: %p (call %ld, armed failure fired in %s)\n", name, p, (long) g_calls, g_failed_name); int* boom = nullptr; *boom = 1; }
+        g_blocks.erase(it);
+        free(p);
+    }
+    return e;
+}
+hipError_t hipMalloc(void** p, size_t n) { return alloc("hipMalloc", p, n); }
+hipError_t hipFree(void* p) { return release("hipFree", p); }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return alloc("hipHostMalloc", p, n); }
+hipError_t hipHostFree(void* p) { return release("hipHostFree", p); }
+hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { if (tick("hipHostGetDevicePointer") != hipSuccess) return g_last; *d = h; return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (tick("hipMemcpy") != hipSuccess) return g_last; memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (tick("hipMemcpyAsync") != hipSuccess) return g_last; memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if (tick("hipMemsetAsync") != hipSuccess) return g_last; memset(d, v, n); return hipSuccess; }
+
+} // extern "C"
+template <typename T> static hipError_t make(const char* name, T** out)
+{
+    *out = nullptr;
+    if (tick(name) != hipSuccess) return g_last;
+    *out = new T();
+    std::lock_guard<std::mutex> g(g_m);
+    g_objects++;
+    return hipSuccess;
+}
+template <typename T> static hipError_t unmake(const char* name, T* p)
+{
+    const hipError_t e = tick(name);
+    if (p) { delete p; std::lock_guard<std::mutex> g(g_m); g_objects--; }
+    return e;
+}
+extern "C" {
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return make("hipStreamCreateWithFlags", s); }
+hipError_t hipStreamDestroy(hipStream_t s) { return unmake("hipStreamDestroy", s); }
+hipError_t hipStreamSynchronize(hipStream_t) { return tick("hipStreamSynchronize"); }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return tick("hipStreamWaitEvent"); }
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) { if (tick("hipStreamBeginCapture") != hipSuccess) return g_last; if (s) s->capturing = 1; return hipSuccess; }
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t* g)
+{
+    // (ends the capture even when it is the call that fails, as the real one does)
+    *g = nullptr;
+    if (s) s->capturing = 0;
+    return make("hipStreamEndCapture", g);
+}
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t, void*, void*, size_t) { return make("hipGraphInstantiate", e); }
+hipError_t hipGraphDestroy(hipGraph_t g) { return unmake("hipGraphDestroy", g); }
+hipError_t hipGraphExecDestroy(hipGraphExec_t e) { return unmake("hipGraphExecDestroy", e); }
+hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return tick("hipGraphLaunch"); }
+hipError_t hipEventCreate(hipEvent_t* e) { return make("hipEventCreate", e); }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return make("hipEventCreateWithFlags", e); }
+hipError_t hipEventDestroy(hipEvent_t e) { return unmake("hipEventDestroy", e); }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { if (tick("hipEventRecord") != hipSuccess) return g_last; if (e) e->recorded = 1; return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return tick("hipEventSynchronize"); }
+hipError_t hipEventQuery(hipEvent_t) { return tick("hipEventQuery"); }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { if (tick("hipEventElapsedTime") != hipSuccess) return g_last; *ms = 0.001f; return hipSuccess; }
+} // extern "C"
+
+// ---- csrc/fx_kernels.h: launchers that launch nothing (each one a countable call), host helpers with plausible answers ----
+namespace fxk {
+void build_pass_twiddles(int n, const float* canonical, float* out) { memcpy(out, canonical, sizeof(float) * 2 * (size_t) n); }
+void fill_first_pass_twiddles(int, const float*, float* out18) { for (int i = 0; i < 18; i++) out18[i] = 0.0f; }
+bool first_pass_twiddles_hermitian(int, const float*) { return true; }
+int build_twiddle_image(int, const float*, float*) { return 0; }
+bool twiddles_have_quarter_turn(int, const float*) { return true; }
+size_t frame_kernel_lds_bytes(int n, int ch, int k, bool direct) { return (size_t) 8 * n + (direct ? 0 : (size_t) ch * 9 * n / 4) + (size_t) ch * k * (n <= 1024 ? 17 * n / 2 : 9 * n / 2); }
+int frame_kernel_max_waves(int n) { return n <= 512 ? 16 : 8; }
+void frame_kernel_preferred_shape(int n, int* ch, int* k) { *ch = 1; *k = n == 2048 ? 4 : 8; }
+hipError_t launch_frame_kernel(int, const FrameParams& p, int, hipStream_t) { if (p.C <= 0 || p.T <= 0) return hipSuccess; return fake_hip_count("launch_frame_kernel"); }
+hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t) { if (p.C <= 0 || p.T <= 0) return hipSuccess; return fake_hip_count("launch_epilogue_kernels"); }
+hipError_t launch_frame_tail_kernel(int, const FrameParams&, const EpilogueParams&, hipStream_t) { return fake_hip_count("launch_frame_tail_kernel"); }
+hipError_t prepare_kernels(int) { return fake_hip_count("prepare_kernels"); }
+hipError_t prepare_hop_kernel(int) { return fake_hip_count("prepare_hop_kernel"); }
+bool pair_kernel_available(int n) { return n == 2048 || n == 4096; }
+int pair_kernel_max_pairs(int n) { return n == 2048 ? 8 : 6; }
+size_t pair_kernel_lds_bytes(int n, int ch, int k) { return (size_t) 8 * n + (size_t) ch * k * 17408; }
+hipError_t prepare_pair_kernel(int) { return fake_hip_count("prepare_pair_kernel"); }
+hipError_t launch_pair_kernel(int, const FrameParams&, hipStream_t) { return fake_hip_count("launch_pair_kernel"); }
+bool hop_kernel_available(int n) { return n == 1024 || n == 2048 || n == 4096; }
+hipError_t launch_hop_kernel(int, const FrameParams&, const EpilogueParams& ep, const HopSignal& sig, hipStream_t, bool)
+{
+    const hipError_t e = fake_hip_count("launch_hop_kernel");
+    // the real kernel raises the slot's flag when the hop is done; fx_stream_collect polls it
+    if (e == hipSuccess && sig.host_flag) *sig.host_flag = sig.seq;
+    (void) ep;
+    return e;
+}
+hipError_t launch_reblock_kernel(const ReblockParams& p, hipStream_t)
+{
+    if (p.C <= 0 || (long long) p.carry_bytes + p.in_row_bytes <= 0) return hipSuccess;
+    const hipError_t e = fake_hip_count("launch_reblock_kernel");
+    if (e != hipSuccess) return e;
+    // the byte movement of fx_reblock.hip, on the host: ASan then checks every bound the shim handed over
+    for (int c = 0; c < p.C; c++) {
+        const long long total = (long long) p.carry_bytes + p.in_row_bytes;
+        for (long long d = 0; d < total; d++) {
+            const unsigned char v = d < p.carry_bytes ? p.carry_in[(size_t) c * p.carry_row_bytes + d] : p.in[(size_t) c * p.in_row_bytes + (d - p.carry_bytes)];
+            if (d < p.out_row_bytes) p.hops_out[(size_t) c * p.out_row_bytes + d] = v;
+            else p.carry_out[(size_t) c * p.carry_row_bytes + (d - p.out_row_bytes)] = v;
+        }
+    }
+    return hipSuccess;
+}
+hipError_t clear_carry(unsigned char* carry, size_t bytes, hipStream_t s) { return bytes ? hipMemsetAsync(carry, 0, bytes, s) : hipSuccess; }
+} // namespace fxk
