@@ -40,6 +40,80 @@ def test_configs3_shard_8192_channels(gpu_fx, oracle):
     signals.assert_features_close(sm[pick], osm, 1e-5, oracle.FEATURE_NAMES, "8192-channel shard smoothed")
 
 
+def _device_signal(torch, C, samples, seed, dtype):
+    """[C][samples] on the GPU, made there (the whole of configs[3] is gigabytes): three harmonics of a per-channel pitch + noise"""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    out = torch.empty((C, samples), dtype=dtype, device="cuda")
+    t = torch.arange(samples, device="cuda", dtype=torch.float32)
+    for c0 in range(0, C, 4096):
+        c1 = min(C, c0 + 4096)
+        f = 55.0 * 2.0 ** ((torch.arange(c0, c1, device="cuda") % 72).to(torch.float32) / 12.0)
+        ph = (2.0 * np.pi / 48000.0) * f[:, None] * t[None, :]
+        x = 0.4 * torch.sin(ph) + 0.2 * torch.sin(2 * ph) + 0.1 * torch.sin(3 * ph)
+        x += 0.05 * (2.0 * torch.rand(x.shape, generator=g, device="cuda") - 1.0)
+        out[c0:c1] = x.to(dtype)
+    return out
+
+
+def test_configs3_whole_65536_channels_in_one_context_equal_the_eight_shards(gpu_fx, oracle):
+    """BASELINE configs[3] at full size on the one GPU there is: ONE context of 65 536 channels x 1024-pt x 16 hops (what eight ranks of
+    8192 channels hold between them) gives, bit for bit, what eight contexts of 8192 channels give on their blocks -- a channel's result does
+    not depend on the shard it lands in, at the sizes the 8-GPU run uses -- and 24 channels of it meet the oracle.  Then the index space
+    beyond 2^32: 65 536 channels x 72 assembled fp16 windows of 1024 points = 4.8e9 samples in one call; and a device block of 700 samples
+    per channel through fx_push_samples (the re-blocking kernel walks the channels in slices of 65 535).  xGMI is the part this cannot
+    reach: the gather of the eight blocks stays unmeasured."""
+    import signals
+    import torch
+    N, C, T, S = 1024, 65536, 16, 8192
+    hops = _device_signal(torch, C, T * (N // 2), 11, torch.float32).reshape(C, T, N // 2)
+    whole = gpu_fx.BatchAnalyser(C, N)
+    raw, sm = whole.push_hops(hops)
+    whole.sync()
+    for r in range(C // S):
+        shard = gpu_fx.BatchAnalyser(S, N)
+        a, b = shard.push_hops(hops[r * S:(r + 1) * S].contiguous())
+        shard.sync()
+        assert torch.equal(a.view(torch.int32), raw[r * S:(r + 1) * S].view(torch.int32)), r
+        assert torch.equal(b.view(torch.int32), sm[r * S:(r + 1) * S].view(torch.int32)), r
+        assert np.array_equal(shard.get_features(), sm[r * S:(r + 1) * S, -1].cpu().numpy(), equal_nan=True)
+        shard.close()
+    pick = np.sort(np.concatenate([np.random.default_rng(5).choice(C, 21, replace=False), [0, C - 1, S]]))
+    idx = torch.from_numpy(pick).cuda()
+    oraw, osm = oracle.push_hops(hops[idx].cpu().numpy(), N)
+    signals.assert_features_close(raw[idx].cpu().numpy(), oraw, 1e-5, oracle.FEATURE_NAMES, "65536-channel context raw")
+    signals.assert_features_close(sm[idx].cpu().numpy(), osm, 1e-5, oracle.FEATURE_NAMES, "65536-channel context smoothed")
+    # a device block of 700 samples per channel on top: 1 hop + 188 pending, the same bits as the hop itself
+    more = _device_signal(torch, C, 700, 12, torch.float32)
+    r2, s2 = whole.push_samples(more)
+    whole.sync()
+    assert r2.shape == (C, 1, 12) and whole.pending_samples() == 188
+    ref = gpu_fx.BatchAnalyser(S, N)
+    ref.push_hops(hops[C - S:].contiguous())
+    a, b = ref.push_hops(more[C - S:, :512].contiguous().reshape(S, 1, 512))
+    ref.sync()
+    assert torch.equal(a.view(torch.int32), r2[C - S:].view(torch.int32)) and torch.equal(b.view(torch.int32), s2[C - S:].view(torch.int32))
+    del hops, raw, sm, whole, ref, more
+    torch.cuda.empty_cache()
+    # more than 2^32 samples in one call: assembled fp16 windows, 65 536 x 72 x 1024
+    T2 = 72
+    frames = _device_signal(torch, C, T2 * N, 13, torch.float16).reshape(C, T2, N)
+    assert frames.numel() > 2 ** 32
+    big = gpu_fx.BatchAnalyser(C, N)
+    raw, sm = big.process_frames(frames)
+    big.sync()
+    for r in (0, 3, 7):
+        shard = gpu_fx.BatchAnalyser(S, N)
+        a, b = shard.process_frames(frames[r * S:(r + 1) * S].contiguous())
+        shard.sync()
+        assert torch.equal(a.view(torch.int32), raw[r * S:(r + 1) * S].view(torch.int32)), r
+        assert torch.equal(b.view(torch.int32), sm[r * S:(r + 1) * S].view(torch.int32)), r
+        shard.close()
+    tail = torch.tensor([C - 1, C - 2, C - 4097], device="cuda")
+    oraw, osm = oracle.process_frames(frames[tail].float().cpu().numpy(), N)
+    signals.assert_features_close(raw[tail].cpu().numpy(), oraw, 1e-5, oracle.FEATURE_NAMES, "windows beyond 2^32 samples raw")
+    signals.assert_features_close(sm[tail].cpu().numpy(), osm, 1e-5, oracle.FEATURE_NAMES, "windows beyond 2^32 samples smoothed")
+
+
 def test_one_rank_rccl_gather_through_the_c_abi(gpu_fx):
     """fx_comm_create / fx_gather_smoothed / fx_comm_sync on a one-rank communicator: host and device destinations,
     several gathers in flight behind analysis calls."""
@@ -99,6 +173,18 @@ def _bench(args, timeout=600):
 def test_bench_debug_collective_runs_the_rccl_path_on_one_rank():
     d, err = _bench(["--gpus", "1", "--debug-collective", "--steps", "3", "--warmup", "1", "--frames", "32", "--no-cpu-baseline", "--no-extra"])
     assert d["n_gpus"] == 1 and "RCCL" in d["config"]["sharding"]
+    assert "gathered block equals the local features" in err
+
+
+def test_bench_four_ranks_of_configs3_shards_share_the_one_gpu():
+    """`bench.py --gpus 4 --backend gloo --channels-per-gpu 8192 --frames 16`: the real shard plan of configs[3] -- 8192 channels x 1024-pt
+    per rank -- as FOUR rank processes on the one GPU of this box (the GPU box's process guard allows six processes on a card, the test
+    runner being one; eight ranks on one card is not something this pool lets a test do), the control group, the gather of every step to the
+    sink through host memory, the sink's check of its own block, per-rank records.  What it cannot show is RCCL between GPUs."""
+    d, err = _bench(["--gpus", "4", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--channels-per-gpu", "8192", "--frames", "16"], timeout=1100)
+    assert d["n_gpus"] == 4 and d["config"]["workload"].startswith("configs[3]") and d["config"]["total_channels"] == 4 * 8192
+    assert d["value"] > 0 and d["scaling"] == "weak"
+    assert len(d["per_rank"]) == 4 and all(r["frames_per_s"] > 0 for r in d["per_rank"])
     assert "gathered block equals the local features" in err
 
 
