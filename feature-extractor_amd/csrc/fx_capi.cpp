@@ -492,7 +492,8 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int in_ki
         // points and fewer lose either way (4096 channels 34.7 / 33.2): their frames are no longer than the tail.
         const long long groups = ((long long) c->C + step.fp.ch_per_wg - 1) / step.fp.ch_per_wg;
         const long long one_round = (long long) c->compute_units * ((c->N == 4096 && step.fp.ch_per_wg > 4) ? 1 : 2);
-        const bool one_launch = step.fp.direct_state && ((c->test_hooks & FX_HOOK_TAIL_ALWAYS_FUSED) || (!(c->test_hooks & FX_HOOK_TAIL_NEVER_FUSED) && c->N >= 1024 && groups <= one_round));
+        const bool one_launch = step.fp.direct_state && fxk::frame_tail_kernel_available(c->N) &&
+                                ((c->test_hooks & FX_HOOK_TAIL_ALWAYS_FUSED) || (!(c->test_hooks & FX_HOOK_TAIL_NEVER_FUSED) && groups <= one_round));
         if (one_launch) {
             HIP_TRY(fxk::launch_frame_tail_kernel(c->N, step.fp, step.ep, c->stream));
             FX_EV(e1);

@@ -191,6 +191,7 @@ hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t stream);
 // launch_frame_kernel (p.direct_state: one frame per channel, one wavefront each) and launch_epilogue_kernels in ONE launch: the
 // workgroup's first wavefronts finish its channels' hops when the frames are done (fx_frame_tail_kernel)
 hipError_t launch_frame_tail_kernel(int window_size, const FrameParams& p, const EpilogueParams& ep, hipStream_t stream);
+bool frame_tail_kernel_available(int window_size);   // windows of 1024 points and more (below that it is not built: it loses to two launches)
 hipError_t prepare_kernels(int window_size);   // raises the kernels' dynamic-LDS limit on the CURRENT device (every fx_create: the attribute is per device)
 hipError_t prepare_hop_kernel(int window_size);   // the same for fx_hop_kernel; hipSuccess where there is none for this size
 // One frame across a PAIR of wavefronts (windows of 2048 / 4096 points, both analysers): p.waves_per_ch is then the number

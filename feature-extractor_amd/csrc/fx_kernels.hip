@@ -116,8 +116,13 @@ template <int N> hipError_t prepare_t()
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, true, true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_tail_kernel<N>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // frames + tails in one launch exists from 1024 points on (frame_tail_kernel_available): below that a frame is no longer than the
+    // tail and the fused form loses either way (profiles/r04_live_cadence.txt), so those sizes are not instantiated
+    if constexpr (N >= 1024)
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_tail_kernel<N>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    else
+        return hipSuccess;
 }
 
 template <int N> hipError_t launch_t(const FrameParams& p, int analysers, hipStream_t stream)
@@ -145,8 +150,12 @@ template <int N> hipError_t launch_tail_t(const FrameParams& p, const EpiloguePa
     if (tail > lds) lds = tail;                               // (small windows: the transform buffers are smaller than a tail's ring copies)
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const dim3 grid((unsigned) ((p.C + p.ch_per_wg - 1) / p.ch_per_wg)), block((unsigned) p.ch_per_wg * 64);
-    hipLaunchKernelGGL((fx_frame_tail_kernel<N>), grid, block, lds, stream, p, ep);
-    return hipGetLastError();
+    if constexpr (N >= 1024) {
+        hipLaunchKernelGGL((fx_frame_tail_kernel<N>), grid, block, lds, stream, p, ep);
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
 }
 
 #if FX_PART == 0 || FX_PART == 2
@@ -359,9 +368,11 @@ hipError_t launch_frame_kernel(int n, const FrameParams& p, int analysers, hipSt
     }
 }
 
+bool frame_tail_kernel_available(int n) { return n >= 1024; }
 hipError_t launch_frame_tail_kernel(int n, const FrameParams& p, const EpilogueParams& ep, hipStream_t stream)
 {
     if (p.C <= 0) return hipSuccess;
+    if (!frame_tail_kernel_available(n)) return hipErrorInvalidValue;
     if (p.ch_per_wg < 1 || p.ch_per_wg > frame_kernel_max_waves(n)) return hipErrorInvalidValue;
     switch (n) {
         case 256:  return launch_tail_t<256>(p, ep, stream);

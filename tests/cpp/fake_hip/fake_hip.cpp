@@ -139,6 +139,7 @@ int frame_kernel_max_waves(int n) { return n <= 512 ? 16 : 8; }
 void frame_kernel_preferred_shape(int n, int* ch, int* k) { *ch = 1; *k = n == 2048 ? 4 : 8; }
 hipError_t launch_frame_kernel(int, const FrameParams& p, int, hipStream_t) { if (p.C <= 0 || p.T <= 0) return hipSuccess; return fake_hip_count("launch_frame_kernel"); }
 hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t) { if (p.C <= 0 || p.T <= 0) return hipSuccess; return fake_hip_count("launch_epilogue_kernels"); }
+bool frame_tail_kernel_available(int n) { return n >= 1024; }
 hipError_t launch_frame_tail_kernel(int, const FrameParams&, const EpilogueParams&, hipStream_t) { return fake_hip_count("launch_frame_tail_kernel"); }
 hipError_t prepare_kernels(int) { return fake_hip_count("prepare_kernels"); }
 hipError_t prepare_hop_kernel(int) { return fake_hip_count("prepare_hop_kernel"); }

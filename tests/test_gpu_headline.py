@@ -86,7 +86,7 @@ def test_failed_handover_between_work_units_is_reported(gpu_fx):
 def test_one_frame_calls_finish_their_tail_in_the_frame_kernel(gpu_fx, N, C):
     """One frame per channel through the batch kernels is ONE launch while the chip holds the call's workgroups at once
     (fx_frame_tail_kernel: the workgroup's first wavefronts finish its channels' hops when the frames are done), else the frame
-    kernel and the fused tail kernel.  fx_set_tuning_internal bits 3 / 2 force the one and the other: the same bits, hop after hop, with an onset window that reaches far into the history ring, channel
+    kernel and the fused tail kernel (windows of 1024 points and more: below that the one-launch form is not built).  fx_set_tuning_internal bits 3 / 2 force the one and the other: the same bits, hop after hop, with an onset window that reaches far into the history ring, channel
     counts that leave the last workgroup partly filled, and device buffers."""
     import torch
     T = 60
