@@ -40,7 +40,7 @@ class Tuning(ctypes.Structure):
     _fields_ = [("waves_per_channel", ctypes.c_int), ("channels_per_workgroup", ctypes.c_int), ("waves_per_frame", ctypes.c_int),
                 ("frames_per_unit", ctypes.c_int), ("unit_plan_len", ctypes.c_int), ("unit_plan", ctypes.c_int * MAX_UNITS),
                 ("stream_graph", ctypes.c_int), ("stream_hop_kernel", ctypes.c_int), ("stream_zero_copy", ctypes.c_int),
-                ("one_hop_kernel", ctypes.c_int), ("call_timing", ctypes.c_int), ("handover_spin_limit", ctypes.c_int)]
+                ("one_hop_kernel", ctypes.c_int), ("call_timing", ctypes.c_int), ("handover_spin_limit", ctypes.c_int), ("stream_fill_streaming", ctypes.c_int)]
 
     @classmethod
     def defaults(cls):

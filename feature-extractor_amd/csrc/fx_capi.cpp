@@ -173,7 +173,7 @@ extern "C" void fx_tuning_defaults(fx_tuning* t)
     if (!t) return;
     memset(t, 0, sizeof *t);
     t->frames_per_unit = -1;
-    t->stream_graph = t->stream_hop_kernel = t->stream_zero_copy = t->one_hop_kernel = t->call_timing = -1;
+    t->stream_graph = t->stream_hop_kernel = t->stream_zero_copy = t->one_hop_kernel = t->call_timing = t->stream_fill_streaming = -1;
 }
 
 // The ONLY place the library reads the environment: called once per context, by fx_create.
@@ -197,6 +197,7 @@ extern "C" void fx_tuning_from_env(fx_tuning* t)
     geti("FX_ONE_HOP_KERNEL", &t->one_hop_kernel, 0);
     geti("FX_CALL_TIMING", &t->call_timing, 0);
     geti("FX_HANDOVER_SPINS", &t->handover_spin_limit, 1);
+    geti("FX_STREAM_FILL_STREAMING", &t->stream_fill_streaming, 0);
 }
 
 extern "C" fx_status fx_get_tuning(fx_context* c, fx_tuning* out)
@@ -857,9 +858,34 @@ fx_status fx_profile_end(fx_context* c, double* frame_ms, double* epi_ms, int* c
 // The producer's copy into a pinned slot, by several host threads (fx_stream_push): a caller whose audio sits in ordinary memory
 // has to move every sample once more before PCIe sees it, and one memcpy thread moves ~12 GB/s where the link takes 55.  A small
 // persistent pool: workers sleep on a generation counter, each copies its share of the bytes, the last one wakes the caller.
+// A slot is written once by the producer and read next by the DMA engine, never again by the core that wrote it: non-temporal stores
+// skip the read-for-ownership of every destination line (a third of the copy's memory traffic; glibc's memcpy only switches to them
+// far above the ~8 MB a fill thread copies).  x86-64 only; elsewhere, and for the head / tail of a piece, plain memcpy.
+#if defined(__x86_64__)
+#include <emmintrin.h>
+static void copy_streaming(unsigned char* d, const unsigned char* s, size_t n)
+{
+    size_t head = (64 - (reinterpret_cast<uintptr_t>(d) & 63)) & 63;
+    if (head > n) head = n;
+    memcpy(d, s, head); d += head; s += head; n -= head;
+    for (size_t blocks = n / 64; blocks > 0; blocks--) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s)), b = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + 16)),
+                      c = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + 32)), e = _mm_loadu_si128(reinterpret_cast<const __m128i*>(s + 48));
+        _mm_stream_si128(reinterpret_cast<__m128i*>(d), a); _mm_stream_si128(reinterpret_cast<__m128i*>(d + 16), b);
+        _mm_stream_si128(reinterpret_cast<__m128i*>(d + 32), c); _mm_stream_si128(reinterpret_cast<__m128i*>(d + 48), e);
+        s += 64; d += 64;
+    }
+    _mm_sfence();
+    memcpy(d, s, n & 63);
+}
+#else
+static void copy_streaming(unsigned char* d, const unsigned char* s, size_t n) { memcpy(d, s, n); }
+#endif
+
 class FillPool {
 public:
     ~FillPool() { resize(0); }
+    bool streaming = true;          // fx_tuning::stream_fill_streaming (taken by fx_stream_create)
     void copy(void* dst, const void* src, size_t bytes, int threads)
     {
         if (threads <= 1 || bytes < (1u << 20)) { memcpy(dst, src, bytes); return; }
@@ -880,7 +906,10 @@ private:
     void slice(int k)
     {
         const size_t at = piece_ * (size_t) k;
-        if (at < bytes_) memcpy(dst_ + at, src_ + at, bytes_ - at < piece_ ? bytes_ - at : piece_);
+        if (at >= bytes_) return;
+        const size_t n = bytes_ - at < piece_ ? bytes_ - at : piece_;
+        if (streaming) copy_streaming(dst_ + at, src_ + at, n);
+        else memcpy(dst_ + at, src_ + at, n);
     }
     void resize(int n)
     {
@@ -1011,6 +1040,7 @@ fx_status fx_stream_create(fx_context* c, int hops_per_batch, int slots, int sam
     fx_stream* s = new (std::nothrow) fx_stream();
     if (!s) return fx_fail(FX_ERR_OUT_OF_MEMORY, "host allocation failed");
     s->ctx = c; s->hops = hops_per_batch; s->slots = slots; s->fmt = sample_format;
+    s->fill.streaming = c->tuning.stream_fill_streaming != 0;
     s->in_bytes = (size_t) c->C * hops_per_batch * (c->N / 2) * sample_size(sample_format);
     s->out_bytes = (size_t) c->C * hops_per_batch * FX_NUM_FEATURES * sizeof(float);
     s->ring.resize((size_t) slots);

@@ -248,6 +248,8 @@ typedef struct fx_tuning {
                                     Calls between fx_profile_begin / fx_profile_end are timed regardless */
     int handover_spin_limit;     /* FX_HANDOVER_SPINS: polls a work unit spends waiting for its predecessor's flux state
                                     before it gives up and the call is reported failed (FX_ERR_HIP); 0 = default (1 << 22) */
+    int stream_fill_streaming;   /* FX_STREAM_FILL_STREAMING: fx_stream_push's fill threads write the pinned slot with non-temporal stores
+                                    (1, and -1 = default) or with memcpy (0) */
 } fx_tuning;
 void fx_tuning_defaults(fx_tuning* t);     /* every knob "measured best" */
 void fx_tuning_from_env(fx_tuning* t);     /* defaults overridden by the FX_* variables set right now */

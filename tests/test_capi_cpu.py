@@ -140,7 +140,7 @@ def test_tuning_comes_from_the_environment_once(fx, monkeypatch):
     capi = import_module("feature-extractor_amd.capi")
     fx.load_library(build_if_missing=True)
     for var in ("FX_WAVES", "FX_CHANNELS_PER_WG", "FX_WAVES_PER_FRAME", "FX_FRAMES_PER_CHUNK", "FX_CHUNK_PLAN", "FX_STREAM_GRAPH",
-                "FX_STREAM_HOP_KERNEL", "FX_STREAM_ZEROCOPY", "FX_ONE_HOP_KERNEL", "FX_CALL_TIMING", "FX_HANDOVER_SPINS"):
+                "FX_STREAM_HOP_KERNEL", "FX_STREAM_ZEROCOPY", "FX_ONE_HOP_KERNEL", "FX_CALL_TIMING", "FX_HANDOVER_SPINS", "FX_STREAM_FILL_STREAMING"):
         monkeypatch.delenv(var, raising=False)
     d, e = capi.Tuning.defaults(), capi.Tuning.from_env()
     assert bytes(d) == bytes(e)
