@@ -933,12 +933,52 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
             del src32
         return res
 
+    def offline():
+        # The legacy offline analyser's three full-spectrum functions (ref AudioAnalysis.h:463-515, :566-609, :623-665) on
+        # device-resident magnitude frames: a block per channel stages the frame (and the flux state) in LDS and ONE thread walks the bins
+        # in the reference's order -- these are serial double sums and a serial IEEE product, kept exact rather than fast.  Timed so that the
+        # cost of that choice is on record: calls per second of 1024 analysers x one 1025-bin frame (a 2048-point window's magnitudes).
+        import ctypes
+        lib = fx.load_library(build_if_missing=False)
+        C5, B5 = 1024, 1025
+        an5 = fx.offline.AudioAnalyser(C5, 24000.0, device=dev)
+        g = torch.Generator(device="cuda:%d" % dev).manual_seed(5)
+        mags = torch.rand((C5, B5), generator=g, device="cuda:%d" % dev, dtype=torch.float32)
+        data = torch.randn((C5, B5 - 1, 2), generator=g, device="cuda:%d" % dev, dtype=torch.float32)
+        out4 = torch.empty((C5, 4), device=mags.device, dtype=torch.float32)
+        out1 = torch.empty((C5,), device=mags.device, dtype=torch.float32)
+        peaks = torch.empty((C5,), device=mags.device, dtype=torch.int32)
+        freqs = torch.empty((C5,), device=mags.device, dtype=torch.float64)
+        vp = ctypes.c_void_p
+        calls = {
+            "spectral_characteristics": lambda: lib.fx_offline_spectral_characteristics(an5._h, vp(mags.data_ptr()), B5, vp(out4.data_ptr()), fx.capi.MEM_DEVICE),
+            "spectral_slope": lambda: lib.fx_offline_spectral_slope(an5._h, vp(mags.data_ptr()), B5, vp(out1.data_ptr()), fx.capi.MEM_DEVICE),
+            "auto_correlation": lambda: lib.fx_offline_auto_correlation(an5._h, vp(data.data_ptr()), B5 - 1, vp(peaks.data_ptr()), vp(freqs.data_ptr()), fx.capi.MEM_DEVICE),
+        }
+        torch.cuda.synchronize(dev)
+        res = {"workload": "%d analysers x one frame of %d magnitudes per call, device-resident" % (C5, B5),
+               "note": "a block per channel stages the frame in LDS; one thread runs the reference's serial double sums / IEEE product in bin order (exactness over speed)"}
+        for name, call in calls.items():
+            for _ in range(3):
+                fx.capi.check(call())
+            fx.capi.check(lib.fx_offline_sync(an5._h))
+            t0 = time.perf_counter()
+            for _ in range(20):
+                fx.capi.check(call())
+            fx.capi.check(lib.fx_offline_sync(an5._h))
+            dt = (time.perf_counter() - t0) / 20
+            res[name] = {"us_per_call": dt * 1e6, "frames_per_s": C5 / dt, "bytes_in_per_call": int(mags.numel() * 4 if name != "auto_correlation" else data.numel() * 4),
+                         "GBps": (mags.numel() * 4 if name != "auto_correlation" else data.numel() * 4) / dt / 1e9}
+        an5.close()
+        return res
+
     guarded("spectral_only", spectral_only)
     guarded("data_dependence", data_dependence)
     guarded("other_windows", other_windows)
     guarded("live_cadence", live_cadence)
     guarded("streaming_hop", streaming_hop)
     guarded("stream_ingest", stream_ingest)
+    guarded("offline", offline)
 
 
 if __name__ == "__main__":

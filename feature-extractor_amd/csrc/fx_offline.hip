@@ -281,60 +281,89 @@ fx_status check_args(fx_offline* o, const void* in, const void* out, int mem_kin
 }
 
 // ---- ref AudioAnalysis.h:463-515 calculateSpectralCharacteristics: block = channel.  Every sum of the reference is a serial double
-// sum in bin order, and the product a serial IEEE product (inf / 0 sticky): the block stages the frame and the state in LDS,
-// ONE thread runs the reference's two loops as written, the block writes the state back.  (An offline function: exactness over speed.)
+// sum in bin order, and the product a serial IEEE product (inf / 0 sticky).  What is serial is only the ADDITIONS: each bin's terms --
+// the rectified difference, fc * m, the pow() of the spread -- are a function of that bin alone, so the whole block forms them side by side
+// into LDS (the same expressions, so the same roundings: no contraction in this file), and ONE thread then adds them up in bin order, four
+// independent chains per pass.  (Round 4 had that one thread evaluate everything, 1025 pow() calls in a row: 1.98 ms per call of 1024
+// analysers; bench.py `offline`.)
+// LDS: prev[bins] doubles | a[bins] doubles | b[bins] doubles | mag[bins] floats = 28 bytes per bin (115 KB at 4097 bins).
+constexpr size_t SPECTRAL_LDS_PER_BIN = 3 * sizeof(double) + sizeof(float);
 __global__ void __launch_bounds__(NT) spectral_characteristics_kernel(const float* mags, int num_bins, double nyquist, double* prev_bins, float* out4)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* prev = reinterpret_cast<double*>(smem);                         // [num_bins]
-    float* mag = reinterpret_cast<float*>(prev + num_bins);                 // [num_bins]
+    double* ta = prev + num_bins;                                           // per-bin terms, first pass: rectified difference; second: spread term
+    double* tb = ta + num_bins;                                             // first pass: fc * m
+    float* mag = reinterpret_cast<float*>(tb + num_bins);                   // [num_bins]
     __shared__ int s_accepted;
+    __shared__ float s_centroid;
+    __shared__ double s_sum, s_flux, s_product;
     const int c = blockIdx.x;
     double* gprev = prev_bins + (size_t) c * num_bins;
-    for (int i = threadIdx.x; i < num_bins; i += NT) { mag[i] = mags[(size_t) c * num_bins + i]; prev[i] = gprev[i]; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const size_t n = (size_t) num_bins;
-        const double frpb = nyquist / n;                                    // :466
-        double weighted = 0.0, var = 0.0, sum = 0.0, product = 1.0, flux = 0.0;
-        for (size_t i = 0; i < n; ++i) {                                    // :479-496
-            const double fc = (double) i * frpb + (frpb / 2.0);
-            const double m = (double) mag[i];
-            const double diff = fabs(m) - fabs(prev[i]);
-            const double rectified = (diff + fabs(diff)) / 2.0;
-            if (diff > 0.0) flux += rectified;
-            sum += m;
-            product *= m;
-            weighted += fc * m;
-        }
-        float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, r3 = 0.0f;
-        const bool accepted = sum > 0.001;                                  // :498-500
-        if (accepted) {
-            const float centroid = (float) (weighted / sum);
-            const double inv = 1.0 / n;
-            const float flatness = (float) (pow(product, inv) / (inv * sum));        // :505
-            for (size_t i = 0; i < n; ++i) {
-                const double fc = (double) i * frpb + (frpb / 2.0);         // binCentreFrequencies[i], the same expression
-                var += pow((fc / nyquist) - (centroid / nyquist), 2.0) * (double) mag[i];   // :509
-            }
-            const float max_spread = (float) ((centroid / nyquist) * (1.0 - (centroid / nyquist)));
-            r0 = centroid / (float) nyquist; r1 = (float) ((var / sum) / max_spread); r2 = flatness; r3 = (float) flux;
-        }
-        out4[4 * c] = r0; out4[4 * c + 1] = r1; out4[4 * c + 2] = r2; out4[4 * c + 3] = r3;
-        s_accepted = accepted ? 1 : 0;
+    const size_t n = (size_t) num_bins;
+    const double frpb = nyquist / n;                                        // :466
+    for (int i = threadIdx.x; i < num_bins; i += NT) {
+        const float mf = mags[(size_t) c * num_bins + i];
+        const double pv = gprev[i];
+        mag[i] = mf; prev[i] = pv;
+        const double fc = (double) i * frpb + (frpb / 2.0);                 // :479-496, the per-bin part
+        const double m = (double) mf;
+        const double diff = fabs(m) - fabs(pv);
+        const double rectified = (diff + fabs(diff)) / 2.0;
+        ta[i] = diff > 0.0 ? rectified : -1.0;                              // (-1: "not added", as the reference's `if (diff > 0.0)`)
+        tb[i] = fc * m;
     }
     __syncthreads();
-    if (s_accepted)
-        for (int i = threadIdx.x; i < num_bins; i += NT) gprev[i] = (double) mag[i];          // :510
+    if (threadIdx.x == 0) {
+        double weighted = 0.0, sum = 0.0, product = 1.0, flux = 0.0;
+        for (size_t i = 0; i < n; ++i) {                                    // the additions, in bin order
+            const double m = (double) mag[i];
+            if (ta[i] >= 0.0) flux += ta[i];
+            sum += m;
+            product *= m;
+            weighted += tb[i];
+        }
+        const bool accepted = sum > 0.001;                                  // :498-500
+        s_accepted = accepted ? 1 : 0;
+        s_centroid = accepted ? (float) (weighted / sum) : 0.0f;
+        s_sum = sum; s_flux = flux; s_product = product;
+    }
+    __syncthreads();
+    if (!s_accepted) {
+        if (threadIdx.x == 0) { out4[4 * c] = 0.0f; out4[4 * c + 1] = 0.0f; out4[4 * c + 2] = 0.0f; out4[4 * c + 3] = 0.0f; }
+        return;
+    }
+    const float centroid = s_centroid;
+    for (int i = threadIdx.x; i < num_bins; i += NT) {
+        const double fc = (double) i * frpb + (frpb / 2.0);                 // binCentreFrequencies[i], the same expression
+        ta[i] = pow((fc / nyquist) - (centroid / nyquist), 2.0) * (double) mag[i];       // :509, the per-bin part
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double sum = s_sum;
+        double var = 0.0;
+        for (size_t i = 0; i < n; ++i) var += ta[i];
+        const double inv = 1.0 / n;
+        const float flatness = (float) (pow(s_product, inv) / (inv * sum));               // :505
+        const float max_spread = (float) ((centroid / nyquist) * (1.0 - (centroid / nyquist)));
+        out4[4 * c] = centroid / (float) nyquist; out4[4 * c + 1] = (float) ((var / sum) / max_spread); out4[4 * c + 2] = flatness; out4[4 * c + 3] = (float) s_flux;
+    }
+    for (int i = threadIdx.x; i < num_bins; i += NT) gprev[i] = (double) mag[i];          // :510
 }
 
 // ---- ref AudioAnalysis.h:566-609 calculateNormalisedSpectralSlope: block = channel; the maximum in parallel (order does not matter),
-// the double sums by one thread in the reference's order ----
+// each bin's quotient and squares by the whole block, the double sums by one thread in the reference's order ----
+// LDS: e[bins] doubles | t[bins] doubles | mag[bins] floats = 20 bytes per bin
+constexpr size_t SLOPE_LDS_PER_BIN = 2 * sizeof(double) + sizeof(float);
 __global__ void __launch_bounds__(NT) spectral_slope_kernel(const float* mags, int num_bins, float* out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* mag = reinterpret_cast<float*>(smem);
+    double* te = reinterpret_cast<double*>(smem);                           // e_i = mag[i] / magnitude
+    double* tt = te + num_bins;                                             // first pass: i * e_i; second: (e_i - mean)^2
+    float* mag = reinterpret_cast<float*>(tt + num_bins);
     __shared__ float s_max[NT];
+    __shared__ double s_mean, s_prod;
+    __shared__ float s_peak;
     const int c = blockIdx.x;
     float peak = 0.0f;
     for (int i = threadIdx.x; i < num_bins; i += NT) { const float v = mags[(size_t) c * num_bins + i]; mag[i] = v; const float a = fabsf(v); if (a > peak) peak = a; }
@@ -342,30 +371,41 @@ __global__ void __launch_bounds__(NT) spectral_slope_kernel(const float* mags, i
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int k = 1; k < NT; k++) if (s_max[k] > peak) peak = s_max[k];
-        const double bins = (double) num_bins, mean_bin = 0.5, magnitude = (double) peak;      // getMagnitude, :573
-        float result = 0.0f;
-        if (magnitude > 0.0001) {
-            double mean_energy = 0.0, prod_sum = 0.0;
-            for (int i = 0; i < (int) bins; i++) {
-                const double e = mag[i] / magnitude;
-                mean_energy += e;
-                prod_sum += (double) i * e;
-            }
-            mean_energy /= bins;
-            double bin_var = 0.0, energy_var = 0.0;
-            for (double i = 0.0; i < bins; i++) {
-                const double ni = i / bins;
-                bin_var += (ni - mean_bin) * (ni - mean_bin);
-                const double e = mag[(int) i] / magnitude;
-                energy_var += (e - mean_energy) * (e - mean_energy);
-            }
-            bin_var /= bins;
-            energy_var /= bins;
-            const double bin_std = sqrt(bin_var), energy_std = sqrt(energy_var);
-            const double r = (prod_sum - (bins * mean_energy * mean_bin)) / (bins - 1.0f) * energy_std * bin_std;      // :602
-            result = (float) (r * (bin_std / energy_std));
+        s_peak = peak;
+    }
+    __syncthreads();
+    const double bins = (double) num_bins, mean_bin = 0.5, magnitude = (double) s_peak;      // getMagnitude, :573
+    if (!(magnitude > 0.0001)) { if (threadIdx.x == 0) out[c] = 0.0f; return; }
+    for (int i = threadIdx.x; i < num_bins; i += NT) {
+        const double e = mag[i] / magnitude;
+        te[i] = e;
+        tt[i] = (double) i * e;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double mean_energy = 0.0, prod_sum = 0.0;
+        for (int i = 0; i < num_bins; i++) { mean_energy += te[i]; prod_sum += tt[i]; }
+        s_mean = mean_energy / bins; s_prod = prod_sum;
+    }
+    __syncthreads();
+    const double mean_energy = s_mean;
+    for (int i = threadIdx.x; i < num_bins; i += NT) {
+        const double e = te[i], ni = (double) i / bins;
+        tt[i] = (e - mean_energy) * (e - mean_energy);
+        te[i] = (ni - mean_bin) * (ni - mean_bin);                             // (e is not needed again)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double bin_var = 0.0, energy_var = 0.0;
+        for (int i = 0; i < num_bins; i++) {
+            bin_var += te[i];
+            energy_var += tt[i];
         }
-        out[c] = result;
+        bin_var /= bins;
+        energy_var /= bins;
+        const double bin_std = sqrt(bin_var), energy_std = sqrt(energy_var);
+        const double r = (s_prod - (bins * mean_energy * mean_bin)) / (bins - 1.0f) * energy_std * bin_std;      // :602
+        out[c] = (float) (r * (bin_std / energy_std));
     }
 }
 
@@ -429,7 +469,9 @@ fx_status fx_offline_create(fx_offline** out, int device_id, int num_channels, d
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&harmonic_characteristics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int) harmonic_lds_bytes(MAX_BINS));      // (beside ~9 KB of static LDS)
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectral_characteristics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   (int) ((sizeof(double) + sizeof(float)) * MAX_BINS));
+                                                   (int) (SPECTRAL_LDS_PER_BIN * MAX_BINS));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectral_slope_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int) (SLOPE_LDS_PER_BIN * MAX_BINS));
     if (e == hipSuccess) e = hipStreamSynchronize(o->stream);
     if (e != hipSuccess) { fx_offline_destroy(o); return fx_fail(FX_ERR_HIP, "setting up the offline analyser failed: %s", hipGetErrorString(e)); }
     *out = o;
@@ -564,7 +606,7 @@ fx_status fx_offline_spectral_characteristics(fx_offline* o, const float* magnit
     if ((st = stage_in(o, mem_kind, magnitudes, in_bytes, nullptr, 0, &da, &db)) != FX_OK) return st;
     float* d_out = out4;
     if (mem_kind == FX_MEM_HOST) { if ((st = grow_bytes(&o->d_out, &o->out_cap, out_bytes)) != FX_OK) return st; d_out = static_cast<float*>(o->d_out); }
-    hipLaunchKernelGGL(spectral_characteristics_kernel, dim3((unsigned) o->C), dim3(NT), (sizeof(double) + sizeof(float)) * (size_t) num_bins, o->stream,
+    hipLaunchKernelGGL(spectral_characteristics_kernel, dim3((unsigned) o->C), dim3(NT), SPECTRAL_LDS_PER_BIN * (size_t) num_bins, o->stream,
                        static_cast<const float*>(da), num_bins, o->nyquist, o->d_prev_bins, d_out);
     HIP_TRY(hipGetLastError());
     if (mem_kind == FX_MEM_HOST) { HIP_TRY(hipMemcpyAsync(out4, d_out, out_bytes, hipMemcpyDeviceToHost, o->stream)); HIP_TRY(hipStreamSynchronize(o->stream)); }
@@ -591,7 +633,7 @@ fx_status fx_offline_spectral_slope(fx_offline* o, const float* magnitudes, int 
     if ((st = stage_in(o, mem_kind, magnitudes, in_bytes, nullptr, 0, &da, &db)) != FX_OK) return st;
     float* d_out = out;
     if (mem_kind == FX_MEM_HOST) { if ((st = grow_bytes(&o->d_out, &o->out_cap, out_bytes)) != FX_OK) return st; d_out = static_cast<float*>(o->d_out); }
-    hipLaunchKernelGGL(spectral_slope_kernel, dim3((unsigned) o->C), dim3(NT), sizeof(float) * (size_t) num_bins, o->stream, static_cast<const float*>(da), num_bins, d_out);
+    hipLaunchKernelGGL(spectral_slope_kernel, dim3((unsigned) o->C), dim3(NT), SLOPE_LDS_PER_BIN * (size_t) num_bins, o->stream, static_cast<const float*>(da), num_bins, d_out);
     HIP_TRY(hipGetLastError());
     if (mem_kind == FX_MEM_HOST) { HIP_TRY(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, o->stream)); HIP_TRY(hipStreamSynchronize(o->stream)); }
     return FX_OK;
