@@ -809,6 +809,67 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
                        "frames/s over the frames/s that many live 48 kHz channels produce" % (N, N // 2))
         return res
 
+    def device_blocks():
+        # The collector's real interface at scale (fx_push_samples, round 5; ref AudioDataCollector.h:36-94, RealTimeAudioAnalysis.h:205-219):
+        # an audio device delivers blocks of ITS length -- 480 samples at 48 kHz / 10 ms -- not hops.  Every call cuts (pending + block) into
+        # hops on the device (fx_reblock_kernel: pure byte movement), analyses the hops that completed and keeps the rest.  Device-resident
+        # blocks, calls back to back on the library's stream, beside the same samples delivered as whole hops.
+        res = {}
+        block, n_blocks = 480, 64                                  # 30 720 samples = 60 hops of 512 per channel
+        for c4 in (1024, 8192):
+            hops = torch.from_numpy(fx.synth.hops(c4, block * n_blocks // (N // 2), N)).cuda(dev)
+            flat = hops.reshape(c4, -1)
+            pieces = [flat[:, k * block:(k + 1) * block].contiguous() for k in range(n_blocks)]
+            views = [hops[:, k:k + 1].contiguous() for k in range(hops.shape[1])]
+            an4 = fx.BatchAnalyser(c4, N, device=dev)
+            rec = {}
+            with torch.cuda.stream(an4.torch_stream()):
+                for name in ("blocks", "hops"):
+                    best = None
+                    for _ in range(3):
+                        an4.reset_state()
+                        t_s = time.perf_counter()
+                        if name == "blocks":
+                            for piece in pieces:
+                                an4.push_samples(piece)
+                        else:
+                            for v in views:
+                                an4.push_hops(v)
+                        an4.sync()
+                        dt4 = time.perf_counter() - t_s
+                        best = dt4 if best is None or dt4 < best else best
+                    calls = n_blocks if name == "blocks" else len(views)
+                    rec[name] = {"calls": calls, "us_per_call": best / calls * 1e6, "frames_per_s": c4 * len(views) / best,
+                                 "real_time_factor": (c4 * len(views) / best) / (c4 * 48000.0 / (N // 2))}
+                # one call with every sample: the re-blocking kernel's share of a batch call (whole hops from an aligned buffer are analysed in place,
+                # so the block is offset by one pending sample)
+                first, rest = flat[:, :1].contiguous(), flat[:, 1:].contiguous()
+                dt_all = dt_ref = None
+                for _ in range(3):                                  # (the first pass allocates the library's hop buffer and scratch: best of three)
+                    an4.reset_state()
+                    an4.push_samples(first)
+                    an4.sync()
+                    t_s = time.perf_counter()
+                    an4.push_samples(rest)
+                    an4.sync()
+                    d = time.perf_counter() - t_s
+                    dt_all = d if dt_all is None or d < dt_all else dt_all
+                    an4.reset_state()
+                    t_s = time.perf_counter()
+                    an4.push_hops(hops)
+                    an4.sync()
+                    d = time.perf_counter() - t_s
+                    dt_ref = d if dt_ref is None or d < dt_ref else dt_ref
+            rec["one_call"] = {"samples_per_channel": int(flat.shape[1] - 1), "ms_through_push_samples": dt_all * 1e3, "ms_as_whole_hops": dt_ref * 1e3,
+                               "reblocked_bytes": int(2 * (flat.shape[1] - 1) * c4 * 4)}
+            an4.close()
+            res[str(c4)] = rec
+            del hops, flat, pieces, views
+        res["note"] = ("%d-pt windows; `blocks`: %d calls of fx_push_samples with %d-sample device blocks per channel (an audio device at 48 kHz / 10 ms) = the "
+                       "same %d hops per channel that `hops` delivers as one fx_push_hops call per hop; best of three passes; real_time_factor as in live_cadence"
+                       % (N, n_blocks, block, block * n_blocks // (N // 2)))
+        return res
+
     def streaming_hop():
         # BASELINE configs[4]: 1 channel, 4096-pt windows, fp16 samples, ONE hop per call through the pinned ring (one launch of
         # fx_hop_kernel / fx_hop_pair_kernel, the host polls a flag): the round trip of a hop, for the default kernel family and for
@@ -976,6 +1037,7 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
     guarded("data_dependence", data_dependence)
     guarded("other_windows", other_windows)
     guarded("live_cadence", live_cadence)
+    guarded("device_blocks", device_blocks)
     guarded("streaming_hop", streaming_hop)
     guarded("stream_ingest", stream_ingest)
     guarded("offline", offline)

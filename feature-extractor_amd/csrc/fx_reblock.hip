@@ -4,9 +4,9 @@
 // and RealTimeAudioDataOverlapper::getNextBuffer (RealTimeAudioAnalysis.h:205-219) reads it back window/2 samples at a time.
 // Here a channel's pending samples (< window/2, the "carry") and the new block form one byte stream per channel; its first
 // hops x window/2 samples go to the hop buffer the frame kernels read ([C][hops][window/2], rows 16-byte aligned), the rest is
-// the next carry.  Pure byte movement, HBM-bound: one thread per output dword, the source read as two aligned dwords and
-// shifted into place (v_alignbyte_b32), so 16-bit and packed 24-bit samples move at dword rate whatever the block length
-// makes of their alignment.  Samples are not converted and no gain is applied here: the frame kernels' load stage does both
+// the next carry.  Pure byte movement, HBM-bound: one thread per 16 output bytes (one global_store_dwordx4 per lane, 1 KB per wavefront),
+// the source read as five aligned dwords and shifted into place (v_alignbyte_b32), so 16-bit and packed 24-bit samples move at full
+// rate whatever the block length makes of their alignment.  Samples are not converted and no gain is applied here: the frame kernels' load stage does both
 // when the hop is analysed, as getAnalysisBuffer multiplies by the gain at read time (AudioDataCollector.h:88).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,38 +19,56 @@ namespace {
 
 constexpr int RB_THREADS = 256;
 
+// four dwords that need only dword alignment (the hardware's requirement for a 16-byte global access)
+struct __attribute__((packed, aligned(4))) dwords4 { unsigned x, y, z, w; };
+
 __global__ void __launch_bounds__(RB_THREADS)
 fx_reblock_kernel(const ReblockParams p)
 {
     const int c = blockIdx.y;
-    const long long d0 = 4 * ((long long) blockIdx.x * RB_THREADS + threadIdx.x);       // byte offset in the channel's stream
+    const long long d0 = 16 * ((long long) blockIdx.x * RB_THREADS + threadIdx.x);      // byte offset in the channel's stream
     const long long total = (long long) p.carry_bytes + p.in_row_bytes;
     if (d0 >= total) return;
     const unsigned char* in_row = p.in + (size_t) c * (size_t) p.in_row_bytes;
     const unsigned char* carry_row = p.carry_in + (size_t) c * (size_t) p.carry_row_bytes;
-    unsigned v;
+    unsigned v[4];
     const long long b0 = d0 - p.carry_bytes;
-    if (b0 >= 0 && b0 + 8 <= p.in_row_bytes) {
-        // wholly inside the new block, and so is the aligned pair of dwords around it
-        const uintptr_t a = reinterpret_cast<uintptr_t>(in_row + b0);
-        const unsigned* q = reinterpret_cast<const unsigned*>(a & ~(uintptr_t) 3);
-        v = __builtin_amdgcn_alignbyte(q[1], q[0], (unsigned) (a & 3));
+    if (b0 >= 0 && b0 + 20 <= p.in_row_bytes) {
+        // wholly inside the new block, and so are the five aligned dwords around it
+        // (pointer arithmetic, not an integer round trip: the compiler keeps the global address space and emits global_load_dwordx4)
+        const unsigned char* at = in_row + b0;
+        const unsigned sh = (unsigned) (reinterpret_cast<uintptr_t>(at) & 3);
+        const unsigned char* base = at - sh;
+        const dwords4 q = *reinterpret_cast<const dwords4*>(base);
+        const unsigned q4 = *reinterpret_cast<const unsigned*>(base + 16);
+        v[0] = __builtin_amdgcn_alignbyte(q.y, q.x, sh);
+        v[1] = __builtin_amdgcn_alignbyte(q.z, q.y, sh);
+        v[2] = __builtin_amdgcn_alignbyte(q.w, q.z, sh);
+        v[3] = __builtin_amdgcn_alignbyte(q4, q.w, sh);
+    } else if (d0 + 16 <= p.carry_bytes) {
+        // wholly inside the pending samples: the carry row starts on a 16-byte boundary and so does this piece
+        const uint4 q = *reinterpret_cast<const uint4*>(carry_row + d0);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
     } else {
         // across the carry / block boundary or at the end of the block: byte by byte, zeros past the end
-        v = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const long long s = d0 + k;
-            if (s < total) {
-                const unsigned b = s < p.carry_bytes ? carry_row[s] : in_row[s - p.carry_bytes];
-                v |= b << (8 * k);
+        for (int j = 0; j < 4; j++) {
+            v[j] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const long long s = d0 + 4 * j + k;
+                if (s < total) {
+                    const unsigned b = s < p.carry_bytes ? carry_row[s] : in_row[s - p.carry_bytes];
+                    v[j] |= b << (8 * k);
+                }
             }
         }
     }
-    // (rows of whole hops are a multiple of 16 bytes, so a dword never straddles the two destinations; the last dword of the
-    // carry may carry up to three bytes of zeros past the pending samples, inside the row)
-    if (d0 < p.out_row_bytes) *reinterpret_cast<unsigned*>(p.hops_out + (size_t) c * (size_t) p.out_row_bytes + d0) = v;
-    else *reinterpret_cast<unsigned*>(p.carry_out + (size_t) c * (size_t) p.carry_row_bytes + (d0 - p.out_row_bytes)) = v;
+    // (rows of whole hops and carry rows are multiples of 16 bytes, so a thread's 16 bytes never straddle the two destinations; the last
+    // piece of the carry may hold up to fifteen bytes of zeros past the pending samples, inside the row)
+    uint4* dst = d0 < p.out_row_bytes ? reinterpret_cast<uint4*>(p.hops_out + (size_t) c * (size_t) p.out_row_bytes + d0)
+                                      : reinterpret_cast<uint4*>(p.carry_out + (size_t) c * (size_t) p.carry_row_bytes + (d0 - p.out_row_bytes));
+    *dst = uint4{v[0], v[1], v[2], v[3]};
 }
 
 } // namespace
@@ -62,7 +80,7 @@ hipError_t launch_reblock_kernel(const ReblockParams& p, hipStream_t stream)
     if (p.carry_bytes < 0 || p.in_row_bytes < 0 || p.out_row_bytes < 0 || p.out_row_bytes > total || (p.out_row_bytes & 15) || (p.carry_row_bytes & 15) ||
         total - p.out_row_bytes > p.carry_row_bytes)
         return hipErrorInvalidValue;
-    const long long dwords = (total + 3) / 4;
+    const long long dwords = (total + 15) / 16;         // (pieces of 16 bytes, one per thread)
     // grid.y is limited to 65535: more channels than that go in slices (a context of 65 536 channels is configs[3])
     for (int c0 = 0; c0 < p.C; c0 += 65535) {
         ReblockParams q = p;

@@ -31,6 +31,7 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True, 
     pair_cases = [0]
     hop_cases = [0]
     pcm_cases = [0]
+    block_cases = [0]
     last_note = time.time()
     while time.time() < t_end and (max_cases is None or cases < max_cases):
         N = int(rng.choice(list(windows)))
@@ -81,6 +82,20 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True, 
                 parts.append(st.collect())
             st.close()
             ring_cases[0] += 1
+        elif rng.random() < 0.15:
+            # the collector's interface (fx_push_samples, round 5): the same stream as device blocks of random lengths -- an audio device's
+            # 441 / 480 / 512, single samples, blocks longer than a window -- cut into hops on the device
+            H = N // 2
+            per = 3 if feed.dtype == np.uint8 else 1
+            flat = np.ascontiguousarray(feed.reshape(C, -1))
+            parts, at, total = [], 0, T * H
+            while at < total:
+                n = int(rng.choice([1, 63, 441, 480, 512, 1000, 4097, int(rng.integers(1, 3 * N))]))
+                n = min(n, total - at)
+                parts.append(an.push_samples(np.ascontiguousarray(flat[:, at * per:(at + n) * per]), sample_format="s24" if per == 3 else None))
+                at += n
+            assert an.pending_samples() == 0
+            block_cases[0] += 1
         elif T <= 40 and rng.random() < 0.2:
             # hop by hop through fx_push_hops: fx_hop_kernel, or -- every other such case -- the batch kernels forced
             # (frame kernel + the one-frame form of fx_tail_fused_kernel: a lane per slot, the logarithms side by side)
@@ -119,8 +134,9 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True, 
                           % (name, N, C, T, order, otype, owin, len(bad), c, t, fx.FEATURE_NAMES[f], g[c, t, f], w[c, t, f]), flush=True)
     if verbose:
         print("cases run one hop per call through the ring (fx_hop_kernel / fx_hop_pair_kernel): %d; cases on wavefront pairs (fx_pair_kernel): %d; "
-              "cases hop by hop through fx_push_hops (half of them on the batch kernels + one-frame fused tail): %d; cases fed as 16- or 24-bit PCM: %d"
-              % (ring_cases[0], pair_cases[0], hop_cases[0], pcm_cases[0]), flush=True)
+              "cases hop by hop through fx_push_hops (half of them on the batch kernels + one-frame fused tail): %d; cases fed as 16- or 24-bit PCM: %d; "
+              "cases fed as device blocks of random lengths through fx_push_samples: %d"
+              % (ring_cases[0], pair_cases[0], hop_cases[0], pcm_cases[0], block_cases[0]), flush=True)
     if verbose and inexact.any():
         print("raw values not bit-identical (within tolerance), per slot:", dict((fx.FEATURE_NAMES[i], int(n)) for i, n in enumerate(inexact) if n), flush=True)
     return cases, frames, bad_cases, worst
