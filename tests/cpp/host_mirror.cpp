@@ -218,6 +218,85 @@ int main (int argc, char** argv)
         fam.setTuning (tf);
         EXPECT (fam.getTuning().waves_per_frame == 2);
     }
+    // round 5: fx::AudioDataCollector (ref AudioDataCollector.h:18-138) -- device blocks of any length for several channels through
+    // audioDeviceIOCallback, the gain at read time, clearBuffer -- and the ring fed with sample blocks: the bits of pushHops on the same stream
+    {
+        const int C5 = 3, N5 = 1024, H5 = N5 / 2, T5 = 13;
+        std::vector<float> stream ((size_t) C5 * T5 * H5);
+        unsigned r = 4242;
+        for (size_t i = 0; i < stream.size(); i++)
+        {
+            r = r * 1664525u + 1013904223u;
+            stream[i] = 0.5f * std::sin (0.02f * (float) (i % 7001) * (1.0f + (float) (i / (T5 * H5)))) + 0.03f * ((r >> 8) / 16777216.0f - 0.5f);
+        }
+        std::vector<float> wr ((size_t) C5 * T5 * 12), ws (wr.size()), gr (wr.size(), -1.0f), gs (wr.size(), -1.0f);
+        fx::RealTimeBatchAnalyser ref (C5, N5), blocks (C5, N5), ringed (C5, N5);
+        ref.setGain (0.75f);
+        ref.pushHops (stream.data(), T5, wr.data(), ws.data());
+        auto sameBits = [&] (const std::vector<float>& a, const std::vector<float>& b) { return std::memcmp (a.data(), b.data(), a.size() * sizeof (float)) == 0; };
+        {
+            fx::AudioDataCollector collector (blocks);
+            collector.setGain (0.75f);
+            int notified = 0, frames = 0;
+            collector.setNotifyAnalysisThreadCallback ([&] (int n) { notified += n; });
+            const int lengths[] = { 480, 441, 1, 63, 512, 1000, 4097, 7 };
+            size_t at = 0;
+            for (int k = 0; at < (size_t) T5 * H5; k++)
+            {
+                size_t n = (size_t) lengths[k % 8];
+                if (n > (size_t) T5 * H5 - at) n = (size_t) T5 * H5 - at;
+                const float* channels[3] = { stream.data() + at, stream.data() + (size_t) T5 * H5 + at, stream.data() + 2 * (size_t) T5 * H5 + at };
+                const int got = collector.audioDeviceIOCallback (channels, C5, (int) n);
+                EXPECT (got == collector.getNumFrames());
+                for (int c = 0; c < C5; c++)
+                    for (int f = 0; f < got; f++)
+                    {
+                        std::memcpy (&gr[((size_t) c * T5 + frames + f) * 12], collector.raw() + ((size_t) c * got + f) * 12, 12 * sizeof (float));
+                        std::memcpy (&gs[((size_t) c * T5 + frames + f) * 12], collector.smoothed() + ((size_t) c * got + f) * 12, 12 * sizeof (float));
+                    }
+                frames += got;
+                at += n;
+            }
+            EXPECT (frames == T5 && notified == T5 && collector.getNumPendingSamples() == 0);
+            EXPECT (sameBits (gr, wr) && sameBits (gs, ws));
+            // clearBuffer: what is pending becomes zeros, the indices stay (ref :122)
+            const float* head[3] = { stream.data(), stream.data() + (size_t) T5 * H5, stream.data() + 2 * (size_t) T5 * H5 };
+            EXPECT (collector.audioDeviceIOCallback (head, C5, 100) == 0 && collector.getNumPendingSamples() == 100);
+            collector.clearBuffer();
+            EXPECT (collector.getNumPendingSamples() == 100);
+            bool refused = false;
+            try { blocks.pushHops (stream.data(), 1, gr.data(), gs.data()); } catch (const fx::Error& e) { refused = e.code == FX_ERR_INVALID_ARGUMENT; }
+            EXPECT (refused);                       // whole hops would overtake the pending samples
+        }
+        {
+            // the ring: blocks of 700 samples per channel into slots that hold up to two hops' worth
+            fx::HopRing ring (ringed, 2, 3, FX_SAMPLE_F32);
+            ringed.setGain (0.75f);
+            std::fill (gr.begin(), gr.end(), -1.0f); std::fill (gs.begin(), gs.end(), -1.0f);
+            std::vector<float> br ((size_t) C5 * 2 * 12), bs (br.size()), piece;
+            int frames = 0;
+            auto take = [&] {
+                const int got = ring.collectSamples (br.data(), bs.data());
+                for (int c = 0; c < C5; c++)
+                    for (int f = 0; f < got; f++)
+                    {
+                        std::memcpy (&gr[((size_t) c * T5 + frames + f) * 12], &br[((size_t) c * got + f) * 12], 12 * sizeof (float));
+                        std::memcpy (&gs[((size_t) c * T5 + frames + f) * 12], &bs[((size_t) c * got + f) * 12], 12 * sizeof (float));
+                    }
+                frames += got;
+            };
+            for (size_t at = 0; at < (size_t) T5 * H5; at += 700)
+            {
+                const size_t n = (size_t) T5 * H5 - at < 700 ? (size_t) T5 * H5 - at : 700;
+                piece.resize ((size_t) C5 * n);
+                for (int c = 0; c < C5; c++) std::memcpy (&piece[(size_t) c * n], stream.data() + (size_t) c * T5 * H5 + at, n * sizeof (float));
+                if (ring.inFlight() == 3) take();
+                ring.pushSamples (piece.data(), (int) n);
+            }
+            while (ring.inFlight()) take();
+            EXPECT (frames == T5 && sameBits (gr, wr) && sameBits (gs, ws));
+        }
+    }
     // the legacy offline analyser's mirror (ref AudioAnalysis.h)
     {
         const int C3 = 2, S = 4000, B = 513;
