@@ -122,8 +122,10 @@ fx_status fx_set_gain(fx_context* ctx, float gain);
  *   out_smoothed [num_channels][num_hops][12]  AudioFeatures::getValue of every
  *                slot after each hop (RealTimeAnalyser.h:84-88), or NULL
  * Buffers are caller-owned and, for FX_MEM_DEVICE, must stay valid until the
- * stream reaches this call's work (fx_sync).  FX_MEM_HOST buffers are copied
- * synchronously. */
+ * stream reaches this call's work (fx_sync); a FX_MEM_DEVICE input must start on a
+ * 16-byte boundary in every sample format (FX_ERR_INVALID_ARGUMENT otherwise: the
+ * kernels read 16 bytes per lane, and a packed 24-bit sample may sit at any byte of
+ * them).  FX_MEM_HOST buffers are copied synchronously. */
 fx_status fx_push_hops(fx_context* ctx, const void* hops, int num_hops, int sample_format,
                        int mem_kind, float* out_raw, float* out_smoothed);
 

@@ -180,16 +180,18 @@ def _bench_rank(rank, world, port, out_path):
         assert out is None
 
 
-def test_bench_rank_path_two_ranks_gloo_cpu(tmp_path):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_rank_path_two_ranks_gloo_cpu(tmp_path, world):
     """bench.py's N>1 entry (rank_main: shard plan, control group, per-step gather to the sink, the max over ranks, the
-    sink's check of its block, one line from rank 0) with world_size 2 on CPU: a stand-in engine analyses each rank's shard
-    with the oracle, everything else is the code `bench.py --gpus N` runs.  A wrong shard offset or gather order fails the
-    run's own collective check (exit 3)."""
+    sink's check of its block, one line from rank 0) with world_size 2, 4 and 8 -- the driver's 1/2/4/8 ladder -- on CPU: a
+    stand-in engine analyses each rank's shard with the oracle, everything else is the code `bench.py --gpus N` runs.  A wrong
+    shard offset or gather order fails the run's own collective check (exit 3)."""
     import json
     out = str(tmp_path / "line.json")
-    mp.spawn(_bench_rank, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_bench_rank, args=(world, _free_port(), out), nprocs=world, join=True)
     d = json.load(open(out))
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["total_channels"] == 6 and d["config"]["channels_per_gpu"] == 3
+    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["config"]["total_channels"] == 3 * world and d["config"]["channels_per_gpu"] == 3
+    assert [r["rank"] for r in d["per_rank"]] == list(range(world))
     assert d["value"] > 0 and d["steps"] == 2 and "gloo" in d["config"]["sharding"]
     assert d["roofline"]["bound"] == "valu" and d["roofline"]["compute"]["flops_per_frame"] > 2e5
 
