@@ -554,6 +554,8 @@ typedef struct {
     double   worst[FXO_NUM_FEATURES];       /* worst finite relative error */
     uint64_t lag_flips, peak_flips, gate_flip_frames, level_flips;
     uint64_t violating;                     /* frames with any of the above that shows in a value */
+    uint64_t violating_harm;                /* ... in a slot of the harmonic analyser (f0, HER, OER, inharmonicity): what a HYBRID -- spectral analyser on the exact DAG,
+                                               only the pitch pair and the raw-frame transform on the variant -- would still have to replay */
     uint64_t tainted, tainted_by[8], missed; /* the guard: frames it taints, violating frames it lets through */
     uint64_t missed_slot[FXO_NUM_FEATURES];
     double   worst_ratio_pair, worst_ratio_filt;     /* observed transform error / the guard's scale (GUARD_K = 1) */
@@ -562,7 +564,7 @@ typedef struct {
 static void stats_merge(stats_t* a, const stats_t* b)
 {
     a->frames += b->frames; a->lag_flips += b->lag_flips; a->peak_flips += b->peak_flips; a->gate_flip_frames += b->gate_flip_frames;
-    a->level_flips += b->level_flips; a->violating += b->violating; a->tainted += b->tainted; a->missed += b->missed;
+    a->level_flips += b->level_flips; a->violating += b->violating; a->violating_harm += b->violating_harm; a->tainted += b->tainted; a->missed += b->missed;
     for (int i = 0; i < 8; i++) a->tainted_by[i] += b->tainted_by[i];
     for (int i = 0; i < FXO_NUM_FEATURES; i++) {
         a->beyond[i] += b->beyond[i]; a->special[i] += b->special[i]; a->missed_slot[i] += b->missed_slot[i];
@@ -635,6 +637,7 @@ static void* worker(void* arg)
             }
             if ((ve.mag_sum_w > 0.05) != (vf.mag_sum_w > 0.05) || (ve.max_e_w > 0.0001) != (vf.max_e_w > 0.0001) || (ve.mag_sum_r < 0.005) != (vf.mag_sum_r < 0.005)) st->level_flips++;
             if (violated) st->violating++;
+            if (slot_bad[FXO_F0] || slot_bad[FXO_HER] || slot_bad[FXO_OER] || slot_bad[FXO_INHARM]) st->violating_harm++;
             /* transform error against the guard's scale (for the choice of GUARD_K) */
             {
                 const double eps32 = 5.96e-8;
@@ -673,6 +676,7 @@ static void print_stats(const char* title, const stats_t* s)
     if (!s->frames) return;
     printf("  %-24s %12" PRIu64 " frames | violating %10" PRIu64 " (%.4f %%) | guard taints %10" PRIu64 " (%.4f %%), misses %" PRIu64 "\n", title, s->frames,
            s->violating, 100.0 * (double) s->violating / (double) s->frames, s->tainted, 100.0 * (double) s->tainted / (double) s->frames, s->missed);
+    printf("      frames with a harmonic-analyser slot (f0, HER, OER, inharmonicity) outside the bar: %" PRIu64 " (%.4f %%)\n", s->violating_harm, 100.0 * (double) s->violating_harm / (double) s->frames);
     printf("      flips: lag %" PRIu64 ", peak list %" PRIu64 ", flatness-gate frames %" PRIu64 ", level gates %" PRIu64 ", onset %" PRIu64 "\n",
            s->lag_flips, s->peak_flips, s->gate_flip_frames, s->level_flips, s->beyond[FXO_ONSET]);
     printf("      slot       beyond 1e-5   NaN/inf/0 mismatch   worst finite rel err   missed by the guard\n");
