@@ -22,16 +22,9 @@ constexpr int RB_THREADS = 256;
 // four dwords that need only dword alignment (the hardware's requirement for a 16-byte global access)
 struct __attribute__((packed, aligned(4))) dwords4 { unsigned x, y, z, w; };
 
-__global__ void __launch_bounds__(RB_THREADS)
-fx_reblock_kernel(const ReblockParams p)
+// One 16-byte piece of a channel's stream at byte offset d0 (see the file header), returned in v.
+__device__ __forceinline__ void reblock_piece(const ReblockParams& p, const unsigned char* in_row, const unsigned char* carry_row, long long total, long long d0, unsigned (&v)[4])
 {
-    const int c = blockIdx.y;
-    const long long d0 = 16 * ((long long) blockIdx.x * RB_THREADS + threadIdx.x);      // byte offset in the channel's stream
-    const long long total = (long long) p.carry_bytes + p.in_row_bytes;
-    if (d0 >= total) return;
-    const unsigned char* in_row = p.in + (size_t) c * (size_t) p.in_row_bytes;
-    const unsigned char* carry_row = p.carry_in + (size_t) c * (size_t) p.carry_row_bytes;
-    unsigned v[4];
     const long long b0 = d0 - p.carry_bytes;
     if (b0 >= 0 && b0 + 20 <= p.in_row_bytes) {
         // wholly inside the new block, and so are the five aligned dwords around it
@@ -64,11 +57,34 @@ fx_reblock_kernel(const ReblockParams p)
             }
         }
     }
-    // (rows of whole hops and carry rows are multiples of 16 bytes, so a thread's 16 bytes never straddle the two destinations; the last
-    // piece of the carry may hold up to fifteen bytes of zeros past the pending samples, inside the row)
-    uint4* dst = d0 < p.out_row_bytes ? reinterpret_cast<uint4*>(p.hops_out + (size_t) c * (size_t) p.out_row_bytes + d0)
-                                      : reinterpret_cast<uint4*>(p.carry_out + (size_t) c * (size_t) p.carry_row_bytes + (d0 - p.out_row_bytes));
-    *dst = uint4{v[0], v[1], v[2], v[3]};
+}
+
+// PIECES pieces per thread, a workgroup's span apart (every access of a wavefront is 1 KB of consecutive bytes): the loads of all
+// pieces are issued before the first store, so a lane keeps PIECES x 20 bytes in flight.
+template <int PIECES>
+__global__ void __launch_bounds__(RB_THREADS)
+fx_reblock_kernel(const ReblockParams p)
+{
+    const int c = blockIdx.y;
+    const long long total = (long long) p.carry_bytes + p.in_row_bytes;
+    const unsigned char* in_row = p.in + (size_t) c * (size_t) p.in_row_bytes;
+    const unsigned char* carry_row = p.carry_in + (size_t) c * (size_t) p.carry_row_bytes;
+    unsigned v[PIECES][4];
+    long long at[PIECES];
+#pragma unroll
+    for (int k = 0; k < PIECES; k++) {
+        at[k] = 16 * (((long long) blockIdx.x * PIECES + k) * RB_THREADS + threadIdx.x);      // byte offset in the channel's stream
+        if (at[k] < total) reblock_piece(p, in_row, carry_row, total, at[k], v[k]);
+    }
+    // (rows of whole hops and carry rows are multiples of 16 bytes, so a piece never straddles the two destinations; the last piece of the
+    // carry may hold up to fifteen bytes of zeros past the pending samples, inside the row)
+#pragma unroll
+    for (int k = 0; k < PIECES; k++) {
+        if (at[k] >= total) continue;
+        uint4* dst = at[k] < p.out_row_bytes ? reinterpret_cast<uint4*>(p.hops_out + (size_t) c * (size_t) p.out_row_bytes + at[k])
+                                             : reinterpret_cast<uint4*>(p.carry_out + (size_t) c * (size_t) p.carry_row_bytes + (at[k] - p.out_row_bytes));
+        *dst = uint4{v[k][0], v[k][1], v[k][2], v[k][3]};
+    }
 }
 
 } // namespace
@@ -80,7 +96,10 @@ hipError_t launch_reblock_kernel(const ReblockParams& p, hipStream_t stream)
     if (p.carry_bytes < 0 || p.in_row_bytes < 0 || p.out_row_bytes < 0 || p.out_row_bytes > total || (p.out_row_bytes & 15) || (p.carry_row_bytes & 15) ||
         total - p.out_row_bytes > p.carry_row_bytes)
         return hipErrorInvalidValue;
-    const long long dwords = (total + 15) / 16;         // (pieces of 16 bytes, one per thread)
+    const long long pieces = (total + 15) / 16;         // (of 16 bytes)
+    // rows shorter than a workgroup's span of four pieces per thread (16 KB) would leave most of such a workgroup idle
+    const int per_thread = pieces >= 4 * RB_THREADS ? 4 : (pieces >= 2 * RB_THREADS ? 2 : 1);
+    const unsigned gx = (unsigned) ((pieces + (long long) per_thread * RB_THREADS - 1) / ((long long) per_thread * RB_THREADS));
     // grid.y is limited to 65535: more channels than that go in slices (a context of 65 536 channels is configs[3])
     for (int c0 = 0; c0 < p.C; c0 += 65535) {
         ReblockParams q = p;
@@ -89,7 +108,9 @@ hipError_t launch_reblock_kernel(const ReblockParams& p, hipStream_t stream)
         q.carry_in += (size_t) c0 * (size_t) p.carry_row_bytes;
         q.hops_out += (size_t) c0 * (size_t) p.out_row_bytes;
         q.carry_out += (size_t) c0 * (size_t) p.carry_row_bytes;
-        hipLaunchKernelGGL(fx_reblock_kernel, dim3((unsigned) ((dwords + RB_THREADS - 1) / RB_THREADS), (unsigned) cn), dim3(RB_THREADS), 0, stream, q);
+        if (per_thread == 4) hipLaunchKernelGGL(fx_reblock_kernel<4>, dim3(gx, (unsigned) cn), dim3(RB_THREADS), 0, stream, q);
+        else if (per_thread == 2) hipLaunchKernelGGL(fx_reblock_kernel<2>, dim3(gx, (unsigned) cn), dim3(RB_THREADS), 0, stream, q);
+        else hipLaunchKernelGGL(fx_reblock_kernel<1>, dim3(gx, (unsigned) cn), dim3(RB_THREADS), 0, stream, q);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
