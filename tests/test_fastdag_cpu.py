@@ -1,0 +1,32 @@
+"""tools/fastdag/fastdag.c (the CPU study behind DESIGN.md 3.3 "Round 5") builds and runs: a few thousand frames of the stress mix through the
+oracle and the variant transform DAG.  The committed record of the full run is profiles/r05_fastdag.txt; this keeps the tool alive and checks
+the two facts the conclusion rests on at small scale: with FMA as the ONLY change a few per cent of the mix's frames already leave the 1e-5 bar,
+and on bench.py's own signal next to none do."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not installed")
+
+
+def _run(exe, *args):
+    p = subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    m = re.search(r"ALL KINDS\s+(\d+) frames \| violating\s+(\d+)", p.stdout)
+    assert m, p.stdout[-2000:]
+    return int(m.group(1)), int(m.group(2)), p.stdout
+
+
+def test_fastdag_builds_and_reproduces_the_shape_of_the_record(tmp_path):
+    exe = str(tmp_path / "fastdag")
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-mfma", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tools", "fastdag", "fastdag.c"), "-lm", "-lpthread"])
+    frames, bad, out = _run(exe, 2e4, 2, 3, 1024, 4, -1, 1)           # variant 1: the reference's DAG, fused twiddle products only
+    assert frames >= 20000 and 0.02 < bad / frames < 0.12, out[:1500]
+    assert "harmonic-analyser slot" in out and "lag" in out
+    frames, bad, out = _run(exe, 2e4, 2, 3, 1024, 4, 1, 0, 8)         # variant 0 on bench.py's synthetic mix
+    assert frames >= 20000 and bad / frames < 0.01, out[:1500]
