@@ -9,6 +9,7 @@
 //   * fx::AudioDataCollector        -- ref Source/AudioDataCollector.h:18-138: audioDeviceIOCallback takes device blocks of ANY
 //                                      length for all channels; whole hops are analysed as they complete (fx_push_samples).
 //   * fx::OSCFeatureMessage         -- ref Source/OSCFeatureAnalysisOutput.h:89-113 wire format.
+//   * fx::OSCFeatureAnalysisOutput  -- ref Source/OSCFeatureAnalysisOutput.h:23-145: the 60 Hz timer that sends a track's latest values.
 // No JUCE.  Errors are thrown as fx::Error (the reference only jasserts).
 #ifndef FX_REALTIME_HPP
 #define FX_REALTIME_HPP
@@ -388,6 +389,92 @@ private:
     int fd = -1;
     bool connected = false;
     sockaddr_in dest {};
+};
+} // namespace fx
+
+#include <atomic>
+#include <chrono>
+#include <mutex>
+#include <thread>
+
+namespace fx
+{
+// OSCFeatureAnalysisOutput, ref Source/OSCFeatureAnalysisOutput.h:23-145: a 60 Hz timer that reads the track's AudioFeatures::getValue of
+// every slot and sends them as one OSC message to ip[:port] (:89-113, :133).  The reference's timer reads the AudioFeatures object the
+// analysis threads are writing, unsynchronised; here the analysis side hands over a snapshot -- updateFeatures (smoothed12), the
+// `smoothed` vector of the channel's newest frame -- and the timer thread sends the latest snapshot, so a datagram is always the twelve
+// values of ONE frame.  One object per track and target, as the reference builds them (AnalyserTrackController.h:22-23: two per track).
+class OSCFeatureAnalysisOutput
+{
+public:
+    OSCFeatureAnalysisOutput (const std::string& ip, const std::string& bundle) : bundleAddress (bundle)
+    {
+        for (float& v : latest) v = 0.0f;
+        if (! bundle.empty()) connectToAddress (ip);                                   // ref :79-80
+    }
+    ~OSCFeatureAnalysisOutput() { stopTimer(); }
+    OSCFeatureAnalysisOutput (const OSCFeatureAnalysisOutput&) = delete;
+    OSCFeatureAnalysisOutput& operator= (const OSCFeatureAnalysisOutput&) = delete;
+
+    // the analysis side: the smoothed vector (AudioFeatures::getValue of every slot) after the channel's newest frame
+    void updateFeatures (const float* smoothed12)
+    {
+        std::lock_guard<std::mutex> g (lock);
+        for (int i = 0; i < FX_NUM_FEATURES; i++) latest[i] = smoothed12[i];
+        have = true;
+    }
+    // ref :89-113: one message with what getValue returns right now (nothing before the first frame: the reference would send 0/0 = NaN)
+    bool sendSpectralFeaturesViaOSC()
+    {
+        float v[FX_NUM_FEATURES];
+        {
+            std::lock_guard<std::mutex> g (lock);
+            if (! have) return false;
+            for (int i = 0; i < FX_NUM_FEATURES; i++) v[i] = latest[i];
+        }
+        if (! sender.send (bundleAddress, v)) return false;
+        sent++;
+        return true;
+    }
+    // ref :115-136: "ip[:port]" (port 9000 by default); a successful connect starts the 60 Hz timer
+    bool connectToAddress (const std::string& newAddress)
+    {
+        stopTimer();
+        if (! sender.connectToAddress (newAddress)) return false;
+        startTimerHz (60);
+        return true;
+    }
+    void startTimerHz (int hz)
+    {
+        stopTimer();
+        running = true;
+        timer = std::thread ([this, hz] {
+            const std::chrono::nanoseconds period (1000000000ll / (hz > 0 ? hz : 60));
+            std::chrono::steady_clock::time_point next = std::chrono::steady_clock::now() + period;
+            while (running.load())
+            {
+                std::this_thread::sleep_until (next);
+                next += period;
+                if (running.load()) (void) sendSpectralFeaturesViaOSC();                  // timerCallback, ref :84-87
+            }
+        });
+    }
+    void stopTimer()
+    {
+        running = false;
+        if (timer.joinable()) timer.join();
+    }
+    long getNumMessagesSent() const { return sent.load(); }
+
+private:
+    OSCFeatureSender sender;
+    std::string bundleAddress { "/Audio/Features" };                                    // ref :144
+    std::mutex lock;
+    float latest[FX_NUM_FEATURES];
+    bool have = false;
+    std::atomic<bool> running { false };
+    std::atomic<long> sent { 0 };
+    std::thread timer;
 };
 } // namespace fx
 

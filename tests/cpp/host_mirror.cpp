@@ -54,6 +54,37 @@ int main (int argc, char** argv)
         fx::OSCFeatureSender dflt;
         EXPECT (dflt.connectToAddress ("127.0.0.1"));          // default port 9000
     }
+    {
+        // fx::OSCFeatureAnalysisOutput (ref OSCFeatureAnalysisOutput.h:23-145): connecting starts a 60 Hz timer that sends the latest snapshot;
+        // nothing before the first frame; every datagram is the twelve values of ONE updateFeatures call
+        int rx = ::socket (AF_INET, SOCK_DGRAM, 0);
+        sockaddr_in a {};
+        a.sin_family = AF_INET; a.sin_port = 0; a.sin_addr.s_addr = htonl (INADDR_LOOPBACK);
+        EXPECT (::bind (rx, reinterpret_cast<sockaddr*> (&a), sizeof a) == 0);
+        socklen_t len = sizeof a;
+        ::getsockname (rx, reinterpret_cast<sockaddr*> (&a), &len);
+        timeval tv { 0, 300000 };
+        ::setsockopt (rx, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof tv);
+        char buf[256];
+        {
+            fx::OSCFeatureAnalysisOutput out ("127.0.0.1:" + std::to_string ((int) ntohs (a.sin_port)), "/Audio/A3");
+            EXPECT (::recv (rx, buf, sizeof buf, 0) < 0);                        // no frame yet: the timer has nothing to read
+            float w[12];
+            for (int i = 0; i < 12; i++) w[i] = 0.5f + (float) i;
+            out.updateFeatures (w);
+            const std::string want = fx::OSCFeatureMessage ("/Audio/A3", w);
+            int got = 0;
+            for (int k = 0; k < 6; k++) { const ssize_t n = ::recv (rx, buf, sizeof buf, 0); if (n == (ssize_t) want.size() && std::memcmp (buf, want.data(), want.size()) == 0) got++; }
+            EXPECT (got == 6);                                                    // 60 Hz: six datagrams well inside the time-outs
+            for (int i = 0; i < 12; i++) w[i] = -1.0f - (float) i;
+            out.updateFeatures (w);
+            const std::string next = fx::OSCFeatureMessage ("/Audio/A3", w);
+            bool seen = false;
+            for (int k = 0; k < 6 && ! seen; k++) { const ssize_t n = ::recv (rx, buf, sizeof buf, 0); seen = n == (ssize_t) next.size() && std::memcmp (buf, next.data(), next.size()) == 0; }
+            EXPECT (seen && out.getNumMessagesSent() >= 7);
+        }                                                                         // (the destructor joins the timer thread)
+        ::close (rx);
+    }
 
     if (! gpu)
     {
