@@ -106,6 +106,50 @@ def test_packed_24_bit_blocks_and_mixed_block_lengths(gpu_fx):
         an.push_samples(packed[:, :30])                          # bytes are not 24-bit PCM on their dtype alone
 
 
+@pytest.mark.parametrize("N", [256, 512])
+@pytest.mark.parametrize("fmt", ["f16", "s24", "f32"])
+@pytest.mark.parametrize("C", [1, 7])
+def test_small_windows_single_channels_and_every_format(gpu_fx, N, fmt, C):
+    """the smallest windows (carry rows of 512 / 1024 bytes), one channel, half floats and three-byte samples, random block lengths incl. empty ones"""
+    import torch
+    H, T = N // 2, 23
+    rng = np.random.default_rng(N + C)
+    x = signals.tone_vibrato_noise(C, T, N, seed=N).reshape(C, -1)
+    if fmt == "f16":
+        stream = x.astype(np.float16)
+        want = gpu_fx.BatchAnalyser(C, N).push_hops(stream.reshape(C, T, H))
+        per, sf = 1, None
+    elif fmt == "s24":
+        v = np.clip(np.round(x.astype(np.float64) * 8388608.0), -8388608, 8388607).astype(np.int32)
+        stream = np.asarray(gpu_fx.pack_s24(v))
+        want = gpu_fx.BatchAnalyser(C, N).push_hops(gpu_fx.pack_s24(v.reshape(C, T, H)))
+        per, sf = 3, "s24"
+    else:
+        stream = x
+        want = gpu_fx.BatchAnalyser(C, N).push_hops(stream.reshape(C, T, H))
+        per, sf = 1, None
+    for device in (False, True):
+        an = gpu_fx.BatchAnalyser(C, N)
+        raws, sms, at = [], [], 0
+        while at < T * H:
+            n = min(int(rng.choice([0, 1, 2, 3, 17, 100, H - 1, H, H + 1, 3 * H + 5])), T * H - at)
+            piece = np.ascontiguousarray(stream[:, at * per:(at + n) * per])
+            if device and n > 0:
+                # a device buffer that starts 4 bytes into an allocation: dword-aligned, not 16-byte aligned
+                pad = torch.zeros(piece.nbytes + 64, dtype=torch.uint8, device="cuda")
+                view = pad[4:4 + piece.nbytes]
+                view.copy_(torch.from_numpy(piece.view(np.uint8).reshape(-1)))
+                tv = view.view({"f16": torch.float16, "s24": torch.uint8, "f32": torch.float32}[fmt]).reshape(C, -1)
+                r, s_ = an.push_samples(tv, sample_format=sf)
+                r, s_ = r.cpu().numpy(), s_.cpu().numpy()
+            else:
+                r, s_ = an.push_samples(piece, sample_format=sf)
+            raws.append(r); sms.append(s_)
+            at += n
+        assert same(np.concatenate(raws, 1), want[0]) and same(np.concatenate(sms, 1), want[1]), (N, fmt, C, device)
+        assert an.pending_samples() == 0
+
+
 def test_gain_reaches_pending_samples_and_clear_buffer_zeroes_them(gpu_fx):
     """getAnalysisBuffer multiplies by the gain at READ time (AudioDataCollector.h:88): a change applies to what is still pending;
     clearBuffer (:122) turns the pending samples into zeros and keeps the indices."""
