@@ -102,6 +102,20 @@ template <bool INV> __device__ __forceinline__ f2 twmul(f2 a, f2 t)
     //   inverse: p = (a.r*t.r, a.r*(-t.i)), q = (a.i*t.i, a.i*t.r), result = p + q
     // (-x)*y == -(x*y) and p + (-q) == p - q exactly, so the roundings are those of the reference form.
     f2 p, q, r;
+#ifdef FX_EXP_FMA_TWIDDLES
+    // EXPERIMENT BUILD ONLY (round 5, profiles/r05_fma_experiment.txt): the second product fused into the sum -- two packed instructions, one
+    // rounding fewer per component, and spectra that are no longer the reference's.  What the FMA lever is worth on this chip, measured;
+    // the library is never built with it ("Round 5").
+    if (INV) {
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(p) : "v"(a), "v"(t));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(t), "v"(p));
+    } else {
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(p) : "v"(a), "v"(t));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(t), "v"(p));
+    }
+    (void) q;
+    return r;
+#else
     if (INV) {
         asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(p) : "v"(a), "v"(t));
         asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(q) : "v"(a), "v"(t));
@@ -111,6 +125,7 @@ template <bool INV> __device__ __forceinline__ f2 twmul(f2 a, f2 t)
     }
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(p), "v"(q));
     return r;
+#endif
 }
 // the same for a purely real a = (r, 0): the products with 0 only contribute exact zeros
 template <bool INV> __device__ __forceinline__ f2 twmul_real(float r, f2 t)

@@ -18,10 +18,13 @@ SWITCHES = {
     "FX_WITH_TAIL_KERNELS": "set by fx_kernels.hip from FX_PART: the object that holds the __global__ tail kernels",
     "FX_EXP_WIDE_BAND": "test build: the logRMS bracket catches (almost) every frame, so the exact gate threshold runs everywhere",
     "FX_EXP_STOP_AT": "costing builds (tools/section_costs.sh): a frame's work ends at stop point k",
+    "FX_EXP_FMA_TWIDDLES": "experiment build (round 5): the twiddle products' second multiply fused into the sum -- spectra no longer the reference's; "
+                           "measures what FMA is worth on the chip (profiles/r05_fma_experiment.txt), never shipped",
 }
 
 VARIANTS = ([("part%d" % k, ["-DFX_PART=%d" % k]) for k in range(4)]
             + [("wide_band", ["-DFX_EXP_WIDE_BAND"])]
+            + [("fma_twiddles", ["-DFX_EXP_FMA_TWIDDLES"])]
             + [("stop_at_%d" % k, ["-DFX_EXP_STOP_AT=%d" % k]) for k in range(1, 12)])
 
 
