@@ -862,6 +862,37 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
                     dt_ref = d if dt_ref is None or d < dt_ref else dt_ref
             rec["one_call"] = {"samples_per_channel": int(flat.shape[1] - 1), "ms_through_push_samples": dt_all * 1e3, "ms_as_whole_hops": dt_ref * 1e3,
                                "reblocked_bytes": int(2 * (flat.shape[1] - 1) * c4 * 4)}
+            if c4 == 1024:
+                # the same blocks from HOST memory, where an audio callback has them: fx_push_samples on a host block (a synchronous call: copy in,
+                # analysis, vectors out) and the pinned ring's form (fx_stream_push_samples / fx_stream_collect_samples, three blocks in flight)
+                host_pieces = [p4.cpu().numpy() for p4 in pieces[:8]]
+                an4.reset_state()
+                for k in range(8):
+                    an4.push_samples(host_pieces[k % 8])
+                an4.reset_state()
+                t_s = time.perf_counter()
+                for k in range(n_blocks):
+                    an4.push_samples(host_pieces[k % 8])
+                dt_h = time.perf_counter() - t_s
+                an4.reset_state()
+                ring4 = fx.HopStream(an4, 1, slots=3, dtype=np.float32)
+                got = 0
+                t_s = None
+                warm4 = 400                                       # (a new ring's first few hundred blocks carry its allocations' first touches: 80 us in steady state, spikes of milliseconds before)
+                for k in range(n_blocks + warm4):
+                    if k == warm4:
+                        while ring4.in_flight():
+                            ring4.collect_samples()
+                        t_s = time.perf_counter()
+                    if ring4.in_flight() == 3:
+                        got += ring4.collect_samples()[0].shape[1]
+                    ring4.push_samples(host_pieces[k % 8])
+                while ring4.in_flight():
+                    got += ring4.collect_samples()[0].shape[1]
+                dt_r = time.perf_counter() - t_s
+                ring4.close()
+                rec["from_host_memory"] = {"push_samples_us_per_call": dt_h / n_blocks * 1e6, "ring_us_per_block": dt_r / n_blocks * 1e6,
+                                           "block_bytes": int(host_pieces[0].nbytes), "real_time_factor_ring": (block / 48000.0) / (dt_r / n_blocks)}
             an4.close()
             res[str(c4)] = rec
             del hops, flat, pieces, views
