@@ -127,6 +127,28 @@ hipError_t hipEventQuery(hipEvent_t) { return tick("hipEventQuery"); }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { if (tick("hipEventElapsedTime") != hipSuccess) return g_last; *ms = 0.001f; return hipSuccess; }
 } // extern "C"
 
+// ---- the hops the shim hands to the analysis kernels (hop mode), per channel ----
+#include <vector>
+namespace {
+std::vector<std::vector<unsigned char>> g_hops;
+int g_hop_log = 0;
+void log_hops(const fxk::FrameParams& p, int window)
+{
+    if (!g_hop_log || !p.hop_mode || !p.in) return;
+    const size_t esz = p.sample_format == FX_SAMPLE_F32 ? 4 : (p.sample_format == FX_SAMPLE_S24 ? 3 : 2);
+    const size_t row = (size_t) p.T * (size_t) (window / 2) * esz;
+    if ((int) g_hops.size() < p.C) g_hops.resize((size_t) p.C);
+    const unsigned char* in = static_cast<const unsigned char*>(p.in);
+    for (int c = 0; c < p.C; c++) g_hops[(size_t) c].insert(g_hops[(size_t) c].end(), in + (size_t) c * row, in + (size_t) (c + 1) * row);
+}
+}
+extern "C" {
+void fake_hop_log_clear(void) { g_hops.clear(); }
+void fake_hop_log_enable(int on) { g_hop_log = on; }
+const unsigned char* fake_hop_log_bytes(int c) { return c < (int) g_hops.size() ? g_hops[(size_t) c].data() : nullptr; }
+size_t fake_hop_log_size(int c) { return c < (int) g_hops.size() ? g_hops[(size_t) c].size() : 0; }
+}
+
 // ---- csrc/fx_kernels.h: launchers that launch nothing (each one a countable call), host helpers with plausible answers ----
 namespace fxk {
 void build_pass_twiddles(int n, const float* canonical, float* out) { memcpy(out, canonical, sizeof(float) * 2 * (size_t) n); }
@@ -137,21 +159,22 @@ bool twiddles_have_quarter_turn(int, const float*) { return true; }
 size_t frame_kernel_lds_bytes(int n, int ch, int k, bool direct) { return (size_t) 8 * n + (direct ? 0 : (size_t) ch * 9 * n / 4) + (size_t) ch * k * (n <= 1024 ? 17 * n / 2 : 9 * n / 2); }
 int frame_kernel_max_waves(int n) { return n <= 512 ? 16 : 8; }
 void frame_kernel_preferred_shape(int n, int* ch, int* k) { *ch = 1; *k = n == 2048 ? 4 : 8; }
-hipError_t launch_frame_kernel(int, const FrameParams& p, int, hipStream_t) { if (p.C <= 0 || p.T <= 0) return hipSuccess; return fake_hip_count("launch_frame_kernel"); }
+hipError_t launch_frame_kernel(int n, const FrameParams& p, int, hipStream_t) { if (p.C <= 0 || p.T <= 0) return hipSuccess; const hipError_t e = fake_hip_count("launch_frame_kernel"); if (e == hipSuccess) log_hops(p, n); return e; }
 hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t) { if (p.C <= 0 || p.T <= 0) return hipSuccess; return fake_hip_count("launch_epilogue_kernels"); }
 bool frame_tail_kernel_available(int n) { return n >= 1024; }
-hipError_t launch_frame_tail_kernel(int, const FrameParams&, const EpilogueParams&, hipStream_t) { return fake_hip_count("launch_frame_tail_kernel"); }
+hipError_t launch_frame_tail_kernel(int n, const FrameParams& p, const EpilogueParams&, hipStream_t) { const hipError_t e = fake_hip_count("launch_frame_tail_kernel"); if (e == hipSuccess) log_hops(p, n); return e; }
 hipError_t prepare_kernels(int) { return fake_hip_count("prepare_kernels"); }
 hipError_t prepare_hop_kernel(int) { return fake_hip_count("prepare_hop_kernel"); }
 bool pair_kernel_available(int n) { return n == 2048 || n == 4096; }
 int pair_kernel_max_pairs(int n) { return n == 2048 ? 8 : 6; }
 size_t pair_kernel_lds_bytes(int n, int ch, int k) { return (size_t) 8 * n + (size_t) ch * k * 17408; }
 hipError_t prepare_pair_kernel(int) { return fake_hip_count("prepare_pair_kernel"); }
-hipError_t launch_pair_kernel(int, const FrameParams&, hipStream_t) { return fake_hip_count("launch_pair_kernel"); }
+hipError_t launch_pair_kernel(int n, const FrameParams& p, hipStream_t) { const hipError_t e = fake_hip_count("launch_pair_kernel"); if (e == hipSuccess) log_hops(p, n); return e; }
 bool hop_kernel_available(int n) { return n == 1024 || n == 2048 || n == 4096; }
-hipError_t launch_hop_kernel(int, const FrameParams&, const EpilogueParams& ep, const HopSignal& sig, hipStream_t, bool)
+hipError_t launch_hop_kernel(int n, const FrameParams& p, const EpilogueParams& ep, const HopSignal& sig, hipStream_t, bool)
 {
     const hipError_t e = fake_hip_count("launch_hop_kernel");
+    if (e == hipSuccess) log_hops(p, n);
     // the real kernel raises the slot's flag when the hop is done; fx_stream_collect polls it
     if (e == hipSuccess && sig.host_flag) *sig.host_flag = sig.seq;
     (void) ep;

@@ -63,5 +63,11 @@ long fake_hip_live_bytes(void);
 int  fake_hip_failed(void);                // whether the armed failure has fired
 const char* fake_hip_failed_name(void);    // ... and in which entry point
 hipError_t fake_hip_count(const char* name);   // for the kernel-launch stubs: counts as a call, fails if armed
+// every hop the shim has handed to a frame / hop kernel since fake_hop_log_clear(), channel by channel in the order of analysis: the
+// samples of channel c are bytes [fake_hop_log_bytes(c), + fake_hop_log_size(c)) -- what the analysers would have consumed
+void fake_hop_log_clear(void);
+void fake_hop_log_enable(int on);
+const unsigned char* fake_hop_log_bytes(int channel);
+size_t fake_hop_log_size(int channel);
 }
 #endif

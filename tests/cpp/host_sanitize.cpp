@@ -235,6 +235,75 @@ bool scenario_comm(World& w)
     return true;
 }
 
+// F: the arithmetic of fx_push_samples / fx_stream_submit_samples, on the host: random block lengths, every sample format, host and "device"
+// blocks, a long block, empty blocks -- the hops the shim hands to the analysis kernels (the fake launchers log them, the fake re-blocking
+// launcher really moves the bytes), put end to end per channel, must be the stream that went in, cut at whole hops.  ASan checks every bound
+// the shim computed on the way.
+bool scenario_block_arithmetic(World& w)
+{
+    unsigned r = 12345;
+    auto rnd = [&] (unsigned m) { r = r * 1664525u + 1013904223u; return (r >> 8) % m; };
+    const int formats[4] = { FX_SAMPLE_F32, FX_SAMPLE_S16, FX_SAMPLE_S24, FX_SAMPLE_F16 };
+    const size_t widths[4] = { 4, 2, 3, 2 };
+    for (int round = 0; round < 12; round++) {
+        const int fi = round % 4, N = round % 3 == 0 ? 256 : (round % 3 == 1 ? 1024 : 4096), C = 1 + (int) rnd(5), H = N / 2;
+        const size_t esz = widths[fi];
+        const int total = 5 * H + (int) rnd((unsigned) (3 * H));
+        World v;
+        if (!make_context(v, C, N, round == 7 ? FX_LOW_LATENCY : 0u)) { recover_and_destroy(v, false); return false; }
+        std::vector<unsigned char> stream ((size_t) C * (size_t) total * esz);
+        for (size_t i = 0; i < stream.size(); i++) stream[i] = (unsigned char) (rnd(251) + 1);
+        std::vector<float> raw ((size_t) C * (size_t) (total / H + 1) * 12), sm (raw.size());
+        fake_hop_log_clear();
+        fake_hop_log_enable(1);
+        int at = 0, frames_total = 0;
+        bool ok = true;
+        while (at < total && ok) {
+            static const int lengths[] = { 0, 1, 2, 3, 63, 441, 480, 512, 1000, 4097 };
+            int n = lengths[rnd(10)];
+            if (rnd(7) == 0) n = (int) rnd((unsigned) (2 * N));
+            if (n > total - at) n = total - at;
+            std::vector<unsigned char> block ((size_t) C * (size_t) n * esz + 16);
+            for (int c = 0; c < C; c++) std::memcpy (&block[(size_t) c * (size_t) n * esz], &stream[((size_t) c * (size_t) total + (size_t) at) * esz], (size_t) n * esz);
+            int frames = -1;
+            const bool device = rnd(3) == 0;
+            void* d_block = nullptr;
+            const void* src = block.data();
+            if (device) {
+                if (hipMalloc (&d_block, block.size()) != hipSuccess) { ok = false; break; }
+                std::memcpy (d_block, block.data(), block.size());
+                src = d_block;
+            }
+            const fx_status st = fx_push_samples (v.ctx, src, n, formats[fi], device ? FX_MEM_DEVICE : FX_MEM_HOST, device ? nullptr : raw.data(), nullptr, &frames);
+            if (d_block) (void) hipFree (d_block);
+            if (st != FX_OK) { ok = false; break; }
+            frames_total += frames;
+            at += n;
+            if (fx_pending_samples (v.ctx) != at % H) problem ("pending sample count after a block");
+        }
+        fake_hop_log_enable(0);
+        if (ok) {
+            if (frames_total != total / H) problem ("frames out of the blocks");
+            for (int c = 0; c < C; c++) {
+                const size_t want = (size_t) (total / H) * (size_t) H * esz;
+                if (fake_hop_log_size (c) != want || std::memcmp (fake_hop_log_bytes (c), &stream[(size_t) c * (size_t) total * esz], want) != 0) {
+                    char msg[128];
+                    std::snprintf (msg, sizeof msg, "round %d: window %d, %d channels, format %d, channel %d", round, N, C, formats[fi], c);
+                    problem ("the hops handed to the kernels are not the stream cut at whole hops:", msg);
+                    break;
+                }
+            }
+        }
+        fake_hop_log_clear();
+        const bool failed_here = !ok;
+        recover_and_destroy (v, fake_hip_failed() != 0);
+        if (failed_here) return false;
+    }
+    // the scenario's own world stays empty: every round built and destroyed its context
+    (void) w;
+    return true;
+}
+
 typedef bool (*Scenario)(World&);
 bool ring_graph_zero(World& w) { return scenario_ring_graph(w, true); }
 bool ring_graph_copy(World& w) { return scenario_ring_graph(w, false); }
@@ -286,6 +355,7 @@ int main(int argc, char** argv)
         walk("ring, captured step (copies)", ring_graph_copy, true);
         walk("ring, large batches", ring_large, true);
         walk("rccl gather", scenario_comm, true);
+        walk("block arithmetic", scenario_block_arithmetic, false);
         // failures of RCCL itself
         void (*reset)(void) = (void (*)(void)) dlsym(RTLD_DEFAULT, "fake_rccl_reset");
         if (!reset) problem("the fake librccl is not the one loaded");

@@ -3,7 +3,8 @@
 csrc/fx_capi.cpp and csrc/fx_comm.cpp -- ring slots, captured steps, the fill pool's threads, the re-blocking plumbing of fx_push_samples,
 the RCCL gather -- are compiled UNCHANGED for the host against tests/cpp/fake_hip/ (a malloc-backed hip_runtime.h whose every call can be
 made to fail, launch stubs for csrc/fx_kernels.h, a one-rank librccl.so.1) with -fsanitize=address,undefined, and tests/cpp/host_sanitize.cpp
-walks six scenarios once per HIP call with that call failing: no crash, no overrun, no leak, no wedged ring, the next call works.  A second
+walks six scenarios once per HIP call with that call failing: no crash, no overrun, no leak, no wedged ring, the next call works; a seventh checks
+fx_push_samples' arithmetic on the host (random block lengths x formats x windows: the hops handed to the kernels, put end to end, are the stream).  A second
 build with -fsanitize=thread runs the fill pool (1 .. 64 threads, resized up and down, jobs back to back).
 What this found when it was written (round 5): grow() freed a scratch buffer twice when hipFree itself reported a failure."""
 import os
@@ -60,6 +61,8 @@ def test_every_hip_call_site_failed_once_under_asan_and_ubsan(tmp_path, fake_rcc
     assert len(walked) == 6, p.stdout
     total = sum(int(line.split("run:")[1].split()[0]) for line in p.stdout.splitlines() if "clean run:" in line)
     assert total > 800, p.stdout
+    # and the arithmetic of fx_push_samples on the host: the hops handed to the (fake) kernels, end to end, are the stream cut at whole hops
+    assert any(line.startswith("block arithmetic") and "clean run" in line for line in p.stdout.splitlines()), p.stdout
 
 
 def test_fill_pool_under_tsan(tmp_path, fake_rccl):
