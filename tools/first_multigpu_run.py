@@ -92,6 +92,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--max-gpus", type=int, default=8)
     ap.add_argument("--timeout", type=int, default=600, help="seconds per child")
+    ap.add_argument("--rehearse-ranks", type=int, default=0,
+                    help="REHEARSAL on a box with fewer GPUs than ranks: run bench.py --gpus 1, 2, 4 ... up to this many rank processes with --backend gloo "
+                         "(the ranks share the GPUs there are and gather through host memory): the real shard plan, control group, per-step gather, sink check "
+                         "and per-rank records -- everything but RCCL between GPUs.  Its scaling factors mean nothing (one GPU does all the work) and the report says so.")
+    ap.add_argument("--channels-per-gpu", type=int, default=None)
+    ap.add_argument("--frames", type=int, default=None)
     args = ap.parse_args()
     import bench
     started = time.time()
@@ -107,15 +113,22 @@ def main():
     subprocess.check_call(["g++", "-O1", "-std=c++14", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "comm_ranks.cpp"),
                            "-o", exe, "-L", lib_dir, "-lfx_hip", "-Wl,-rpath," + lib_dir])
     comm = {}
-    for n in sorted({2, max([k for k in (2, 4, 8) if k <= gpus] or [2])}):
+    rehearsal = args.rehearse_ranks > 0
+    for n in ([] if rehearsal else sorted({2, max([k for k in (2, 4, 8) if k <= gpus] or [2])})):
         rc, so, se = run([exe, str(n)], args.timeout, env)
         comm[n] = {"rc": rc, "skipped": rc == 77, "tail": (so + se)[-1500:]}
     lines = {}
+    extra = []
+    if args.channels_per_gpu is not None:
+        extra += ["--channels-per-gpu", str(args.channels_per_gpu)]
+    if args.frames is not None:
+        extra += ["--frames", str(args.frames)]
     for n in (1, 2, 4, 8):
-        if n > max(gpus, 1):
+        if n > (args.rehearse_ranks if rehearsal else max(gpus, 1)):
             continue
         rc, so, se = run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", str(args.steps), "--warmup", str(args.warmup),
-                          "--no-extra", "--no-cpu-baseline", "--no-pmc", "--rank-timeout", str(args.timeout)], args.timeout + 60, env)
+                          "--no-extra", "--no-cpu-baseline", "--no-pmc", "--rank-timeout", str(args.timeout)] + (["--backend", "gloo"] if rehearsal and n > 1 else []) + extra,
+                         args.timeout + 60, env)
         line = None
         for l in so.splitlines():
             if l.startswith("{"):
@@ -127,6 +140,10 @@ def main():
         if line is not None:
             lines[n]["stderr_tail"] = se[-1200:]
     rep = assemble(visible, comm, lines, started)
+    if rehearsal:
+        rep["rehearsal"] = ("REHEARSAL on %d visible GPU(s): the rank processes of n > 1 share them (--backend gloo, gather through host memory).  Shard plan, control "
+                            "group, per-step gather, sink check and per-rank records are the real ones; `scaling` is NOT a scaling measurement and RCCL / xGMI did not run."
+                            % visible)
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     json.dump(rep, open(args.out, "w"), indent=1)
     print(json.dumps({"out": args.out, "visible_gpus": visible, "scaling": rep["scaling"], "findings": rep["findings"]}, indent=1))
