@@ -1,0 +1,57 @@
+"""The collector's semantics, pinned by the reference's own collector: tests/golden/blocks/cases.npz holds what the reference's
+AudioDataCollector + overlapper + analysers (headers compiled unmodified, tools/refdiff/refdiff_blocks.cpp) produce when they are fed device
+blocks of any length with setGain / clearBuffer in between.  Here the MODEL that fx_push_samples implements -- a FIFO of raw samples per
+channel, whole hops read as soon as they are there, the gain applied when a hop is read (ref AudioDataCollector.h:88), clearBuffer zeroing what
+is pending and keeping the indices (:122) -- is replayed on the CPU oracle and must reproduce those vectors bit for bit.  (The GPU replays the
+same cases through fx_push_samples in tests/test_gpu_samples.py.)"""
+import os
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+from block_cases import CASES, replay, stream_of  # noqa: E402
+
+FIXTURE = os.path.join(HERE, "golden", "blocks", "cases.npz")
+
+
+def _same(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+@pytest.mark.parametrize("k", range(len(CASES)), ids=[c[0] for c in CASES])
+def test_the_model_of_the_collector_reproduces_the_reference_collectors_vectors(oracle, k):
+    g = np.load(FIXTURE)
+    name, N, C, hops, extra, block, order, events = CASES[k]
+    stream = stream_of(name, N, C, hops, extra, seed=100 + k)
+    assert np.uint32(zlib.crc32(stream.tobytes())) == g[name + "_crc"], "the regenerated stream is not the one the fixture was made from"
+    H = N // 2
+    chans = [oracle.Channel(N, 48000.0, order) for _ in range(C)]
+    pending = [np.zeros(0, np.float32) for _ in range(C)]
+    raws, sms = [[] for _ in range(C)], [[] for _ in range(C)]
+
+    def push_block(piece):
+        for c in range(C):
+            pending[c] = np.concatenate([pending[c], piece[c]])
+            while pending[c].size >= H:
+                r, s = chans[c].push_hops(pending[c][:H])          # (the oracle multiplies the hop by its current gain: the gain at READ time)
+                raws[c].append(r[0]); sms[c].append(s[0])
+                pending[c] = pending[c][H:]
+
+    def set_gain(v):
+        for ch in chans:
+            ch.set_gain(v)
+
+    def clear():
+        for c in range(C):
+            pending[c] = np.zeros_like(pending[c])                  # contents to zero, the count stays
+
+    replay(stream, N, block, events, push_block, set_gain, clear)
+    raw, sm = np.array(raws), np.array(sms)
+    assert raw.shape == g[name + "_raw"].shape
+    assert _same(raw, g[name + "_raw"]) and _same(sm, g[name + "_smoothed"]), name
+    assert all(p.size == stream.shape[1] % H for p in pending)

@@ -83,6 +83,33 @@ def test_committed_fixtures_through_device_blocks(gpu_fx, name, block):
     signals.assert_features_close(sm, g["smoothed"], 1e-5, fo.FEATURE_NAMES, "golden smoothed")
 
 
+def test_the_reference_collectors_own_vectors(gpu_fx):
+    """tests/golden/blocks/cases.npz: what the reference's AudioDataCollector + overlapper + analysers produce when fed device blocks with setGain /
+    clearBuffer in between (made by the unmodified headers, tools/refdiff/refdiff_blocks.cpp) -- replayed through fx_push_samples / fx_set_gain /
+    fx_clear_pending, host blocks and device blocks"""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from block_cases import CASES, replay, stream_of
+    from oracle import fx_oracle as fo
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "blocks", "cases.npz"))
+    for k, (name, N, C, hops, extra, block, order, events) in enumerate(CASES):
+        stream = stream_of(name, N, C, hops, extra, seed=100 + k)
+        for device in (False, True):
+            an = gpu_fx.BatchAnalyser(C, N, order=order)
+
+            def push_block(piece):
+                r, s = an.push_samples(torch.from_numpy(piece).cuda() if device else piece)
+                return (r.cpu().numpy(), s.cpu().numpy()) if device else (r, s)
+
+            got = replay(stream, N, block, events, push_block, an.set_gain, an.clear_buffer)
+            raw, sm = np.concatenate([x[0] for x in got], axis=1), np.concatenate([x[1] for x in got], axis=1)
+            signals.assert_features_close(raw, g[name + "_raw"], 1e-5, fo.FEATURE_NAMES, name + " raw")
+            signals.assert_features_close(sm, g[name + "_smoothed"], 1e-5, fo.FEATURE_NAMES, name + " smoothed")
+            assert an.pending_samples() == stream.shape[1] % (N // 2)
+            an.close()
+
+
 def test_packed_24_bit_blocks_and_mixed_block_lengths(gpu_fx):
     """three-byte samples at every byte alignment a block length can produce, block lengths changing from call to call, empty blocks"""
     C, N, T = 5, 1024, 11

@@ -48,6 +48,30 @@ def test_order_modes_and_onset_settings(oracle, order, otype, window, sens):
     assert _same_bits(raw, oraw).all() and _same_bits(sm, osm).all()
 
 
+# (a block longer than (4097 - N/2) / 2 samples cannot be given to the reference single-threaded: with the writer less than a block behind the
+# reader its getAnalysisBuffer spins on indexesOverlap until another thread moves the indices, AudioDataCollector.h:77,96-105)
+@pytest.mark.parametrize("N,block", [(1024, 480), (1024, 441), (2048, 1), (4096, 1000), (512, 63), (1024, 1700)])
+def test_the_reference_collector_fed_device_blocks_is_a_fifo_of_hops(oracle, N, block):
+    """the reference's OWN AudioDataCollector (ref AudioDataCollector.h:36-94) fed blocks of any length through audioDeviceIOCallback, its
+    analysers stepped whenever half a window is waiting: bit for bit the oracle fed the same stream as whole hops -- the equivalence
+    fx_push_samples rests on"""
+    C, T = 2, 10 if block > 1 else 4
+    hops = signals.bursts(C, T, N, seed=N + block)
+    raw, sm = refdiff.run_blocks(hops.reshape(C, -1), N, block, order=1)
+    oraw, osm = oracle.push_hops(hops, N, order=1)
+    assert _same_bits(raw, oraw).all() and _same_bits(sm, osm).all()
+
+
+def test_committed_block_fixture_is_what_the_reference_collector_produces():
+    """tests/golden/blocks/cases.npz regenerated from the headers (gain changes and clearBuffer between blocks included)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from block_cases import CASES, stream_of
+    g = np.load(os.path.join(ROOT, "tests", "golden", "blocks", "cases.npz"))
+    for k, (name, N, C, hops, extra, block, order, events) in enumerate(CASES):
+        raw, sm = refdiff.run_blocks(stream_of(name, N, C, hops, extra, seed=100 + k), N, block, order=order, events=events)
+        assert _same_bits(raw, g[name + "_raw"]).all() and _same_bits(sm, g[name + "_smoothed"]).all(), name
+
+
 def test_sample_rate_other_than_48k(oracle):
     N, C, T = 2048, 2, 12
     hops = signals.tone_vibrato_noise(C, T, N, seed=9)

@@ -61,6 +61,40 @@ def run(hops, window_size, order=0, onset_type=1, onset_window=5, onset_sensitiv
     return out[:n].reshape(C, T, 12), out[n:2 * n].reshape(C, T, 12)
 
 
+# ---- the reference's own collector fed with device blocks of any length (refdiff_blocks.cpp) ----
+def build_blocks():
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "refdiff_blocks")
+    srcs = [os.path.join(HERE, "refdiff_blocks.cpp"), os.path.join(HERE, "juce_standin.h")]
+    if os.path.exists(exe) and all(os.path.getmtime(s) <= os.path.getmtime(exe) for s in srcs):
+        return exe
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-w", "-ffp-contract=off", "-fno-fast-math", "-DREFDIFF_LOG10_CR", "-I", REFERENCE, "-I", HERE, srcs[0], "-o", exe])
+    return exe
+
+
+def run_blocks(stream, window_size, block, order=0, events=(), sample_rate=48000.0):
+    """stream [C][total] float32 fed to the reference's AudioDataCollector::audioDeviceIOCallback in blocks of `block` samples (the last one
+    shorter); events = [(at_sample, "gain", value) | (at_sample, "clear")], each taking effect before the block that starts at or after
+    at_sample.  -> (raw [C][frames][12], smoothed [C][frames][12]) of the total // (window_size / 2) hops the analysers read."""
+    import tempfile
+    stream = np.ascontiguousarray(stream, np.float32)
+    C, total = stream.shape
+    exe = build_blocks()
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<6id", window_size, C, total, block, order, len(events), sample_rate))
+            for e in events:
+                f.write(struct.pack("<iifi", int(e[0]), 0 if e[1] == "gain" else 1, float(e[2]) if e[1] == "gain" else 0.0, 0))
+            f.write(stream.tobytes())
+        subprocess.run([exe, fin, fout], check=True, timeout=120)
+        blob = open(fout, "rb").read()
+    frames = struct.unpack("<i", blob[:4])[0]
+    out = np.frombuffer(blob[4:], np.float32)
+    n = C * frames * 12
+    return out[:n].reshape(C, frames, 12).copy(), out[n:2 * n].reshape(C, frames, 12).copy()
+
+
 # ---- the legacy offline analyser (AudioAnalysis.h / AudioFeatures.h, SURVEY.md 8f rank 4) ----
 LEGACY_HEADERS = ["AudioAnalysis.h", "AudioFeatures.h"]
 

@@ -1,0 +1,102 @@
+// refdiff_blocks.cpp -- the reference's OWN collector + overlapper + analysers (headers compiled unmodified from /root/reference/Source
+// against tools/refdiff/juce_standin.h) fed the way an audio device feeds them: AudioDataCollector::audioDeviceIOCallback with blocks of
+// ANY length, the analysers stepped whenever half a window is waiting in the ring (ref AudioDataCollector.h:36-94,
+// RealTimeAudioAnalysis.h:205-219).  What it pins for fx_push_samples: the ring is a FIFO of raw samples, the gain is applied when a hop is
+// READ (:88), clearBuffer (:122) zeroes the ring's contents and leaves its indices.  Build container only (tools/refdiff/README.md).
+//
+//   refdiff_blocks <in.bin> <out.bin>
+//   in : int32 N, C, total, block, order, num_events; float64 sample_rate;
+//        events[num_events]: int32 at_sample (an event takes effect before the block that STARTS at or after this sample), int32 kind
+//                            (0 = setGain, 1 = clearBuffer), float32 value, int32 pad
+//        float32 stream[C][total]
+//   out: int32 frames; float32 raw[C][frames][12], smoothed[C][frames][12]
+#include "juce_standin.h"
+
+#define private public
+#include "AudioDataCollector.h"
+#include "RealTimeAudioAnalysis.h"
+#include "PitchAnalyser.h"
+#include "SpectralCharacteristics.h"
+#include "HarmonicCharacteristics.h"
+#include "RealTimeAnalyser.h"
+#undef private
+
+#include <cstdint>
+#include <cstdio>
+
+struct Header { int32_t N, C, total, block, order, num_events; double sample_rate; };
+struct Event { int32_t at, kind; float value; int32_t pad; };
+
+int main (int argc, char** argv)
+{
+    if (argc != 3) return 2;
+    FILE* f = fopen (argv[1], "rb");
+    if (! f) return 2;
+    Header h;
+    if (fread (&h, sizeof h, 1, f) != 1) return 2;
+    std::vector<Event> events ((size_t) h.num_events);
+    if (h.num_events && fread (events.data(), sizeof (Event), events.size(), f) != events.size()) return 2;
+    std::vector<float> stream ((size_t) h.C * h.total);
+    if (fread (stream.data(), sizeof (float), stream.size(), f) != stream.size()) return 2;
+    fclose (f);
+    const int half = h.N / 2, frames = h.total / half;
+    std::vector<float> raw ((size_t) h.C * frames * 12), sm (raw.size());
+
+    for (int c = 0; c < h.C; c++)
+    {
+        AudioDataCollector specCollector (0), harmCollector (0);
+        specCollector.setExpectedSamplesPerBlock (h.block);
+        harmCollector.setExpectedSamplesPerBlock (h.block);
+        AudioFeatures shared, harmOwn;
+        AudioFeatures& specFeatures = shared;
+        AudioFeatures& harmFeatures = h.order == 2 ? harmOwn : shared;
+        RealTimeSpectralAnalyser spectral (specCollector, specFeatures, h.N, h.sample_rate);
+        RealTimeHarmonicAnalyser harmonic (harmCollector, harmFeatures, h.N, h.sample_rate);
+        int waiting = 0, done = 0;
+        size_t next_event = 0;
+        for (int at = 0; at < h.total; at += h.block)
+        {
+            while (next_event < events.size() && events[next_event].at <= at)
+            {
+                const Event& e = events[next_event++];
+                if (e.kind == 0) { specCollector.setGain (e.value); harmCollector.setGain (e.value); }
+                else             { specCollector.clearBuffer(); harmCollector.clearBuffer(); }
+            }
+            const int n = h.total - at < h.block ? h.total - at : h.block;
+            const float* in[1] = { stream.data() + (size_t) c * h.total + at };
+            specCollector.audioDeviceIOCallback (in, 1, nullptr, 0, n);
+            harmCollector.audioDeviceIOCallback (in, 1, nullptr, 0, n);
+            waiting += n;
+            // the reference's ring holds 4096 samples, and its reader spins (indexesOverlap, :96-105) while the writer is less than a block behind
+            // it: single-threaded that would never end, so such a case is refused instead of run
+            if (waiting > 4096 - h.block) return 3;
+            // the analysis threads are notified by every block (:68-69) and read half a window whenever it is there
+            while (waiting >= half)
+            {
+                if (h.order == 1) { harmonic.step(); spectral.step(); }
+                else              { spectral.step(); harmonic.step(); }
+                waiting -= half;
+                float* r = raw.data() + ((size_t) c * frames + done) * 12;
+                float* s = sm.data() + ((size_t) c * frames + done) * 12;
+                for (int i = 0; i < 12; i++)
+                {
+                    const bool harmSlot = i == AudioFeatures::enF0 || i == AudioFeatures::enHarmonicEnergyRatio
+                                       || i == AudioFeatures::enOddEvenHarmonicRatio || i == AudioFeatures::enInharmonicity;
+                    AudioFeatures& a = harmSlot ? harmFeatures : specFeatures;
+                    r[i] = a.smoothedFeatures[(size_t) i].history.back();
+                    s[i] = a.getValue ((AudioFeatures::eAudioFeature) i);
+                }
+                done++;
+            }
+        }
+        if (done != frames) return 4;
+    }
+    f = fopen (argv[2], "wb");
+    if (! f) return 2;
+    const int32_t nf = frames;
+    fwrite (&nf, sizeof nf, 1, f);
+    fwrite (raw.data(), sizeof (float), raw.size(), f);
+    fwrite (sm.data(), sizeof (float), sm.size(), f);
+    fclose (f);
+    return 0;
+}
