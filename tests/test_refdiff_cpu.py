@@ -72,6 +72,26 @@ def test_committed_block_fixture_is_what_the_reference_collector_produces():
         assert _same_bits(raw, g[name + "_raw"]).all() and _same_bits(sm, g[name + "_smoothed"]).all(), name
 
 
+def test_osc_message_is_the_reference_senders(fx, oracle):
+    """The reference's OWN OSCFeatureAnalysisOutput (ref OSCFeatureAnalysisOutput.h:23-145, compiled unmodified; the stand-in's OSCSender records what it is
+    handed): the twelve values and their order, the "ip[:port]" parsing with its default port and the 60 Hz timer -- against fx_pack_osc12 / fx_osc_encode,
+    the oracle's message and the sink's target parsing."""
+    import ctypes
+    from importlib import import_module
+    sharded = import_module("feature-extractor_amd.sharded")
+    host, port, hz, addr, args = refdiff.osc_probe("192.168.1.20:7001")
+    assert (host, port, hz, addr) == ("192.168.1.20", 7001, 60, "/Audio/A7") and len(args) == 12
+    lib = fx.load_library()
+    slots = (np.arange(12) + 100).astype(np.float32)
+    wire = np.empty(12, np.float32)
+    lib.fx_pack_osc12(slots.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), wire.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    assert wire.tolist() == args                                                 # onset, rms, f0, centroid, slope, spread, flatness, ler, flux, her, oer, inharm
+    msg = oracle.osc_message(addr, slots)
+    assert [float(v) for v in np.frombuffer(msg[-48:], ">f4")] == args
+    assert refdiff.osc_probe("127.0.0.1")[:2] == ("127.0.0.1", 9000)             # the default port
+    assert sharded.parse_osc_target("127.0.0.1") == ("127.0.0.1", 9000) and sharded.parse_osc_target("192.168.1.20:7001") == ("192.168.1.20", 7001)
+
+
 def test_sample_rate_other_than_48k(oracle):
     N, C, T = 2048, 2, 12
     hops = signals.tone_vibrato_noise(C, T, N, seed=9)

@@ -90,10 +90,55 @@ public:
     String operator+ (const char* o) const   { String r; r.s = s + o; return r; }
     String& operator<< (const String& o)     { s += o.s; return *this; }
     String& operator<< (const char* o)       { s += o; return *this; }
+    // what only OSCFeatureAnalysisOutput.h touches (its address parsing, :115-123), by JUCE's documented behaviour
+    bool operator!= (const String& o) const  { return s != o.s; }
+    bool operator== (const String& o) const  { return s == o.s; }
+    int lastIndexOfAnyOf (const String& chars) const { const size_t p = s.find_last_of (chars.s); return p == std::string::npos ? -1 : (int) p; }
+    String fromLastOccurrenceOf (const String& sub, bool includeSub, bool) const
+    {
+        const size_t p = s.rfind (sub.s);
+        String r;
+        r.s = p == std::string::npos ? s : s.substr (includeSub ? p : p + sub.s.size());
+        return r;
+    }
+    String upToFirstOccurrenceOf (const String& sub, bool includeSub, bool) const
+    {
+        const size_t p = s.find (sub.s);
+        String r;
+        r.s = p == std::string::npos ? s : s.substr (0, includeSub ? p + sub.s.size() : p);
+        return r;
+    }
+    int getIntValue() const { return std::atoi (s.c_str()); }
     static const String empty;
     std::string s;
 };
 const String String::empty;
+
+// ---- what only OSCFeatureAnalysisOutput.h touches: a timer that never fires by itself and a sender that records what it is given ----
+class Timer
+{
+public:
+    virtual ~Timer() {}
+    virtual void timerCallback() = 0;
+    void startTimerHz (int hz) { timerHz = hz; }
+    void stopTimer() { timerHz = 0; }
+    int timerHz = 0;
+};
+class OSCSender
+{
+public:
+    bool connect (const String& host, int port) { connectedHost = host.s; connectedPort = port; return true; }
+    template <typename... Args> bool send (const String& address, Args... args)
+    {
+        lastAddress = address.s;
+        lastArguments = { (float) args... };
+        ++messages;
+        return true;
+    }
+    std::string connectedHost, lastAddress;
+    int connectedPort = 0, messages = 0;
+    std::vector<float> lastArguments;
+};
 
 template <typename T> class Atomic
 {

@@ -95,6 +95,20 @@ def run_blocks(stream, window_size, block, order=0, events=(), sample_rate=48000
     return out[:n].reshape(C, frames, 12).copy(), out[n:2 * n].reshape(C, frames, 12).copy()
 
 
+# ---- the reference's own OSCFeatureAnalysisOutput against a sender that records what it is handed (refdiff_osc.cpp) ----
+def osc_probe(address):
+    """-> (host, port, timer Hz, OSC address, the 12 arguments of one sendSpectralFeaturesViaOSC(true) when slot k's getValue() is 100 + k)"""
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "refdiff_osc")
+    srcs = [os.path.join(HERE, "refdiff_osc.cpp"), os.path.join(HERE, "juce_standin.h")]
+    if not (os.path.exists(exe) and all(os.path.getmtime(s) <= os.path.getmtime(exe) for s in srcs)):
+        subprocess.check_call(["g++", "-std=c++14", "-O1", "-w", "-I", REFERENCE, "-I", HERE, srcs[0], "-o", exe])
+    out = subprocess.run([exe, address], capture_output=True, text=True, check=True, timeout=60).stdout
+    head, addr, args = [part.strip() for part in out.split("|")]
+    host, port, hz = head.split()
+    return host, int(port), int(hz), addr, [float(v) for v in args.split()]
+
+
 # ---- the legacy offline analyser (AudioAnalysis.h / AudioFeatures.h, SURVEY.md 8f rank 4) ----
 LEGACY_HEADERS = ["AudioAnalysis.h", "AudioFeatures.h"]
 

@@ -89,11 +89,23 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True, 
             per = 3 if feed.dtype == np.uint8 else 1
             flat = np.ascontiguousarray(feed.reshape(C, -1))
             parts, at, total = [], 0, T * H
+            # a third of these cases through the pinned ring's form (fx_stream_push_samples / fx_stream_collect_samples), up to three blocks in flight
+            st = fx.HopStream(an, max(4097, 3 * N) // H + 2, slots=3, dtype=feed.dtype) if rng.random() < 0.33 else None
             while at < total:
                 n = int(rng.choice([1, 63, 441, 480, 512, 1000, 4097, int(rng.integers(1, 3 * N))]))
                 n = min(n, total - at)
-                parts.append(an.push_samples(np.ascontiguousarray(flat[:, at * per:(at + n) * per]), sample_format="s24" if per == 3 else None))
+                piece = np.ascontiguousarray(flat[:, at * per:(at + n) * per])
+                if st is not None:
+                    if st.in_flight() == 3:
+                        parts.append(st.collect_samples())
+                    st.push_samples(piece)
+                else:
+                    parts.append(an.push_samples(piece, sample_format="s24" if per == 3 else None))
                 at += n
+            if st is not None:
+                while st.in_flight():
+                    parts.append(st.collect_samples())
+                st.close()
             assert an.pending_samples() == 0
             block_cases[0] += 1
         elif T <= 40 and rng.random() < 0.2:
