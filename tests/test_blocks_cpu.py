@@ -50,7 +50,11 @@ def test_the_model_of_the_collector_reproduces_the_reference_collectors_vectors(
         for c in range(C):
             pending[c] = np.zeros_like(pending[c])                  # contents to zero, the count stays
 
-    replay(stream, N, block, events, push_block, set_gain, clear)
+    def control(name, value):
+        for ch in chans:
+            {"sensitivity": ch.set_onset_sensitivity, "onset_window": ch.set_onset_window, "onset_type": ch.set_onset_type, "sample_rate": ch.set_sample_rate}[name](value)
+
+    replay(stream, N, block, events, push_block, set_gain, clear, control)
     raw, sm = np.array(raws), np.array(sms)
     assert raw.shape == g[name + "_raw"].shape
     assert _same(raw, g[name + "_raw"]) and _same(sm, g[name + "_smoothed"]), name

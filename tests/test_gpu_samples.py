@@ -102,7 +102,11 @@ def test_the_reference_collectors_own_vectors(gpu_fx):
                 r, s = an.push_samples(torch.from_numpy(piece).cuda() if device else piece)
                 return (r.cpu().numpy(), s.cpu().numpy()) if device else (r, s)
 
-            got = replay(stream, N, block, events, push_block, an.set_gain, an.clear_buffer)
+            def control(name, value):
+                {"sensitivity": an.set_onset_detection_sensitivity, "onset_window": an.set_onset_window_length, "onset_type": an.set_onset_detection_type,
+                 "sample_rate": an.sample_rate_changed}[name](value)
+
+            got = replay(stream, N, block, events, push_block, an.set_gain, an.clear_buffer, control)
             raw, sm = np.concatenate([x[0] for x in got], axis=1), np.concatenate([x[1] for x in got], axis=1)
             signals.assert_features_close(raw, g[name + "_raw"], 1e-5, fo.FEATURE_NAMES, name + " raw")
             signals.assert_features_close(sm, g[name + "_smoothed"], 1e-5, fo.FEATURE_NAMES, name + " smoothed")

@@ -74,8 +74,8 @@ def build_blocks():
 
 def run_blocks(stream, window_size, block, order=0, events=(), sample_rate=48000.0):
     """stream [C][total] float32 fed to the reference's AudioDataCollector::audioDeviceIOCallback in blocks of `block` samples (the last one
-    shorter); events = [(at_sample, "gain", value) | (at_sample, "clear")], each taking effect before the block that starts at or after
-    at_sample.  -> (raw [C][frames][12], smoothed [C][frames][12]) of the total // (window_size / 2) hops the analysers read."""
+    shorter); events = [(at_sample, "gain" | "sensitivity" | "onset_window" | "onset_type" | "sample_rate", value) | (at_sample, "clear")], each
+    taking effect before the block that starts at or after at_sample (the setters of ref AudioDataCollector.h:122-124 and RealTimeAnalyser.h:111-114,244-258).  -> (raw [C][frames][12], smoothed [C][frames][12]) of the total // (window_size / 2) hops the analysers read."""
     import tempfile
     stream = np.ascontiguousarray(stream, np.float32)
     C, total = stream.shape
@@ -84,8 +84,9 @@ def run_blocks(stream, window_size, block, order=0, events=(), sample_rate=48000
         fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
         with open(fin, "wb") as f:
             f.write(struct.pack("<6id", window_size, C, total, block, order, len(events), sample_rate))
+            kinds = {"gain": 0, "clear": 1, "sensitivity": 2, "onset_window": 3, "onset_type": 4, "sample_rate": 5}
             for e in events:
-                f.write(struct.pack("<iifi", int(e[0]), 0 if e[1] == "gain" else 1, float(e[2]) if e[1] == "gain" else 0.0, 0))
+                f.write(struct.pack("<iifi", int(e[0]), kinds[e[1]], float(e[2]) if len(e) > 2 else 0.0, 0))
             f.write(stream.tobytes())
         subprocess.run([exe, fin, fout], check=True, timeout=120)
         blob = open(fout, "rb").read()

@@ -7,7 +7,8 @@
 //   refdiff_blocks <in.bin> <out.bin>
 //   in : int32 N, C, total, block, order, num_events; float64 sample_rate;
 //        events[num_events]: int32 at_sample (an event takes effect before the block that STARTS at or after this sample), int32 kind
-//                            (0 = setGain, 1 = clearBuffer), float32 value, int32 pad
+//                            (0 = AudioDataCollector::setGain, 1 = clearBuffer, 2 = setOnsetDetectionSensitivity, 3 = setOnsetWindowLength,
+//                            4 = setOnsetDetectionType, 5 = sampleRateChanged on both analysers: ref RealTimeAnalyser.h:111-114,244-258), float32 value, int32 pad
 //        float32 stream[C][total]
 //   out: int32 frames; float32 raw[C][frames][12], smoothed[C][frames][12]
 #include "juce_standin.h"
@@ -59,8 +60,12 @@ int main (int argc, char** argv)
             while (next_event < events.size() && events[next_event].at <= at)
             {
                 const Event& e = events[next_event++];
-                if (e.kind == 0) { specCollector.setGain (e.value); harmCollector.setGain (e.value); }
-                else             { specCollector.clearBuffer(); harmCollector.clearBuffer(); }
+                if (e.kind == 0)      { specCollector.setGain (e.value); harmCollector.setGain (e.value); }
+                else if (e.kind == 1) { specCollector.clearBuffer(); harmCollector.clearBuffer(); }
+                else if (e.kind == 2) spectral.setOnsetDetectionSensitivity (e.value);
+                else if (e.kind == 3) spectral.setOnsetWindowLength ((int) e.value);
+                else if (e.kind == 4) spectral.setOnsetDetectionType ((OnsetDetector::eOnsetDetectionType) (int) e.value);
+                else if (e.kind == 5) { spectral.sampleRateChanged ((double) e.value); harmonic.sampleRateChanged ((double) e.value); }
             }
             const int n = h.total - at < h.block ? h.total - at : h.block;
             const float* in[1] = { stream.data() + (size_t) c * h.total + at };
