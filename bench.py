@@ -896,6 +896,32 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
             an4.close()
             res[str(c4)] = rec
             del hops, flat, pieces, views
+        # the byte mover behind it, alone: a block that completes no hop (the call is the re-blocking launch and nothing else), HIP events on the library's
+        # stream behind a 1 GB fill so that the launch is queued when the events pass and the Infinity Cache is cold.  HBM-bound: 2 x the sample bytes.
+        an6 = fx.BatchAnalyser(16384, 4096, device=dev)
+        x6 = torch.rand((16384, 2047), device="cuda:%d" % dev) - 0.5
+        busy = torch.empty(1 << 30, dtype=torch.uint8, device="cuda:%d" % dev)
+        lib6 = an6.torch_stream()
+        best6 = None
+        with torch.cuda.stream(lib6):
+            for _ in range(6):
+                an6.reset_state()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                busy.zero_()
+                e0.record(lib6)
+                an6.push_samples(x6, want_raw=False, want_smoothed=False)
+                e1.record(lib6)
+                an6.sync()
+                ms6 = e0.elapsed_time(e1)
+                best6 = ms6 if best6 is None or ms6 < best6 else best6
+        an6.close()
+        moved6 = 2 * x6.numel() * 4
+        res["reblock_kernel"] = {"workload": "16384 channels x 2047 fp32 samples onto an empty carry (no hop completes)", "bytes_moved": moved6, "us": best6 * 1e3,
+                                 "roofline": {"bound": "hbm", "achieved": moved6 / (best6 / 1e3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                              "frac": moved6 / (best6 / 1e3) / 1e9 / HBM_PEAK_GBPS,
+                                              "note": "algorithmic bytes = sample bytes read + written; from cold HBM (a 1 GB fill runs in front); the runtime's own "
+                                                      "device-to-device copy of the same bytes reaches 3.7-3.9 TB/s measured the same way (profiles/r05_reblock_rate.txt)"}}
+        del x6, busy
         res["note"] = ("%d-pt windows; `blocks`: %d calls of fx_push_samples with %d-sample device blocks per channel (an audio device at 48 kHz / 10 ms) = the "
                        "same %d hops per channel that `hops` delivers as one fx_push_hops call per hop; best of three passes; real_time_factor as in live_cadence"
                        % (N, n_blocks, block, block * n_blocks // (N // 2)))
