@@ -24,7 +24,7 @@
  * taints and the violations it misses.
  *
  *   gcc -O2 -std=gnu11 -mfma -ffp-contract=off -o fastdag fastdag.c -lm -lpthread
- *   ./fastdag <frames per window size, e.g. 3e7> [threads] [seed] [windows, e.g. 1024,2048,4096] [guard K] [onset type, -1 = random] [variant 0 | 1] [kind, -1 = the mix, 8 = bench.py's signal]
+ *   ./fastdag <frames per window size, e.g. 3e7> [threads] [seed] [windows, e.g. 1024,2048,4096] [guard K] [onset type, -1 = random] [variant 0 | 1 | 2 = null test] [kind, -1 = the mix, 8 = bench.py's signal]
  */
 #define _GNU_SOURCE
 #include "../../oracle/fx_oracle.c"
@@ -41,6 +41,7 @@ static int VARIANT = 0;      /* 0: FMA + two frames per transform + half-length 
 /* ------------------------------------------------------------------------- */
 static inline cpx c_mul_f(cpx a, cpx b)
 {
+    if (VARIANT == 2) return c_mul(a, b);          /* the harness's own null test: the reference's products, so the "fast" side IS the exact one */
     cpx c = { fmaf(a.r, b.r, -(a.i * b.i)), fmaf(a.r, b.i, a.i * b.r) };
     return c;
 }
@@ -263,7 +264,7 @@ static void fast_frame(fxo_channel* c, fast_cfg* f, fast_bufs* b, frame_view* v)
     s.log_rms = h.log_rms = log10_float(rms * 9.0f + 1.0f);
     memcpy(b->win, c->overlap, sizeof(float) * (size_t) N);
     fxo_bartlett(N, b->win);
-    if (VARIANT == 1) {
+    if (VARIANT >= 1) {
         for (int i = 0; i < N; i++) { f->z[i].r = b->win[i]; f->z[i].i = 0.0f; }
         fast_perform(&f->full, f->z, (cpx*) b->wspec, 1, f->full.factors);
         for (int i = 0; i < N; i++) { f->z[i].r = c->overlap[i]; f->z[i].i = 0.0f; }
@@ -278,7 +279,7 @@ static void fast_frame(fxo_channel* c, fast_cfg* f, fast_bufs* b, frame_view* v)
     fxo_lowpass(N, c->overlap, c->filt);
     fxo_bartlett(N, c->filt);
     const float scale = 1.0f / N;
-    if (VARIANT == 1) {
+    if (VARIANT >= 1) {
         /* the reference's DAG, fused: forward of the filtered frame, re^2 with imag := 0, the inverse as the forward transform of the
          * conjugate (= of the same real data), planar real part scaled by 1/N */
         for (int i = 0; i < N; i++) { f->z[i].r = c->filt[i]; f->z[i].i = 0.0f; }
@@ -702,7 +703,8 @@ int main(int argc, char** argv)
     if (argc > 8) ONLY_KIND = atoi(argv[8]);
     printf("fastdag: %.3g frames per window size, %d threads, seed %" PRIu64 ", guard K = %.2f, onset type %s\nvariant %d: %s\n", per_size, threads, seed, GUARD_K,
            otype_fixed < 0 ? "random" : (otype_fixed == 1 ? "amplitude (the reference's default)" : "fixed"), VARIANT,
-           VARIANT == 1 ? "the reference's own transform DAG with fused (FMA) twiddle products, nothing else changed"
+           VARIANT == 2 ? "NULL TEST: the reference's own transform DAG and products through this tool's own driver (must give 0 violating frames)"
+           : VARIANT == 1 ? "the reference's own transform DAG with fused (FMA) twiddle products, nothing else changed"
                         : "FMA twiddle products + windowed || raw frame in one complex transform + half-length real transforms for the pitch pair");
     for (int si = 0; si < ns; si++) {
         const int N = sizes[si];
