@@ -26,7 +26,7 @@ def test_fastdag_builds_and_reproduces_the_shape_of_the_record(tmp_path):
     exe = str(tmp_path / "fastdag")
     subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-mfma", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tools", "fastdag", "fastdag.c"), "-lm", "-lpthread"])
     frames, bad, out = _run(exe, 1e4, 2, 3, "1024,2048", 4, -1, 2)    # the null test: the reference's own products through the tool's driver
-    assert frames >= 20000 and bad == 0, out[:1500]
+    assert frames >= 10000 and bad == 0 and out.count("violating          0 (0.0000 %)") >= 2, out[:1500]      # (both window sizes)
     frames, bad, out = _run(exe, 2e4, 2, 3, 1024, 4, -1, 1)           # variant 1: the reference's DAG, fused twiddle products only
     assert frames >= 20000 and 0.02 < bad / frames < 0.12, out[:1500]
     assert "harmonic-analyser slot" in out and "lag" in out
