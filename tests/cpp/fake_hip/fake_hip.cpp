@@ -47,7 +47,8 @@ hipError_t fake_hip_count(const char* name) { return tick(name); }
 
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : (e == hipErrorOutOfMemory ? "out of memory (fake)" : "injected failure (fake)"); }
 hipError_t hipGetLastError(void) { const hipError_t e = g_last; g_last = hipSuccess; return e; }
-hipError_t hipGetDeviceCount(int* n) { if (tick("hipGetDeviceCount") != hipSuccess) return g_last; *n = 1; return hipSuccess; }
+// FAKE_HIP_DEVICES: how many "GPUs" there are (default 1; the multi-rank gather tests give every rank process its own)
+hipError_t hipGetDeviceCount(int* n) { if (tick("hipGetDeviceCount") != hipSuccess) return g_last; const char* e = getenv("FAKE_HIP_DEVICES"); *n = e && atoi(e) > 0 ? atoi(e) : 1; return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { if (tick("hipGetDeviceProperties") != hipSuccess) return g_last; memset(p, 0, sizeof *p); strcpy(p->gcnArchName, "gfx950:sramecc+:xnack-"); p->multiProcessorCount = 256; return hipSuccess; }
 hipError_t hipSetDevice(int) { return tick("hipSetDevice"); }
 
@@ -142,6 +143,34 @@ void log_hops(const fxk::FrameParams& p, int window)
     for (int c = 0; c < p.C; c++) g_hops[(size_t) c].insert(g_hops[(size_t) c].end(), in + (size_t) c * row, in + (size_t) (c + 1) * row);
 }
 }
+// What the fake "analysis" leaves in `latest` ([C][12]): a hash of each channel's input in the call and of the calls so far, as a small
+// whole number -- so that every channel of every rank holds something of its own for the gather tests (tests/cpp/comm_ranks.cpp), and a
+// block that lands at the wrong offset, or a stale snapshot, shows.
+namespace {
+std::vector<unsigned> g_input_hash;
+unsigned g_latest_calls = 0;
+void hash_input(const fxk::FrameParams& p, int window)
+{
+    if ((int) g_input_hash.size() < p.C) g_input_hash.resize((size_t) p.C, 0u);
+    if (!p.in) return;
+    const size_t esz = p.sample_format == FX_SAMPLE_F32 ? 4 : (p.sample_format == FX_SAMPLE_S24 ? 3 : 2);
+    const size_t row = (size_t) p.T * (size_t) (p.hop_mode ? window / 2 : window) * esz;
+    const unsigned char* in = static_cast<const unsigned char*>(p.in);
+    for (int c = 0; c < p.C; c++) {
+        unsigned h = 2166136261u;
+        for (size_t i = 0; i < row; i++) h = (h ^ in[(size_t) c * row + i]) * 16777619u;
+        g_input_hash[(size_t) c] = h;
+    }
+}
+void fill_latest(const fxk::EpilogueParams& ep)
+{
+    if (!ep.latest) return;
+    g_latest_calls++;
+    for (int c = 0; c < ep.C; c++)
+        for (int k = 0; k < FX_NUM_FEATURES; k++)
+            ep.latest[(size_t) c * FX_NUM_FEATURES + k] = (float) (((c < (int) g_input_hash.size() ? g_input_hash[(size_t) c] : 0u) + 7919u * g_latest_calls + 31u * (unsigned) k) % 1000003u);
+}
+}
 extern "C" {
 void fake_hop_log_clear(void) { g_hops.clear(); }
 void fake_hop_log_enable(int on) { g_hop_log = on; }
@@ -159,25 +188,24 @@ bool twiddles_have_quarter_turn(int, const float*) { return true; }
 size_t frame_kernel_lds_bytes(int n, int ch, int k, bool direct) { return (size_t) 8 * n + (direct ? 0 : (size_t) ch * 9 * n / 4) + (size_t) ch * k * (n <= 1024 ? 17 * n / 2 : 9 * n / 2); }
 int frame_kernel_max_waves(int n) { return n <= 512 ? 16 : 8; }
 void frame_kernel_preferred_shape(int n, int* ch, int* k) { *ch = 1; *k = n == 2048 ? 4 : 8; }
-hipError_t launch_frame_kernel(int n, const FrameParams& p, int, hipStream_t) { if (p.C <= 0 || p.T <= 0) return hipSuccess; const hipError_t e = fake_hip_count("launch_frame_kernel"); if (e == hipSuccess) log_hops(p, n); return e; }
-hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t) { if (p.C <= 0 || p.T <= 0) return hipSuccess; return fake_hip_count("launch_epilogue_kernels"); }
+hipError_t launch_frame_kernel(int n, const FrameParams& p, int, hipStream_t) { if (p.C <= 0 || p.T <= 0) return hipSuccess; const hipError_t e = fake_hip_count("launch_frame_kernel"); if (e == hipSuccess) { log_hops(p, n); hash_input(p, n); } return e; }
+hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t) { if (p.C <= 0 || p.T <= 0) return hipSuccess; const hipError_t e = fake_hip_count("launch_epilogue_kernels"); if (e == hipSuccess) fill_latest(p); return e; }
 bool frame_tail_kernel_available(int n) { return n >= 1024; }
-hipError_t launch_frame_tail_kernel(int n, const FrameParams& p, const EpilogueParams&, hipStream_t) { const hipError_t e = fake_hip_count("launch_frame_tail_kernel"); if (e == hipSuccess) log_hops(p, n); return e; }
+hipError_t launch_frame_tail_kernel(int n, const FrameParams& p, const EpilogueParams& ep, hipStream_t) { const hipError_t e = fake_hip_count("launch_frame_tail_kernel"); if (e == hipSuccess) { log_hops(p, n); hash_input(p, n); fill_latest(ep); } return e; }
 hipError_t prepare_kernels(int) { return fake_hip_count("prepare_kernels"); }
 hipError_t prepare_hop_kernel(int) { return fake_hip_count("prepare_hop_kernel"); }
 bool pair_kernel_available(int n) { return n == 2048 || n == 4096; }
 int pair_kernel_max_pairs(int n) { return n == 2048 ? 8 : 6; }
 size_t pair_kernel_lds_bytes(int n, int ch, int k) { return (size_t) 8 * n + (size_t) ch * k * 17408; }
 hipError_t prepare_pair_kernel(int) { return fake_hip_count("prepare_pair_kernel"); }
-hipError_t launch_pair_kernel(int n, const FrameParams& p, hipStream_t) { const hipError_t e = fake_hip_count("launch_pair_kernel"); if (e == hipSuccess) log_hops(p, n); return e; }
+hipError_t launch_pair_kernel(int n, const FrameParams& p, hipStream_t) { const hipError_t e = fake_hip_count("launch_pair_kernel"); if (e == hipSuccess) { log_hops(p, n); hash_input(p, n); } return e; }
 bool hop_kernel_available(int n) { return n == 1024 || n == 2048 || n == 4096; }
 hipError_t launch_hop_kernel(int n, const FrameParams& p, const EpilogueParams& ep, const HopSignal& sig, hipStream_t, bool)
 {
     const hipError_t e = fake_hip_count("launch_hop_kernel");
-    if (e == hipSuccess) log_hops(p, n);
+    if (e == hipSuccess) { log_hops(p, n); hash_input(p, n); fill_latest(ep); }
     // the real kernel raises the slot's flag when the hop is done; fx_stream_collect polls it
     if (e == hipSuccess && sig.host_flag) *sig.host_flag = sig.seq;
-    (void) ep;
     return e;
 }
 hipError_t launch_reblock_kernel(const ReblockParams& p, hipStream_t)

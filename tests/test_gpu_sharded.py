@@ -143,9 +143,11 @@ def test_one_rank_rccl_gather_through_the_c_abi(gpu_fx):
 def _build_comm_ranks(fx, tmp_path):
     exe = str(tmp_path / "comm_ranks")
     lib_dir = os.path.dirname(fx.library_path())
-    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    # (the HIP runtime only for the sink's device-resident destination tables: hipMalloc / hipMemcpy / hipFree)
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(rocm, "include"), "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "comm_ranks.cpp"), "-o", exe,
-                           "-L", lib_dir, "-lfx_hip", "-Wl,-rpath," + lib_dir])
+                           "-L", lib_dir, "-lfx_hip", "-Wl,-rpath," + lib_dir, "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-ldl"])
     return exe
 
 
@@ -157,7 +159,7 @@ def test_cpp_one_rank_comm(gpu_fx, tmp_path):
 
 def test_cpp_two_rank_comm(gpu_fx, tmp_path):
     """Two processes, two GPUs, ragged shards; skipped on a one-GPU box."""
-    out = subprocess.run([_build_comm_ranks(gpu_fx, tmp_path), "2"], capture_output=True, text=True, env=_env(), timeout=300)
+    out = subprocess.run([_build_comm_ranks(gpu_fx, tmp_path), "2", "shards=8192,37", "sinks=0,0,0,1,0"], capture_output=True, text=True, env=_env(), timeout=300)
     if out.returncode == 77:
         pytest.skip("one GPU visible")
     assert out.returncode == 0, out.stdout + out.stderr
