@@ -427,6 +427,8 @@ def build_parser():
     ap.add_argument("--window", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements (spectral-only, noise / silence, other windows, live cadence)")
+    ap.add_argument("--only-extra", default=None, help="comma-separated names: run only these extra measurements (e.g. osc_sink,sustained)")
+    ap.add_argument("--sustained-seconds", type=float, default=12.0, help="length of the `sustained` extra's back-to-back run of the headline step")
     ap.add_argument("--no-pmc", action="store_true", help="do not read hardware counters in this run (rocprofv3 --pmc children)")
     ap.add_argument("--write-counters", action="store_true", help="also store this run's counters in profiles/counters.json (the labelled fallback)")
     ap.add_argument("--signal", default="synth", choices=["synth", "noise", "silence"],
@@ -1053,9 +1055,10 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
 
     def offline():
         # The legacy offline analyser's three full-spectrum functions (ref AudioAnalysis.h:463-515, :566-609, :623-665) on
-        # device-resident magnitude frames: a block per channel stages the frame (and the flux state) in LDS and ONE thread walks the bins
-        # in the reference's order -- these are serial double sums and a serial IEEE product, kept exact rather than fast.  Timed so that the
-        # cost of that choice is on record: calls per second of 1024 analysers x one 1025-bin frame (a 2048-point window's magnitudes).
+        # device-resident magnitude frames: a block per channel; since round 5 the per-bin TERMS (incl. the pow() calls) are formed by the whole
+        # block in parallel into LDS and only the additions / the IEEE product run serially, in the reference's bin order, on one thread --
+        # exact rather than fast.  Timed so that the cost of that choice is on record: calls per second of 1024 analysers x one 1025-bin
+        # frame (a 2048-point window's magnitudes).  (Round 4's numbers were of the form where one thread did everything.)
         import ctypes
         lib = fx.load_library(build_if_missing=False)
         C5, B5 = 1024, 1025
@@ -1075,7 +1078,7 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
         }
         torch.cuda.synchronize(dev)
         res = {"workload": "%d analysers x one frame of %d magnitudes per call, device-resident" % (C5, B5),
-               "note": "a block per channel stages the frame in LDS; one thread runs the reference's serial double sums / IEEE product in bin order (exactness over speed)"}
+               "note": "a block per channel: per-bin terms formed in parallel into LDS, the additions / IEEE product serial in the reference's bin order on one thread (exactness over speed)"}
         for name, call in calls.items():
             for _ in range(3):
                 fx.capi.check(call())
@@ -1090,14 +1093,186 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
         an5.close()
         return res
 
-    guarded("spectral_only", spectral_only)
-    guarded("data_dependence", data_dependence)
-    guarded("other_windows", other_windows)
-    guarded("live_cadence", live_cadence)
-    guarded("device_blocks", device_blocks)
-    guarded("streaming_hop", streaming_hop)
-    guarded("stream_ingest", stream_ingest)
-    guarded("offline", offline)
+    def osc_sink():
+        # The sink at scale (ref OSCFeatureAnalysisOutput.h:84-113,133: one message per track per 60 Hz tick; AnalyserTrackController.h:22-23;
+        # MainComponent.cpp:170): messages formed on the device (fx_get_osc_datagrams), handed to the kernel by the batch sender
+        # (fx_osc_sender: sender threads, sendmmsg, optionally segmented sends) and counted by a local receiver.  Per channel count:
+        # (1) what it costs to have the datagrams on the host, device-formed against vectors + host encoder; (2) the most the sender hands
+        # to the kernel back to back; (3) two seconds of the 60 Hz timer with a fresh publication every tick: ticks late, datagrams lost.
+        capi = fx.capi
+        cores = usable_cores()
+        res = {"loopback": "127.0.0.1, sender and receiver in this process, %d usable cores" % cores,
+               "bar": "60 Hz x channels datagrams/s handed to the kernel and received, no tick late (8192 channels: 4.9e5 /s; 65 536: 3.9e6 /s)"}
+        variants = [("segmented_sends_gro_receiver", True, True), ("segmented_sends", True, False), ("sendmmsg", False, False)]
+        for C in (1024, 8192, 65536):
+            an_o = fx.BatchAnalyser(C, N, device=dev)
+            g = torch.Generator(device="cuda:%d" % dev).manual_seed(C)
+            hop = 0.25 * torch.randn((C, 2, N // 2), generator=g, device="cuda:%d" % dev, dtype=torch.float32)
+            an_o.push_hops(hop, want_raw=False, want_smoothed=False)
+            an_o.sync()
+            rec = {}
+            reps = 20
+            d, n = an_o.osc_datagrams("/Audio/A", 0)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                d, n = an_o.osc_datagrams("/Audio/A", 0)
+            t_dev = (time.perf_counter() - t0) / reps
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                d2, n2 = capi.osc_encode_batch("/Audio/A", 0, an_o.get_features())
+            t_host = (time.perf_counter() - t0) / reps
+            rec["datagrams_on_host_ms"] = {"device_formed": t_dev * 1e3, "vectors_then_host_encoder": t_host * 1e3, "identical": bool((d == d2).all() and (n == n2).all()),
+                                           "bytes": int(d.nbytes)}
+            threads = max(1, min(8, cores // 2))
+            for name, gso, gro in variants:
+                rx = capi.OscReceiver("127.0.0.1:0", threads=threads, prefix="/Audio/A", keep_channels=C, gro=gro)
+                tx = capi.OscSender("127.0.0.1:%d" % rx.port, threads=threads, gso=gso)
+                tx.update(d, n)
+                # (2) back to back
+                t0 = time.perf_counter()
+                sent = 0
+                while time.perf_counter() - t0 < 1.0:
+                    sent += tx.send()
+                dt = time.perf_counter() - t0
+                time.sleep(0.3)
+                got = rx.stats()["datagrams"]
+                st0 = tx.stats()
+                v = {"threads": threads, "back_to_back": {"handed_to_kernel_per_s": sent / dt, "received_share": got / max(sent, 1), "syscalls_per_tick": st0["syscalls"] / max(st0["ticks"], 1)}}
+                # (3) the timer, a fresh publication per tick from the analysis side
+                tx.start(60.0)
+                t0 = time.perf_counter()
+                pubs = 0
+                while time.perf_counter() - t0 < 2.0:
+                    tx.update(*an_o.osc_datagrams("/Audio/A", 0))
+                    pubs += 1
+                    time.sleep(max(0.0, t0 + pubs / 60.0 - time.perf_counter()))
+                tx.stop()
+                time.sleep(0.3)
+                st = tx.stats()
+                got1 = rx.stats()["datagrams"] - got
+                ticks = st["ticks"] - st0["ticks"]
+                sent1 = st["datagrams"] - st0["datagrams"]
+                ok = bool(st["late_ticks"] == 0 and st["dropped"] == st0["dropped"] and ticks >= 110 and got1 >= 0.999 * sent1 and sent1 == ticks * C)
+                sample_ok = all(rx.last(c) for c in (0, C // 2, C - 1))
+                v["paced_60hz"] = {"seconds": 2.0, "ticks": ticks, "late_ticks": st["late_ticks"], "publications": pubs, "datagrams_per_s": sent1 / 2.0, "received_share": got1 / max(sent1, 1),
+                                   "dropped_by_sender": st["dropped"] - st0["dropped"], "max_tick_ms": st["max_tick_ms"], "sustained": "yes" if ok else "no", "sample_channels_seen": bool(sample_ok)}
+                rec[name] = v
+                tx.close()
+                rx.close()
+            best = rec["segmented_sends_gro_receiver"]["back_to_back"]["handed_to_kernel_per_s"]
+            rec["bottleneck"] = ("per-datagram work of the kernel's UDP path: one thread hands over %.2g datagrams/s with sendmmsg, %.2g with segmented sends to a receiver that "
+                                 "splits them itself (loopback never cuts the buffer); a receiver that takes every datagram through the stack is the slower side"
+                                 % (rec["sendmmsg"]["back_to_back"]["handed_to_kernel_per_s"] / threads, best / threads))
+            res[str(C)] = rec
+            an_o.close()
+        return res
+
+    def sustained():
+        # >= 10 s of the headline step back to back with no host synchronisation between steps: HIP events on the context's stream
+        # every few steps give frames/s per one-second window; clocks, power and temperature come from a CHILD process that polls the driver's
+        # sysfs files (tools/smi_poll.py -- it never touches HIP).  The burst figure of the headline line is a 20-step region; this is the state
+        # a node under load is in.
+        import subprocess
+        seconds = float(args.sustained_seconds)
+        lib_stream = an._torch_stream(torch.device("cuda", dev))
+        poll = None
+        samples = []
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            where = ["--pci", "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)] if hasattr(pr, "pci_bus_id") else ["--device", str(dev)]
+            poll = subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "smi_poll.py"), "--interval", "0.2"] + where,
+                                    stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+        except Exception:
+            poll = None
+        every, lag = 10, 8
+        step_s = max(avg_launch_s, 1e-4)
+        max_marks = int(seconds / (every * step_s) * 1.5) + 64
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(max_marks)]
+        used = 0
+        with torch.cuda.stream(lib_stream):
+            for _ in range(5):
+                an.process_frames(frames, out_raw=raw, out_smoothed=sm)
+            an.sync()
+            t_wall0 = time.time()
+            t0 = time.perf_counter()
+            marks[0].record()
+            used = 1
+            steps_done = 0
+            while used < max_marks:
+                for _ in range(every):
+                    an.process_frames(frames, out_raw=raw, out_smoothed=sm)
+                steps_done += every
+                marks[used].record()
+                used += 1
+                # The host may run ahead of the device by `lag` rounds (~0.2 s of queued steps: the queue is never empty, the device never
+                # waits for the host) and no further, so that the run ends on the DEVICE's clock.  The wait is for a mark that lies `lag`
+                # rounds back, not for the step just issued.
+                if used > lag:
+                    marks[used - lag].synchronize()
+                    if marks[0].elapsed_time(marks[used - lag]) >= seconds * 1e3:
+                        break
+            an.sync()
+            wall = time.perf_counter() - t0
+        t_wall1 = time.time()
+        if poll is not None:
+            poll.terminate()
+            try:
+                text, _ = poll.communicate(timeout=5)
+            except Exception:
+                poll.kill()
+                text = ""
+            for line in text.splitlines():
+                try:
+                    rec = json.loads(line)
+                except ValueError:
+                    continue
+                if "t" in rec and t_wall0 <= rec["t"] <= t_wall1:
+                    samples.append(rec)
+                elif "source" in rec:
+                    smi_source = rec
+        at = [marks[0].elapsed_time(marks[k]) / 1e3 for k in range(used)]            # seconds since the first mark, at the end of every `every` steps
+        per_step_frames = count * T
+        total_s = at[-1]
+        windows = []
+        k0 = 0
+        for w in range(int(total_s)):
+            k1 = max(k for k in range(used) if at[k] <= w + 1.0)
+            if k1 > k0:
+                windows.append((k1 - k0) * every * per_step_frames / (at[k1] - at[k0]))
+            k0 = k1
+        windows_sorted = sorted(windows)
+        value = steps_done * per_step_frames / total_s
+        burst = out.get("value") or value
+        first_ms = 1e3 * (at[min(used - 1, max(1, int(1.0 / (every * step_s))))] / (min(used - 1, max(1, int(1.0 / (every * step_s)))) * every))
+        last_k = max(0, used - 1 - max(1, int(1.0 / (every * step_s))))
+        last_ms = 1e3 * (at[-1] - at[last_k]) / ((used - 1 - last_k) * every)
+
+        def stat(key):
+            xs = [s_[key] for s_ in samples if key in s_]
+            return {"min": min(xs), "median": sorted(xs)[len(xs) // 2], "max": max(xs), "samples": len(xs)} if xs else None
+
+        sclk = stat("sclk_mhz_hwmon") or stat("sclk_mhz")
+        rec = {"value": value, "unit": "frames/s", "seconds": total_s, "steps": steps_done, "host_wall_s": wall,
+               "workload": out.get("config", {}).get("workload"),
+               "per_second_windows": {"min": windows_sorted[0], "median": windows_sorted[len(windows_sorted) // 2], "max": windows_sorted[-1], "n": len(windows)} if windows else None,
+               "frac_of_burst": value / burst, "burst_value": burst,
+               "step_ms_first_second": first_ms, "step_ms_last_second": last_ms,
+               "sclk_mhz": sclk, "sclk_mhz_min": sclk["min"] if sclk else None, "mclk_mhz": stat("mclk_mhz"), "power_w": stat("power_w"), "temp_c": stat("temp_c"), "busy_pct": stat("busy_pct"),
+               "smi_source": locals().get("smi_source"),
+               "note": "the device queue is never empty (the host waits only for a mark 80 steps back); time from HIP events on the context's stream every %d steps; clocks / power / temperature polled by a child process "
+                       "(tools/smi_poll.py: amdgpu sysfs, never HIP)" % every}
+        # the roofline fractions at the sustained rate, beside the burst ones
+        if out.get("roofline") and out["roofline"].get("frac") is not None:
+            rec["roofline_frac_sustained"] = out["roofline"]["frac"] * (avg_launch_s * 1e3) / last_ms if last_ms > 0 else None
+        return rec
+
+    table = [("spectral_only", spectral_only), ("data_dependence", data_dependence), ("other_windows", other_windows), ("live_cadence", live_cadence),
+             ("device_blocks", device_blocks), ("streaming_hop", streaming_hop), ("stream_ingest", stream_ingest), ("offline", offline),
+             ("osc_sink", osc_sink), ("sustained", sustained)]
+    only = set(args.only_extra.split(",")) if getattr(args, "only_extra", None) else None
+    for name, fn in table:
+        if only is None or name in only:
+            guarded(name, fn)
 
 
 if __name__ == "__main__":

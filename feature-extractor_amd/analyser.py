@@ -332,6 +332,15 @@ class BatchAnalyser:
         capi.check(self._lib.fx_get_smoothed(self._h, out.ctypes.data_as(ctypes.c_void_p), capi.MEM_HOST))
         return out
 
+    def osc_datagrams(self, prefix="/Audio/A", first_channel=0, stride=None):
+        """fx_get_osc_datagrams: every channel's wire-ready OSC feature message, written on the device from the latest smoothed vectors
+        (ref OSCFeatureAnalysisOutput.h:89-113, MainComponent.cpp:170).  Returns (datagrams uint8 [C][stride], lengths int32 [C])."""
+        stride = capi.osc_stride(prefix, first_channel, self.num_channels) if stride is None else int(stride)
+        out = np.empty((self.num_channels, stride), np.uint8)
+        lengths = np.empty(self.num_channels, np.int32)
+        capi.check(self._lib.fx_get_osc_datagrams(self._h, prefix.encode(), int(first_channel), out.ctypes.data_as(ctypes.c_void_p), stride,
+                                                  lengths.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), capi.MEM_HOST))
+        return out, lengths
 
     # ---- multi-GPU: gather of the latest smoothed vectors to the OSC sink rank (RCCL, through the C ABI) ----
     @staticmethod

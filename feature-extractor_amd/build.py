@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfx_hip.so")
-SOURCES = ["fx_kernels.hip", "fx_capi.cpp", "fx_comm.cpp", "fx_offline.hip", "fx_reblock.hip"]
+SOURCES = ["fx_kernels.hip", "fx_capi.cpp", "fx_comm.cpp", "fx_offline.hip", "fx_reblock.hip", "fx_osc.hip", "fx_osc_sender.cpp"]
 # fx_kernels.hip is compiled twice: frame kernels up to 1024 points (+ tail kernels + host helpers) with the scheduler's
 # alternative register-pressure tracker (+3.5 % at 1024 points), the 2048- / 4096-point frame kernels without (-7 % at 4096)
 UNITS = [("fx_kernels.hip", "fx_kernels_small.o", ["-DFX_PART=1", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"]),
@@ -18,6 +18,8 @@ UNITS = [("fx_kernels.hip", "fx_kernels_small.o", ["-DFX_PART=1", "-mllvm", "-am
          ("fx_kernels.hip", "fx_kernels_hop.o", ["-DFX_PART=3"]),
          ("fx_offline.hip", "fx_offline.o", []),
          ("fx_reblock.hip", "fx_reblock.o", []),
+         ("fx_osc.hip", "fx_osc.o", []),
+         ("fx_osc_sender.cpp", "fx_osc_sender.o", []),
          ("fx_capi.cpp", "fx_capi.o", []),
          ("fx_comm.cpp", "fx_comm.o", [])]
 HEADERS = ["fx_kernels.h", "fx_context.h", "fx_wave.hip.h", "fx_fft.hip.h", "fx_frame_kernel.hip.h", "fx_pair_kernel.hip.h", "fx_tail_kernels.hip.h", "fx_hop_kernel.hip.h",
@@ -110,7 +112,7 @@ def build(force=False, verbose=False):
             with ThreadPoolExecutor(max_workers=min(4, os.cpu_count() or 1)) as pool:
                 list(pool.map(compile_unit, UNITS))
             # (librccl is NOT linked: fx_comm.cpp loads it on the first fx_comm_* call, so single-GPU users never map it)
-            cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + tag] + objs + ["-ldl"]
+            cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH + tag] + objs + ["-ldl", "-lpthread"]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -24,14 +24,26 @@ EXPORTS = ["fx_create", "fx_destroy", "fx_reset_state", "fx_set_sample_rate", "f
            "fx_get_smoothed", "fx_sync", "fx_get_stream", "fx_last_kernel_ms", "fx_profile_begin", "fx_profile_end",
            "fx_stream_create", "fx_stream_destroy", "fx_stream_acquire", "fx_stream_submit", "fx_stream_push", "fx_stream_collect", "fx_stream_in_flight", "fx_pack_osc12",
            "fx_pack_osc10", "fx_osc_encode", "fx_last_error", "fx_abi_version",
+           "fx_osc_message_bytes", "fx_osc_encode_batch", "fx_get_osc_datagrams", "fx_osc_sender_create", "fx_osc_sender_destroy", "fx_osc_sender_update",
+           "fx_osc_sender_send", "fx_osc_sender_start", "fx_osc_sender_stop", "fx_osc_sender_get_stats", "fx_osc_receiver_create", "fx_osc_receiver_destroy",
+           "fx_osc_receiver_port", "fx_osc_receiver_get_stats", "fx_osc_receiver_last",
            "fx_comm_unique_id", "fx_comm_create", "fx_comm_destroy", "fx_comm_layout", "fx_gather_smoothed", "fx_comm_sync", "fx_comm_stats",
            "fx_plan_units", "fx_twiddle_symmetry", "fx_tuning_defaults", "fx_tuning_from_env", "fx_get_tuning", "fx_set_tuning",
            "fx_offline_create", "fx_offline_destroy", "fx_offline_reset", "fx_offline_sync", "fx_offline_get_previous_f0", "fx_offline_zero_crosses",
            "fx_offline_log_attack_time", "fx_offline_fft_lbp", "fx_offline_harmonic_characteristics", "fx_offline_spectral_characteristics",
            "fx_offline_get_previous_bins", "fx_offline_spectral_slope", "fx_offline_auto_correlation"]
 COMM_ID_BYTES = 128
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_UNITS = 24
+
+
+class OscSenderStats(ctypes.Structure):
+    """struct fx_osc_sender_stats of include/fx.h"""
+    _fields_ = [("ticks", ctypes.c_longlong), ("late_ticks", ctypes.c_longlong), ("datagrams", ctypes.c_longlong), ("dropped", ctypes.c_longlong),
+                ("syscalls", ctypes.c_longlong), ("last_tick_ms", ctypes.c_double), ("max_tick_ms", ctypes.c_double), ("total_tick_ms", ctypes.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class Tuning(ctypes.Structure):
@@ -155,6 +167,23 @@ def load_library(build_if_missing=True):
     L.fx_pack_osc10.argtypes = [fp, fp]
     L.fx_pack_osc10.restype = None
     L.fx_osc_encode.argtypes = [ctypes.c_char_p, fp, ctypes.POINTER(ctypes.c_ubyte), i]
+    ip = ctypes.POINTER(i)
+    ll = ctypes.c_longlong
+    L.fx_osc_message_bytes.argtypes = [ctypes.c_char_p, i]
+    L.fx_osc_encode_batch.argtypes = [ctypes.c_char_p, i, i, fp, vp, i, ip]
+    L.fx_get_osc_datagrams.argtypes = [vp, ctypes.c_char_p, i, vp, i, ip, i]
+    L.fx_osc_sender_create.argtypes = [ctypes.POINTER(vp), ctypes.c_char_p, ctypes.c_char_p, i, u]
+    L.fx_osc_sender_destroy.argtypes = [vp]
+    L.fx_osc_sender_update.argtypes = [vp, vp, i, ip, i]
+    L.fx_osc_sender_send.argtypes = [vp, ctypes.POINTER(ll)]
+    L.fx_osc_sender_start.argtypes = [vp, d]
+    L.fx_osc_sender_stop.argtypes = [vp]
+    L.fx_osc_sender_get_stats.argtypes = [vp, ctypes.POINTER(OscSenderStats)]
+    L.fx_osc_receiver_create.argtypes = [ctypes.POINTER(vp), ctypes.c_char_p, i, ctypes.c_char_p, i, u]
+    L.fx_osc_receiver_destroy.argtypes = [vp]
+    L.fx_osc_receiver_port.argtypes = [vp]
+    L.fx_osc_receiver_get_stats.argtypes = [vp, ctypes.POINTER(ll), ctypes.POINTER(ll), ctypes.POINTER(ll)]
+    L.fx_osc_receiver_last.argtypes = [vp, i, vp, i, ip]
     L.fx_last_error.restype = ctypes.c_char_p
     _lib = L
     return L
@@ -198,3 +227,108 @@ def osc_encode(address, features12):
     if n < 0:
         raise FxError(FX_ERR_INVALID_ARGUMENT, "OSC address too long")
     return bytes(buf[:n])
+
+
+OSC_SENDER_GSO = 1
+OSC_RECEIVER_NO_GRO = 1
+
+
+def osc_message_bytes(prefix, channel):
+    return load_library().fx_osc_message_bytes(prefix.encode(), int(channel))
+
+
+def osc_stride(prefix, first_channel, num_channels):
+    """the smallest legal stride for these channels' messages: the longest message (already a multiple of 4)"""
+    n = osc_message_bytes(prefix, first_channel + max(num_channels, 1) - 1)
+    if n < 0:
+        raise FxError(FX_ERR_INVALID_ARGUMENT, "OSC prefix too long or a negative channel number")
+    return n
+
+
+def osc_encode_batch(prefix, first_channel, smoothed, stride=None):
+    """fx_osc_encode_batch: (datagrams uint8 [C][stride], lengths int32 [C]) for smoothed [C][12]; message c = datagrams[c, :lengths[c]]"""
+    v = np.ascontiguousarray(smoothed, np.float32).reshape(-1, 12)
+    stride = osc_stride(prefix, first_channel, v.shape[0]) if stride is None else int(stride)
+    out = np.empty((v.shape[0], stride), np.uint8)
+    lengths = np.empty(v.shape[0], np.int32)
+    n = load_library().fx_osc_encode_batch(prefix.encode(), int(first_channel), v.shape[0], _fp(v), out.ctypes.data_as(ctypes.c_void_p), stride,
+                                           lengths.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    if n != v.shape[0]:
+        raise FxError(FX_ERR_INVALID_ARGUMENT, "fx_osc_encode_batch refused its arguments (prefix, channel range or stride)")
+    return out, lengths
+
+
+class OscSender:
+    """fx_osc_sender: sendmmsg batches from `threads` threads to a primary and an optional secondary target, paced by start(rate_hz)."""
+
+    def __init__(self, primary="127.0.0.1:9000", secondary=None, threads=1, gso=False):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        check(self._lib.fx_osc_sender_create(ctypes.byref(self._h), primary.encode(), secondary.encode() if secondary else None, int(threads), OSC_SENDER_GSO if gso else 0))
+
+    def update(self, datagrams, lengths):
+        d = np.ascontiguousarray(datagrams, np.uint8)
+        n = np.ascontiguousarray(lengths, np.int32)
+        if d.ndim != 2 or n.shape != (d.shape[0],):
+            raise ValueError("datagrams [count][stride] and lengths [count]")
+        check(self._lib.fx_osc_sender_update(self._h, d.ctypes.data_as(ctypes.c_void_p), d.shape[1], n.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), d.shape[0]))
+
+    def send(self):
+        sent = ctypes.c_longlong(0)
+        check(self._lib.fx_osc_sender_send(self._h, ctypes.byref(sent)))
+        return sent.value
+
+    def start(self, rate_hz=60.0):
+        check(self._lib.fx_osc_sender_start(self._h, float(rate_hz)))
+
+    def stop(self):
+        check(self._lib.fx_osc_sender_stop(self._h))
+
+    def stats(self):
+        st = OscSenderStats()
+        check(self._lib.fx_osc_sender_get_stats(self._h, ctypes.byref(st)))
+        return st.as_dict()
+
+    def close(self):
+        if self._h:
+            self._lib.fx_osc_sender_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class OscReceiver:
+    """fx_osc_receiver: counts OSC feature messages arriving on a local UDP port (tests, benchmarks, soak runs)."""
+
+    def __init__(self, bind="127.0.0.1:0", threads=1, prefix=None, keep_channels=0, gro=True):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        check(self._lib.fx_osc_receiver_create(ctypes.byref(self._h), bind.encode(), int(threads), prefix.encode() if prefix else None, int(keep_channels),
+                                               0 if gro else OSC_RECEIVER_NO_GRO))
+        self.port = self._lib.fx_osc_receiver_port(self._h)
+
+    def stats(self):
+        a, b, c = ctypes.c_longlong(0), ctypes.c_longlong(0), ctypes.c_longlong(0)
+        check(self._lib.fx_osc_receiver_get_stats(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return {"datagrams": a.value, "bytes": b.value, "malformed": c.value}
+
+    def last(self, channel):
+        buf = (ctypes.c_ubyte * 160)()
+        n = ctypes.c_int(0)
+        check(self._lib.fx_osc_receiver_last(self._h, int(channel), buf, 160, ctypes.byref(n)))
+        return bytes(buf[:n.value])
+
+    def close(self):
+        if self._h:
+            self._lib.fx_osc_receiver_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

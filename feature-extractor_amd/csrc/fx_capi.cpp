@@ -628,7 +628,7 @@ fx_status fx_destroy(fx_context* c)
     fx_comm_release(c);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     void* bufs[] = {c->d_tw, c->d_prev, c->d_tail[0], c->d_tail[1], c->d_hist, c->d_latest,
-                    c->d_raw, c->d_part, c->d_in, c->d_out_raw, c->d_queue, c->d_carry[0], c->d_carry[1], c->d_hops};
+                    c->d_raw, c->d_part, c->d_in, c->d_out_raw, c->d_queue, c->d_carry[0], c->d_carry[1], c->d_hops, c->d_osc};
     for (void* b : bufs) if (b) (void) hipFree(b);
     if (c->h_err) (void) hipHostFree(c->h_err);
     for (int i = 0; i < 3; i++) if (c->ev[i]) (void) hipEventDestroy(c->ev[i]);
@@ -792,6 +792,40 @@ fx_status fx_get_smoothed(fx_context* c, float* out, int mem_kind)
     return FX_OK;
 }
 
+
+// ref OSCFeatureAnalysisOutput.h:89-113 for every track at once: the messages are formed by fx_osc_kernel from `latest`
+fx_status fx_get_osc_datagrams(fx_context* c, const char* prefix, int first_channel, unsigned char* out, int stride, int* lengths, int mem_kind)
+{
+    if (!c || !prefix || !out) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    if (mem_kind != FX_MEM_HOST && mem_kind != FX_MEM_DEVICE) return fx_fail(FX_ERR_INVALID_ARGUMENT, "unknown memory kind %d", mem_kind);
+    const int longest = first_channel < 0 || first_channel > 0x7fffffff - c->C ? -1 : fx_osc_message_bytes(prefix, first_channel + c->C - 1);
+    if (longest < 0) return fx_fail(FX_ERR_INVALID_ARGUMENT, "OSC prefix longer than %d bytes, or a channel number out of range", fxk::FX_OSC_PREFIX_MAX);
+    if (stride < longest || (stride & 3)) return fx_fail(FX_ERR_INVALID_ARGUMENT, "stride %d: must be a multiple of 4 and hold the longest message (%d bytes)", stride, longest);
+    if (mem_kind == FX_MEM_DEVICE && (reinterpret_cast<uintptr_t>(out) & 3)) return fx_fail(FX_ERR_INVALID_ARGUMENT, "a device buffer of messages must start on a 4-byte boundary");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t) c->C * (size_t) stride;
+    if (mem_kind == FX_MEM_HOST && c->osc_cap < bytes) {
+        if (c->d_osc) { unsigned char* old = c->d_osc; c->d_osc = nullptr; c->osc_cap = 0; HIP_TRY(hipFree(old)); }
+        HIP_TRY(hipMalloc((void**) &c->d_osc, bytes));
+        c->osc_cap = bytes;
+    }
+    fxk::OscParams p = {};
+    p.latest = c->d_latest;
+    p.out = mem_kind == FX_MEM_HOST ? c->d_osc : out;
+    p.C = c->C;
+    p.stride = stride;
+    p.first_channel = first_channel;
+    p.prefix_len = (int) strlen(prefix);
+    memcpy(p.prefix, prefix, (size_t) p.prefix_len);
+    HIP_TRY(fxk::launch_osc_kernel(p, c->stream));
+    if (lengths) for (int i = 0; i < c->C; i++) lengths[i] = fx_osc_message_bytes(prefix, first_channel + i);
+    if (mem_kind == FX_MEM_HOST) {
+        HIP_TRY(hipMemcpyAsync(out, c->d_osc, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return fx_check_device_error(c);
+    }
+    return FX_OK;
+}
 
 fx_status fx_sync(fx_context* c)
 {
@@ -1352,6 +1386,37 @@ int fx_osc_encode(const char* address, const float* f, unsigned char* out, int c
         p += 4;
     }
     return total;
+}
+
+int fx_osc_message_bytes(const char* prefix, int channel)
+{
+    if (!prefix || channel < 0) return -1;
+    const size_t plen = strlen(prefix);
+    if (plen > (size_t) fxk::FX_OSC_PREFIX_MAX) return -1;
+    int digits = 1;
+    for (int t = channel; t >= 10; t /= 10) digits++;
+    return (((int) plen + digits + 4) & ~3) + 16 + 48;
+}
+
+int fx_osc_encode_batch(const char* prefix, int first_channel, int num_channels, const float* smoothed, unsigned char* out, int stride, int* lengths)
+{
+    if (!prefix || !smoothed || !out || num_channels < 0 || first_channel < 0 || (stride & 3)) return -1;
+    if (num_channels == 0) return 0;
+    if (first_channel > 0x7fffffff - num_channels) return -1;
+    const int longest = fx_osc_message_bytes(prefix, first_channel + num_channels - 1);
+    if (longest < 0 || stride < longest) return -1;
+    const size_t plen = strlen(prefix);
+    char address[fxk::FX_OSC_PREFIX_MAX + 16];
+    memcpy(address, prefix, plen);
+    for (int c = 0; c < num_channels; c++) {
+        snprintf(address + plen, sizeof address - plen, "%d", first_channel + c);
+        unsigned char* slot = out + (size_t) c * (size_t) stride;
+        const int n = fx_osc_encode(address, smoothed + (size_t) c * FX_NUM_FEATURES, slot, stride);
+        if (n < 0) return -1;
+        memset(slot + n, 0, (size_t) (stride - n));
+        if (lengths) lengths[c] = n;
+    }
+    return num_channels;
 }
 
 } // extern "C"

@@ -72,6 +72,9 @@ struct fx_context {
     float* d_out_sm = nullptr;
     size_t raw_cap = 0, in_cap = 0, out_cap = 0;
 
+    unsigned char* d_osc = nullptr;   // [C][stride]: fx_get_osc_datagrams' messages before they go to a host buffer
+    size_t osc_cap = 0;
+
     double bin_var = 0.0;
     float  lpf_a = 0.0f, lpf_b = 0.0f;
     float  first_tw[18] = {0};

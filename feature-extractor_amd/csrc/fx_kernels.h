@@ -160,6 +160,19 @@ struct ReblockParams {
 hipError_t launch_reblock_kernel(const ReblockParams& p, hipStream_t stream);
 hipError_t clear_carry(unsigned char* carry, size_t bytes, hipStream_t stream);
 
+// fx_get_osc_datagrams (fx_osc.hip): message c = OSC message "<prefix><first_channel + c>" with the twelve values of latest[c] in wire
+// order (ref OSCFeatureAnalysisOutput.h:107), written at out + c * stride
+constexpr int FX_OSC_PREFIX_MAX = 64;
+struct OscParams {
+    const float*   latest;        // [C][12]
+    unsigned char* out;           // [C][stride], 4-byte aligned
+    int            C, stride;     // stride: a multiple of 4, >= the longest message
+    int            first_channel; // >= 0
+    int            prefix_len;    // <= FX_OSC_PREFIX_MAX
+    unsigned char  prefix[FX_OSC_PREFIX_MAX];
+};
+hipError_t launch_osc_kernel(const OscParams& p, hipStream_t stream);
+
 // Re-order the reference's N-entry twiddle table (canonical[i] = (re, im) of e^{-2*pi*i/N} as floats)
 // into the order the FFT passes read it; `out` has room for window_size complex entries.
 void build_pass_twiddles(int window_size, const float* canonical, float* out);

@@ -87,68 +87,55 @@ class OscSink:
     vectors [C][12] and, paced by a 60 Hz timer (ref :133 startTimerHz (60)), sends one OSC message per
     channel -- address /Audio/A<channel> (ref MainComponent.cpp:170), 12 big-endian floats in the order of
     ref :107 -- to a primary and an optional secondary target (ref AnalyserTrackController.h:22-23).
-    Sampling is asynchronous to frame production, as in the reference: a value may be sent twice."""
+    Sampling is asynchronous to frame production, as in the reference: a value may be sent twice.
 
-    def __init__(self, encode, target="127.0.0.1:9000", secondary=None, bundle_prefix="/Audio/A", rate_hz=60.0, first_channel=0):
-        import socket
-        import threading
-        self.encode = encode
+    Scale-shaped since round 6: the messages of a tick are formed in ONE call (fx_osc_encode_batch on the host, or handed over
+    ready-made by BatchAnalyser.osc_datagrams, which writes them on the GPU) and go to the kernel in sendmmsg batches from the
+    library's sender threads (fx_osc_sender, csrc/fx_osc_sender.cpp), which also run the timer: no Python in a tick.
+    `encode` (the per-message encoder of earlier rounds) is accepted and ignored."""
+
+    def __init__(self, encode=None, target="127.0.0.1:9000", secondary=None, bundle_prefix="/Audio/A", rate_hz=60.0, first_channel=0, threads=1, gso=False):
+        from . import capi
+        self._capi = capi
         self.targets = [parse_osc_target(target)] + ([parse_osc_target(secondary)] if secondary else [])
         self.prefix = bundle_prefix
         self.first_channel = first_channel
-        self.period = 1.0 / rate_hz
-        self.sock = socket.socket(socket.AF_INET, socket.SOCK_DGRAM)
-        self._lock = threading.Lock()
-        self._latest = None
-        self._timer = None
-        self._stop = threading.Event()
-        self.sent = 0
+        self.rate_hz = rate_hz
+        self.sender = capi.OscSender(target, secondary, threads=threads, gso=gso)
+        self._have = False
 
     def update(self, smoothed):
         """Publish the newest AudioFeatures::getValue vectors [C][12] (what the timer will sample)."""
-        v = np.array(smoothed, np.float32).reshape(-1, 12)
-        with self._lock:
-            self._latest = v
+        d, n = self._capi.osc_encode_batch(self.prefix, self.first_channel, np.asarray(smoothed, np.float32).reshape(-1, 12))
+        self.update_datagrams(d, n)
 
-    def datagrams(self, smoothed=None):
-        if smoothed is None:
-            with self._lock:
-                smoothed = self._latest
-        if smoothed is None:
-            return []
-        smoothed = np.asarray(smoothed, np.float32).reshape(-1, 12)
-        return [self.encode("%s%d" % (self.prefix, self.first_channel + c), smoothed[c]) for c in range(smoothed.shape[0])]
+    def update_datagrams(self, datagrams, lengths):
+        """Publish messages that are already formed ([C][stride] bytes + lengths: BatchAnalyser.osc_datagrams)."""
+        self.sender.update(datagrams, lengths)
+        self._have = True
+
+    def datagrams(self, smoothed):
+        d, n = self._capi.osc_encode_batch(self.prefix, self.first_channel, np.asarray(smoothed, np.float32).reshape(-1, 12))
+        return [bytes(d[c, :n[c]]) for c in range(d.shape[0])]
 
     def send(self, smoothed=None):
-        """One timer tick: sendSpectralFeaturesViaOSC for every channel (ref :89-113)."""
-        msgs = self.datagrams(smoothed)
-        for m in msgs:
-            for t in self.targets:
-                self.sock.sendto(m, t)
-        self.sent += len(msgs) * len(self.targets)
-        return len(msgs)
+        """One timer tick now: sendSpectralFeaturesViaOSC for every channel (ref :89-113).  Returns the datagrams handed to the kernel."""
+        if smoothed is not None:
+            self.update(smoothed)
+        return self.sender.send() if self._have else 0
+
+    @property
+    def sent(self):
+        return self.sender.stats()["datagrams"]
+
+    def stats(self):
+        return self.sender.stats()
 
     def start(self):
-        import threading
-
-        def loop():
-            import time
-            nxt = time.perf_counter()
-            while not self._stop.is_set():
-                self.send()
-                nxt += self.period
-                self._stop.wait(max(0.0, nxt - time.perf_counter()))
-
-        self._stop.clear()
-        self._timer = threading.Thread(target=loop, daemon=True)
-        self._timer.start()
+        self.sender.start(self.rate_hz)
 
     def stop(self):
-        self._stop.set()
-        if self._timer is not None:
-            self._timer.join()
-            self._timer = None
+        self.sender.stop()
 
     def close(self):
-        self.stop()
-        self.sock.close()
+        self.sender.close()

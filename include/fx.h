@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 5
+#define FX_ABI_VERSION 6
 
 typedef int fx_status;
 enum {
@@ -372,6 +372,69 @@ void fx_pack_osc10(const float* features12, float* out10);
 /* Encode the OSC 1.0 message OSCSender::send(address, 12 floats) emits.
  * Returns the byte count (76 for "/Audio/A0") or -1 if cap is too small. */
 int fx_osc_encode(const char* address, const float* features12, unsigned char* out, int cap);
+
+
+/* ---- the sink at scale: every track's message in one call, every tick's datagrams in a few system calls ----
+ * The reference sends one message per track per 60 Hz tick (OSCFeatureAnalysisOutput.h:84-113,133), from two senders per track
+ * (AnalyserTrackController.h:22-23), addressed "/Audio/A<row>" (MainComponent.cpp:170).  At configs[3] that is 65 536 x 60 = 3.9e6
+ * datagrams a second: they are formatted in bulk (on the GPU, straight from the context's latest vectors, so that the copy to the host
+ * is already the datagrams) and handed to the kernel in batches (sendmmsg), by a few threads, paced at 60 Hz. */
+/* Bytes of the message for address "<prefix><channel>" (76 for "/Audio/A", 0): address + NUL padded to 4, 16 bytes of type tags,
+ * 48 of floats.  -1 if prefix is NULL, longer than 64 bytes, or channel < 0. */
+int fx_osc_message_bytes(const char* prefix, int channel);
+/* fx_osc_encode for num_channels tracks at once, on the host: message c = "<prefix><first_channel + c>" with smoothed[c][12]
+ * (AudioFeatures slot order) is written at out + c * stride and its length to lengths[c] (lengths may be NULL); the rest of each
+ * slot is zeroed.  stride: a multiple of 4, >= fx_osc_message_bytes(prefix, first_channel + num_channels - 1).
+ * Returns num_channels, or -1 on a bad argument. */
+int fx_osc_encode_batch(const char* prefix, int first_channel, int num_channels, const float* smoothed12,
+                        unsigned char* out, int stride, int* lengths);
+/* The same bytes for every channel of the context, formed ON THE DEVICE from the latest AudioFeatures::getValue vectors (what
+ * fx_get_smoothed returns), ordered after the analysis calls made so far.  out: [num_channels][stride] bytes, FX_MEM_HOST (the call
+ * returns when they are there) or FX_MEM_DEVICE (4-byte aligned; asynchronous on the context's stream -- pinned host memory mapped
+ * into the device works the same way); lengths: host array [num_channels] or NULL. */
+fx_status fx_get_osc_datagrams(fx_context* ctx, const char* prefix, int first_channel, unsigned char* out, int stride,
+                               int* lengths, int mem_kind);
+
+/* The sender: one UDP socket per target and thread, sendmmsg in chunks, `threads` sender threads each owning a slice of the tracks,
+ * a 60 Hz timer (OSCFeatureAnalysisOutput::startTimerHz (60), :133) and a primary plus an optional secondary target
+ * (AnalyserTrackController.h:22-23); targets are "ip[:port]", port 9000 by default, parsed as connectToAddress does (:115-123).
+ * No GPU involved.  Like the reference's timer, a tick sends whatever was published last: a vector may go out twice, or never. */
+typedef struct fx_osc_sender fx_osc_sender;
+#define FX_OSC_SENDER_GSO 1u   /* runs of equal-length messages go to the kernel as ONE segmented send (UDP_SEGMENT) where the host's
+                                  kernel supports it; the datagrams on the wire are the same */
+fx_status fx_osc_sender_create(fx_osc_sender** out, const char* primary, const char* secondary /* or NULL */, int threads, unsigned flags);
+fx_status fx_osc_sender_destroy(fx_osc_sender* s);
+/* Publish the datagrams the next ticks send: `count` messages, message i at datagrams + i * stride, lengths[i] bytes.  Copied. */
+fx_status fx_osc_sender_update(fx_osc_sender* s, const unsigned char* datagrams, int stride, const int* lengths, int count);
+/* One tick, now, on the caller's thread + the sender's threads: every published message to every target; *sent (may be NULL) =
+ * datagrams the kernel accepted. */
+fx_status fx_osc_sender_send(fx_osc_sender* s, long long* sent);
+/* startTimerHz / stopTimer */
+fx_status fx_osc_sender_start(fx_osc_sender* s, double rate_hz);
+fx_status fx_osc_sender_stop(fx_osc_sender* s);
+typedef struct fx_osc_sender_stats {
+    long long ticks;            /* timer ticks and fx_osc_sender_send calls so far */
+    long long late_ticks;       /* timer ticks that began after the next one was due (the sender does not keep up with the rate) */
+    long long datagrams;        /* accepted by the kernel */
+    long long dropped;          /* refused by the kernel (full socket buffer: EAGAIN / ENOBUFS) or failed */
+    long long syscalls;         /* sendmmsg / sendmsg calls */
+    double    last_tick_ms, max_tick_ms, total_tick_ms;   /* time to hand a tick's datagrams to the kernel */
+} fx_osc_sender_stats;
+fx_status fx_osc_sender_get_stats(fx_osc_sender* s, fx_osc_sender_stats* out);
+
+/* A counting receiver for tests, benchmarks and soak runs of the sender (loopback diagnostics, not part of the analysis path):
+ * `threads` sockets bound to bind_address ("127.0.0.1:0" = any free port) with SO_REUSEPORT, drained by recvmmsg.  With
+ * keep_channels > 0 and a prefix it also keeps the newest message of every address "<prefix><n>", n < keep_channels. */
+typedef struct fx_osc_receiver fx_osc_receiver;
+#define FX_OSC_RECEIVER_NO_GRO 1u   /* do not ask for UDP_GRO: every datagram makes its own way through the receiving stack, as it would from a
+                                       remote sender (with it, a segmented send over loopback arrives whole and is split in user space) */
+fx_status fx_osc_receiver_create(fx_osc_receiver** out, const char* bind_address, int threads, const char* prefix, int keep_channels, unsigned flags);
+fx_status fx_osc_receiver_destroy(fx_osc_receiver* r);
+int fx_osc_receiver_port(fx_osc_receiver* r);
+/* datagrams and bytes received so far, and those that were not an OSC message of twelve floats; any pointer may be NULL */
+fx_status fx_osc_receiver_get_stats(fx_osc_receiver* r, long long* datagrams, long long* bytes, long long* malformed);
+/* newest message kept for `channel`: copied to out (cap bytes), its length to *len (0 = none seen yet) */
+fx_status fx_osc_receiver_last(fx_osc_receiver* r, int channel, unsigned char* out, int cap, int* len);
 
 const char* fx_last_error(void);
 int fx_abi_version(void);

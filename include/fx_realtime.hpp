@@ -404,6 +404,8 @@ namespace fx
 // analysis threads are writing, unsynchronised; here the analysis side hands over a snapshot -- updateFeatures (smoothed12), the
 // `smoothed` vector of the channel's newest frame -- and the timer thread sends the latest snapshot, so a datagram is always the twelve
 // values of ONE frame.  One object per track and target, as the reference builds them (AnalyserTrackController.h:22-23: two per track).
+// That shape -- a thread, a socket and a system call per track and tick -- is kept for source compatibility and is meant for the
+// reference's own scale (up to ~100 tracks); a host with thousands of tracks uses fx::OSCBatchSender below.
 class OSCFeatureAnalysisOutput
 {
 public:
@@ -475,6 +477,56 @@ private:
     std::atomic<bool> running { false };
     std::atomic<long> sent { 0 };
     std::thread timer;
+};
+
+// The sink at scale: ONE object for all tracks.  A tick's messages arrive formed -- fx_get_osc_datagrams writes them on the GPU from the
+// context's latest vectors, fx_osc_encode_batch on the host -- and go out in sendmmsg batches from `threads` sender threads to a primary
+// and an optional secondary target, paced by a 60 Hz timer (ref OSCFeatureAnalysisOutput.h:84-136, AnalyserTrackController.h:22-23).
+// Thin wrapper of the fx_osc_sender_* entries of include/fx.h.
+class OSCBatchSender
+{
+public:
+    OSCBatchSender (const std::string& primary, const std::string& secondary = std::string(), int threads = 1, bool segmentedSends = false)
+    {
+        check (fx_osc_sender_create (&sender, primary.c_str(), secondary.empty() ? nullptr : secondary.c_str(), threads, segmentedSends ? FX_OSC_SENDER_GSO : 0u));
+    }
+    ~OSCBatchSender() { fx_osc_sender_destroy (sender); }
+    OSCBatchSender (const OSCBatchSender&) = delete;
+    OSCBatchSender& operator= (const OSCBatchSender&) = delete;
+
+    // publish formed messages: message i at datagrams + i * stride, lengths[i] bytes (copied)
+    void updateDatagrams (const unsigned char* datagrams, int stride, const int* lengths, int count) { check (fx_osc_sender_update (sender, datagrams, stride, lengths, count)); }
+    // publish smoothed vectors [count][12] (AudioFeatures slot order) of tracks "<prefix><firstChannel + i>", formed on the host
+    void updateFeatures (const std::string& prefix, int firstChannel, const float* smoothed12, int count)
+    {
+        const int stride = fx_osc_message_bytes (prefix.c_str(), firstChannel + (count > 0 ? count - 1 : 0));
+        if (stride < 0) throw Error (FX_ERR_INVALID_ARGUMENT, "OSC prefix too long or a negative channel number");
+        scratch.resize ((std::size_t) count * (std::size_t) stride);
+        lengths.resize ((std::size_t) count);
+        if (fx_osc_encode_batch (prefix.c_str(), firstChannel, count, smoothed12, scratch.data(), stride, lengths.data()) != count)
+            throw Error (FX_ERR_INVALID_ARGUMENT, "fx_osc_encode_batch refused its arguments");
+        updateDatagrams (scratch.data(), stride, lengths.data(), count);
+    }
+    // publish the context's latest vectors, formed on the device (the copy to the host is the datagrams)
+    void updateFromContext (fx_context* ctx, int numChannels, const std::string& prefix, int firstChannel)
+    {
+        const int stride = fx_osc_message_bytes (prefix.c_str(), firstChannel + (numChannels > 0 ? numChannels - 1 : 0));
+        if (stride < 0) throw Error (FX_ERR_INVALID_ARGUMENT, "OSC prefix too long or a negative channel number");
+        scratch.resize ((std::size_t) numChannels * (std::size_t) stride);
+        lengths.resize ((std::size_t) numChannels);
+        check (fx_get_osc_datagrams (ctx, prefix.c_str(), firstChannel, scratch.data(), stride, lengths.data(), FX_MEM_HOST));
+        updateDatagrams (scratch.data(), stride, lengths.data(), numChannels);
+    }
+    long long sendNow() { long long n = 0; check (fx_osc_sender_send (sender, &n)); return n; }          // one timerCallback for every track
+    void startTimerHz (int hz) { check (fx_osc_sender_start (sender, (double) hz)); }                    // ref :133
+    void stopTimer() { check (fx_osc_sender_stop (sender)); }
+    fx_osc_sender_stats getStats() const { fx_osc_sender_stats st; check (fx_osc_sender_get_stats (sender, &st)); return st; }
+    fx_osc_sender* handle() { return sender; }
+
+private:
+    fx_osc_sender* sender = nullptr;
+    std::vector<unsigned char> scratch;
+    std::vector<int> lengths;
 };
 } // namespace fx
 

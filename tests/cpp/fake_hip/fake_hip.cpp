@@ -224,5 +224,15 @@ hipError_t launch_reblock_kernel(const ReblockParams& p, hipStream_t)
     }
     return hipSuccess;
 }
+hipError_t launch_osc_kernel(const OscParams& p, hipStream_t)
+{
+    if (p.C <= 0) return hipSuccess;
+    const hipError_t e = fake_hip_count("launch_osc_kernel");
+    if (e != hipSuccess) return e;
+    // the bytes of fx_osc.hip through the host encoder: ASan checks the bounds the shim handed over
+    char prefix[FX_OSC_PREFIX_MAX + 1] = {0};
+    memcpy(prefix, p.prefix, (size_t) p.prefix_len);
+    return fx_osc_encode_batch(prefix, p.first_channel, p.C, p.latest, p.out, p.stride, nullptr) == p.C ? hipSuccess : hipErrorInvalidValue;
+}
 hipError_t clear_carry(unsigned char* carry, size_t bytes, hipStream_t s) { return bytes ? hipMemsetAsync(carry, 0, bytes, s) : hipSuccess; }
 } // namespace fxk

@@ -86,6 +86,45 @@ int main (int argc, char** argv)
         ::close (rx);
     }
 
+    {
+        // fx::OSCBatchSender: 1500 tracks to a primary and a secondary fx_osc_receiver, three ticks by hand, then the 60 Hz timer;
+        // every message is fx::OSCFeatureMessage of its track ("/Audio/A999" is 76 bytes, "/Audio/A1000" 80)
+        const int tracks = 1500;
+        fx_osc_receiver* rx[2] = { nullptr, nullptr };
+        for (int k = 0; k < 2; k++) EXPECT (fx_osc_receiver_create (&rx[k], "127.0.0.1:0", 1, "/Audio/A", tracks, 0u) == FX_OK);
+        std::vector<float> v12 ((size_t) tracks * 12);
+        for (size_t i = 0; i < v12.size(); i++) v12[i] = 0.001f * (float) i - 3.0f;
+        {
+            fx::OSCBatchSender out ("127.0.0.1:" + std::to_string (fx_osc_receiver_port (rx[0])), "127.0.0.1:" + std::to_string (fx_osc_receiver_port (rx[1])), 2, true);
+            EXPECT (out.sendNow() == 0);                                          // nothing published yet
+            out.updateFeatures ("/Audio/A", 0, v12.data(), tracks);
+            long long sent = 0;
+            for (int k = 0; k < 3; k++) sent += out.sendNow();
+            EXPECT (sent == 3ll * 2 * tracks);
+            out.startTimerHz (60);
+            std::this_thread::sleep_for (std::chrono::milliseconds (250));
+            out.stopTimer();
+            const fx_osc_sender_stats st = out.getStats();
+            EXPECT (st.ticks >= 3 + 8 && st.ticks <= 3 + 20 && st.dropped == 0 && st.datagrams == (st.ticks - 1) * 2 * tracks);
+            std::this_thread::sleep_for (std::chrono::milliseconds (100));
+            for (int k = 0; k < 2; k++)
+            {
+                long long n = 0, bad = 0;
+                EXPECT (fx_osc_receiver_get_stats (rx[k], &n, nullptr, &bad) == FX_OK);
+                EXPECT (n == (st.ticks - 1) * tracks && bad == 0);
+                for (int c : { 0, 9, 10, 999, 1000, tracks - 1 })
+                {
+                    unsigned char got[160]; int len = 0;
+                    EXPECT (fx_osc_receiver_last (rx[k], c, got, (int) sizeof got, &len) == FX_OK);
+                    const std::string want = fx::OSCFeatureMessage ("/Audio/A" + std::to_string (c), v12.data() + (size_t) c * 12);
+                    EXPECT (len == (int) want.size() && std::memcmp (got, want.data(), want.size()) == 0);
+                    EXPECT (len == (c < 1000 ? 76 : 80));
+                }
+            }
+        }
+        for (int k = 0; k < 2; k++) fx_osc_receiver_destroy (rx[k]);
+    }
+
     if (! gpu)
     {
         bool threw = false;

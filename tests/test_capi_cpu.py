@@ -28,7 +28,7 @@ def test_library_builds_loads_and_exports_every_symbol(fx):
     assert os.path.exists(fx.library_path())
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.fx_abi_version() == fx.capi.ABI_VERSION == 5
+    assert lib.fx_abi_version() == fx.capi.ABI_VERSION == 6
 
 
 def test_library_contains_gfx950_code(fx):
