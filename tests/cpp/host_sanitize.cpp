@@ -11,6 +11,7 @@
 //
 // Built and run by tests/test_host_sanitized_cpu.py.  usage: host_sanitize [asan | tsan]
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -339,6 +340,50 @@ void walk(const char* name, Scenario run, bool inject)
     std::printf("%-28s %ld injected failures walked, %d reported to the caller, problems so far: %d\n", name, calls, reported, g_problems);
 }
 
+// G: the batch sender and the counting receiver (csrc/fx_osc_sender.cpp: sender threads, the timer thread, publications swapped under
+// them, the receiver's threads) -- no HIP in it, so nothing to inject: the sanitizers watch the threads.  Publications race the timer on
+// purpose; sender and receiver are destroyed while the other is still running.
+void osc_threads()
+{
+    g_where = "osc sender / receiver";
+    const int C = 3000;
+    std::vector<float> v((size_t) C * 12);
+    for (size_t i = 0; i < v.size(); i++) v[i] = (float) i * 0.25f;
+    const int stride = fx_osc_message_bytes("/Audio/A", C - 1);
+    std::vector<unsigned char> d((size_t) C * (size_t) stride);
+    std::vector<int> len((size_t) C);
+    if (fx_osc_encode_batch("/Audio/A", 0, C, v.data(), d.data(), stride, len.data()) != C) { problem("fx_osc_encode_batch"); return; }
+    for (unsigned flags : {0u, FX_OSC_SENDER_GSO}) {
+        fx_osc_receiver* rx = nullptr;
+        fx_osc_sender* tx = nullptr;
+        if (fx_osc_receiver_create(&rx, "127.0.0.1:0", 3, "/Audio/A", C, flags ? 0u : FX_OSC_RECEIVER_NO_GRO) != FX_OK) { problem("fx_osc_receiver_create"); return; }
+        char target[64];
+        std::snprintf(target, sizeof target, "127.0.0.1:%d", fx_osc_receiver_port(rx));
+        if (fx_osc_sender_create(&tx, target, target, 4, flags) != FX_OK) { problem("fx_osc_sender_create"); fx_osc_receiver_destroy(rx); return; }
+        long long sent = -1;
+        if (fx_osc_sender_send(tx, &sent) != FX_OK || sent != 0) problem("a tick before anything was published");
+        if (fx_osc_sender_update(tx, d.data(), stride, len.data(), C) != FX_OK) problem("fx_osc_sender_update");
+        if (fx_osc_sender_send(tx, &sent) != FX_OK || sent != 2ll * C) problem("one tick by hand");
+        if (fx_osc_sender_start(tx, 500.0) != FX_OK) problem("fx_osc_sender_start");
+        for (int k = 0; k < 60; k++) {                         // publications of changing size under a running timer, ticks by hand against it
+            const int n = C - (k % 7) * 100;
+            if (fx_osc_sender_update(tx, d.data(), stride, len.data(), n) != FX_OK) problem("fx_osc_sender_update under the timer");
+            if (k % 5 == 0 && fx_osc_sender_send(tx, nullptr) != FX_OK) problem("fx_osc_sender_send under the timer");
+            unsigned char got[160]; int n_got = 0;
+            if (fx_osc_receiver_last(rx, k, got, (int) sizeof got, &n_got) != FX_OK) problem("fx_osc_receiver_last");
+            if (n_got != 0 && (n_got != len[(size_t) k] || std::memcmp(got, d.data() + (size_t) k * (size_t) stride, (size_t) n_got) != 0)) problem("a received message differs from the one sent");
+            usleep(2000);
+        }
+        fx_osc_sender_stats st;
+        if (fx_osc_sender_get_stats(tx, &st) != FX_OK || st.ticks < 10 || st.datagrams < 10ll * (C - 600)) problem("sender statistics");
+        long long n = 0, bad = 0;
+        if (fx_osc_receiver_get_stats(rx, &n, nullptr, &bad) != FX_OK || n <= 0 || bad != 0) problem("receiver statistics");
+        if (flags) { fx_osc_receiver_destroy(rx); usleep(20000); fx_osc_sender_destroy(tx); }      // the timer still running in both orders
+        else { fx_osc_sender_destroy(tx); fx_osc_receiver_destroy(rx); }
+    }
+    std::printf("%-28s clean run (threads only)\n", "osc sender / receiver");
+}
+
 } // namespace
 
 int main(int argc, char** argv)
@@ -348,6 +393,7 @@ int main(int argc, char** argv)
         // the fill pool: resize up and down between 1 and 64 threads, jobs back to back, destroyed while idle
         walk("ring, large batches x64", ring_large_many_threads, false);
         walk("ring, large batches", ring_large, false);
+        osc_threads();
     } else {
         walk("batch calls", scenario_batch, true);
         walk("ring, one-launch hop kernel", scenario_ring_hop_kernel, true);
@@ -356,6 +402,7 @@ int main(int argc, char** argv)
         walk("ring, large batches", ring_large, true);
         walk("rccl gather", scenario_comm, true);
         walk("block arithmetic", scenario_block_arithmetic, false);
+        osc_threads();
         // failures of RCCL itself
         void (*reset)(void) = (void (*)(void)) dlsym(RTLD_DEFAULT, "fake_rccl_reset");
         if (!reset) problem("the fake librccl is not the one loaded");

@@ -31,7 +31,7 @@ def _build(tmp, sanitizer, exe):
     out = os.path.join(tmp, exe)
     cmd = ["g++", "-std=c++17", "-g", "-O1", "-fsanitize=" + sanitizer, "-fno-omit-frame-pointer", "-Wno-tsan",
            "-I", FAKE, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           os.path.join(CSRC, "fx_capi.cpp"), os.path.join(CSRC, "fx_comm.cpp"), os.path.join(FAKE, "fake_hip.cpp"),
+           os.path.join(CSRC, "fx_capi.cpp"), os.path.join(CSRC, "fx_comm.cpp"), os.path.join(CSRC, "fx_osc_sender.cpp"), os.path.join(FAKE, "fake_hip.cpp"),
            os.path.join(ROOT, "tests", "cpp", "host_sanitize.cpp"), "-o", out, "-ldl", "-lpthread"]
     p = subprocess.run(cmd, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -105,6 +105,7 @@ def test_every_hip_call_site_failed_once_under_asan_and_ubsan(tmp_path, fake_rcc
     assert total > 800, p.stdout
     # and the arithmetic of fx_push_samples on the host: the hops handed to the (fake) kernels, end to end, are the stream cut at whole hops
     assert any(line.startswith("block arithmetic") and "clean run" in line for line in p.stdout.splitlines()), p.stdout
+    assert any(line.startswith("osc sender / receiver") and "clean run" in line for line in p.stdout.splitlines()), p.stdout
 
 
 def test_fill_pool_under_tsan(tmp_path, fake_rccl):
@@ -116,6 +117,7 @@ def test_fill_pool_under_tsan(tmp_path, fake_rccl):
     assert p.returncode == 0, tail
     assert "WARNING: ThreadSanitizer" not in p.stderr, tail
     assert "host_sanitize: 0 problem(s)" in p.stdout, tail
+    assert any(line.startswith("osc sender / receiver") and "clean run" in line for line in p.stdout.splitlines()), p.stdout
 
 
 @pytest.mark.parametrize("world, shards, sinks", [
