@@ -22,7 +22,7 @@ UNITS = [("fx_kernels.hip", "fx_kernels_small.o", ["-DFX_PART=1", "-mllvm", "-am
          ("fx_osc_sender.cpp", "fx_osc_sender.o", []),
          ("fx_capi.cpp", "fx_capi.o", []),
          ("fx_comm.cpp", "fx_comm.o", [])]
-HEADERS = ["fx_kernels.h", "fx_context.h", "fx_wave.hip.h", "fx_fft.hip.h", "fx_frame_kernel.hip.h", "fx_pair_kernel.hip.h", "fx_tail_kernels.hip.h", "fx_hop_kernel.hip.h",
+HEADERS = ["fx_kernels.h", "fx_context.h", "fx_wave.hip.h", "fx_fft.hip.h", "fx_blocks.hip.h", "fx_frame_kernel.hip.h", "fx_pair_kernel.hip.h", "fx_tail_kernels.hip.h", "fx_hop_kernel.hip.h",
            os.path.join("..", "..", "include", "fx.h")]
 
 # -ffp-contract=off : the reference FFT never fuses a*b+c; spectra must be bit-identical.

@@ -83,7 +83,9 @@ _lib = None
 
 
 def library_path():
-    return _build.LIB_PATH
+    """The shipped library -- or, for experiments only, the file FX_LIBRARY_OVERRIDE names (a variant built by tools/build_variants.py:
+    selected by path, never copied over the shipped one)."""
+    return os.environ.get("FX_LIBRARY_OVERRIDE") or _build.LIB_PATH
 
 
 def load_library(build_if_missing=True):
@@ -91,10 +93,11 @@ def load_library(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
-    if build_if_missing:
+    override = os.environ.get("FX_LIBRARY_OVERRIDE")
+    if build_if_missing and not override:
         _build.build()
-    if not os.path.exists(_build.LIB_PATH):
-        raise FxError(FX_ERR_UNSUPPORTED, "libfx_hip.so has not been built (run feature-extractor_amd/build.py)")
+    if not os.path.exists(library_path()):
+        raise FxError(FX_ERR_UNSUPPORTED, "libfx_hip.so has not been built (run feature-extractor_amd/build.py)" if not override else "FX_LIBRARY_OVERRIDE names no file: %s" % override)
     # One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64 / librccl (same SONAMEs as
     # /opt/rocm's): if libfx_hip.so is loaded first it binds /opt/rocm's copies, a later `import torch` then brings a
     # second runtime into the process and that one finds no GPU ("No HIP GPUs are available").  Loading torch's first
@@ -103,7 +106,7 @@ def load_library(build_if_missing=True):
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = ctypes.CDLL(_build.LIB_PATH)
+    L = ctypes.CDLL(library_path())
     vp, fp, i, d, f, u = ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.c_double, ctypes.c_float, ctypes.c_uint
     L.fx_create.argtypes = [ctypes.POINTER(vp), i, i, i, d, u]
     L.fx_destroy.argtypes = [vp]

@@ -284,6 +284,7 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     for (int i = 0; i < 18; i++) fp.first_tw[i] = c->first_tw[i];
     fp.tw_quarter_turn = (c->tw_quarter_turn && !(c->test_hooks & FX_HOOK_NO_QUARTER_TURN)) ? 1 : 0;
     fp.tw_at_quarter[0] = c->tw_at_quarter[0]; fp.tw_at_quarter[1] = c->tw_at_quarter[1];
+    fp.block_mode = 0; fp.blk_carry_bytes = fp.blk_carry_row_bytes = 0; fp.blk_in_row_bytes = 0; fp.blk_carry_in = nullptr; fp.blk_carry_out = nullptr;
 
     // Workgroup shape: channels per workgroup x wavefronts per channel (= frames of one channel in flight): the
     // measured-best shape for this window size, fewer waves when the call has fewer frames, fewer channels when the
@@ -392,10 +393,28 @@ void advance(fx_context* c, int T)
     c->frames_seen += T;
 }
 
+// fx_push_samples' call that completes exactly one hop, without the re-blocking pass: `in` of run() is then the device BLOCK of every
+// channel (rows of in_row_bytes) and the one-frame kernels read the hop from [pending samples | block] themselves and write the new
+// pending samples (FrameParams::block_mode, csrc/fx_blocks.hip.h)
+struct BlockFeed {
+    const unsigned char* carry_in;
+    unsigned char*       carry_out;
+    int                  carry_bytes, carry_row_bytes;
+    long long            in_row_bytes;
+};
+
+// Whether this context's one-hop calls can take blocks directly: windows from 1024 points, both analysers, the default kernel family
+// (the pair family and the single-analyser forms read hops: those calls go through fx_reblock_kernel).
+bool blocks_feed_kernels(const fx_context* c)
+{
+    return c->N >= 1024 && !(c->flags & (FX_SPECTRAL_ONLY | FX_HARMONIC_ONLY)) && !uses_pairs(c, c->tuning.waves_per_frame) &&
+           !(c->test_hooks & FX_HOOK_NO_BLOCK_FEED);
+}
+
 // in_kind / out_kind: where the caller's samples and result buffers live (fx_push_samples hands over hops it has assembled in device
 // memory with results that may go to the host)
 fx_status run(fx_context* c, const void* in, int T, int sample_format, int in_kind, int out_kind, int hop_mode,
-              float* out_raw, float* out_smoothed)
+              float* out_raw, float* out_smoothed, const BlockFeed* blocks = nullptr)
 {
     if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");
     if (T < 0) return fx_fail(FX_ERR_INVALID_ARGUMENT, "negative frame count");
@@ -443,12 +462,22 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int in_ki
         HIP_TRY(hipMemcpyAsync(c->d_in, in, in_bytes, hipMemcpyHostToDevice, c->stream));
         d_in = c->d_in;
     } else {
-        if (reinterpret_cast<uintptr_t>(in) % 16 != 0)
-            return fx_fail(FX_ERR_INVALID_ARGUMENT, "device input must be 16-byte aligned");
+        if (reinterpret_cast<uintptr_t>(in) % (blocks ? 4 : 16) != 0)
+            return fx_fail(FX_ERR_INVALID_ARGUMENT, "device input must be %d-byte aligned", blocks ? 4 : 16);
     }
+    if (blocks && (T != 1 || !hop_mode || in_kind != FX_MEM_DEVICE)) return fx_fail(FX_ERR_INVALID_ARGUMENT, "a block feed is one hop per channel from device memory");
 
     Step step;
     if ((st = prepare_step(c, d_in, T, sample_format, hop_mode, d_or, d_os, c->d_part, c->d_raw, nullptr, &step)) != FX_OK) return st;
+    if (blocks) {
+        step.fp.block_mode = 1;
+        step.fp.blk_carry_in = blocks->carry_in;
+        step.fp.blk_carry_out = blocks->carry_out;
+        step.fp.blk_carry_bytes = blocks->carry_bytes;
+        step.fp.blk_carry_row_bytes = blocks->carry_row_bytes;
+        step.fp.blk_in_row_bytes = blocks->in_row_bytes;
+        if (step.pair || step.analysers != 3) return fx_fail(FX_ERR_INVALID_ARGUMENT, "this context's kernels do not read blocks");
+    }
 
     // The three events fx_last_kernel_ms() reads.  Each is a barrier packet between launches, which a call of milliseconds does not
     // notice and a one-frame call does (back to back 27 us per call with them, 14.6 without): those record none unless asked to.
@@ -736,6 +765,12 @@ fx_status fx_push_samples(fx_context* c, const void* samples, int num_samples, i
         if (st == FX_OK && frames_out) *frames_out = hops;
         return st;
     }
+    // ... and so is a host block of whole hops (512-sample callbacks against a 1024-point window): one copy in, no re-blocking
+    if (mem_kind == FX_MEM_HOST && c->carry_count == 0 && rest == 0) {
+        const fx_status st = run(c, samples, hops, sample_format, FX_MEM_HOST, FX_MEM_HOST, 1, out_raw, out_smoothed);
+        if (st == FX_OK && frames_out) *frames_out = hops;
+        return st;
+    }
     fx_status st;
     const unsigned char* d_block = static_cast<const unsigned char*>(samples);
     const size_t block_bytes = (size_t) c->C * (size_t) num_samples * esz;
@@ -745,6 +780,19 @@ fx_status fx_push_samples(fx_context* c, const void* samples, int num_samples, i
         d_block = static_cast<const unsigned char*>(c->d_in);
     } else if (reinterpret_cast<uintptr_t>(samples) % 4 != 0) {
         return fx_fail(FX_ERR_INVALID_ARGUMENT, "device input must be 4-byte aligned (16-byte aligned to be analysed in place)");
+    }
+    if (hops == 1 && blocks_feed_kernels(c)) {
+        // The live case -- a device block of 441 / 480 / 512 ... samples completes exactly one hop: the one-frame kernels read their window
+        // from [pending | block] directly and leave the rest in the other carry buffer.  No pass over the samples beside the analysis.
+        const BlockFeed feed = {c->d_carry[c->carry_cur], c->d_carry[c->carry_cur ^ 1], (int) ((size_t) c->carry_count * esz), H * 4,
+                                (long long) num_samples * (long long) esz};
+        st = run(c, d_block, 1, sample_format, FX_MEM_DEVICE, mem_kind, 1, out_raw, out_smoothed, &feed);
+        if (st != FX_OK) return st;             // (nothing was launched: the pending samples are what they were, the block is lost)
+        c->carry_cur ^= 1;
+        c->carry_count = rest;
+        c->carry_format = sample_format;
+        if (frames_out) *frames_out = 1;
+        return FX_OK;
     }
     const size_t hop_bytes = (size_t) c->C * (size_t) hops * H * esz;
     if ((st = grow(&c->d_hops, &c->hops_cap, hop_bytes)) != FX_OK) return st;

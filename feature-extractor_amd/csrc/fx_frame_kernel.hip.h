@@ -108,9 +108,11 @@ __device__ __forceinline__ void load_half(const void* src, int sample_format, fl
 // Both halves of a window with every global load issued before the first one is consumed (one memory
 // round trip per frame instead of one per 1 KB piece).  FMT_A / FMT_B: sample format of the source of
 // the first / second half (the carried-over tail is always fp32).  N >= 512.
-template <int N, int FMT_A, int FMT_B>
+// BLOCKS: the second half is the first N/2 samples of the stream `bs` (a channel's pending samples followed by its new block,
+// fx_blocks.hip.h) instead of a hop at src_b.
+template <int N, int FMT_A, int FMT_B, bool BLOCKS = false>
 __device__ __forceinline__ double load_window(const void* src_a, const void* src_b, float gain_a, float gain_b,
-                                              float* rbuf, float* tail_out, int lane)
+                                              float* rbuf, float* tail_out, int lane, const BlockStream* bs = nullptr)
 {
     double ssq = 0.0;           // this lane's share of getRMSLevel's sum (ref RealTimeAnalyser.h:207): float squares, double sum
     constexpr int HALF = N / 2, QH = HALF / 256;
@@ -118,7 +120,10 @@ __device__ __forceinline__ double load_window(const void* src_a, const void* src
 #pragma unroll
     for (int q = 0; q < QH; q++) ra[q] = fetch_four<FMT_A>(src_a, 256 * q + 4 * lane);
 #pragma unroll
-    for (int q = 0; q < QH; q++) rb[q] = fetch_four<FMT_B>(src_b, 256 * q + 4 * lane);
+    for (int q = 0; q < QH; q++) {
+        if constexpr (BLOCKS) rb[q] = stream_four<sample_bytes(FMT_B)>(*bs, 256 * q + 4 * lane);
+        else                  rb[q] = fetch_four<FMT_B>(src_b, 256 * q + 4 * lane);
+    }
 #pragma unroll
     for (int q = 0; q < QH; q++) {
         const int i = 256 * q + 4 * lane;
@@ -140,9 +145,9 @@ __device__ __forceinline__ double load_window(const void* src_a, const void* src
 // The same window straight from global memory into registers in the order the first FFT pass consumes it (split
 // sizes: the raw frame is not kept in registers across the four transforms; it is fetched again -- from L2 -- when
 // the spectral and the harmonic analyser need it).  For a fixed (g, j) the 64 lanes read 64 consecutive samples.
-template <int N, int FMT_A, int FMT_B, bool LAST_USE = false>
+template <int N, int FMT_A, int FMT_B, bool LAST_USE = false, bool BLOCKS = false>
 __device__ __forceinline__ void load_window_first_pass_order(const void* src_a, const void* src_b, float gain_a, float gain_b,
-                                                             int lane, float (&x)[Geo<N>::P])
+                                                             int lane, float (&x)[Geo<N>::P], const BlockStream* bs = nullptr)
 {
     typedef Geo<N> G;
     // sample index = rev4(lane + 64*g) + ITEMS_A*r(j), and rev4(lane + 64*g) = rev4(lane) + g (lane's three base-4 digits
@@ -160,6 +165,13 @@ __device__ __forceinline__ void load_window_first_pass_order(const void* src_a, 
             const int r = (G::RA == 4) ? j : (G::RA == 8) ? ((j >> 1) + 4 * (j & 1)) : ((j >> 2) + 4 * (j & 3));
             const bool second = r >= G::RA / 2;                                // low + g < ITEMS_A <= N/2
             const int k = g + G::ITEMS_A * (second ? r - G::RA / 2 : r);       // compile-time part of the sample index
+            if constexpr (BLOCKS) {
+                if (second) {
+                    // (the sample's place in the stream decides which of its two pieces holds it: a compare and two selects per load)
+                    x[g * G::RA + j] = widen_one<FMT_B, LAST_USE>(stream_sample<sample_bytes(FMT_B)>(*bs, (int) low + k));
+                    continue;
+                }
+            }
             const char* at = static_cast<const char*>(second ? src_b : src_a) + (second ? off_b : off_a) + k * sample_bytes(second ? FMT_B : FMT_A);
             x[g * G::RA + j] = second ? widen_one<FMT_B, LAST_USE>(at) : widen_one<FMT_A, LAST_USE>(at);
         }
@@ -324,7 +336,9 @@ static_assert(FrameLds<4096>::bytes(1, 8, false) <= 160 * 1024 && FrameLds<4096>
 // WIDE: the frame kernel's 4096-point layout -- the flux state stays in global memory for calls of any length (handed from frame to
 // frame through the `turn` counter, as the LDS image is elsewhere) and `tw` is the compact twiddle image (CompactTw): what it takes
 // to give a CU an eighth wavefront at this size.
-template <int N, bool DIRECT = false, bool HOIST = false, bool WIDE = false> struct FrameWave {
+// BLOCKS (one-frame calls, hop mode): p.in holds every channel's new BLOCK (rows of p.blk_in_row_bytes) and the hop analysed is the first
+// N/2 samples of [the channel's pending samples | its block] -- fx_push_samples without the re-blocking pass (FrameParams::block_mode).
+template <int N, bool DIRECT = false, bool HOIST = false, bool WIDE = false, bool BLOCKS = false> struct FrameWave {
     typedef Geo<N> G;
     static constexpr int M = G::M, P = G::P, U = G::U, HALF = N / 2;
 
@@ -347,13 +361,21 @@ template <int N, bool DIRECT = false, bool HOIST = false, bool WIDE = false> str
     struct HarmonicSpectrum { float hre[U]; float left2, left1, right1; double sum, max; };
 
     // where the two halves of this frame's window come from (a1, ref RealTimeAudioAnalysis.h:205-219)
-    struct Sources { const void* a; const void* b; float gain_a, gain_b; int fmt_a, fmt_b; };
+    struct Sources { const void* a; const void* b; float gain_a, gain_b; int fmt_a, fmt_b; BlockStream bs; };
     __device__ __forceinline__ Sources sources() const
     {
         const size_t esz = (size_t) sample_bytes(p.sample_format);
         const unsigned char* in = static_cast<const unsigned char*>(p.in);
         Sources s;
         s.fmt_a = s.fmt_b = p.sample_format;
+        if constexpr (BLOCKS) {
+            // T == 1, t == 0: the carried-over tail and the stream's first hop
+            s.a = p.tail_in + (size_t) c * HALF; s.fmt_a = FX_SAMPLE_F32; s.gain_a = 1.0f;
+            s.b = nullptr; s.gain_b = p.gain;
+            s.bs = BlockStream{p.blk_carry_in + (size_t) c * (size_t) p.blk_carry_row_bytes, in + (size_t) c * (size_t) p.blk_in_row_bytes,
+                               p.blk_carry_bytes, p.blk_in_row_bytes};
+            return s;
+        }
         if (p.hop_mode) {
             s.gain_a = s.gain_b = p.gain;
             s.b = in + ((size_t) c * T + t) * HALF * esz;
@@ -373,7 +395,7 @@ template <int N, bool DIRECT = false, bool HOIST = false, bool WIDE = false> str
     {
         asm volatile("" ::: "memory");        // a fetch of its own each time: the point is not to keep x live in between
         const Sources s = sources();
-        FX_FORMATS(s.fmt_a, s.fmt_b, (load_window_first_pass_order<N, FA, FB, LAST_USE>(s.a, s.b, s.gain_a, s.gain_b, lane, x)));
+        FX_FORMATS(s.fmt_a, s.fmt_b, (load_window_first_pass_order<N, FA, FB, LAST_USE, BLOCKS>(s.a, s.b, s.gain_a, s.gain_b, lane, x, &s.bs)));
     }
 
     // returns the lane's share of the frame's sum of squares (split sizes only; otherwise sum_squares() computes it)
@@ -388,7 +410,7 @@ FX_MARK("load");
             const void* src_a = sr.a; const void* src_b = sr.b;
             const float gain_a = sr.gain_a, gain_b = sr.gain_b;
             if constexpr (N >= 512) {
-                FX_FORMATS(sr.fmt_a, sr.fmt_b, (ssq = load_window<N, FA, FB>(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane)));
+                FX_FORMATS(sr.fmt_a, sr.fmt_b, (ssq = load_window<N, FA, FB, BLOCKS>(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane, &sr.bs)));
             } else {
                 load_half<N, HALF>(src_a, sr.fmt_a, gain_a, gain_a != 1.0f, rbuf, 0, nullptr, lane);
                 load_half<N, HALF>(src_b, sr.fmt_b, gain_b, gain_b != 1.0f, rbuf, HALF, tail_dst, lane);
@@ -1060,9 +1082,10 @@ FX_MARK("harm2");
 // DIRECT: calls of one frame per channel (FrameWave): p.T == 1, p.waves_per_ch == 1, a workgroup is p.ch_per_wg channels, no flux
 // state in LDS.
 // (the kernel's body as a device function: fx_frame_tail_kernel -- fx_tail_kernels.hip.h -- runs it too and finishes the hop itself)
-template <int N, bool SPEC, bool HARM, bool DIRECT>
+template <int N, bool SPEC, bool HARM, bool DIRECT, bool BLOCKS = false>
 __device__ __forceinline__ void frame_kernel_body(const FrameParams& p_arg)
 {
+    static_assert(!BLOCKS || (DIRECT && N >= 512), "the block-fed form is a one-frame form");
     FrameParams p = p_arg;
     if (p.dyn) { p.gain = p.dyn->gain; p.nyquist = p.dyn->nyquist; }         // captured step (hipGraph): per-call scalars
     typedef Geo<N> G;
@@ -1176,7 +1199,7 @@ __device__ __forceinline__ void frame_kernel_body(const FrameParams& p_arg)
         // in every lane for the whole frame
         FramePart* fpl = p.part + ((size_t) c * T + t);
         if (lane == 0) fpl->flags = 0;            // the harmonic tail sets it; the other fields are read only where written
-        const FrameWave<N, DIRECT, HOIST, WIDE> w{p, tw, &twr, prev, turn, cbuf, rbuf, fpl, nyquist, rnyq, frpb, scale, c, T, t};
+        const FrameWave<N, DIRECT, HOIST, WIDE, BLOCKS> w{p, tw, &twr, prev, turn, cbuf, rbuf, fpl, nyquist, rnyq, frpb, scale, c, T, t};
 
         const double ssq_lane = w.load_frame(lane);
         float xr[P];
@@ -1203,12 +1226,17 @@ __device__ __forceinline__ void frame_kernel_body(const FrameParams& p_arg)
         }
         FX_STOP(6, continue); FX_STOP(7, continue); FX_STOP(8, continue); FX_STOP(9, continue); FX_STOP(10, continue);
         if constexpr (HARM) {
-            typename FrameWave<N, DIRECT, HOIST, WIDE>::HarmonicSpectrum hs;
+            typename FrameWave<N, DIRECT, HOIST, WIDE, BLOCKS>::HarmonicSpectrum hs;
             if constexpr (G::SPLIT) w.template load_raw<true>(lane, xr);
             w.harmonic_spectrum(lane, xr, hs);
             FX_STOP(11, FX_KEEP(hs.sum); FX_KEEP(hs.max); FX_KEEP(hs.left2); FX_KEEP(hs.left1); FX_KEEP(hs.right1); for (int j = 0; j < G::U; j++) FX_KEEP(hs.hre[j]); continue);
             w.harmonic_tail(lane, hs, f0);
         }
+        // BLOCKS: what the block leaves over becomes the channel's pending samples (the other of the context's two carry buffers).  Measured
+        // at 8192 channels x 1024 points (tools/ab_blocks.sh): here, right behind the window's loads, or with its loads issued in front of
+        // the window's and its stores behind them (8 - 32 more registers across the load stage: scratch at 4096 points) -- 66.5 us per call
+        // all three.  What did matter was the row's last piece (stream_piece16): byte by byte it cost 1.7 us per launch.
+        if constexpr (BLOCKS) stream_keep_rest(w.sources().bs, (long long) (N / 2) * sample_bytes(p.sample_format), p.blk_carry_out + (size_t) c * (size_t) p.blk_carry_row_bytes, lane, 64);
     }
 
     if constexpr (DIRECT) return;                       // (the flux state was replaced in place)
@@ -1229,9 +1257,9 @@ __device__ __forceinline__ void frame_kernel_body(const FrameParams& p_arg)
     }
 }
 
-template <int N, bool SPEC, bool HARM, bool DIRECT = false>
+template <int N, bool SPEC, bool HARM, bool DIRECT = false, bool BLOCKS = false>
 __global__ void __launch_bounds__(Occ<N>::MAX_THREADS, Occ<N>::WAVES_PER_SIMD)
 fx_frame_kernel(const FrameParams p_arg)
 {
-    frame_kernel_body<N, SPEC, HARM, DIRECT>(p_arg);
+    frame_kernel_body<N, SPEC, HARM, DIRECT, BLOCKS>(p_arg);
 }

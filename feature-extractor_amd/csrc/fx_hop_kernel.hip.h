@@ -30,12 +30,13 @@ template <int N> struct HopGeo {
     static_assert(OFF_WAVES % 16 == 0 && OFF_PART % 16 == 0, "16-byte aligned sections");
 };
 
-template <int N>
+template <int N, bool BLOCKS = false>
 // (4096 points: two workgroups per CU, so <= 256 VGPRs -- the harmonic wave, which is not the one the hop waits for, then keeps
 // six register pairs of its transform in scratch, 52 bytes per lane; measured 34.1 -> 32.6 us per hop all the same)
 __global__ void __launch_bounds__(192, HopGeo<N>::WIDE ? 2 : 1)
 fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSignal sig)
 {
+    // BLOCKS: p.in is the channels' new block and the hop is the head of [pending samples | block] (FrameParams::block_mode)
     FrameParams p = p_arg;
     typedef Geo<N> G;
     typedef HopGeo<N> HG;
@@ -64,7 +65,7 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
         for (int i = threadIdx.x; i < HLEN * FX_NUM_FEATURES / 4; i += 192) reinterpret_cast<uint4*>(s_hist)[i] = hs4[i];
     }
     if (threadIdx.x == 0) part->flags = 0;
-    if (sig.stage) {
+    if (!BLOCKS && sig.stage) {
         // the hop itself: out of the pinned host slot into device memory, 16 bytes per lane, once
         const size_t hop_bytes = (size_t) (N / 2) * (size_t) sample_bytes(p.sample_format);
         const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(p.in) + (size_t) c * hop_bytes);
@@ -77,7 +78,7 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
     TwRegs<N> twr;
     if constexpr (TwRegs<N>::USE) twr.load(tw, lane);
     const double nyquist = p.nyquist;
-    typedef FrameWave<N, true, false, HG::WIDE> Wave;
+    typedef FrameWave<N, true, false, HG::WIDE, BLOCKS> Wave;
     const Wave w{p, tw, &twr, nullptr, nullptr, cbuf, rbuf, part, nyquist, 1.0 / nyquist, nyquist / (double) M,
                  1.0f / (float) N, c, 1, 0};
 
@@ -109,6 +110,13 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
             s_raw[FX_FLATNESS] = out[FX_FLATNESS]; s_raw[FX_LER] = out[FX_LER]; s_raw[FX_FLUX] = out[FX_FLUX]; s_raw[FX_SLOPE] = out[FX_SLOPE];
         }
         wave_fence();
+        if constexpr (BLOCKS) {
+            // what the block leaves over becomes the channel's pending samples: this wavefront is done and the hop still waits for the pitch
+            // estimate (in the prologue the copy's trip to memory stood in front of all three: 20.7 us per launch against 18.8)
+            const BlockStream bs{p.blk_carry_in + (size_t) c * (size_t) p.blk_carry_row_bytes, static_cast<const unsigned char*>(p.in) + (size_t) c * (size_t) p.blk_in_row_bytes,
+                                 p.blk_carry_bytes, p.blk_in_row_bytes};
+            stream_keep_rest(bs, (long long) (N / 2) * sample_bytes(p.sample_format), p.blk_carry_out + (size_t) c * (size_t) p.blk_carry_row_bytes, lane, 64);
+        }
     } else {
         float xr[P];
         if constexpr (G::SPLIT) {
@@ -335,10 +343,16 @@ template <int N> hipError_t hop_pair_launch_t(const FrameParams& p, const Epilog
 
 template <int N> hipError_t hop_prepare_t()
 {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_hop_kernel<N>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_hop_kernel<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_hop_kernel<N, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 template <int N> hipError_t hop_launch_t(const FrameParams& p, const EpilogueParams& ep, const HopSignal& sig, hipStream_t stream)
 {
-    hipLaunchKernelGGL((fx_hop_kernel<N>), dim3((unsigned) p.C), dim3(192), HopGeo<N>::BYTES, stream, p, ep, sig);
+    if (p.block_mode) {
+        if (sig.stage || !block_feed_valid(N, p)) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((fx_hop_kernel<N, true>), dim3((unsigned) p.C), dim3(192), HopGeo<N>::BYTES, stream, p, ep, sig);
+    } else {
+        hipLaunchKernelGGL((fx_hop_kernel<N, false>), dim3((unsigned) p.C), dim3(192), HopGeo<N>::BYTES, stream, p, ep, sig);
+    }
     return hipGetLastError();
 }

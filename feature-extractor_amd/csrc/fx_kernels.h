@@ -99,6 +99,15 @@ struct FrameParams {
     float        tw_at_quarter[2];  // canonical[N/4] = ((float) cos(pi/2), -1): the one entry of those that is never a quarter turn of another
     float        first_tw[18];  // the <= 9 twiddles of the first FFT pass (re, im pairs): wave-uniform, so they travel as
                                 // kernel arguments (SGPRs) instead of LDS reads; filled by fill_first_pass_twiddles
+    // fx_push_samples without the re-blocking pass (block_mode = 1; one-frame forms of windows >= 1024 points, both analysers: T == 1,
+    // hop_mode == 1): `in` holds every channel's new BLOCK, rows of blk_in_row_bytes back to back; the hop a channel analyses is the
+    // first N/2 samples of [its pending samples: blk_carry_in row, blk_carry_bytes valid | its block], and the kernel writes what is left
+    // over to the channel's row of blk_carry_out (fx_blocks.hip.h).  Last in the struct: the other forms never look at these.
+    int          block_mode;
+    int          blk_carry_bytes, blk_carry_row_bytes;
+    long long    blk_in_row_bytes;
+    const unsigned char* blk_carry_in;
+    unsigned char*       blk_carry_out;
 };
 
 struct EpilogueParams {
@@ -228,10 +237,13 @@ hipError_t launch_hop_kernel(int window_size, const FrameParams& p, const Epilog
 //      symmetry: same values, read from the whole table)
 //   2 / 3  one-frame calls through the batch kernels never / always finish the hop's tail in the frame kernel (default: while the
 //      chip holds the call's workgroups at once)
+//   4  fx_push_samples never feeds a block to the one-frame kernels directly (FrameParams::block_mode): every call re-blocks first, as
+//      calls that complete several hops do
 // None changes a result bit (bit 0 makes the call fail, as it must).
 #define FX_HOOK_NO_HANDOVER      1u
 #define FX_HOOK_NO_QUARTER_TURN  2u
 #define FX_HOOK_TAIL_NEVER_FUSED 4u
 #define FX_HOOK_TAIL_ALWAYS_FUSED 8u
+#define FX_HOOK_NO_BLOCK_FEED    16u
 extern "C" fx_status fx_set_tuning_internal(fx_context* ctx, unsigned test_hooks);
 #endif

@@ -39,6 +39,7 @@ namespace fxk {
 
 #include "fx_wave.hip.h"
 #include "fx_fft.hip.h"
+#include "fx_blocks.hip.h"
 #include "fx_frame_kernel.hip.h"
 
 // The library builds this file twice (build.py): FX_PART=1 holds the frame kernels up to 1024 points, the tail kernels
@@ -80,6 +81,7 @@ hipError_t launch_hop_kernel(int n, const FrameParams& p, const EpilogueParams& 
     if (p.C <= 0) return hipSuccess;
     if (p.T != 1 || ep.T != 1 || ep.analysers != 3) return hipErrorInvalidValue;
     if (!hop_kernel_available(n)) return hipErrorInvalidValue;
+    if (pairs && p.block_mode) return hipErrorInvalidValue;      // (the pair family reads hops: fx_push_samples re-blocks for it)
     if (pairs && n == 2048) return hop_pair_launch_t<2048>(p, ep, sig, stream);
     if (pairs && n == 4096) return hop_pair_launch_t<4096>(p, ep, sig, stream);
     switch (n) {
@@ -118,11 +120,16 @@ template <int N> hipError_t prepare_t()
     if (e != hipSuccess) return e;
     // frames + tails in one launch exists from 1024 points on (frame_tail_kernel_available): below that a frame is no longer than the
     // tail and the fused form loses either way (profiles/r04_live_cadence.txt), so those sizes are not instantiated
-    if constexpr (N >= 1024)
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_tail_kernel<N>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    else
+    if constexpr (N >= 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_tail_kernel<N, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        // the block-fed one-frame forms (FrameParams::block_mode)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_tail_kernel<N, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, true, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    } else {
         return hipSuccess;
+    }
 }
 
 template <int N> hipError_t launch_t(const FrameParams& p, int analysers, hipStream_t stream)
@@ -132,8 +139,18 @@ template <int N> hipError_t launch_t(const FrameParams& p, int analysers, hipStr
                block((unsigned) (p.ch_per_wg * p.waves_per_ch) * 64);
     if (p.direct_state) {
         if (analysers != 3 || p.T != 1 || p.waves_per_ch != 1 || p.num_chunks > 1) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((fx_frame_kernel<N, true, true, true>), grid, block, lds, stream, p);
+        if (p.block_mode) {
+            if constexpr (N >= 1024) {
+                if (!block_feed_valid(N, p)) return hipErrorInvalidValue;
+                hipLaunchKernelGGL((fx_frame_kernel<N, true, true, true, true>), grid, block, lds, stream, p);
+            } else {
+                return hipErrorInvalidValue;
+            }
+        } else {
+            hipLaunchKernelGGL((fx_frame_kernel<N, true, true, true>), grid, block, lds, stream, p);
+        }
     }
+    else if (p.block_mode) return hipErrorInvalidValue;          // (only the one-frame forms read blocks)
     else if (analysers == 3) hipLaunchKernelGGL((fx_frame_kernel<N, true, true>), grid, block, lds, stream, p);
     else if (analysers == 1) hipLaunchKernelGGL((fx_frame_kernel<N, true, false>), grid, block, lds, stream, p);
     else if (analysers == 2) hipLaunchKernelGGL((fx_frame_kernel<N, false, true>), grid, block, lds, stream, p);
@@ -151,7 +168,12 @@ template <int N> hipError_t launch_tail_t(const FrameParams& p, const EpiloguePa
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     const dim3 grid((unsigned) ((p.C + p.ch_per_wg - 1) / p.ch_per_wg)), block((unsigned) p.ch_per_wg * 64);
     if constexpr (N >= 1024) {
-        hipLaunchKernelGGL((fx_frame_tail_kernel<N>), grid, block, lds, stream, p, ep);
+        if (p.block_mode) {
+            if (!block_feed_valid(N, p)) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((fx_frame_tail_kernel<N, true>), grid, block, lds, stream, p, ep);
+        } else {
+            hipLaunchKernelGGL((fx_frame_tail_kernel<N, false>), grid, block, lds, stream, p, ep);
+        }
         return hipGetLastError();
     } else {
         return hipErrorInvalidValue;
@@ -185,7 +207,7 @@ hipError_t prepare_pair_kernel(int n)
 hipError_t launch_pair_kernel(int n, const FrameParams& p, hipStream_t stream)
 {
     if (p.C <= 0 || p.T <= 0) return hipSuccess;
-    if (!pair_kernel_available(n) || p.ch_per_wg < 1 || p.waves_per_ch < 1 || p.ch_per_wg * p.waves_per_ch > pair_kernel_max_pairs(n)) return hipErrorInvalidValue;
+    if (!pair_kernel_available(n) || p.ch_per_wg < 1 || p.waves_per_ch < 1 || p.ch_per_wg * p.waves_per_ch > pair_kernel_max_pairs(n) || p.block_mode) return hipErrorInvalidValue;
     if (p.num_chunks > 1) {
         if (!p.queue || p.num_chunks > FX_MAX_CHUNKS || p.chunk_begin[0] != 0 || p.chunk_begin[p.num_chunks] != p.T) return hipErrorInvalidValue;
         for (int k = 0; k < p.num_chunks; k++) if (p.chunk_begin[k + 1] <= p.chunk_begin[k]) return hipErrorInvalidValue;

@@ -15,49 +15,11 @@
 
 namespace fxk {
 
+#include "fx_blocks.hip.h"
+
 namespace {
 
 constexpr int RB_THREADS = 256;
-
-// four dwords that need only dword alignment (the hardware's requirement for a 16-byte global access)
-struct __attribute__((packed, aligned(4))) dwords4 { unsigned x, y, z, w; };
-
-// One 16-byte piece of a channel's stream at byte offset d0 (see the file header), returned in v.
-__device__ __forceinline__ void reblock_piece(const ReblockParams& p, const unsigned char* in_row, const unsigned char* carry_row, long long total, long long d0, unsigned (&v)[4])
-{
-    const long long b0 = d0 - p.carry_bytes;
-    if (b0 >= 0 && b0 + 20 <= p.in_row_bytes) {
-        // wholly inside the new block, and so are the five aligned dwords around it
-        // (pointer arithmetic, not an integer round trip: the compiler keeps the global address space and emits global_load_dwordx4)
-        const unsigned char* at = in_row + b0;
-        const unsigned sh = (unsigned) (reinterpret_cast<uintptr_t>(at) & 3);
-        const unsigned char* base = at - sh;
-        const dwords4 q = *reinterpret_cast<const dwords4*>(base);
-        const unsigned q4 = *reinterpret_cast<const unsigned*>(base + 16);
-        v[0] = __builtin_amdgcn_alignbyte(q.y, q.x, sh);
-        v[1] = __builtin_amdgcn_alignbyte(q.z, q.y, sh);
-        v[2] = __builtin_amdgcn_alignbyte(q.w, q.z, sh);
-        v[3] = __builtin_amdgcn_alignbyte(q4, q.w, sh);
-    } else if (d0 + 16 <= p.carry_bytes) {
-        // wholly inside the pending samples: the carry row starts on a 16-byte boundary and so does this piece
-        const uint4 q = *reinterpret_cast<const uint4*>(carry_row + d0);
-        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-    } else {
-        // across the carry / block boundary or at the end of the block: byte by byte, zeros past the end
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            v[j] = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const long long s = d0 + 4 * j + k;
-                if (s < total) {
-                    const unsigned b = s < p.carry_bytes ? carry_row[s] : in_row[s - p.carry_bytes];
-                    v[j] |= b << (8 * k);
-                }
-            }
-        }
-    }
-}
 
 // PIECES pieces per thread, a workgroup's span apart (every access of a wavefront is 1 KB of consecutive bytes): the loads of all
 // pieces are issued before the first store, so a lane keeps PIECES x 20 bytes in flight.
@@ -67,14 +29,13 @@ fx_reblock_kernel(const ReblockParams p)
 {
     const int c = blockIdx.y;
     const long long total = (long long) p.carry_bytes + p.in_row_bytes;
-    const unsigned char* in_row = p.in + (size_t) c * (size_t) p.in_row_bytes;
-    const unsigned char* carry_row = p.carry_in + (size_t) c * (size_t) p.carry_row_bytes;
+    const BlockStream s{p.carry_in + (size_t) c * (size_t) p.carry_row_bytes, p.in + (size_t) c * (size_t) p.in_row_bytes, p.carry_bytes, p.in_row_bytes};
     unsigned v[PIECES][4];
     long long at[PIECES];
 #pragma unroll
     for (int k = 0; k < PIECES; k++) {
         at[k] = 16 * (((long long) blockIdx.x * PIECES + k) * RB_THREADS + threadIdx.x);      // byte offset in the channel's stream
-        if (at[k] < total) reblock_piece(p, in_row, carry_row, total, at[k], v[k]);
+        if (at[k] < total) stream_piece16(s, total, at[k], v[k]);
     }
     // (rows of whole hops and carry rows are multiples of 16 bytes, so a piece never straddles the two destinations; the last piece of the
     // carry may hold up to fifteen bytes of zeros past the pending samples, inside the row)
@@ -87,6 +48,25 @@ fx_reblock_kernel(const ReblockParams p)
     }
 }
 
+// Short rows (fewer 16-byte pieces than a workgroup has threads: blocks of a few hundred samples, the live case): a workgroup per channel
+// would leave most of its lanes idle, so the pieces of ALL channels are dealt out in one run -- thread g takes piece g % pieces of channel
+// g / pieces -- and a workgroup spans as many channels as fill it.
+__global__ void __launch_bounds__(RB_THREADS)
+fx_reblock_rows_kernel(const ReblockParams p, const unsigned pieces)
+{
+    const unsigned long long g = (unsigned long long) blockIdx.x * RB_THREADS + threadIdx.x;
+    const unsigned c = (unsigned) (g / pieces);
+    if (c >= (unsigned) p.C) return;
+    const long long at = 16ll * (long long) (g - (unsigned long long) c * pieces);
+    const long long total = (long long) p.carry_bytes + p.in_row_bytes;
+    const BlockStream s{p.carry_in + (size_t) c * (size_t) p.carry_row_bytes, p.in + (size_t) c * (size_t) p.in_row_bytes, p.carry_bytes, p.in_row_bytes};
+    unsigned v[4];
+    stream_piece16(s, total, at, v);
+    uint4* dst = at < p.out_row_bytes ? reinterpret_cast<uint4*>(p.hops_out + (size_t) c * (size_t) p.out_row_bytes + at)
+                                      : reinterpret_cast<uint4*>(p.carry_out + (size_t) c * (size_t) p.carry_row_bytes + (at - p.out_row_bytes));
+    *dst = uint4{v[0], v[1], v[2], v[3]};
+}
+
 } // namespace
 
 hipError_t launch_reblock_kernel(const ReblockParams& p, hipStream_t stream)
@@ -97,6 +77,11 @@ hipError_t launch_reblock_kernel(const ReblockParams& p, hipStream_t stream)
         total - p.out_row_bytes > p.carry_row_bytes)
         return hipErrorInvalidValue;
     const long long pieces = (total + 15) / 16;         // (of 16 bytes)
+    if (pieces < RB_THREADS) {
+        const unsigned long long all = (unsigned long long) p.C * (unsigned long long) pieces;
+        hipLaunchKernelGGL(fx_reblock_rows_kernel, dim3((unsigned) ((all + RB_THREADS - 1) / RB_THREADS)), dim3(RB_THREADS), 0, stream, p, (unsigned) pieces);
+        return hipGetLastError();
+    }
     // rows shorter than a workgroup's span of four pieces per thread (16 KB) would leave most of such a workgroup idle
     const int per_thread = pieces >= 4 * RB_THREADS ? 4 : (pieces >= 2 * RB_THREADS ? 2 : 1);
     const unsigned gx = (unsigned) ((pieces + (long long) per_thread * RB_THREADS - 1) / ((long long) per_thread * RB_THREADS));

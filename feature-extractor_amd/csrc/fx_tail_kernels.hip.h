@@ -568,11 +568,11 @@ __device__ __forceinline__ void tail_one_hop(const EpilogueParams& p, int c_firs
 // in the transform buffers nobody needs any more; the others leave.  What it buys a live call over thousands of channels is the
 // second launch and its ramp: the tails of the workgroups that finish first run beside the frames of those still at work.
 #if FX_PART != 3
-template <int N>
+template <int N, bool BLOCKS = false>
 __global__ void __launch_bounds__(Occ<N>::MAX_THREADS, Occ<N>::WAVES_PER_SIMD)
 fx_frame_tail_kernel(const FrameParams p, const EpilogueParams ep_arg)
 {
-    frame_kernel_body<N, true, true, true>(p);
+    frame_kernel_body<N, true, true, true, BLOCKS>(p);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            // the frames' records (global memory) ...
     __syncthreads();

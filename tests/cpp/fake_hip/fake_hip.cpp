@@ -178,6 +178,33 @@ const unsigned char* fake_hop_log_bytes(int c) { return c < (int) g_hops.size() 
 size_t fake_hop_log_size(int c) { return c < (int) g_hops.size() ? g_hops[(size_t) c].size() : 0; }
 }
 
+// A block-fed one-frame launch (FrameParams::block_mode), on the host: what the BLOCKS kernels do with the bytes -- the hop is the head of
+// [pending | block], the rest goes to the other carry buffer -- so that the hop log and the next call's pending samples are what the real
+// kernels would leave, and ASan checks every bound the shim handed over.  Returns the parameters of the equivalent hop-fed launch.
+namespace {
+std::vector<unsigned char> g_block_hops;
+fxk::FrameParams from_blocks(const fxk::FrameParams& p, int window)
+{
+    if (!p.block_mode) return p;
+    const size_t esz = p.sample_format == FX_SAMPLE_F32 ? 4 : (p.sample_format == FX_SAMPLE_S24 ? 3 : 2);
+    const size_t hop = (size_t) (window / 2) * esz;
+    const size_t total = (size_t) p.blk_carry_bytes + (size_t) p.blk_in_row_bytes;
+    if (p.T != 1 || !p.hop_mode || total < hop || total >= 2 * hop || total - hop > (size_t) p.blk_carry_row_bytes) { fprintf(stderr, "fake hip: a block feed that is not one hop\n"); int* boom = nullptr; *boom = 1; }
+    g_block_hops.assign((size_t) p.C * hop, 0);
+    const unsigned char* in = static_cast<const unsigned char*>(p.in);
+    for (int c = 0; c < p.C; c++)
+        for (size_t d = 0; d < total; d++) {
+            const unsigned char v = d < (size_t) p.blk_carry_bytes ? p.blk_carry_in[(size_t) c * p.blk_carry_row_bytes + d] : in[(size_t) c * (size_t) p.blk_in_row_bytes + (d - p.blk_carry_bytes)];
+            if (d < hop) g_block_hops[(size_t) c * hop + d] = v;
+            else p.blk_carry_out[(size_t) c * p.blk_carry_row_bytes + (d - hop)] = v;
+        }
+    fxk::FrameParams q = p;
+    q.in = g_block_hops.data();
+    q.block_mode = 0;
+    return q;
+}
+}
+
 // ---- csrc/fx_kernels.h: launchers that launch nothing (each one a countable call), host helpers with plausible answers ----
 namespace fxk {
 void build_pass_twiddles(int n, const float* canonical, float* out) { memcpy(out, canonical, sizeof(float) * 2 * (size_t) n); }
@@ -188,10 +215,10 @@ bool twiddles_have_quarter_turn(int, const float*) { return true; }
 size_t frame_kernel_lds_bytes(int n, int ch, int k, bool direct) { return (size_t) 8 * n + (direct ? 0 : (size_t) ch * 9 * n / 4) + (size_t) ch * k * (n <= 1024 ? 17 * n / 2 : 9 * n / 2); }
 int frame_kernel_max_waves(int n) { return n <= 512 ? 16 : 8; }
 void frame_kernel_preferred_shape(int n, int* ch, int* k) { *ch = 1; *k = n == 2048 ? 4 : 8; }
-hipError_t launch_frame_kernel(int n, const FrameParams& p, int, hipStream_t) { if (p.C <= 0 || p.T <= 0) return hipSuccess; const hipError_t e = fake_hip_count("launch_frame_kernel"); if (e == hipSuccess) { log_hops(p, n); hash_input(p, n); } return e; }
+hipError_t launch_frame_kernel(int n, const FrameParams& p0, int, hipStream_t) { if (p0.C <= 0 || p0.T <= 0) return hipSuccess; const hipError_t e = fake_hip_count("launch_frame_kernel"); if (e == hipSuccess) { const FrameParams p = from_blocks(p0, n); log_hops(p, n); hash_input(p, n); } return e; }
 hipError_t launch_epilogue_kernels(const EpilogueParams& p, hipStream_t) { if (p.C <= 0 || p.T <= 0) return hipSuccess; const hipError_t e = fake_hip_count("launch_epilogue_kernels"); if (e == hipSuccess) fill_latest(p); return e; }
 bool frame_tail_kernel_available(int n) { return n >= 1024; }
-hipError_t launch_frame_tail_kernel(int n, const FrameParams& p, const EpilogueParams& ep, hipStream_t) { const hipError_t e = fake_hip_count("launch_frame_tail_kernel"); if (e == hipSuccess) { log_hops(p, n); hash_input(p, n); fill_latest(ep); } return e; }
+hipError_t launch_frame_tail_kernel(int n, const FrameParams& p0, const EpilogueParams& ep, hipStream_t) { const hipError_t e = fake_hip_count("launch_frame_tail_kernel"); if (e == hipSuccess) { const FrameParams p = from_blocks(p0, n); log_hops(p, n); hash_input(p, n); fill_latest(ep); } return e; }
 hipError_t prepare_kernels(int) { return fake_hip_count("prepare_kernels"); }
 hipError_t prepare_hop_kernel(int) { return fake_hip_count("prepare_hop_kernel"); }
 bool pair_kernel_available(int n) { return n == 2048 || n == 4096; }
@@ -200,10 +227,10 @@ size_t pair_kernel_lds_bytes(int n, int ch, int k) { return (size_t) 8 * n + (si
 hipError_t prepare_pair_kernel(int) { return fake_hip_count("prepare_pair_kernel"); }
 hipError_t launch_pair_kernel(int n, const FrameParams& p, hipStream_t) { const hipError_t e = fake_hip_count("launch_pair_kernel"); if (e == hipSuccess) { log_hops(p, n); hash_input(p, n); } return e; }
 bool hop_kernel_available(int n) { return n == 1024 || n == 2048 || n == 4096; }
-hipError_t launch_hop_kernel(int n, const FrameParams& p, const EpilogueParams& ep, const HopSignal& sig, hipStream_t, bool)
+hipError_t launch_hop_kernel(int n, const FrameParams& p0, const EpilogueParams& ep, const HopSignal& sig, hipStream_t, bool)
 {
     const hipError_t e = fake_hip_count("launch_hop_kernel");
-    if (e == hipSuccess) { log_hops(p, n); hash_input(p, n); fill_latest(ep); }
+    if (e == hipSuccess) { const FrameParams p = from_blocks(p0, n); log_hops(p, n); hash_input(p, n); fill_latest(ep); }
     // the real kernel raises the slot's flag when the hop is done; fx_stream_collect polls it
     if (e == hipSuccess && sig.host_flag) *sig.host_flag = sig.seq;
     return e;

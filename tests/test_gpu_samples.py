@@ -261,3 +261,69 @@ def test_wav_to_osc_device_blocks_give_identical_datagrams(gpu_fx, tmp_path):
         outs[tag] = _records(dump)
     assert len(outs["hops"]) == (48000 + 333) // 1024
     assert outs["b480"] == outs["hops"] and outs["b441"] == outs["hops"] and outs["b4097"] == outs["hops"]
+
+
+@pytest.mark.parametrize("N", [1024, 2048, 4096])
+@pytest.mark.parametrize("fmt", ["f32", "s16", "s24", "f16"])
+def test_block_feed_of_every_one_frame_kernel_equals_the_reblocked_path_bitwise(gpu_fx, N, fmt):
+    """Round 6: a call that completes exactly one hop no longer re-blocks -- fx_hop_kernel / fx_frame_tail_kernel / fx_frame_kernel<direct>
+    read their window from [pending | block] and write what is left over (FrameParams::block_mode, csrc/fx_blocks.hip.h).  Each of the
+    three kernels (steered by the knobs the one-frame tests use), every sample format, block lengths that leave the block row on every
+    byte alignment and the hop boundary anywhere in a lane's piece: the vectors, the pending samples and the state after the stream are
+    those of the same context with the feed switched off (test hook 16: every call through fx_reblock_kernel), bit for bit, host blocks and
+    device blocks."""
+    import torch
+    C, H = 21, N // 2
+    rng = np.random.default_rng(N + len(fmt))
+    total = 7 * H + 3
+    x = signals.tone_vibrato_noise(C, 8, N, seed=N)[:, :, :].reshape(C, -1)[:, :total]
+    if fmt == "s16":
+        stream, per = np.clip(np.round(x * 32768.0), -32768, 32767).astype(np.int16), 1
+    elif fmt == "f16":
+        stream, per = x.astype(np.float16), 1
+    elif fmt == "s24":
+        stream, per = np.asarray(gpu_fx.pack_s24(np.clip(np.round(x * 8388608.0), -2 ** 23, 2 ** 23 - 1).astype(np.int32))), 3
+    else:
+        stream, per = x, 1
+    sf = "s24" if fmt == "s24" else None
+    lengths = []
+    at = 0
+    while at < total:                          # block lengths between H/2 + 1 and H + H/2 - 1: (almost) every call completes exactly one hop
+        n = int(rng.integers(H // 2 + 1, H + H // 2))
+        n = min(n, total - at)
+        lengths.append(n)
+        at += n
+
+    def feed(an, device):
+        raws, sms, at = [], [], 0
+        for n in lengths:
+            piece = np.ascontiguousarray(stream[:, per * at:per * (at + n)])
+            r, s = an.push_samples(torch.from_numpy(piece).cuda() if device else piece, sample_format=sf)
+            if hasattr(r, "cpu"):
+                r, s = r.cpu().numpy(), s.cpu().numpy()
+            raws.append(r); sms.append(s)
+            at += n
+        return np.concatenate(raws, 1), np.concatenate(sms, 1), an.pending_samples(), an.get_features()
+
+    ref = gpu_fx.BatchAnalyser(C, N)
+    ref.set_gain(0.5)
+    ref.set_test_hooks(16)                      # never feed blocks to the kernels
+    want = feed(ref, False)
+    assert want[0].shape[1] == total // H
+    more = np.ascontiguousarray(stream[:, :per * (H - total % H)])       # the pending samples themselves: this block completes a hop out of them
+    want_more = ref.push_samples(more, sample_format=sf)
+    assert want_more[0].shape == (C, 1, 12)
+    ref.close()
+    shapes = {"hop kernel": dict(one_hop_kernel=1), "frames + tails in one launch": dict(one_hop_kernel=0, hooks=8), "frame kernel, then the tail kernel": dict(one_hop_kernel=0, hooks=4)}
+    for name, knobs in shapes.items():
+        for device in ((False, True) if fmt != "s24" else (False,)):
+            an = gpu_fx.BatchAnalyser(C, N)
+            an.set_gain(0.5)
+            an.set_tuning(one_hop_kernel=knobs["one_hop_kernel"])
+            an.set_test_hooks(knobs.get("hooks", 0))
+            got = feed(an, device)
+            assert got[2] == want[2] == total % H
+            assert same(got[0], want[0]) and same(got[1], want[1]) and same(got[3], want[3]), (N, fmt, name, device)
+            got_more = an.push_samples(more, sample_format=sf)
+            assert same(got_more[0], want_more[0]) and same(got_more[1], want_more[1]), (N, fmt, name, device, "the block after")
+            an.close()

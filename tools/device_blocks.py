@@ -1,5 +1,5 @@
 """A stream of device blocks through fx_push_samples, for rocprofv3 (kernel trace or --pmc FETCH_SIZE / WRITE_SIZE passes):
-    python tools/device_blocks.py [channels window block blocks]        default 8192 1024 480 64
+    python tools/device_blocks.py [channels window block blocks][reblock]        default 8192 1024 480 64
 and, with block >= 100000, ONE long block per call (the re-blocking kernel at HBM-bound sizes): e.g.  16384 4096 262243 1
 Prints the algorithmic bytes of the re-blocking launches (2 x sample bytes moved) so that the counters can be held against them."""
 import importlib
@@ -16,6 +16,8 @@ import torch  # noqa: E402
 def main():
     C, N, n, blocks = (int(v) for v in sys.argv[1:5]) if len(sys.argv) > 4 else (8192, 1024, 480, 64)
     an = fx.BatchAnalyser(C, N)
+    if len(sys.argv) > 5 and sys.argv[5] == "reblock":
+        an.set_test_hooks(16)                   # FX_HOOK_NO_BLOCK_FEED: every call through fx_reblock_kernel, as before round 6
     g = torch.Generator(device="cuda").manual_seed(1)
     pieces = [(torch.rand((C, n), generator=g, device="cuda") - 0.5) for _ in range(min(blocks, 8))]
     moved = 0

@@ -20,7 +20,7 @@ THREADS = usable_cores()
 from stress_signals import make_signal  # noqa: E402
 
 
-def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True, windows=(256, 512, 1024, 1024, 2048, 2048, 4096)):
+def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True, windows=(256, 512, 1024, 1024, 2048, 2048, 4096), block_share=0.15):
     """Returns (cases, frames, mismatching cases, worst finite relative error)."""
     rng = np.random.default_rng(seed)
     t_end = time.time() + seconds
@@ -32,6 +32,8 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True, 
     hop_cases = [0]
     pcm_cases = [0]
     block_cases = [0]
+    fed_cases = [0]
+    block_frames = [0]
     last_note = time.time()
     while time.time() < t_end and (max_cases is None or cases < max_cases):
         N = int(rng.choice(list(windows)))
@@ -82,7 +84,7 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True, 
                 parts.append(st.collect())
             st.close()
             ring_cases[0] += 1
-        elif rng.random() < 0.15:
+        elif rng.random() < block_share:
             # the collector's interface (fx_push_samples, round 5): the same stream as device blocks of random lengths -- an audio device's
             # 441 / 480 / 512, single samples, blocks longer than a window -- cut into hops on the device
             H = N // 2
@@ -91,10 +93,29 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True, 
             parts, at, total = [], 0, T * H
             # a third of these cases through the pinned ring's form (fx_stream_push_samples / fx_stream_collect_samples), up to three blocks in flight
             st = fx.HopStream(an, max(4097, 3 * N) // H + 2, slots=3, dtype=feed.dtype) if rng.random() < 0.33 else None
+            # Round 6: a call that completes exactly one hop feeds the block to the one-frame kernels (FrameParams::block_mode).  Half of the
+            # cases use an audio device's lengths only, so that nearly every call is such a call; which of the three kernels reads the block
+            # (hop kernel / frames + tails in one launch / frame kernel then tail kernel) and where the block lives (host, device) is drawn too.
+            live = rng.random() < 0.5
+            on_device = st is None and per == 1 and rng.random() < 0.5
+            kernel = int(rng.integers(0, 3))
+            if kernel:
+                an.set_tuning(one_hop_kernel=0)
+                an.set_test_hooks(8 if kernel == 1 else 4)
+            fed_cases[0] += live
+            block_frames[0] += C * T
+            if on_device:
+                import torch
             while at < total:
-                n = int(rng.choice([1, 63, 441, 480, 512, 1000, 4097, int(rng.integers(1, 3 * N))]))
+                n = int(rng.choice([441, 480, 512, H, H - 1, H + 1, int(rng.integers(H // 2 + 1, H + H // 2))])) if live else \
+                    int(rng.choice([1, 63, 441, 480, 512, 1000, 4097, int(rng.integers(1, 3 * N))]))
                 n = min(n, total - at)
                 piece = np.ascontiguousarray(flat[:, at * per:(at + n) * per])
+                if on_device:
+                    r_, s_ = an.push_samples(torch.from_numpy(piece).cuda())
+                    parts.append((r_.cpu().numpy(), s_.cpu().numpy()))
+                    at += n
+                    continue
                 if st is not None:
                     if st.in_flight() == 3:
                         parts.append(st.collect_samples())
@@ -147,8 +168,9 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True, 
     if verbose:
         print("cases run one hop per call through the ring (fx_hop_kernel / fx_hop_pair_kernel): %d; cases on wavefront pairs (fx_pair_kernel): %d; "
               "cases hop by hop through fx_push_hops (half of them on the batch kernels + one-frame fused tail): %d; cases fed as 16- or 24-bit PCM: %d; "
-              "cases fed as device blocks of random lengths through fx_push_samples: %d"
-              % (ring_cases[0], pair_cases[0], hop_cases[0], pcm_cases[0], block_cases[0]), flush=True)
+              "cases fed as device blocks of random lengths through fx_push_samples: %d (%d frames; %d of the cases in an audio device's block lengths, "
+              "where a call completes one hop and the one-frame kernels read the block themselves)"
+              % (ring_cases[0], pair_cases[0], hop_cases[0], pcm_cases[0], block_cases[0], block_frames[0], fed_cases[0]), flush=True)
     if verbose and inexact.any():
         print("raw values not bit-identical (within tolerance), per slot:", dict((fx.FEATURE_NAMES[i], int(n)) for i, n in enumerate(inexact) if n), flush=True)
     return cases, frames, bad_cases, worst
@@ -157,7 +179,9 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True, 
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    kw = dict(windows=tuple(int(v) for v in sys.argv[3].split(","))) if len(sys.argv) > 3 else {}      # e.g. 4096  or  2048,4096
+    kw = dict(windows=tuple(int(v) for v in sys.argv[3].split(","))) if len(sys.argv) > 3 and sys.argv[3] != "-" else {}      # e.g. 4096  or  2048,4096
+    if len(sys.argv) > 4:
+        kw["block_share"] = float(sys.argv[4])            # share of the cases (after the ring's) fed as device blocks
     cases, frames, bad_cases, worst = run(seconds, seed, **kw)
     print("stress: %d cases, %d frames, %d mismatching cases, worst finite rel err %.3e" % (cases, frames, bad_cases, worst))
 
