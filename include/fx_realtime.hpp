@@ -10,6 +10,10 @@
 //                                      length for all channels; whole hops are analysed as they complete (fx_push_samples).
 //   * fx::OSCFeatureMessage         -- ref Source/OSCFeatureAnalysisOutput.h:89-113 wire format.
 //   * fx::OSCFeatureAnalysisOutput  -- ref Source/OSCFeatureAnalysisOutput.h:23-145: the 60 Hz timer that sends a track's latest values.
+//   * fx::OSCBatchSender            -- the same sink for thousands of tracks: formed datagrams, sendmmsg, sender threads, one 60 Hz timer.
+//   * fx::LiveAnalyser              -- the live engine: audioDeviceIOCallback on the audio thread NEVER blocks (a copy into a FIFO, as the
+//                                      reference's collector copies into its ring, AudioDataCollector.h:36-70); a worker thread feeds the
+//                                      GPU ring, collects the vectors and publishes them (callback, OSCBatchSender).
 // No JUCE.  Errors are thrown as fx::Error (the reference only jasserts).
 #ifndef FX_REALTIME_HPP
 #define FX_REALTIME_HPP
@@ -392,8 +396,10 @@ private:
 };
 } // namespace fx
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 
@@ -527,6 +533,211 @@ private:
     fx_osc_sender* sender = nullptr;
     std::vector<unsigned char> scratch;
     std::vector<int> lengths;
+};
+
+// The live engine.  The reference's audio callback copies the device block into the collector's ring and notify()s the analysis thread
+// (AudioDataCollector.h:36-70); the analysis thread takes window/2 samples when they are there, analyses and writes AudioFeatures
+// (RealTimeAnalyser.h:141-177, :201-234).  Same split here, for all channels at once:
+//   audio thread   audioDeviceIOCallback / pushBlock: ONE copy of the block into a preallocated FIFO slot and a notify -- no allocation, no
+//                  lock, no HIP call, never waits for the GPU.  A full FIFO (the worker has fallen `fifoBlocks` blocks behind) drops the
+//                  block and counts it, where the reference's writer would overrun the reader (AudioDataCollector.h:96-105).
+//   worker thread  owns every call on the context (fx.h: calls on one context are serialised by the caller): fx_stream_push_samples of
+//                  the next block (pinned ring: samples in, kernels, vectors back overlap), fx_stream_collect_samples of the batches that
+//                  are done, then the publication -- the frames callback (the place of the run() loops' updateFeature calls) and, if an
+//                  OSCBatchSender is attached, every channel's message formed on the GPU from the latest vectors.
+// Latency is recorded per block that completed frames: arrival on the audio thread -> publication.
+// Construct after the analyser, destroy before it.  Link with -pthread.
+class LiveAnalyser
+{
+public:
+    typedef std::function<void (int frames, const float* raw, const float* smoothed)> FramesCallback;   // [channels][frames][12], worker thread
+
+    LiveAnalyser (RealTimeBatchAnalyser& analyserToFeed, int maxBlockSamples, int fifoBlocks = 8, int ringSlots = 3, int fillThreads = 1)
+        : analyser (analyserToFeed), channels (analyserToFeed.getNumChannels()), hop (analyserToFeed.getWindowSize() / 2),
+          maxBlock (maxBlockSamples), fill (fillThreads), slots ((std::size_t) (fifoBlocks > 1 ? fifoBlocks : 2))
+    {
+        if (maxBlockSamples < 1) throw Error (FX_ERR_INVALID_ARGUMENT, "maxBlockSamples must be positive");
+        hopsPerBatch = (maxBlockSamples + hop - 1) / hop + 1;                       // what a block plus the pending samples can complete
+        for (Slot& s : slots) s.samples.resize ((std::size_t) channels * (std::size_t) maxBlockSamples);
+        check (fx_stream_create (analyser.handle(), hopsPerBatch, ringSlots, FX_SAMPLE_F32, &ring));
+        depth = ringSlots;
+        rawValues.resize ((std::size_t) channels * (std::size_t) hopsPerBatch * FX_NUM_FEATURES);
+        smoothedValues.resize (rawValues.size());
+        latencies.reserve (1 << 20);
+        running = true;
+        worker = std::thread ([this] { run(); });
+    }
+    ~LiveAnalyser()
+    {
+        stop();
+        fx_stream_destroy (ring);
+    }
+    LiveAnalyser (const LiveAnalyser&) = delete;
+    LiveAnalyser& operator= (const LiveAnalyser&) = delete;
+
+    // AUDIO THREAD, ref AudioDataCollector.h:36-70: inputChannelData[c] -> numberOfSamples floats of channel c.  false: the block was dropped.
+    bool audioDeviceIOCallback (const float* const* inputChannelData, int numInputChannels, int numberOfSamples)
+    {
+        if (numInputChannels < channels || numberOfSamples < 0 || numberOfSamples > maxBlock) { dropped++; return false; }
+        Slot* s = claim();
+        if (s == nullptr) return false;
+        for (int c = 0; c < channels; ++c)
+            std::memcpy (s->samples.data() + (std::size_t) c * (std::size_t) numberOfSamples, inputChannelData[c], sizeof (float) * (std::size_t) numberOfSamples);
+        publish (s, numberOfSamples);
+        return true;
+    }
+    // the same for a block that is already [channels][numberOfSamples] in one piece
+    bool pushBlock (const float* samples, int numberOfSamples)
+    {
+        if (numberOfSamples < 0 || numberOfSamples > maxBlock) { dropped++; return false; }
+        Slot* s = claim();
+        if (s == nullptr) return false;
+        std::memcpy (s->samples.data(), samples, sizeof (float) * (std::size_t) channels * (std::size_t) numberOfSamples);
+        publish (s, numberOfSamples);
+        return true;
+    }
+
+    // set before the first block (not synchronised against the worker)
+    void setFramesAnalysedCallback (FramesCallback f)                               { framesAnalysed = f; }
+    void attachOSCSender (OSCBatchSender* sender, const std::string& bundlePrefix = "/Audio/A", int firstChannel = 0)
+    {
+        osc = sender; oscPrefix = bundlePrefix; oscFirst = firstChannel;
+    }
+
+    // wait until everything pushed so far has been analysed and published (not for the audio thread)
+    void drain()
+    {
+        std::unique_lock<std::mutex> g (wake);
+        idle.wait (g, [this] { return written.load() == consumed.load() && inFlight.load() == 0; });
+    }
+    void stop()
+    {
+        if (! running.exchange (false)) return;
+        { std::lock_guard<std::mutex> g (wake); }
+        ready.notify_all();
+        if (worker.joinable()) worker.join();
+    }
+
+    struct Stats
+    {
+        long long blocksIn, blocksDropped, blocksAnalysed, framesPerChannel, errors;
+        double latencyMsP50, latencyMsP99, latencyMsMax;      // audio-thread arrival -> publication, over the blocks that completed frames
+        double workerBusySeconds;                              // time the worker spent between taking a block and having published it
+    };
+    Stats getStats()
+    {
+        Stats st;
+        st.blocksIn = written.load(); st.blocksDropped = dropped.load(); st.blocksAnalysed = consumed.load();
+        std::lock_guard<std::mutex> g (statLock);
+        st.framesPerChannel = frames; st.errors = errors; st.workerBusySeconds = busy;
+        std::vector<float> v (latencies);
+        std::sort (v.begin(), v.end());
+        st.latencyMsP50 = v.empty() ? 0.0 : v[v.size() / 2];
+        st.latencyMsP99 = v.empty() ? 0.0 : v[(std::size_t) ((double) (v.size() - 1) * 0.99)];
+        st.latencyMsMax = v.empty() ? 0.0 : v.back();
+        return st;
+    }
+    std::string lastError() { std::lock_guard<std::mutex> g (statLock); return errorText; }
+    // the latest smoothed vectors [channels][12] as the worker last published them (a copy; any thread)
+    std::vector<float> latestSmoothed() { std::lock_guard<std::mutex> g (statLock); return latest; }
+
+private:
+    typedef std::chrono::steady_clock Clock;
+    struct Slot { std::vector<float> samples; int count = 0; Clock::time_point arrived; };
+
+    // single producer (the audio thread), single consumer (the worker): `written` / `consumed` count blocks, a slot is index mod size
+    Slot* claim()
+    {
+        const long long w = written.load (std::memory_order_relaxed);
+        if (w - consumed.load (std::memory_order_acquire) >= (long long) slots.size()) { dropped++; return nullptr; }
+        return &slots[(std::size_t) (w % (long long) slots.size())];
+    }
+    void publish (Slot* s, int numberOfSamples)
+    {
+        s->count = numberOfSamples;
+        s->arrived = Clock::now();
+        written.fetch_add (1, std::memory_order_release);
+        { std::lock_guard<std::mutex> g (wake); }                                   // (the worker holds it only around its look at the counters, never while it works)
+        ready.notify_one();                                                         // notify(), ref AudioDataCollector.h:68-69
+    }
+
+    void fail (const char* what)
+    {
+        std::lock_guard<std::mutex> g (statLock);
+        errors++;
+        errorText = std::string (what) + ": " + fx_last_error();
+    }
+    // collect the oldest batch in flight and publish what it completed
+    void collectOne()
+    {
+        int got = 0;
+        if (fx_stream_collect_samples (ring, rawValues.data(), smoothedValues.data(), &got) != FX_OK) { fail ("fx_stream_collect_samples"); inFlight--; arrivals.erase (arrivals.begin()); return; }
+        const Clock::time_point arrived = arrivals.front();
+        arrivals.erase (arrivals.begin());
+        inFlight--;
+        if (got <= 0) return;
+        if (framesAnalysed) framesAnalysed (got, rawValues.data(), smoothedValues.data());
+        if (osc != nullptr)
+        {
+            try { osc->updateFromContext (analyser.handle(), channels, oscPrefix, oscFirst); }
+            catch (const Error&) { fail ("fx_get_osc_datagrams"); }
+        }
+        const double ms = std::chrono::duration<double, std::milli> (Clock::now() - arrived).count();
+        std::lock_guard<std::mutex> g (statLock);
+        frames += got;
+        if (latencies.size() < latencies.capacity()) latencies.push_back ((float) ms);
+        latest.resize ((std::size_t) channels * FX_NUM_FEATURES);
+        for (int c = 0; c < channels; ++c)
+            std::memcpy (&latest[(std::size_t) c * FX_NUM_FEATURES], &smoothedValues[((std::size_t) c * (std::size_t) got + (std::size_t) (got - 1)) * FX_NUM_FEATURES], sizeof (float) * FX_NUM_FEATURES);
+    }
+    void run()
+    {
+        for (;;)
+        {
+            {
+                std::unique_lock<std::mutex> g (wake);
+                if (written.load() == consumed.load() && inFlight.load() == 0) idle.notify_all();
+                ready.wait (g, [this] { return ! running.load() || written.load() != consumed.load() || inFlight.load() > 0; });
+                if (! running.load() && written.load() == consumed.load() && inFlight.load() == 0) return;
+            }
+            const Clock::time_point t0 = Clock::now();
+            if (written.load (std::memory_order_acquire) != consumed.load())
+            {
+                Slot& s = slots[(std::size_t) (consumed.load() % (long long) slots.size())];
+                if (inFlight.load() >= depth) collectOne();                         // every ring slot is busy: the oldest must come back first
+                if (fx_stream_push_samples (ring, s.samples.data(), s.count, fill) == FX_OK) { arrivals.push_back (s.arrived); inFlight++; }
+                else fail ("fx_stream_push_samples");
+                consumed.fetch_add (1, std::memory_order_release);                  // the slot is the audio thread's again
+            }
+            // nothing waiting: bring back what is in flight (a live stream is one block at a time, and its vectors are wanted now)
+            while (inFlight.load() > 0 && written.load (std::memory_order_acquire) == consumed.load()) collectOne();
+            const double dt = std::chrono::duration<double> (Clock::now() - t0).count();
+            std::lock_guard<std::mutex> g (statLock);
+            busy += dt;
+        }
+    }
+
+    RealTimeBatchAnalyser& analyser;
+    int channels, hop, maxBlock, fill, hopsPerBatch = 1, depth = 3;
+    fx_stream* ring = nullptr;
+    std::vector<Slot> slots;
+    std::atomic<long long> written { 0 }, consumed { 0 }, dropped { 0 };
+    std::atomic<int> inFlight { 0 };
+    std::vector<Clock::time_point> arrivals;          // of the batches in flight, oldest first (worker only)
+    std::mutex wake;
+    std::condition_variable ready, idle;
+    std::atomic<bool> running { false };
+    std::thread worker;
+    FramesCallback framesAnalysed;
+    OSCBatchSender* osc = nullptr;
+    std::string oscPrefix;
+    int oscFirst = 0;
+    std::vector<float> rawValues, smoothedValues;
+    std::mutex statLock;
+    long long frames = 0, errors = 0;
+    double busy = 0.0;
+    std::vector<float> latencies, latest;
+    std::string errorText;
 };
 } // namespace fx
 

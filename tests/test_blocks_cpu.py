@@ -59,3 +59,37 @@ def test_the_model_of_the_collector_reproduces_the_reference_collectors_vectors(
     assert raw.shape == g[name + "_raw"].shape
     assert _same(raw, g[name + "_raw"]) and _same(sm, g[name + "_smoothed"]), name
     assert all(p.size == stream.shape[1] % H for p in pending)
+
+
+# ---- the application's own stepping (round 6): which samples its threads really read ----
+from startup_cases import CASES as STARTUP_CASES, stream_of as startup_stream_of  # noqa: E402
+from collector_model import app_hops, describe, gather  # noqa: E402
+
+STARTUP = os.path.join(HERE, "golden", "blocks", "startup.npz")
+
+
+@pytest.mark.parametrize("k", range(len(STARTUP_CASES)), ids=[c[0] for c in STARTUP_CASES])
+def test_the_index_model_of_the_apps_threads_reproduces_the_reference_stepped_as_the_app_steps(oracle, k):
+    """tests/golden/blocks/startup.npz: the reference's headers with their threads' loops run as the app runs them (once at start, once per audio
+    callback).  The oracle, fed the hops tests/golden/collector_model.py says the app reads -- zeros first, stale laps where half a window
+    outlasts a device block -- gives those vectors bit for bit: the model is what the app does, and fx_push_hops on those hops is how a host
+    reproduces it."""
+    g = np.load(STARTUP)
+    name, N, C, total, block, order = STARTUP_CASES[k]
+    stream = startup_stream_of(N, C, total, seed=300 + k)
+    assert np.uint32(zlib.crc32(stream.tobytes())) == g[name + "_crc"]
+    hops = gather(stream, app_hops(N, block, total))
+    assert hops.shape[1] == g[name + "_raw"].shape[1]
+    raw, sm = oracle.push_hops(hops, N, order=order)
+    assert _same(raw, g[name + "_raw"]) and _same(sm, g[name + "_smoothed"]), name
+
+
+def test_what_the_app_reads_at_its_defaults():
+    """The statements DESIGN.md section 5 and INTEGRATION.md section 2 make about the app's start-up, held to the model."""
+    assert describe(2048, 512)[:3] == (4, 0, "re-reads")          # the app's own window, a 512-sample device: 4 hops of zeros, then laps read twice
+    assert describe(2048, 441)[:3] == (4, 0, "fifo")
+    assert describe(1024, 512)[:3] == (8, 0, "fifo")              # a whole lap of zeros, then the stream one lap late
+    assert describe(1024, 480)[:2] == (1, 512)                    # the first half window of the stream is never analysed
+    # the canonical stepping (SURVEY 8c, what fx_push_samples implements) analyses total // (N/2) hops; the app at its defaults twice as many
+    n = describe(2048, 512, 200000)[3]
+    assert 2 * (200000 // 1024) - 4 <= n <= 2 * (200000 // 1024) + 4

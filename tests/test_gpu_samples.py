@@ -327,3 +327,25 @@ def test_block_feed_of_every_one_frame_kernel_equals_the_reblocked_path_bitwise(
             got_more = an.push_samples(more, sample_format=sf)
             assert same(got_more[0], want_more[0]) and same(got_more[1], want_more[1]), (N, fmt, name, device, "the block after")
             an.close()
+
+
+def test_the_applications_own_stepping_replayed_hop_by_hop(gpu_fx):
+    """tests/golden/blocks/startup.npz: the reference's headers stepped the way the APPLICATION's threads step (one pass of the loop at thread
+    start, one per audio callback; the reader running ahead of the writer as indexesOverlap lets it -- hops of zeros first, stale laps of the
+    ring where half a window outlasts a device block).  fx_push_samples is a FIFO from the first real sample by design (DESIGN.md section 5);
+    a host that wants the app's sequence feeds fx_push_hops the hops tests/golden/collector_model.py lists, and gets the reference's vectors."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from collector_model import app_hops, gather
+    from startup_cases import CASES, stream_of
+    from oracle import fx_oracle as fo
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "blocks", "startup.npz"))
+    for k, (name, N, C, total, block, order) in enumerate(CASES):
+        stream = stream_of(N, C, total, seed=300 + k)
+        hops = gather(stream, app_hops(N, block, total))
+        an = gpu_fx.BatchAnalyser(C, N, order=order)
+        parts = [an.push_hops(hops[:, t:t + 1]) for t in range(hops.shape[1])]          # one hop per call, as the app analyses them
+        raw, sm = np.concatenate([p[0] for p in parts], 1), np.concatenate([p[1] for p in parts], 1)
+        signals.assert_features_close(raw, g[name + "_raw"], 1e-5, fo.FEATURE_NAMES, name + " raw")
+        signals.assert_features_close(sm, g[name + "_smoothed"], 1e-5, fo.FEATURE_NAMES, name + " smoothed")
+        an.close()

@@ -72,10 +72,12 @@ def build_blocks():
     return exe
 
 
-def run_blocks(stream, window_size, block, order=0, events=(), sample_rate=48000.0):
+def run_blocks(stream, window_size, block, order=0, events=(), sample_rate=48000.0, app_stepping=False):
     """stream [C][total] float32 fed to the reference's AudioDataCollector::audioDeviceIOCallback in blocks of `block` samples (the last one
     shorter); events = [(at_sample, "gain" | "sensitivity" | "onset_window" | "onset_type" | "sample_rate", value) | (at_sample, "clear")], each
-    taking effect before the block that starts at or after at_sample (the setters of ref AudioDataCollector.h:122-124 and RealTimeAnalyser.h:111-114,244-258).  -> (raw [C][frames][12], smoothed [C][frames][12]) of the total // (window_size / 2) hops the analysers read."""
+    taking effect before the block that starts at or after at_sample (the setters of ref AudioDataCollector.h:122-124 and RealTimeAnalyser.h:111-114,244-258).  -> (raw [C][frames][12], smoothed [C][frames][12]) of the total // (window_size / 2) hops the analysers read.
+    app_stepping: the APPLICATION's stepping (--notify-per-block: one pass of the threads' loop at start and one per callback, the reader
+    running ahead of the writer as indexesOverlap lets it) instead of the canonical one; the number of frames is then whatever the app analyses."""
     import tempfile
     stream = np.ascontiguousarray(stream, np.float32)
     C, total = stream.shape
@@ -88,7 +90,7 @@ def run_blocks(stream, window_size, block, order=0, events=(), sample_rate=48000
             for e in events:
                 f.write(struct.pack("<iifi", int(e[0]), kinds[e[1]], float(e[2]) if len(e) > 2 else 0.0, 0))
             f.write(stream.tobytes())
-        subprocess.run([exe, fin, fout], check=True, timeout=120)
+        subprocess.run([exe, fin, fout] + (["--notify-per-block"] if app_stepping else []), check=True, timeout=120)
         blob = open(fout, "rb").read()
     frames = struct.unpack("<i", blob[:4])[0]
     out = np.frombuffer(blob[4:], np.float32)
