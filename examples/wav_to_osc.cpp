@@ -110,6 +110,7 @@ int main (int argc, char** argv)
         fx::AudioDataCollector collector (analyser);
         const std::vector<float> mono = deviceBlock > 0 ? wav.channel (channel) : std::vector<float>();
         const std::vector<std::int16_t> mono16 = (deviceBlock > 0 && pcm16Direct) ? fx::samplesOfChannelPCM16 (wav, channel) : std::vector<std::int16_t>();
+        const std::vector<unsigned char> mono24 = (deviceBlock > 0 && pcm24Direct) ? fx::samplesOfChannelPCM24 (wav, channel) : std::vector<unsigned char>();
         std::size_t played = 0;                                      // --device-block: samples handed to the collector so far
         for (int done = 0; done < numHops; )
         {
@@ -121,6 +122,7 @@ int main (int argc, char** argv)
                 if (played >= mono.size()) break;
                 const int len = (int) (mono.size() - played < (std::size_t) deviceBlock ? mono.size() - played : (std::size_t) deviceBlock);
                 if (pcm16Direct) n = collector.pushBlock (mono16.data() + played, len, FX_SAMPLE_S16);
+                else if (pcm24Direct) n = collector.pushBlock (mono24.data() + 3 * played, len, FX_SAMPLE_S24);
                 else { const float* one[1] = { mono.data() + played }; n = collector.audioDeviceIOCallback (one, 1, len); }
                 played += (std::size_t) len;
                 values = collector.smoothed();

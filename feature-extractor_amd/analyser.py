@@ -256,6 +256,8 @@ class BatchAnalyser:
         [C][frames][12]) with frames = (pending + n) // (window_size / 2); what is left over stays pending in device memory.  Same bits
         as push_hops on the same stream cut into hops.  numpy (host) or torch CUDA tensors, formats as push_hops."""
         C, H = self.num_channels, self.window_size // 2
+        if sample_format is not None and sample_format not in _FORMAT_NAMES:
+            raise ValueError("sample_format must be one of %s" % ", ".join(sorted(_FORMAT_NAMES)))
         want = None if sample_format is None else _FORMAT_NAMES[sample_format]
         frames_out = ctypes.c_int(0)
         if _is_torch(samples):

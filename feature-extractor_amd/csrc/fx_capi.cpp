@@ -1319,9 +1319,12 @@ static fx_status submit_large(fx_stream* s, fx_stream::Slot& sl, size_t in_bytes
     const fx_status st = num_samples < 0 ? run(c, sl.d_in, s->hops, s->fmt, FX_MEM_DEVICE, FX_MEM_DEVICE, 1, sl.d_raw, sl.d_sm)
                                          : fx_push_samples(c, sl.d_in, num_samples, s->fmt, FX_MEM_DEVICE, sl.d_raw, sl.d_sm, &frames);
     if (st != FX_OK) {
-        // the copy is already enqueued: let it finish, then hand the slot back so the ring stays usable
-        // (the caller may fill and submit it again)
+        // The copy is already enqueued, and fx_push_samples may have launched its re-blocking kernel on the context's stream before it failed: both
+        // read the slot, so let both finish before the slot is handed back.  The ring stays usable; the STREAM of a samples submit does not:
+        // the pending samples have moved on without the hops this block completed (fx_push_samples' contract) -- fx_reset_state, not a
+        // re-submit of the same block.
         (void) hipStreamSynchronize(s->copy);
+        if (num_samples >= 0) (void) hipStreamSynchronize(c->stream);
         s->acquired = false;
         return st;
     }

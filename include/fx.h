@@ -214,7 +214,9 @@ fx_status fx_stream_collect(fx_stream* s, float* out_raw, float* out_smoothed);
  * [num_samples] with rows back to back, 0 <= num_samples <= hops_per_batch * window_size/2 (a device callback's block, or several
  * of them); the context's pending samples and the block are cut into hops on the device, analysed, and the rest is kept.  The
  * batch yields frames = (pending + num_samples) / (window_size/2) vectors per channel, which fx_stream_collect_samples reports.
- * Always the three-queue path (samples in, kernels, vectors back). */
+ * Always the three-queue path (samples in, kernels, vectors back).  If it fails the slot is handed back and the ring stays usable, but -- as
+ * with fx_push_samples -- the pending samples may have moved on without the hops this block completed: fx_reset_state, do not submit the
+ * same block again. */
 fx_status fx_stream_submit_samples(fx_stream* s, int num_samples);
 /* acquire + copy (fill_threads host threads) + fx_stream_submit_samples for a block in ordinary host memory */
 fx_status fx_stream_push_samples(fx_stream* s, const void* samples, int num_samples, int fill_threads);

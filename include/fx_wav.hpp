@@ -176,6 +176,16 @@ inline std::vector<std::int16_t> samplesOfChannelPCM16 (const WavData& wav, int 
     for (std::size_t i = 0; i < mono.size(); ++i) mono[i] = wav.pcm16[i * (std::size_t) wav.numChannels + (std::size_t) channel];
     return mono;
 }
+// every sample of one channel of a 24-bit file, packed in three bytes as the file holds it
+inline std::vector<unsigned char> samplesOfChannelPCM24 (const WavData& wav, int channel)
+{
+    std::vector<unsigned char> mono;
+    if (wav.pcm24.empty()) return mono;
+    mono.resize (wav.numFrames() * 3);
+    for (std::size_t i = 0; i < wav.numFrames(); ++i)
+        for (int b = 0; b < 3; ++b) mono[3 * i + (std::size_t) b] = wav.pcm24[(i * (std::size_t) wav.numChannels + (std::size_t) channel) * 3 + (std::size_t) b];
+    return mono;
+}
 // ... and as packed 24-bit PCM (24-bit files only): numHops * windowSize/2 * 3 bytes of the chosen channel.
 inline std::vector<unsigned char> hopsOfChannelPCM24 (const WavData& wav, int channel, int windowSize, int& numHops)
 {

@@ -367,6 +367,69 @@ int main (int argc, char** argv)
             EXPECT (frames == T5 && sameBits (gr, wr) && sameBits (gs, ws));
         }
     }
+    // round 6: the live engine as INTEGRATION.md section 2 binds it -- the audio thread only copies (fx::LiveAnalyser::audioDeviceIOCallback), a
+    // worker owns the GPU ring and writes each track's AudioFeatures exactly as the two run() loops did; the sink's messages are formed on the
+    // GPU and go out through fx::OSCBatchSender.  481-sample device blocks against a 1024-point window: every getValue equals pushHops' smoothed
+    // vectors of the same stream bit for bit, and each track's newest datagram is OSCFeatureMessage of its AudioFeatures.
+    {
+        const int C6 = 5, T6 = 30, N6 = 1024, H6 = N6 / 2, B6 = 481;
+        std::vector<float> stream ((size_t) C6 * T6 * H6), wr ((size_t) C6 * T6 * 12), ws (wr.size());
+        unsigned r6 = 4242;
+        for (size_t i = 0; i < stream.size(); i++) { r6 = r6 * 1664525u + 1013904223u; stream[i] = 0.5f * std::sin (0.017f * (float) (i % 7001)) * ((i / H6) % 4 < 3 ? 1.0f : 0.0f) + 0.03f * ((r6 >> 8) / 16777216.0f - 0.5f); }
+        fx::RealTimeBatchAnalyser ref (C6, N6), liveAn (C6, N6);
+        ref.pushHops (stream.data(), T6, wr.data(), ws.data());
+        fx_osc_receiver* rx = nullptr;
+        EXPECT (fx_osc_receiver_create (&rx, "127.0.0.1:0", 1, "/Audio/A", C6, 0u) == FX_OK);
+        std::vector<AudioFeatures> features ((size_t) C6);
+        int framesSeen = 0, mismatches = 0;
+        {
+            fx::OSCBatchSender sender ("127.0.0.1:" + std::to_string (fx_osc_receiver_port (rx)));
+            fx::LiveAnalyser live (liveAn, 512);
+            live.attachOSCSender (&sender, "/Audio/A", 0);
+            live.setFramesAnalysedCallback ([&] (int frames, const float* raw, const float* smoothed) {       // the worker thread: where the run() loops were
+                for (int c = 0; c < C6; c++)
+                    for (int k = 0; k < frames; k++)
+                    {
+                        const float* v = raw + ((size_t) c * frames + k) * 12;
+                        AudioFeatures& f = features[(size_t) c];
+                        f.updateFeature (AudioFeatures::enRMS, v[FX_RMS]);           f.updateFeature (AudioFeatures::enCentroid, v[FX_CENTROID]);
+                        f.updateFeature (AudioFeatures::enFlatness, v[FX_FLATNESS]); f.updateFeature (AudioFeatures::enLER, v[FX_LER]);
+                        f.updateFeature (AudioFeatures::enSpread, v[FX_SPREAD]);     f.updateFeature (AudioFeatures::enFlux, v[FX_FLUX]);
+                        f.updateFeature (AudioFeatures::enSlope, v[FX_SLOPE]);       f.updateFeature (AudioFeatures::enOnset, v[FX_ONSET]);
+                        f.updateFeature (AudioFeatures::enRMS, v[FX_RMS]);           f.updateFeature (AudioFeatures::enF0, v[FX_F0]);
+                        f.updateFeature (AudioFeatures::enHarmonicEnergyRatio, v[FX_HER]); f.updateFeature (AudioFeatures::enOddEvenHarmonicRatio, v[FX_OER]);
+                        f.updateFeature (AudioFeatures::enInharmonicity, v[FX_INHARM]);
+                        for (int q = 0; q < 12; q++)
+                        {
+                            const float got = f.getValue ((AudioFeatures::eAudioFeature) q), want = ws[((size_t) c * T6 + framesSeen + k) * 12 + q], lib = smoothed[((size_t) c * frames + k) * 12 + q];
+                            if (! ((got == want && lib == want) || (std::isnan (got) && std::isnan (want) && std::isnan (lib)))) mismatches++;
+                        }
+                    }
+                framesSeen += frames;
+            });
+            std::vector<const float*> in ((size_t) C6);
+            for (size_t at = 0; at < (size_t) T6 * H6; at += B6)                       // the "audio thread"
+            {
+                const size_t n = (size_t) T6 * H6 - at < (size_t) B6 ? (size_t) T6 * H6 - at : (size_t) B6;
+                for (int c = 0; c < C6; c++) in[(size_t) c] = stream.data() + (size_t) c * T6 * H6 + at;
+                while (! live.audioDeviceIOCallback (in.data(), C6, (int) n)) std::this_thread::sleep_for (std::chrono::microseconds (200));   // (a device would not wait: here no block may be lost)
+            }
+            live.drain();
+            const fx::LiveAnalyser::Stats st = live.getStats();
+            EXPECT (framesSeen == T6 && mismatches == 0 && st.errors == 0 && st.framesPerChannel == T6 && st.blocksAnalysed == st.blocksIn);
+            EXPECT (sender.sendNow() == C6);
+            std::this_thread::sleep_for (std::chrono::milliseconds (100));
+            for (int c = 0; c < C6; c++)
+            {
+                float v[12];
+                for (int q = 0; q < 12; q++) v[q] = features[(size_t) c].getValue ((AudioFeatures::eAudioFeature) q);
+                const std::string want = fx::OSCFeatureMessage ("/Audio/A" + std::to_string (c), v);
+                unsigned char got[160]; int len = 0;
+                EXPECT (fx_osc_receiver_last (rx, c, got, (int) sizeof got, &len) == FX_OK && len == (int) want.size() && std::memcmp (got, want.data(), want.size()) == 0);
+            }
+        }
+        fx_osc_receiver_destroy (rx);
+    }
     // the legacy offline analyser's mirror (ref AudioAnalysis.h)
     {
         const int C3 = 2, S = 4000, B = 513;

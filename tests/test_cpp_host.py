@@ -13,7 +13,7 @@ def _build(fx, tmp_path):
     lib_dir = os.path.dirname(fx.library_path())
     subprocess.check_call(["g++", "-std=c++14", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "host_mirror.cpp"), "-o", exe,
-                           "-L", lib_dir, "-lfx_hip", "-Wl,-rpath," + lib_dir])
+                           "-L", lib_dir, "-lfx_hip", "-Wl,-rpath," + lib_dir, "-pthread"])
     return exe
 
 

@@ -1,4 +1,6 @@
 #!/usr/bin/env python3
+# (the env shebang is harmless HERE only: this process never touches a GPU -- everything that does is a child it starts -- so the exec it
+# implies happens before any GPU state exists.  Under rocprofv3, or from a process that has initialised HIP, start it as `python3 tools/...`.)
 """First contact with a multi-GPU node: everything about the N > 1 path in ONE run and ONE JSON, so that a scaling result below
 target can be diagnosed without a second run.  (No >= 2-GPU node was available while this was built: see DESIGN.md section 6.)
 
@@ -110,12 +112,19 @@ def main():
     lib_dir = os.path.dirname(lib)
     exe = os.path.join(ROOT, "tools", "_bin", "comm_ranks")
     os.makedirs(os.path.dirname(exe), exist_ok=True)
-    subprocess.check_call(["g++", "-O1", "-std=c++14", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "comm_ranks.cpp"),
-                           "-o", exe, "-L", lib_dir, "-lfx_hip", "-Wl,-rpath," + lib_dir])
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    # (the HIP runtime for the sink's device-resident destination tables: hipMalloc / hipMemcpy / hipFree)
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(rocm, "include"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "comm_ranks.cpp"), "-o", exe, "-L", lib_dir, "-lfx_hip", "-Wl,-rpath," + lib_dir,
+                           "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-ldl"])
     comm = {}
     rehearsal = args.rehearse_ranks > 0
     for n in ([] if rehearsal else sorted({2, max([k for k in (2, 4, 8) if k <= gpus] or [2])})):
-        rc, so, se = run([exe, str(n)], args.timeout, env)
+        # ragged shards, the sink moving off rank 0 once, host and device destinations, every round's gather in flight together -- the
+        # shape tests/test_host_sanitized_cpu.py runs against the multi-process fake RCCL
+        shards = ",".join(str(v) for v in ([8192, 8191, 1, 37, 4096, 5, 640, 2][:n]))
+        sinks = "0,0,0,%d,0" % (n - 1)
+        rc, so, se = run([exe, str(n), "shards=" + shards, "sinks=" + sinks], args.timeout, env)
         comm[n] = {"rc": rc, "skipped": rc == 77, "tail": (so + se)[-1500:]}
     lines = {}
     extra = []
