@@ -54,7 +54,7 @@ def test_live_soak_drops_nothing_and_matches_the_oracle(gpu_fx, oracle, tmp_path
     C, N, B, blocks, pool = struct.unpack("5i", raw[:20])
     assert (C, N, B, pool) == (channels, window, block, 16) and blocks >= 5 * 48000 // block - 2
     smoothed = np.frombuffer(raw[20:], np.float32).reshape(C, 12)
-    sample = [0, 1, 96, 97, C // 2, C - 1]
+    sample = sorted({c for c in (0, 1, 96, 97, C // 2, C - 1) if c < C})
     x = _stream(sample, B, blocks, pool)
     hops = x[:, :x.shape[1] // (N // 2) * (N // 2)].reshape(len(sample), -1, N // 2)
     for k, c in enumerate(sample):
