@@ -1,4 +1,4 @@
-"""The documents' statements about the kernels as built are held to the library itself: DESIGN.md section 3.3 carries a table of
+"""The documents' statements about the kernels as built are held to the library itself: DESIGN.md section 3.8 carries a table of
 registers and scratch per kernel, and this test reads the same numbers out of feature-extractor_amd/lib/libfx_hip.so
 (tools/kernel_resources.py: the gfx950 code objects' metadata).  A kernel change that moves a number fails here until the table is
 regenerated (`python tools/kernel_resources.py --markdown`)."""
@@ -35,7 +35,7 @@ def test_design_resource_table_is_the_library_as_built(fx):
     text = open(os.path.join(ROOT, "DESIGN.md")).read()
     for k in spills:
         assert ("`%s`" % k) in text
-    assert "kernels with scratch: %d" % len(spills) in open(os.path.join(ROOT, "profiles", "r05_resources.txt")).read()
+    assert "kernels with scratch: %d" % len(spills) in open(os.path.join(ROOT, "profiles", "r06_resources.txt")).read()
 
 
 def test_no_frame_tail_kernel_below_1024_points(fx):
@@ -43,5 +43,5 @@ def test_no_frame_tail_kernel_below_1024_points(fx):
     import kernel_resources as kr
     fx.load_library(build_if_missing=True)
     names = [k["pretty"] for k in kr.kernels_of()]
-    assert "fxk::fx_frame_tail_kernel<1024>" in names
-    assert not any(n in names for n in ("fxk::fx_frame_tail_kernel<256>", "fxk::fx_frame_tail_kernel<512>"))
+    assert "fxk::fx_frame_tail_kernel<1024, false>" in names
+    assert not any(n in names for n in ("fxk::fx_frame_tail_kernel<256, false>", "fxk::fx_frame_tail_kernel<512, false>", "fxk::fx_frame_tail_kernel<256>", "fxk::fx_frame_tail_kernel<512>"))

@@ -5,7 +5,7 @@ metadata notes), not from a separate compilation.
     python tools/kernel_resources.py                      # the table
     python tools/kernel_resources.py --write profiles/r05_resources.txt
 
-tests/test_docs_cpu.py holds DESIGN.md section 3.3's scratch / VGPR statements to this dump.
+tests/test_docs_cpu.py holds DESIGN.md section 3.8's scratch / VGPR statements to this dump.
 """
 import argparse
 import os
@@ -80,7 +80,7 @@ def table(kernels):
     return "\n".join(lines) + "\n"
 
 
-# the kernels DESIGN.md section 3.3 tabulates (the analysis kernels; the offline analyser's and the byte mover are in the full dump)
+# the kernels DESIGN.md section 3.8 tabulates (the analysis kernels; the offline analyser's and the byte mover are in the full dump)
 DESIGN_PREFIXES = ("fxk::fx_frame_kernel<", "fxk::fx_frame_tail_kernel<", "fxk::fx_pair_kernel<", "fxk::fx_hop_kernel<", "fxk::fx_hop_pair_kernel<",
                    "fxk::fx_finalise_kernel", "fxk::fx_epilogue_kernel", "fxk::fx_history_kernel", "fxk::fx_tail_fused_kernel")
 
@@ -97,7 +97,7 @@ def markdown(kernels):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--write", default=None)
-    ap.add_argument("--markdown", action="store_true", help="print the table DESIGN.md section 3.3 carries (tests/test_docs_cpu.py compares the two)")
+    ap.add_argument("--markdown", action="store_true", help="print the table DESIGN.md section 3.8 carries (tests/test_docs_cpu.py compares the two)")
     ap.add_argument("--library", default=None)
     args = ap.parse_args()
     if args.markdown:
