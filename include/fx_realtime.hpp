@@ -604,11 +604,20 @@ public:
         osc = sender; oscPrefix = bundlePrefix; oscFirst = firstChannel;
     }
 
+    // Anything else that touches the analyser while the engine runs -- setGain, setOnsetDetectionType, sampleRateChanged, clearBuffer ... from a
+    // GUI / message thread -- goes through here: the call is queued and the WORKER makes it before it takes the next block, so that the
+    // context still has one caller (fx.h).  Not for the audio thread (it takes a lock).
+    void callOnWorker (std::function<void (RealTimeBatchAnalyser&)> f)
+    {
+        { std::lock_guard<std::mutex> g (wake); commands.push_back (std::move (f)); }
+        ready.notify_one();
+    }
+
     // wait until everything pushed so far has been analysed and published (not for the audio thread)
     void drain()
     {
         std::unique_lock<std::mutex> g (wake);
-        idle.wait (g, [this] { return written.load() == consumed.load() && inFlight.load() == 0; });
+        idle.wait (g, [this] { return written.load() == consumed.load() && inFlight.load() == 0 && commands.empty(); });
     }
     void stop()
     {
@@ -694,11 +703,17 @@ private:
     {
         for (;;)
         {
+            std::vector<std::function<void (RealTimeBatchAnalyser&)>> todo;
             {
                 std::unique_lock<std::mutex> g (wake);
-                if (written.load() == consumed.load() && inFlight.load() == 0) idle.notify_all();
-                ready.wait (g, [this] { return ! running.load() || written.load() != consumed.load() || inFlight.load() > 0; });
-                if (! running.load() && written.load() == consumed.load() && inFlight.load() == 0) return;
+                if (written.load() == consumed.load() && inFlight.load() == 0 && commands.empty()) idle.notify_all();
+                ready.wait (g, [this] { return ! running.load() || written.load() != consumed.load() || inFlight.load() > 0 || ! commands.empty(); });
+                if (! running.load() && written.load() == consumed.load() && inFlight.load() == 0 && commands.empty()) return;
+                todo.swap (commands);
+            }
+            for (auto& f : todo)                                                    // the other threads' setter calls, in order, between blocks
+            {
+                try { f (analyser); } catch (const Error&) { fail ("a call queued with callOnWorker"); }
             }
             const Clock::time_point t0 = Clock::now();
             if (written.load (std::memory_order_acquire) != consumed.load())
@@ -726,6 +741,7 @@ private:
     std::vector<Clock::time_point> arrivals;          // of the batches in flight, oldest first (worker only)
     std::mutex wake;
     std::condition_variable ready, idle;
+    std::vector<std::function<void (RealTimeBatchAnalyser&)>> commands;   // guarded by `wake`
     std::atomic<bool> running { false };
     std::thread worker;
     FramesCallback framesAnalysed;

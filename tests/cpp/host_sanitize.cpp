@@ -16,12 +16,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <hip/hip_runtime.h>        // the FAKE one (tests/cpp/fake_hip/hip)
 
 #include "fx.h"
+#include "fx_realtime.hpp"        // fx::LiveAnalyser, fx::OSCBatchSender: the live engine's threads run under the sanitizers too
 
 namespace {
 
@@ -384,6 +387,68 @@ void osc_threads()
     std::printf("%-28s clean run (threads only)\n", "osc sender / receiver");
 }
 
+// H: the live engine (include/fx_realtime.hpp: fx::LiveAnalyser) over the fake runtime -- an "audio thread" pushing blocks of changing length
+// into the FIFO as fast as it can (a full FIFO drops and counts), the worker feeding the ring and publishing to a callback and an
+// OSCBatchSender with its timer running, getStats / latestSmoothed read from a third thread meanwhile, drain, stop, destruction in the
+// documented order.  Every block is accounted for: analysed or counted as dropped; the frames published are those of the blocks analysed.
+void live_engine()
+{
+    g_where = "live engine";
+    fake_hip_reset();
+    const int C = 6, N = 1024, H = N / 2, blocks = 400;
+    try {
+        fx_osc_receiver* rx = nullptr;
+        if (fx_osc_receiver_create(&rx, "127.0.0.1:0", 1, "/Audio/A", C, 0u) != FX_OK) { problem("fx_osc_receiver_create"); return; }
+        {
+            fx::RealTimeBatchAnalyser analyser(C, N);
+            fx::OSCBatchSender sender("127.0.0.1:" + std::to_string(fx_osc_receiver_port(rx)), "", 2, false);
+            sender.startTimerHz(500);
+            long long framesSeen = 0;
+            {
+                fx::LiveAnalyser live(analyser, 700, 4, 3, 2);
+                live.attachOSCSender(&sender, "/Audio/A", 0);
+                live.setFramesAnalysedCallback([&](int frames, const float*, const float*) { framesSeen += frames; });
+                std::atomic<bool> watching{true};
+                std::atomic<int> settersMade{0};
+                std::thread watcher([&] {                        // a "message thread": reads statistics, and changes settings THROUGH the worker
+                    int k = 0;
+                    while (watching.load()) {
+                        (void) live.getStats(); (void) live.latestSmoothed();
+                        const float g = 0.5f + 0.01f * (float) (k++ % 50);
+                        live.callOnWorker([g, &settersMade](fx::RealTimeBatchAnalyser& a) { a.setGain(g); a.setOnsetDetectionSensitivity(g); settersMade++; });
+                        usleep(300);
+                    }
+                });
+                std::vector<float> block((size_t) C * 700, 0.25f);
+                long long samplesIn = 0, pushedOk = 0;
+                std::thread audio([&] {
+                    unsigned r = 99;
+                    for (int b = 0; b < blocks; b++) {
+                        r = r * 1664525u + 1013904223u;
+                        const int n = 1 + (int) ((r >> 8) % 700u);
+                        if (live.pushBlock(block.data(), n)) { samplesIn += n; pushedOk++; }
+                        if (b % 7 == 0) usleep(200);
+                    }
+                });
+                audio.join();
+                live.drain();
+                watching = false;
+                watcher.join();
+                const fx::LiveAnalyser::Stats st = live.getStats();
+                if (st.errors != 0) problem("the live engine reported an analysis error", live.lastError().c_str());
+                if (settersMade.load() < 1) problem("no queued setter call was made by the worker");
+                if (st.blocksIn != pushedOk || st.blocksAnalysed != pushedOk || st.blocksIn + st.blocksDropped != blocks) problem("blocks not accounted for");
+                if (st.framesPerChannel != samplesIn / H || framesSeen != st.framesPerChannel) problem("frames published differ from the frames the accepted blocks completed");
+                live.stop();
+            }
+            sender.stopTimer();
+        }
+        fx_osc_receiver_destroy(rx);
+    } catch (const std::exception& e) { problem("exception", e.what()); }
+    if (fake_hip_live() != 0) problem("the live engine left device objects behind");
+    std::printf("%-28s clean run (threads only)\n", "live engine");
+}
+
 } // namespace
 
 int main(int argc, char** argv)
@@ -394,6 +459,7 @@ int main(int argc, char** argv)
         walk("ring, large batches x64", ring_large_many_threads, false);
         walk("ring, large batches", ring_large, false);
         osc_threads();
+        live_engine();
     } else {
         walk("batch calls", scenario_batch, true);
         walk("ring, one-launch hop kernel", scenario_ring_hop_kernel, true);
@@ -403,6 +469,7 @@ int main(int argc, char** argv)
         walk("rccl gather", scenario_comm, true);
         walk("block arithmetic", scenario_block_arithmetic, false);
         osc_threads();
+        live_engine();
         // failures of RCCL itself
         void (*reset)(void) = (void (*)(void)) dlsym(RTLD_DEFAULT, "fake_rccl_reset");
         if (!reset) problem("the fake librccl is not the one loaded");

@@ -106,6 +106,7 @@ def test_every_hip_call_site_failed_once_under_asan_and_ubsan(tmp_path, fake_rcc
     # and the arithmetic of fx_push_samples on the host: the hops handed to the (fake) kernels, end to end, are the stream cut at whole hops
     assert any(line.startswith("block arithmetic") and "clean run" in line for line in p.stdout.splitlines()), p.stdout
     assert any(line.startswith("osc sender / receiver") and "clean run" in line for line in p.stdout.splitlines()), p.stdout
+    assert any(line.startswith("live engine") and "clean run" in line for line in p.stdout.splitlines()), p.stdout
 
 
 def test_fill_pool_under_tsan(tmp_path, fake_rccl):
@@ -118,6 +119,7 @@ def test_fill_pool_under_tsan(tmp_path, fake_rccl):
     assert "WARNING: ThreadSanitizer" not in p.stderr, tail
     assert "host_sanitize: 0 problem(s)" in p.stdout, tail
     assert any(line.startswith("osc sender / receiver") and "clean run" in line for line in p.stdout.splitlines()), p.stdout
+    assert any(line.startswith("live engine") and "clean run" in line for line in p.stdout.splitlines()), p.stdout
 
 
 @pytest.mark.parametrize("world, shards, sinks", [
