@@ -24,7 +24,7 @@ EXPORTS = ["fx_create", "fx_destroy", "fx_reset_state", "fx_set_sample_rate", "f
            "fx_get_smoothed", "fx_sync", "fx_get_stream", "fx_last_kernel_ms", "fx_profile_begin", "fx_profile_end",
            "fx_stream_create", "fx_stream_destroy", "fx_stream_acquire", "fx_stream_submit", "fx_stream_push", "fx_stream_collect", "fx_stream_in_flight", "fx_pack_osc12",
            "fx_pack_osc10", "fx_osc_encode", "fx_last_error", "fx_abi_version",
-           "fx_osc_message_bytes", "fx_osc_encode_batch", "fx_get_osc_datagrams", "fx_osc_sender_create", "fx_osc_sender_destroy", "fx_osc_sender_update",
+           "fx_host_alloc", "fx_host_free", "fx_osc_message_bytes", "fx_osc_encode_batch", "fx_get_osc_datagrams", "fx_osc_sender_create", "fx_osc_sender_destroy", "fx_osc_sender_update",
            "fx_osc_sender_send", "fx_osc_sender_start", "fx_osc_sender_stop", "fx_osc_sender_get_stats", "fx_osc_receiver_create", "fx_osc_receiver_destroy",
            "fx_osc_receiver_port", "fx_osc_receiver_get_stats", "fx_osc_receiver_last",
            "fx_comm_unique_id", "fx_comm_create", "fx_comm_destroy", "fx_comm_layout", "fx_gather_smoothed", "fx_comm_sync", "fx_comm_stats",
@@ -172,6 +172,8 @@ def load_library(build_if_missing=True):
     L.fx_osc_encode.argtypes = [ctypes.c_char_p, fp, ctypes.POINTER(ctypes.c_ubyte), i]
     ip = ctypes.POINTER(i)
     ll = ctypes.c_longlong
+    L.fx_host_alloc.argtypes = [ctypes.POINTER(vp), ctypes.c_size_t]
+    L.fx_host_free.argtypes = [vp]
     L.fx_osc_message_bytes.argtypes = [ctypes.c_char_p, i]
     L.fx_osc_encode_batch.argtypes = [ctypes.c_char_p, i, i, fp, vp, i, ip]
     L.fx_get_osc_datagrams.argtypes = [vp, ctypes.c_char_p, i, vp, i, ip, i]

@@ -875,6 +875,24 @@ fx_status fx_get_osc_datagrams(fx_context* c, const char* prefix, int first_chan
     return FX_OK;
 }
 
+fx_status fx_host_alloc(void** out, size_t bytes)
+{
+    if (!out) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null argument");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { (void) hipGetLastError(); return fx_fail(FX_ERR_NO_DEVICE, "no HIP device available (page-locked memory is the runtime's)"); }
+    void* p = nullptr;
+    HIP_TRY(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
+    *out = p;
+    return FX_OK;
+}
+
+fx_status fx_host_free(void* p)
+{
+    if (p) HIP_TRY(hipHostFree(p));
+    return FX_OK;
+}
+
 fx_status fx_sync(fx_context* c)
 {
     if (!c) return fx_fail(FX_ERR_INVALID_ARGUMENT, "null context");

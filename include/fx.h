@@ -165,6 +165,12 @@ fx_status fx_process_frames(fx_context* ctx, const void* frames, int num_frames,
  * OSCFeatureAnalysisOutput.h:91-104). */
 fx_status fx_get_smoothed(fx_context* ctx, float* out, int mem_kind);
 
+/* Page-locked host memory for buffers a host hands to the FX_MEM_HOST entry points again and again (a live engine's block FIFO, its result
+ * buffers): copies to and from it run at the link's rate, where ordinary memory goes through the runtime's staging copy first.  Needs a
+ * device (FX_ERR_NO_DEVICE without one); any thread; free with fx_host_free.  Using it is optional: every entry accepts ordinary memory. */
+fx_status fx_host_alloc(void** out, size_t bytes);
+fx_status fx_host_free(void* p);
+
 /* Wait for all enqueued work of this context.  FX_ERR_HIP if a kernel of this context reported a failed
  * hand-over between work units (the results of that call and of the calls after it are not valid;
  * fx_reset_state clears the condition). */

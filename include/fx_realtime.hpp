@@ -12,8 +12,8 @@
 //   * fx::OSCFeatureAnalysisOutput  -- ref Source/OSCFeatureAnalysisOutput.h:23-145: the 60 Hz timer that sends a track's latest values.
 //   * fx::OSCBatchSender            -- the same sink for thousands of tracks: formed datagrams, sendmmsg, sender threads, one 60 Hz timer.
 //   * fx::LiveAnalyser              -- the live engine: audioDeviceIOCallback on the audio thread NEVER blocks (a copy into a FIFO, as the
-//                                      reference's collector copies into its ring, AudioDataCollector.h:36-70); a worker thread feeds the
-//                                      GPU ring, collects the vectors and publishes them (callback, OSCBatchSender).
+//                                      reference's collector copies into its ring, AudioDataCollector.h:36-70); a worker thread analyses
+//                                      each block straight from its page-locked FIFO slot and publishes (callback, OSCBatchSender).
 // No JUCE.  Errors are thrown as fx::Error (the reference only jasserts).
 #ifndef FX_REALTIME_HPP
 #define FX_REALTIME_HPP
@@ -539,12 +539,13 @@ private:
 // (AudioDataCollector.h:36-70); the analysis thread takes window/2 samples when they are there, analyses and writes AudioFeatures
 // (RealTimeAnalyser.h:141-177, :201-234).  Same split here, for all channels at once:
 //   audio thread   audioDeviceIOCallback / pushBlock: ONE copy of the block into a preallocated FIFO slot and a notify -- no allocation, no
-//                  lock, no HIP call, never waits for the GPU.  A full FIFO (the worker has fallen `fifoBlocks` blocks behind) drops the
-//                  block and counts it, where the reference's writer would overrun the reader (AudioDataCollector.h:96-105).
-//   worker thread  owns every call on the context (fx.h: calls on one context are serialised by the caller): fx_stream_push_samples of
-//                  the next block (pinned ring: samples in, kernels, vectors back overlap), fx_stream_collect_samples of the batches that
-//                  are done, then the publication -- the frames callback (the place of the run() loops' updateFeature calls) and, if an
-//                  OSCBatchSender is attached, every channel's message formed on the GPU from the latest vectors.
+//                  HIP call, never waits for the GPU.  A full FIFO (the worker has fallen `fifoBlocks` blocks behind) drops the block and
+//                  counts it, where the reference's writer would overrun the reader (AudioDataCollector.h:96-105).
+//   worker thread  owns every call on the context (fx.h: calls on one context are serialised by the caller): fx_push_samples of the next
+//                  block STRAIGHT from its FIFO slot -- the slots are page-locked (fx_host_alloc), so the copy to the GPU is the link's DMA
+//                  and there is no second host copy; a block that completes one hop is read by the analysis kernels directly -- then the
+//                  publication: the frames callback (the place of the run() loops' updateFeature calls) and, if an OSCBatchSender is
+//                  attached, every channel's message formed on the GPU from the latest vectors.
 // Latency is recorded per block that completed frames: arrival on the audio thread -> publication.
 // Construct after the analyser, destroy before it.  Link with -pthread.
 class LiveAnalyser
@@ -552,17 +553,21 @@ class LiveAnalyser
 public:
     typedef std::function<void (int frames, const float* raw, const float* smoothed)> FramesCallback;   // [channels][frames][12], worker thread
 
-    LiveAnalyser (RealTimeBatchAnalyser& analyserToFeed, int maxBlockSamples, int fifoBlocks = 8, int ringSlots = 3, int fillThreads = 1)
+    LiveAnalyser (RealTimeBatchAnalyser& analyserToFeed, int maxBlockSamples, int fifoBlocks = 8)
         : analyser (analyserToFeed), channels (analyserToFeed.getNumChannels()), hop (analyserToFeed.getWindowSize() / 2),
-          maxBlock (maxBlockSamples), fill (fillThreads), slots ((std::size_t) (fifoBlocks > 1 ? fifoBlocks : 2))
+          maxBlock (maxBlockSamples), slots ((std::size_t) (fifoBlocks > 1 ? fifoBlocks : 2))
     {
         if (maxBlockSamples < 1) throw Error (FX_ERR_INVALID_ARGUMENT, "maxBlockSamples must be positive");
-        hopsPerBatch = (maxBlockSamples + hop - 1) / hop + 1;                       // what a block plus the pending samples can complete
-        for (Slot& s : slots) s.samples.resize ((std::size_t) channels * (std::size_t) maxBlockSamples);
-        check (fx_stream_create (analyser.handle(), hopsPerBatch, ringSlots, FX_SAMPLE_F32, &ring));
-        depth = ringSlots;
-        rawValues.resize ((std::size_t) channels * (std::size_t) hopsPerBatch * FX_NUM_FEATURES);
-        smoothedValues.resize (rawValues.size());
+        const std::size_t most = (std::size_t) ((maxBlockSamples + hop - 1) / hop + 1);            // frames a block plus the pending samples can complete
+        const std::size_t values = (std::size_t) channels * most * FX_NUM_FEATURES * sizeof (float);
+        try
+        {
+            for (Slot& s : slots) { void* p = nullptr; check (fx_host_alloc (&p, sizeof (float) * (std::size_t) channels * (std::size_t) maxBlockSamples)); s.samples = static_cast<float*> (p); }
+            void* p = nullptr;
+            check (fx_host_alloc (&p, values)); rawValues = static_cast<float*> (p);
+            check (fx_host_alloc (&p, values)); smoothedValues = static_cast<float*> (p);
+        }
+        catch (...) { release(); throw; }
         latencies.reserve (1 << 20);
         running = true;
         worker = std::thread ([this] { run(); });
@@ -570,7 +575,7 @@ public:
     ~LiveAnalyser()
     {
         stop();
-        fx_stream_destroy (ring);
+        release();
     }
     LiveAnalyser (const LiveAnalyser&) = delete;
     LiveAnalyser& operator= (const LiveAnalyser&) = delete;
@@ -582,7 +587,7 @@ public:
         Slot* s = claim();
         if (s == nullptr) return false;
         for (int c = 0; c < channels; ++c)
-            std::memcpy (s->samples.data() + (std::size_t) c * (std::size_t) numberOfSamples, inputChannelData[c], sizeof (float) * (std::size_t) numberOfSamples);
+            std::memcpy (s->samples + (std::size_t) c * (std::size_t) numberOfSamples, inputChannelData[c], sizeof (float) * (std::size_t) numberOfSamples);
         publish (s, numberOfSamples);
         return true;
     }
@@ -592,7 +597,7 @@ public:
         if (numberOfSamples < 0 || numberOfSamples > maxBlock) { dropped++; return false; }
         Slot* s = claim();
         if (s == nullptr) return false;
-        std::memcpy (s->samples.data(), samples, sizeof (float) * (std::size_t) channels * (std::size_t) numberOfSamples);
+        std::memcpy (s->samples, samples, sizeof (float) * (std::size_t) channels * (std::size_t) numberOfSamples);
         publish (s, numberOfSamples);
         return true;
     }
@@ -617,7 +622,7 @@ public:
     void drain()
     {
         std::unique_lock<std::mutex> g (wake);
-        idle.wait (g, [this] { return written.load() == consumed.load() && inFlight.load() == 0 && commands.empty(); });
+        idle.wait (g, [this] { return written.load() == consumed.load() && commands.empty() && ! busyNow; });
     }
     void stop()
     {
@@ -652,8 +657,15 @@ public:
 
 private:
     typedef std::chrono::steady_clock Clock;
-    struct Slot { std::vector<float> samples; int count = 0; Clock::time_point arrived; };
+    struct Slot { float* samples = nullptr; int count = 0; Clock::time_point arrived; };
 
+    void release()
+    {
+        for (Slot& s : slots) { if (s.samples != nullptr) fx_host_free (s.samples); s.samples = nullptr; }
+        if (rawValues != nullptr) fx_host_free (rawValues);
+        if (smoothedValues != nullptr) fx_host_free (smoothedValues);
+        rawValues = smoothedValues = nullptr;
+    }
     // single producer (the audio thread), single consumer (the worker): `written` / `consumed` count blocks, a slot is index mod size
     Slot* claim()
     {
@@ -676,22 +688,19 @@ private:
         errors++;
         errorText = std::string (what) + ": " + fx_last_error();
     }
-    // collect the oldest batch in flight and publish what it completed
-    void collectOne()
+    // one block: analysed straight from its page-locked FIFO slot, then what it completed is published
+    void analyse (Slot& s)
     {
         int got = 0;
-        if (fx_stream_collect_samples (ring, rawValues.data(), smoothedValues.data(), &got) != FX_OK) { fail ("fx_stream_collect_samples"); inFlight--; arrivals.erase (arrivals.begin()); return; }
-        const Clock::time_point arrived = arrivals.front();
-        arrivals.erase (arrivals.begin());
-        inFlight--;
+        if (fx_push_samples (analyser.handle(), s.samples, s.count, FX_SAMPLE_F32, FX_MEM_HOST, rawValues, smoothedValues, &got) != FX_OK) { fail ("fx_push_samples"); return; }
         if (got <= 0) return;
-        if (framesAnalysed) framesAnalysed (got, rawValues.data(), smoothedValues.data());
+        if (framesAnalysed) framesAnalysed (got, rawValues, smoothedValues);
         if (osc != nullptr)
         {
             try { osc->updateFromContext (analyser.handle(), channels, oscPrefix, oscFirst); }
             catch (const Error&) { fail ("fx_get_osc_datagrams"); }
         }
-        const double ms = std::chrono::duration<double, std::milli> (Clock::now() - arrived).count();
+        const double ms = std::chrono::duration<double, std::milli> (Clock::now() - s.arrived).count();
         std::lock_guard<std::mutex> g (statLock);
         frames += got;
         if (latencies.size() < latencies.capacity()) latencies.push_back ((float) ms);
@@ -706,26 +715,21 @@ private:
             std::vector<std::function<void (RealTimeBatchAnalyser&)>> todo;
             {
                 std::unique_lock<std::mutex> g (wake);
-                if (written.load() == consumed.load() && inFlight.load() == 0 && commands.empty()) idle.notify_all();
-                ready.wait (g, [this] { return ! running.load() || written.load() != consumed.load() || inFlight.load() > 0 || ! commands.empty(); });
-                if (! running.load() && written.load() == consumed.load() && inFlight.load() == 0 && commands.empty()) return;
+                busyNow = false;
+                if (written.load() == consumed.load() && commands.empty()) idle.notify_all();
+                ready.wait (g, [this] { return ! running.load() || written.load() != consumed.load() || ! commands.empty(); });
+                if (! running.load() && written.load() == consumed.load() && commands.empty()) return;
                 todo.swap (commands);
+                busyNow = true;
             }
             for (auto& f : todo)                                                    // the other threads' setter calls, in order, between blocks
             {
                 try { f (analyser); } catch (const Error&) { fail ("a call queued with callOnWorker"); }
             }
+            if (written.load (std::memory_order_acquire) == consumed.load()) continue;
             const Clock::time_point t0 = Clock::now();
-            if (written.load (std::memory_order_acquire) != consumed.load())
-            {
-                Slot& s = slots[(std::size_t) (consumed.load() % (long long) slots.size())];
-                if (inFlight.load() >= depth) collectOne();                         // every ring slot is busy: the oldest must come back first
-                if (fx_stream_push_samples (ring, s.samples.data(), s.count, fill) == FX_OK) { arrivals.push_back (s.arrived); inFlight++; }
-                else fail ("fx_stream_push_samples");
-                consumed.fetch_add (1, std::memory_order_release);                  // the slot is the audio thread's again
-            }
-            // nothing waiting: bring back what is in flight (a live stream is one block at a time, and its vectors are wanted now)
-            while (inFlight.load() > 0 && written.load (std::memory_order_acquire) == consumed.load()) collectOne();
+            analyse (slots[(std::size_t) (consumed.load() % (long long) slots.size())]);
+            consumed.fetch_add (1, std::memory_order_release);                      // the slot is the audio thread's again
             const double dt = std::chrono::duration<double> (Clock::now() - t0).count();
             std::lock_guard<std::mutex> g (statLock);
             busy += dt;
@@ -733,22 +737,21 @@ private:
     }
 
     RealTimeBatchAnalyser& analyser;
-    int channels, hop, maxBlock, fill, hopsPerBatch = 1, depth = 3;
-    fx_stream* ring = nullptr;
+    int channels, hop, maxBlock;
     std::vector<Slot> slots;
     std::atomic<long long> written { 0 }, consumed { 0 }, dropped { 0 };
-    std::atomic<int> inFlight { 0 };
-    std::vector<Clock::time_point> arrivals;          // of the batches in flight, oldest first (worker only)
     std::mutex wake;
     std::condition_variable ready, idle;
     std::vector<std::function<void (RealTimeBatchAnalyser&)>> commands;   // guarded by `wake`
+    bool busyNow = false;                                                  // guarded by `wake`: the worker is between taking work and having finished it
     std::atomic<bool> running { false };
     std::thread worker;
     FramesCallback framesAnalysed;
     OSCBatchSender* osc = nullptr;
     std::string oscPrefix;
     int oscFirst = 0;
-    std::vector<float> rawValues, smoothedValues;
+    float* rawValues = nullptr;          // page-locked: fx_push_samples copies the vectors back without a staging copy
+    float* smoothedValues = nullptr;
     std::mutex statLock;
     long long frames = 0, errors = 0;
     double busy = 0.0;

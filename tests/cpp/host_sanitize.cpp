@@ -405,7 +405,7 @@ void live_engine()
             sender.startTimerHz(500);
             long long framesSeen = 0;
             {
-                fx::LiveAnalyser live(analyser, 700, 4, 3, 2);
+                fx::LiveAnalyser live(analyser, 700, 4);
                 live.attachOSCSender(&sender, "/Audio/A", 0);
                 live.setFramesAnalysedCallback([&](int frames, const float*, const float*) { framesSeen += frames; });
                 std::atomic<bool> watching{true};

@@ -1,7 +1,7 @@
 // live_soak.cpp -- the whole live path under a clock, end to end, for minutes:
 //   an "audio device" thread delivers a block of every channel every block/48000 s (480 samples = 10 ms by default)
 //     -> fx::LiveAnalyser::pushBlock (a copy into the FIFO; ref AudioDataCollector.h:36-70)
-//     -> worker: fx_stream_push_samples -> GPU (blocks fed to the one-frame kernels) -> fx_stream_collect_samples   (ref :72-94, RealTimeAnalyser.h:141-234)
+//     -> worker: fx_push_samples straight from the page-locked FIFO slot -> GPU (blocks fed to the one-frame kernels) -> vectors   (ref :72-94, RealTimeAnalyser.h:141-234)
 //     -> fx_get_osc_datagrams (messages formed on the GPU) -> fx::OSCBatchSender, 60 Hz timer, sendmmsg (ref OSCFeatureAnalysisOutput.h:84-136)
 //     -> a local fx_osc_receiver that counts datagrams and keeps each channel's newest message.
 // Reports: blocks dropped at the FIFO, ring / analysis errors, sender drops, late ticks, datagrams sent and received, block-arrival ->
@@ -71,7 +71,7 @@ int main(int argc, char** argv)
         fx_osc_receiver* rx = nullptr;
         fx::check(fx_osc_receiver_create(&rx, "127.0.0.1:0", senderThreads, "/Audio/A", channels, 0u));
         fx::OSCBatchSender sender("127.0.0.1:" + std::to_string(fx_osc_receiver_port(rx)), "", senderThreads, gso != 0);
-        fx::LiveAnalyser live(analyser, block, 8, 3, 2);
+        fx::LiveAnalyser live(analyser, block, 8);
         if (withOsc) live.attachOSCSender(&sender, "/Audio/A", 0);
         sender.startTimerHz(60);
 
