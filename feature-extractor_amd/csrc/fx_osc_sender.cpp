@@ -11,6 +11,7 @@
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/udp.h>
+#include <netdb.h>
 #include <sys/socket.h>
 #include <sys/uio.h>
 #include <unistd.h>
@@ -53,7 +54,15 @@ bool parse_target(const char* text, sockaddr_in* out, int default_port)
     *out = sockaddr_in();
     out->sin_family = AF_INET;
     out->sin_port = htons((unsigned short) port);
-    return inet_pton(AF_INET, s.c_str(), &out->sin_addr) == 1;
+    if (inet_pton(AF_INET, s.c_str(), &out->sin_addr) == 1) return true;
+    // a host name ("localhost", "renderer.local"): juce::OSCSender::connect takes one too
+    addrinfo hints = addrinfo(), *found = nullptr;
+    hints.ai_family = AF_INET;
+    hints.ai_socktype = SOCK_DGRAM;
+    if (s.empty() || getaddrinfo(s.c_str(), nullptr, &hints, &found) != 0 || found == nullptr) return false;
+    out->sin_addr = reinterpret_cast<const sockaddr_in*>(found->ai_addr)->sin_addr;
+    freeaddrinfo(found);
+    return true;
 }
 
 double now_ms()

@@ -137,6 +137,14 @@ def test_sender_without_a_listener_counts_drops_and_survives(fx):
     finally:
         tx.close()
     with pytest.raises(fx.FxError):
-        capi.OscSender("not-an-address")
+        capi.OscSender("not-an-address.invalid")
+    # a host name is resolved, as juce::OSCSender::connect resolves one
+    rx = capi.OscReceiver("127.0.0.1:0", prefix="/Audio/A", keep_channels=64)
+    named = capi.OscSender("localhost:%d" % rx.port)
+    named.update(d, n)
+    assert named.send() == 64
+    time.sleep(0.2)
+    assert rx.stats()["datagrams"] == 64 and rx.last(63) == bytes(d[63, :n[63]])
+    named.close(); rx.close()
     with pytest.raises(fx.FxError):
         capi.OscSender("127.0.0.1:9000", threads=0)
