@@ -1274,9 +1274,27 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
             rec["roofline_frac_sustained"] = out["roofline"]["frac"] * (avg_launch_s * 1e3) / last_ms if last_ms > 0 else None
         return rec
 
+    def live_soak():
+        # The live path end to end under a clock, as a CHILD process (tools/live_soak.cpp, built by __graft_entry__.build(); nothing is exec'ed
+        # from here): 8192 channels x 1024 points, 480-sample device blocks at 48 kHz through fx::LiveAnalyser (page-locked FIFO, the worker
+        # analyses each block in place; the one-frame kernels read the block themselves), messages formed on the GPU, fx::OSCBatchSender's 60 Hz
+        # timer to a local receiver.  Eight seconds after two of warm-up; profiles/r06_soak.txt has the minutes-long runs.
+        import subprocess
+        exe = os.path.join(ROOT, "tools", "_bin", "live_soak")
+        if not os.path.exists(exe):
+            return {"error": "tools/_bin/live_soak not built (__graft_entry__.build())"}
+        p = subprocess.run([exe, "channels=8192", "window=%d" % N, "block=480", "seconds=8", "sender_threads=4"], capture_output=True, text=True, timeout=180)
+        line = [l for l in p.stdout.splitlines() if l.startswith('{"live_soak"')]
+        if not line:
+            return {"error": "live_soak gave no record (rc %d): %s" % (p.returncode, (p.stdout + p.stderr)[-300:])}
+        rec = json.loads(line[-1])["live_soak"]
+        rec["note"] = ("latency = block arrival on the audio thread -> vectors published and every channel's OSC message formed; the 60 Hz timer then sends whatever was published "
+                       "last (0 .. 16.7 ms later, as the reference's timer does); real_time_factor = wall time / the worker's busy time")
+        return rec
+
     table = [("spectral_only", spectral_only), ("data_dependence", data_dependence), ("other_windows", other_windows), ("live_cadence", live_cadence),
              ("device_blocks", device_blocks), ("streaming_hop", streaming_hop), ("stream_ingest", stream_ingest), ("offline", offline),
-             ("osc_sink", osc_sink), ("sustained", sustained)]
+             ("osc_sink", osc_sink), ("sustained", sustained), ("live_soak", live_soak)]
     only = set(args.only_extra.split(",")) if getattr(args, "only_extra", None) else None
     for name, fn in table:
         if only is None or name in only:

@@ -130,6 +130,15 @@ int main(int argc, char** argv)
                     rxn - rxw - lastSent, (double) (rxn - rxw - lastSent) / (double) (sent > 0 ? sent : 1), rxbad, wrong, channels);
         std::printf("  resident memory %ld KB after warm-up, %ld KB at the end (%+ld KB)\n", rss0, rss1, rss1 - rss0);
         const bool ok = st.errors == 0 && st.blocksDropped == warm.blocksDropped && ss.dropped == sw.dropped && (wrong == 0 || ! withOsc) && rxbad == 0 && frames > 0;
+        // one machine-readable line (bench.py's `live_soak` extra reads it)
+        std::printf("{\"live_soak\": {\"channels\": %d, \"window\": %d, \"block\": %d, \"seconds\": %d, \"blocks\": %lld, \"dropped_at_fifo\": %lld, \"errors\": %lld, "
+                    "\"frames_per_s\": %.6g, \"worker_busy_share\": %.4f, \"real_time_factor\": %.3f, \"latency_ms_p50\": %.4f, \"latency_ms_p99\": %.4f, \"latency_ms_max\": %.4f, "
+                    "\"sender_ticks\": %lld, \"sender_late_ticks\": %lld, \"datagrams_per_s\": %.6g, \"sender_dropped\": %lld, \"received_share\": %.6f, \"malformed\": %lld, "
+                    "\"channels_with_wrong_datagram\": %lld, \"rss_kb_after_warmup\": %ld, \"rss_kb_end\": %ld, \"ok\": %s}}\n",
+                    channels, window, block, seconds, blocks, st.blocksDropped - warm.blocksDropped, st.errors, (double) frames * channels / wall,
+                    (st.workerBusySeconds - warm.workerBusySeconds) / wall, wall / (st.workerBusySeconds - warm.workerBusySeconds), st.latencyMsP50, st.latencyMsP99, st.latencyMsMax,
+                    ticks, ss.late_ticks - sw.late_ticks, sent / wall, ss.dropped - sw.dropped, (double) (rxn - rxw - lastSent) / (double) (sent > 0 ? sent : 1), rxbad, wrong, rss0, rss1,
+                    ok ? "true" : "false");
         std::printf("live_soak: %s\n", ok ? "ok" : "FAILED");
         if (! dump.empty()) {
             if (FILE* f = std::fopen(dump.c_str(), "wb")) {
