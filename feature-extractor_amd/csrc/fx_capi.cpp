@@ -285,6 +285,7 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     fp.tw_quarter_turn = (c->tw_quarter_turn && !(c->test_hooks & FX_HOOK_NO_QUARTER_TURN)) ? 1 : 0;
     fp.tw_at_quarter[0] = c->tw_at_quarter[0]; fp.tw_at_quarter[1] = c->tw_at_quarter[1];
     fp.block_mode = 0; fp.blk_carry_bytes = fp.blk_carry_row_bytes = 0; fp.blk_in_row_bytes = 0; fp.blk_carry_in = nullptr; fp.blk_carry_out = nullptr;
+    fp.blk_hop0 = 0; fp.blk_keep_rest = 0; fp.in_hop_stride = 0; fp.in_hop0 = 0;
 
     // Workgroup shape: channels per workgroup x wavefronts per channel (= frames of one channel in flight): the
     // measured-best shape for this window size, fewer waves when the call has fewer frames, fewer channels when the
@@ -323,6 +324,10 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
         // Without the direct form (one analyser only): four (2048 points, 4096 channels x 1 hop 152 us against 193 us with one).
         if (T == 1 && !st->pair && c->tuning.channels_per_workgroup < 1)
             ch = !direct ? 4 : (c->N <= 1024 ? kcap : (c->N == 2048 ? 4 : (c->C >= 2048 ? kcap : 4)));
+        // Two frames per call (a 1024-sample device block against a 1024-point window: the live cadence of hosts with larger buffers): two channels
+        // per workgroup share the twiddle table.  Measured (tools/device_blocks.py, us per call of two hops, channels per workgroup 1 / 2 / 4):
+        // 8192 channels x 1024 points 164.8 / 144.4 / 183.3; 4096 channels x 2048 points 169.8 / 163.5 / 172.9.  Four frames per call: one.
+        if (T == 2 && !st->pair && c->N <= 2048 && c->tuning.channels_per_workgroup < 1) ch = 2;
         if (ch > c->C) ch = c->C;
         while (ch > 1 && (ch * k > kcap || lds_bytes(ch, k) > lds_cu)) ch--;
         while (k > 1 && lds_bytes(ch, k) > lds_cu) k--;
@@ -359,6 +364,7 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     ep.hist_base = (int) (c->frames_seen % fxk::HLEN);
     ep.out_raw = d_or;
     ep.out_smoothed = d_os;
+    ep.out_stride = 0; ep.out_t0 = 0;
     ep.latest = c->d_latest;
     ep.C = c->C;
     ep.T = T;
@@ -465,23 +471,24 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int in_ki
         if (reinterpret_cast<uintptr_t>(in) % (blocks ? 4 : 16) != 0)
             return fx_fail(FX_ERR_INVALID_ARGUMENT, "device input must be %d-byte aligned", blocks ? 4 : 16);
     }
-    if (blocks && (T != 1 || !hop_mode || in_kind != FX_MEM_DEVICE)) return fx_fail(FX_ERR_INVALID_ARGUMENT, "a block feed is one hop per channel from device memory");
+    if (blocks && (T < 1 || T > 2 || !hop_mode || in_kind != FX_MEM_DEVICE)) return fx_fail(FX_ERR_INVALID_ARGUMENT, "a block feed is one or two hops per channel from device memory");
 
-    Step step;
-    if ((st = prepare_step(c, d_in, T, sample_format, hop_mode, d_or, d_os, c->d_part, c->d_raw, nullptr, &step)) != FX_OK) return st;
-    if (blocks) {
-        step.fp.block_mode = 1;
-        step.fp.blk_carry_in = blocks->carry_in;
-        step.fp.blk_carry_out = blocks->carry_out;
-        step.fp.blk_carry_bytes = blocks->carry_bytes;
-        step.fp.blk_carry_row_bytes = blocks->carry_row_bytes;
-        step.fp.blk_in_row_bytes = blocks->in_row_bytes;
-        if (step.pair || step.analysers != 3) return fx_fail(FX_ERR_INVALID_ARGUMENT, "this context's kernels do not read blocks");
-    }
+    // A call of TWO hops per channel (a 1024-sample device buffer against a 1024-point window, 960-sample blocks every other call ...) runs
+    // as two one-frame launches over the same buffers -- the second reads hop 1 and writes frame 1 (FrameParams::in_hop_stride / in_hop0,
+    // EpilogueParams::out_stride / out_t0) -- and, like a one-frame call, records no timing events unless asked to.  Measured
+    // (tools/device_blocks.py, us per call of two hops: batch form with its events / batch form without / two one-frame launches):
+    // 8192 channels x 1024 points 144 / 136.6 / 133.8; 1024 x 1024 52 / 42.6 / 39.7; 4096 x 2048 165 / 154.9 / 157.1; 512 x 2048 - / 50.4 / 46.3;
+    // 1024 x 4096 137 / 127.1 / 123.4; 256 x 4096 - / 66.7 / 57.1.  Most of what a two-hop call cost over two one-hop calls was the three event
+    // records (barrier packets); the launches themselves are worth 0 - 14 %.  What this form really buys is the block feed: a block that
+    // completes two hops is read by the kernels directly (1000-sample blocks at 8192 channels: 177 -> 144 us per call).
+    const bool both = !(c->flags & (FX_SPECTRAL_ONLY | FX_HARMONIC_ONLY));
+    const bool in_two = hop_mode && T == 2 && both && c->N >= 1024 && !uses_pairs(c, c->tuning.waves_per_frame) && !(c->test_hooks & FX_HOOK_NO_TWO_LAUNCHES);
+    const int parts = (blocks || in_two) ? T : 1, part_T = (blocks || in_two) ? 1 : T;
 
     // The three events fx_last_kernel_ms() reads.  Each is a barrier packet between launches, which a call of milliseconds does not
     // notice and a one-frame call does (back to back 27 us per call with them, 14.6 without): those record none unless asked to.
-    const bool timed = c->profiling || c->tuning.call_timing == 1 || (c->tuning.call_timing < 0 && T > 1);
+    // (a call made of one-frame launches is a live call: no events by default, like a one-frame call)
+    const bool timed = c->profiling || c->tuning.call_timing == 1 || (c->tuning.call_timing < 0 && part_T > 1);
 #define FX_EV(e) do { if (timed) HIP_TRY(hipEventRecord(e, c->stream)); } while (0)
     hipEvent_t e0 = c->ev[0], e1 = c->ev[1], e2 = c->ev[2];
     bool last_valid = timed;
@@ -495,6 +502,25 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int in_ki
         c->prof_used += 3;
         last_valid = false;
     }
+    for (int part = 0; part < parts; part++) {
+    const bool first = part == 0, last = part == parts - 1;       // (the events bracket the whole call: frame-kernel time is only split out of one-part calls)
+    Step step;
+    if ((st = prepare_step(c, d_in, part_T, sample_format, hop_mode, d_or, d_os, c->d_part, c->d_raw, nullptr, &step)) != FX_OK) return st;
+    if (parts > 1) {
+        step.fp.in_hop_stride = T; step.fp.in_hop0 = part;
+        step.ep.out_stride = T;    step.ep.out_t0 = part;
+    }
+    if (blocks) {
+        step.fp.block_mode = 1;
+        step.fp.blk_hop0 = part;
+        step.fp.blk_keep_rest = last ? 1 : 0;
+        step.fp.blk_carry_in = blocks->carry_in;
+        step.fp.blk_carry_out = blocks->carry_out;
+        step.fp.blk_carry_bytes = blocks->carry_bytes;
+        step.fp.blk_carry_row_bytes = blocks->carry_row_bytes;
+        step.fp.blk_in_row_bytes = blocks->in_row_bytes;
+        if (step.pair || step.analysers != 3) return fx_fail(FX_ERR_INVALID_ARGUMENT, "this context's kernels do not read blocks");
+    }
     // ONE frame per channel -- the reference's own cadence, an analysis per hop as it arrives (AudioDataCollector.h:66-94,
     // RealTimeAnalyser.h:201-234) -- is one launch of fx_hop_kernel: three wavefronts per channel (pitch / spectral /
     // harmonic) and the hop's tail, instead of one wavefront per channel and a second launch.
@@ -504,16 +530,15 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int in_ki
     // tail on a quarter wavefront per channel: 63 against 120 us at 8192 channels x 1024-pt, 76 against 186 us at 2048 channels x 4096-pt;
     // below it the hop kernel wins, 19.9 against 22.9 us at 1024 x 1024-pt, 58.7 against 61.8 us at 1024 x 4096-pt.  The pair family's
     // hop kernel -- six wavefronts and 100 KB per channel -- keeps 2^20 at every size)
-    const bool one_hop = T == 1 && step.analysers == 3 && fxk::hop_kernel_available(c->N) &&
+    const bool one_hop = part_T == 1 && step.analysers == 3 && fxk::hop_kernel_available(c->N) &&
                          (c->tuning.one_hop_kernel == 1 || (c->tuning.one_hop_kernel < 0 && (long long) c->C * c->N <= ((c->N == 4096 && !step.hop_pairs) ? (1ll << 22) : (1ll << 20))));
     if (one_hop) {
         const fxk::HopSignal none = {nullptr, nullptr, 0u, 0u, nullptr};
-        FX_EV(e0);
+        if (first) FX_EV(e0);
         HIP_TRY(fxk::launch_hop_kernel(c->N, step.fp, step.ep, none, c->stream, step.hop_pairs));
-        FX_EV(e1);
-        FX_EV(e2);
+        if (last) { FX_EV(e1); FX_EV(e2); }
     } else {
-        FX_EV(e0);
+        if (first) FX_EV(e0);
         // One frame per channel through the batch kernels: frames and tails in ONE launch (fx_frame_tail_kernel) while the chip holds all
         // of the call's workgroups at once -- two per CU at these sizes, one of eight channels at 4096 points.  Beyond that a workgroup whose
         // first wavefronts are finishing its hops keeps the LDS the next workgroup is waiting for, and the tail is better off as a launch
@@ -526,17 +551,18 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int in_ki
                                 ((c->test_hooks & FX_HOOK_TAIL_ALWAYS_FUSED) || (!(c->test_hooks & FX_HOOK_TAIL_NEVER_FUSED) && groups <= one_round));
         if (one_launch) {
             HIP_TRY(fxk::launch_frame_tail_kernel(c->N, step.fp, step.ep, c->stream));
-            FX_EV(e1);
+            if (last) FX_EV(e1);
         } else {
             HIP_TRY(launch_frames(c, step));
-            FX_EV(e1);
+            if (last) FX_EV(e1);
             HIP_TRY(fxk::launch_epilogue_kernels(step.ep, c->stream));
         }
-        FX_EV(e2);
+        if (last) FX_EV(e2);
+    }
+    advance(c, part_T);
     }
 #undef FX_EV
     c->ev_valid = last_valid;
-    advance(c, T);
 
     if (out_kind == FX_MEM_HOST) {
         if (out_raw) HIP_TRY(hipMemcpyAsync(out_raw, c->d_out_raw, raw_bytes, hipMemcpyDeviceToHost, c->stream));
@@ -781,17 +807,18 @@ fx_status fx_push_samples(fx_context* c, const void* samples, int num_samples, i
     } else if (reinterpret_cast<uintptr_t>(samples) % 4 != 0) {
         return fx_fail(FX_ERR_INVALID_ARGUMENT, "device input must be 4-byte aligned (16-byte aligned to be analysed in place)");
     }
-    if (hops == 1 && blocks_feed_kernels(c)) {
-        // The live case -- a device block of 441 / 480 / 512 ... samples completes exactly one hop: the one-frame kernels read their window
-        // from [pending | block] directly and leave the rest in the other carry buffer.  No pass over the samples beside the analysis.
+    if ((hops == 1 || hops == 2) && blocks_feed_kernels(c)) {
+        // The live case -- a device block of 441 / 480 / 512 ... samples completes exactly one hop (or a 960- / 1000- / 1024-sample one two): the
+        // one-frame kernels read their window from [pending | block] directly, one launch per hop, and the last leaves the rest in the other
+        // carry buffer.  No pass over the samples beside the analysis.
         const BlockFeed feed = {c->d_carry[c->carry_cur], c->d_carry[c->carry_cur ^ 1], (int) ((size_t) c->carry_count * esz), H * 4,
                                 (long long) num_samples * (long long) esz};
-        st = run(c, d_block, 1, sample_format, FX_MEM_DEVICE, mem_kind, 1, out_raw, out_smoothed, &feed);
-        if (st != FX_OK) return st;             // (nothing was launched: the pending samples are what they were, the block is lost)
+        st = run(c, d_block, hops, sample_format, FX_MEM_DEVICE, mem_kind, 1, out_raw, out_smoothed, &feed);
+        if (st != FX_OK) return st;             // (the stream is no longer the caller's: fx_reset_state, as the contract says)
         c->carry_cur ^= 1;
         c->carry_count = rest;
         c->carry_format = sample_format;
-        if (frames_out) *frames_out = 1;
+        if (frames_out) *frames_out = hops;
         return FX_OK;
     }
     const size_t hop_bytes = (size_t) c->C * (size_t) hops * H * esz;

@@ -112,7 +112,7 @@ __device__ __forceinline__ void load_half(const void* src, int sample_format, fl
 // fx_blocks.hip.h) instead of a hop at src_b.
 template <int N, int FMT_A, int FMT_B, bool BLOCKS = false>
 __device__ __forceinline__ double load_window(const void* src_a, const void* src_b, float gain_a, float gain_b,
-                                              float* rbuf, float* tail_out, int lane, const BlockStream* bs = nullptr)
+                                              float* rbuf, float* tail_out, int lane, const BlockStream* bs = nullptr, int hop0 = 0)
 {
     double ssq = 0.0;           // this lane's share of getRMSLevel's sum (ref RealTimeAnalyser.h:207): float squares, double sum
     constexpr int HALF = N / 2, QH = HALF / 256;
@@ -121,7 +121,7 @@ __device__ __forceinline__ double load_window(const void* src_a, const void* src
     for (int q = 0; q < QH; q++) ra[q] = fetch_four<FMT_A>(src_a, 256 * q + 4 * lane);
 #pragma unroll
     for (int q = 0; q < QH; q++) {
-        if constexpr (BLOCKS) rb[q] = stream_four<sample_bytes(FMT_B)>(*bs, 256 * q + 4 * lane);
+        if constexpr (BLOCKS) rb[q] = stream_four<sample_bytes(FMT_B)>(*bs, hop0 + 256 * q + 4 * lane);
         else                  rb[q] = fetch_four<FMT_B>(src_b, 256 * q + 4 * lane);
     }
 #pragma unroll
@@ -147,7 +147,7 @@ __device__ __forceinline__ double load_window(const void* src_a, const void* src
 // the spectral and the harmonic analyser need it).  For a fixed (g, j) the 64 lanes read 64 consecutive samples.
 template <int N, int FMT_A, int FMT_B, bool LAST_USE = false, bool BLOCKS = false>
 __device__ __forceinline__ void load_window_first_pass_order(const void* src_a, const void* src_b, float gain_a, float gain_b,
-                                                             int lane, float (&x)[Geo<N>::P], const BlockStream* bs = nullptr)
+                                                             int lane, float (&x)[Geo<N>::P], const BlockStream* bs = nullptr, int hop0 = 0)
 {
     typedef Geo<N> G;
     // sample index = rev4(lane + 64*g) + ITEMS_A*r(j), and rev4(lane + 64*g) = rev4(lane) + g (lane's three base-4 digits
@@ -168,7 +168,7 @@ __device__ __forceinline__ void load_window_first_pass_order(const void* src_a, 
             if constexpr (BLOCKS) {
                 if (second) {
                     // (the sample's place in the stream decides which of its two pieces holds it: a compare and two selects per load)
-                    x[g * G::RA + j] = widen_one<FMT_B, LAST_USE>(stream_sample<sample_bytes(FMT_B)>(*bs, (int) low + k));
+                    x[g * G::RA + j] = widen_one<FMT_B, LAST_USE>(stream_sample<sample_bytes(FMT_B)>(*bs, hop0 + (int) low + k));
                     continue;
                 }
             }
@@ -361,7 +361,7 @@ template <int N, bool DIRECT = false, bool HOIST = false, bool WIDE = false, boo
     struct HarmonicSpectrum { float hre[U]; float left2, left1, right1; double sum, max; };
 
     // where the two halves of this frame's window come from (a1, ref RealTimeAudioAnalysis.h:205-219)
-    struct Sources { const void* a; const void* b; float gain_a, gain_b; int fmt_a, fmt_b; BlockStream bs; };
+    struct Sources { const void* a; const void* b; float gain_a, gain_b; int fmt_a, fmt_b; BlockStream bs; int hop0; };   // hop0: BLOCKS, first sample of the hop in the stream
     __device__ __forceinline__ Sources sources() const
     {
         const size_t esz = (size_t) sample_bytes(p.sample_format);
@@ -374,13 +374,16 @@ template <int N, bool DIRECT = false, bool HOIST = false, bool WIDE = false, boo
             s.b = nullptr; s.gain_b = p.gain;
             s.bs = BlockStream{p.blk_carry_in + (size_t) c * (size_t) p.blk_carry_row_bytes, in + (size_t) c * (size_t) p.blk_in_row_bytes,
                                p.blk_carry_bytes, p.blk_in_row_bytes};
+            s.hop0 = p.blk_hop0 * HALF;
             return s;
         }
+        s.hop0 = 0;
         if (p.hop_mode) {
             s.gain_a = s.gain_b = p.gain;
-            s.b = in + ((size_t) c * T + t) * HALF * esz;
+            const size_t row = (size_t) c * (size_t) (p.in_hop_stride ? p.in_hop_stride : T) + (size_t) p.in_hop0;    // (one-frame launches over several hops)
+            s.b = in + (row + t) * HALF * esz;
             if (t == 0) { s.a = p.tail_in + (size_t) c * HALF; s.fmt_a = FX_SAMPLE_F32; s.gain_a = 1.0f; }   // tail is fp32, already gained
-            else        s.a = in + ((size_t) c * T + (t - 1)) * HALF * esz;
+            else        s.a = in + (row + (t - 1)) * HALF * esz;
         } else {
             s.gain_a = s.gain_b = 1.0f;
             s.a = in + ((size_t) c * T + t) * N * esz;
@@ -395,7 +398,7 @@ template <int N, bool DIRECT = false, bool HOIST = false, bool WIDE = false, boo
     {
         asm volatile("" ::: "memory");        // a fetch of its own each time: the point is not to keep x live in between
         const Sources s = sources();
-        FX_FORMATS(s.fmt_a, s.fmt_b, (load_window_first_pass_order<N, FA, FB, LAST_USE, BLOCKS>(s.a, s.b, s.gain_a, s.gain_b, lane, x, &s.bs)));
+        FX_FORMATS(s.fmt_a, s.fmt_b, (load_window_first_pass_order<N, FA, FB, LAST_USE, BLOCKS>(s.a, s.b, s.gain_a, s.gain_b, lane, x, &s.bs, s.hop0)));
     }
 
     // returns the lane's share of the frame's sum of squares (split sizes only; otherwise sum_squares() computes it)
@@ -410,7 +413,7 @@ FX_MARK("load");
             const void* src_a = sr.a; const void* src_b = sr.b;
             const float gain_a = sr.gain_a, gain_b = sr.gain_b;
             if constexpr (N >= 512) {
-                FX_FORMATS(sr.fmt_a, sr.fmt_b, (ssq = load_window<N, FA, FB, BLOCKS>(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane, &sr.bs)));
+                FX_FORMATS(sr.fmt_a, sr.fmt_b, (ssq = load_window<N, FA, FB, BLOCKS>(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane, &sr.bs, sr.hop0)));
             } else {
                 load_half<N, HALF>(src_a, sr.fmt_a, gain_a, gain_a != 1.0f, rbuf, 0, nullptr, lane);
                 load_half<N, HALF>(src_b, sr.fmt_b, gain_b, gain_b != 1.0f, rbuf, HALF, tail_dst, lane);
@@ -1236,7 +1239,9 @@ __device__ __forceinline__ void frame_kernel_body(const FrameParams& p_arg)
         // at 8192 channels x 1024 points (tools/ab_blocks.sh): here, right behind the window's loads, or with its loads issued in front of
         // the window's and its stores behind them (8 - 32 more registers across the load stage: scratch at 4096 points) -- 66.5 us per call
         // all three.  What did matter was the row's last piece (stream_piece16): byte by byte it cost 1.7 us per launch.
-        if constexpr (BLOCKS) stream_keep_rest(w.sources().bs, (long long) (N / 2) * sample_bytes(p.sample_format), p.blk_carry_out + (size_t) c * (size_t) p.blk_carry_row_bytes, lane, 64);
+        if constexpr (BLOCKS)
+            if (p.blk_keep_rest)
+                stream_keep_rest(w.sources().bs, (long long) (p.blk_hop0 + 1) * (N / 2) * sample_bytes(p.sample_format), p.blk_carry_out + (size_t) c * (size_t) p.blk_carry_row_bytes, lane, 64);
     }
 
     if constexpr (DIRECT) return;                       // (the flux state was replaced in place)

@@ -115,7 +115,8 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
             // estimate (in the prologue the copy's trip to memory stood in front of all three: 20.7 us per launch against 18.8)
             const BlockStream bs{p.blk_carry_in + (size_t) c * (size_t) p.blk_carry_row_bytes, static_cast<const unsigned char*>(p.in) + (size_t) c * (size_t) p.blk_in_row_bytes,
                                  p.blk_carry_bytes, p.blk_in_row_bytes};
-            stream_keep_rest(bs, (long long) (N / 2) * sample_bytes(p.sample_format), p.blk_carry_out + (size_t) c * (size_t) p.blk_carry_row_bytes, lane, 64);
+            if (p.blk_keep_rest)
+                stream_keep_rest(bs, (long long) (p.blk_hop0 + 1) * (N / 2) * sample_bytes(p.sample_format), p.blk_carry_out + (size_t) c * (size_t) p.blk_carry_row_bytes, lane, 64);
         }
     } else {
         float xr[P];

@@ -99,11 +99,16 @@ struct FrameParams {
     float        tw_at_quarter[2];  // canonical[N/4] = ((float) cos(pi/2), -1): the one entry of those that is never a quarter turn of another
     float        first_tw[18];  // the <= 9 twiddles of the first FFT pass (re, im pairs): wave-uniform, so they travel as
                                 // kernel arguments (SGPRs) instead of LDS reads; filled by fill_first_pass_twiddles
+    // One-frame launches over a buffer of SEVERAL hops per channel (a call of two hops runs as two one-frame launches: measured faster than
+    // the batch form at every size): hop-mode input is read as [C][in_hop_stride][N/2] at hop in_hop0 (+ t).  in_hop_stride == 0: [C][T][N/2].
+    int          in_hop_stride, in_hop0;
     // fx_push_samples without the re-blocking pass (block_mode = 1; one-frame forms of windows >= 1024 points, both analysers: T == 1,
     // hop_mode == 1): `in` holds every channel's new BLOCK, rows of blk_in_row_bytes back to back; the hop a channel analyses is the
     // first N/2 samples of [its pending samples: blk_carry_in row, blk_carry_bytes valid | its block], and the kernel writes what is left
     // over to the channel's row of blk_carry_out (fx_blocks.hip.h).  Last in the struct: the other forms never look at these.
     int          block_mode;
+    int          blk_hop0;      // the hop analysed is hop blk_hop0 of the stream (a call that completes two hops is two one-frame launches)
+    int          blk_keep_rest; // this launch writes what the block leaves over (the call's last launch)
     int          blk_carry_bytes, blk_carry_row_bytes;
     long long    blk_in_row_bytes;
     const unsigned char* blk_carry_in;
@@ -128,6 +133,8 @@ struct EpilogueParams {
     int          hist_base;     // frames_before mod HLEN: the ring row this call's first frame goes to
     float*       out_raw;       // [C][T][12] or nullptr
     float*       out_smoothed;  // [C][T][12] or nullptr
+    int          out_stride;    // one-frame launches: the output buffers are [C][out_stride][12] and this launch's frame is number out_t0 of its
+    int          out_t0;        // channel (a call of two hops = two one-frame launches); out_stride == 0: [C][T][12], frame t
     float*       latest;        // [C][12] smoothed values after the last frame
     int          C, T;
     long long    frames_before; // frames analysed since the last state reset, before this call
@@ -239,11 +246,13 @@ hipError_t launch_hop_kernel(int window_size, const FrameParams& p, const Epilog
 //      chip holds the call's workgroups at once)
 //   4  fx_push_samples never feeds a block to the one-frame kernels directly (FrameParams::block_mode): every call re-blocks first, as
 //      calls that complete several hops do
+//   5  a call of two hops per channel runs the batch kernels' two-frame form instead of two one-frame launches
 // None changes a result bit (bit 0 makes the call fail, as it must).
 #define FX_HOOK_NO_HANDOVER      1u
 #define FX_HOOK_NO_QUARTER_TURN  2u
 #define FX_HOOK_TAIL_NEVER_FUSED 4u
 #define FX_HOOK_TAIL_ALWAYS_FUSED 8u
 #define FX_HOOK_NO_BLOCK_FEED    16u
+#define FX_HOOK_NO_TWO_LAUNCHES  32u
 extern "C" fx_status fx_set_tuning_internal(fx_context* ctx, unsigned test_hooks);
 #endif

@@ -420,7 +420,7 @@ __device__ __forceinline__ void epilogue_hop(const EpilogueParams& p, int c, int
             sm = (harm_slot ? harm : spec) ? total / (float) rec10 : never;
         }
     }
-    const size_t o = ((size_t) c * p.T + t) * FX_NUM_FEATURES;
+    const size_t o = p.out_stride ? ((size_t) c * (size_t) p.out_stride + (size_t) p.out_t0) * FX_NUM_FEATURES : ((size_t) c * p.T + t) * FX_NUM_FEATURES;
     // (Round 3 also tried the twelve slots as three 16-byte stores per vector -- a one-hop call's results go to a pinned host slot,
     // every store a transaction across PCIe: no measurable difference in the hop's round trip, not kept.)
     if (!mine || !live) return;

@@ -185,18 +185,30 @@ namespace {
 std::vector<unsigned char> g_block_hops;
 fxk::FrameParams from_blocks(const fxk::FrameParams& p, int window)
 {
-    if (!p.block_mode) return p;
+    if (!p.block_mode) {
+        if (!p.in_hop_stride || !p.hop_mode || !p.in) return p;
+        // a one-frame launch over a buffer of several hops per channel: hand the log the hop it reads
+        const size_t esz = p.sample_format == FX_SAMPLE_F32 ? 4 : (p.sample_format == FX_SAMPLE_S24 ? 3 : 2);
+        const size_t hop = (size_t) (window / 2) * esz;
+        g_block_hops.assign((size_t) p.C * hop, 0);
+        const unsigned char* in = static_cast<const unsigned char*>(p.in);
+        for (int c = 0; c < p.C; c++) memcpy(&g_block_hops[(size_t) c * hop], in + ((size_t) c * (size_t) p.in_hop_stride + (size_t) p.in_hop0) * hop, hop);
+        fxk::FrameParams q = p;
+        q.in = g_block_hops.data(); q.in_hop_stride = 0; q.in_hop0 = 0;
+        return q;
+    }
     const size_t esz = p.sample_format == FX_SAMPLE_F32 ? 4 : (p.sample_format == FX_SAMPLE_S24 ? 3 : 2);
     const size_t hop = (size_t) (window / 2) * esz;
     const size_t total = (size_t) p.blk_carry_bytes + (size_t) p.blk_in_row_bytes;
-    if (p.T != 1 || !p.hop_mode || total < hop || total >= 2 * hop || total - hop > (size_t) p.blk_carry_row_bytes) { fprintf(stderr, "fake hip: a block feed that is not one hop\n"); int* boom = nullptr; *boom = 1; }
+    const size_t from = (size_t) p.blk_hop0 * hop;
+    if (p.T != 1 || !p.hop_mode || total < from + hop || (p.blk_keep_rest && (total >= from + 2 * hop || total - from - hop > (size_t) p.blk_carry_row_bytes))) { fprintf(stderr, "fake hip: a block feed that is not one hop\n"); int* boom = nullptr; *boom = 1; }
     g_block_hops.assign((size_t) p.C * hop, 0);
     const unsigned char* in = static_cast<const unsigned char*>(p.in);
     for (int c = 0; c < p.C; c++)
-        for (size_t d = 0; d < total; d++) {
+        for (size_t d = from; d < (p.blk_keep_rest ? total : from + hop); d++) {
             const unsigned char v = d < (size_t) p.blk_carry_bytes ? p.blk_carry_in[(size_t) c * p.blk_carry_row_bytes + d] : in[(size_t) c * (size_t) p.blk_in_row_bytes + (d - p.blk_carry_bytes)];
-            if (d < hop) g_block_hops[(size_t) c * hop + d] = v;
-            else p.blk_carry_out[(size_t) c * p.blk_carry_row_bytes + (d - hop)] = v;
+            if (d < from + hop) g_block_hops[(size_t) c * hop + (d - from)] = v;
+            else p.blk_carry_out[(size_t) c * p.blk_carry_row_bytes + (d - from - hop)] = v;
         }
     fxk::FrameParams q = p;
     q.in = g_block_hops.data();

@@ -349,3 +349,68 @@ def test_the_applications_own_stepping_replayed_hop_by_hop(gpu_fx):
         signals.assert_features_close(raw, g[name + "_raw"], 1e-5, fo.FEATURE_NAMES, name + " raw")
         signals.assert_features_close(sm, g[name + "_smoothed"], 1e-5, fo.FEATURE_NAMES, name + " smoothed")
         an.close()
+
+
+@pytest.mark.parametrize("N", [1024, 2048, 4096])
+@pytest.mark.parametrize("fmt", ["f32", "s16", "s24"])
+def test_two_hop_calls_as_two_one_frame_launches_equal_the_batch_form_bitwise(gpu_fx, N, fmt):
+    """Round 6: a call of exactly two hops per channel (a 1024-sample device buffer against a 1024-point window; 960-sample blocks every
+    other call) runs as two one-frame launches over the same buffers -- fx_push_hops reads hop 1 / writes frame 1 of [C][2][..] in the second
+    launch, fx_push_samples feeds the block to both and the second leaves the rest.  Against the batch kernels' two-frame form (test hook 32)
+    and the re-blocked path (hook 16 | 32): vectors, pending samples and the state afterwards, bit for bit, for each of the three one-frame
+    kernels, host and device memory."""
+    import torch
+    C, H = 9, N // 2
+    total = 12 * H + 5
+    x = signals.tone_vibrato_noise(C, 13, N, seed=N + 1).reshape(C, -1)[:, :total]
+    if fmt == "s16":
+        stream, per = np.clip(np.round(x * 32768.0), -32768, 32767).astype(np.int16), 1
+    elif fmt == "s24":
+        stream, per = np.asarray(gpu_fx.pack_s24(np.clip(np.round(x * 8388608.0), -2 ** 23, 2 ** 23 - 1).astype(np.int32))), 3
+    else:
+        stream, per = x, 1
+    sf = "s24" if fmt == "s24" else None
+    rng = np.random.default_rng(N)
+    lengths, at = [], 0
+    while at < total:                              # blocks of 1.5 .. 2.5 hops: calls complete one, two or three hops
+        n = min(int(rng.integers(H + H // 2, 2 * H + H // 2)), total - at)
+        lengths.append(n); at += n
+
+    def feed_blocks_(an, device):
+        raws, at = [], 0
+        for n in lengths:
+            piece = np.ascontiguousarray(stream[:, per * at:per * (at + n)])
+            r, s = an.push_samples(torch.from_numpy(piece).cuda() if device else piece, sample_format=sf)
+            raws.append((r.cpu().numpy(), s.cpu().numpy()) if hasattr(r, "cpu") else (r, s))
+            at += n
+        return np.concatenate([r for r, _ in raws], 1), np.concatenate([s for _, s in raws], 1), an.pending_samples(), an.get_features()
+
+    def feed_pairs(an, device):
+        hops = np.ascontiguousarray(stream[:, :per * 12 * H]).reshape(C, 12, per * H)
+        if fmt == "s24":
+            hops = gpu_fx.pack_s24(np.clip(np.round(x[:, :12 * H].reshape(C, 12, H) * 8388608.0), -2 ** 23, 2 ** 23 - 1).astype(np.int32))
+        out = []
+        for t in range(0, 12, 2):
+            piece = hops[:, t:t + 2]
+            r, s = an.push_hops(torch.from_numpy(np.ascontiguousarray(piece)).cuda() if (device and fmt != "s24") else piece)
+            out.append((r.cpu().numpy(), s.cpu().numpy()) if hasattr(r, "cpu") else (r, s))
+        return np.concatenate([r for r, _ in out], 1), np.concatenate([s for _, s in out], 1), an.get_features()
+
+    ref = gpu_fx.BatchAnalyser(C, N); ref.set_gain(1.5); ref.set_test_hooks(16 | 32)
+    want_blocks = feed_blocks_(ref, False); ref.close()
+    ref = gpu_fx.BatchAnalyser(C, N); ref.set_gain(1.5); ref.set_test_hooks(32)
+    want_pairs = feed_pairs(ref, False); ref.close()
+    assert same(want_pairs[0], want_blocks[0][:, :12])            # the same stream either way
+    for name, knobs in {"hop kernel": dict(one_hop_kernel=1), "frames + tails in one launch": dict(one_hop_kernel=0, hooks=8),
+                        "frame kernel, then the tail kernel": dict(one_hop_kernel=0, hooks=4)}.items():
+        for device in ((False, True) if fmt != "s24" else (False,)):
+            an = gpu_fx.BatchAnalyser(C, N); an.set_gain(1.5)
+            an.set_tuning(one_hop_kernel=knobs["one_hop_kernel"]); an.set_test_hooks(knobs.get("hooks", 0))
+            got = feed_blocks_(an, device)
+            assert got[2] == want_blocks[2] and all(same(g, w) for g, w in zip((got[0], got[1], got[3]), (want_blocks[0], want_blocks[1], want_blocks[3]))), (N, fmt, name, device, "blocks")
+            an.close()
+            an = gpu_fx.BatchAnalyser(C, N); an.set_gain(1.5)
+            an.set_tuning(one_hop_kernel=knobs["one_hop_kernel"]); an.set_test_hooks(knobs.get("hooks", 0))
+            got = feed_pairs(an, device)
+            assert all(same(g, w) for g, w in zip(got, want_pairs)), (N, fmt, name, device, "two hops per call")
+            an.close()

@@ -18,6 +18,8 @@ def main():
     an = fx.BatchAnalyser(C, N)
     if len(sys.argv) > 5 and sys.argv[5] == "reblock":
         an.set_test_hooks(16)                   # FX_HOOK_NO_BLOCK_FEED: every call through fx_reblock_kernel, as before round 6
+    elif len(sys.argv) > 5 and sys.argv[5].startswith("hooks="):
+        an.set_test_hooks(int(sys.argv[5][6:]))  # e.g. hooks=32: two-hop calls through the batch kernels' two-frame form
     g = torch.Generator(device="cuda").manual_seed(1)
     pieces = [(torch.rand((C, n), generator=g, device="cuda") - 0.5) for _ in range(min(blocks, 8))]
     moved = 0
