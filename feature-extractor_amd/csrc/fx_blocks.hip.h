@@ -22,6 +22,16 @@ struct __attribute__((packed, aligned(4))) dwords4 { unsigned x, y, z, w; };
 struct __attribute__((packed, aligned(4))) dwords3 { unsigned x, y, z; };
 struct __attribute__((packed, aligned(4))) dwords2 { unsigned x, y; };
 
+// the same stream from byte `shift` on (a multiple of 16: whole hops): wave-uniform arithmetic, so a launch that analyses hop k of a block
+// pays for it in scalar registers, not in every lane's addresses
+__device__ __forceinline__ BlockStream stream_from(const BlockStream& s, long long shift)
+{
+    BlockStream r = s;
+    if (shift < s.carry_bytes) { r.carry_row += shift; r.carry_bytes -= (int) shift; }
+    else { r.block_row += shift - s.carry_bytes; r.in_row_bytes -= shift - s.carry_bytes; r.carry_bytes = 0; }
+    return r;
+}
+
 // byte s of the stream (s < carry_bytes + in_row_bytes)
 __device__ __forceinline__ unsigned stream_byte(const BlockStream& s, long long at)
 {

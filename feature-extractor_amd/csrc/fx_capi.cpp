@@ -480,7 +480,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int in_ki
     // 8192 channels x 1024 points 144 / 136.6 / 133.8; 1024 x 1024 52 / 42.6 / 39.7; 4096 x 2048 165 / 154.9 / 157.1; 512 x 2048 - / 50.4 / 46.3;
     // 1024 x 4096 137 / 127.1 / 123.4; 256 x 4096 - / 66.7 / 57.1.  Most of what a two-hop call cost over two one-hop calls was the three event
     // records (barrier packets); the launches themselves are worth 0 - 14 %.  What this form really buys is the block feed: a block that
-    // completes two hops is read by the kernels directly (1000-sample blocks at 8192 channels: 177 -> 144 us per call).
+    // completes two hops is read by the kernels directly (1000-sample blocks at 8192 channels: 177 -> 132 us per call).
     const bool both = !(c->flags & (FX_SPECTRAL_ONLY | FX_HARMONIC_ONLY));
     const bool in_two = hop_mode && T == 2 && both && c->N >= 1024 && !uses_pairs(c, c->tuning.waves_per_frame) && !(c->test_hooks & FX_HOOK_NO_TWO_LAUNCHES);
     const int parts = (blocks || in_two) ? T : 1, part_T = (blocks || in_two) ? 1 : T;

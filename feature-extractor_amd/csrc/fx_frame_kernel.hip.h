@@ -372,9 +372,10 @@ template <int N, bool DIRECT = false, bool HOIST = false, bool WIDE = false, boo
             // T == 1, t == 0: the carried-over tail and the stream's first hop
             s.a = p.tail_in + (size_t) c * HALF; s.fmt_a = FX_SAMPLE_F32; s.gain_a = 1.0f;
             s.b = nullptr; s.gain_b = p.gain;
-            s.bs = BlockStream{p.blk_carry_in + (size_t) c * (size_t) p.blk_carry_row_bytes, in + (size_t) c * (size_t) p.blk_in_row_bytes,
-                               p.blk_carry_bytes, p.blk_in_row_bytes};
-            s.hop0 = p.blk_hop0 * HALF;
+            // (the stream from THIS launch's hop on: hop 0 of it is the hop analysed, what lies behind it is what the last launch keeps)
+            s.bs = stream_from(BlockStream{p.blk_carry_in + (size_t) c * (size_t) p.blk_carry_row_bytes, in + (size_t) c * (size_t) p.blk_in_row_bytes,
+                                           p.blk_carry_bytes, p.blk_in_row_bytes}, (long long) p.blk_hop0 * HALF * (long long) esz);
+            s.hop0 = 0;
             return s;
         }
         s.hop0 = 0;
@@ -1241,7 +1242,7 @@ __device__ __forceinline__ void frame_kernel_body(const FrameParams& p_arg)
         // all three.  What did matter was the row's last piece (stream_piece16): byte by byte it cost 1.7 us per launch.
         if constexpr (BLOCKS)
             if (p.blk_keep_rest)
-                stream_keep_rest(w.sources().bs, (long long) (p.blk_hop0 + 1) * (N / 2) * sample_bytes(p.sample_format), p.blk_carry_out + (size_t) c * (size_t) p.blk_carry_row_bytes, lane, 64);
+                stream_keep_rest(w.sources().bs, (long long) (N / 2) * sample_bytes(p.sample_format), p.blk_carry_out + (size_t) c * (size_t) p.blk_carry_row_bytes, lane, 64);
     }
 
     if constexpr (DIRECT) return;                       // (the flux state was replaced in place)

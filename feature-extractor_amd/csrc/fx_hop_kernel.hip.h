@@ -113,10 +113,11 @@ fx_hop_kernel(const FrameParams p_arg, const EpilogueParams ep_arg, const HopSig
         if constexpr (BLOCKS) {
             // what the block leaves over becomes the channel's pending samples: this wavefront is done and the hop still waits for the pitch
             // estimate (in the prologue the copy's trip to memory stood in front of all three: 20.7 us per launch against 18.8)
-            const BlockStream bs{p.blk_carry_in + (size_t) c * (size_t) p.blk_carry_row_bytes, static_cast<const unsigned char*>(p.in) + (size_t) c * (size_t) p.blk_in_row_bytes,
-                                 p.blk_carry_bytes, p.blk_in_row_bytes};
-            if (p.blk_keep_rest)
-                stream_keep_rest(bs, (long long) (p.blk_hop0 + 1) * (N / 2) * sample_bytes(p.sample_format), p.blk_carry_out + (size_t) c * (size_t) p.blk_carry_row_bytes, lane, 64);
+            const long long hop_bytes = (long long) (N / 2) * sample_bytes(p.sample_format);
+            const BlockStream bs = stream_from(BlockStream{p.blk_carry_in + (size_t) c * (size_t) p.blk_carry_row_bytes,
+                                                           static_cast<const unsigned char*>(p.in) + (size_t) c * (size_t) p.blk_in_row_bytes, p.blk_carry_bytes, p.blk_in_row_bytes},
+                                               (long long) p.blk_hop0 * hop_bytes);
+            if (p.blk_keep_rest) stream_keep_rest(bs, hop_bytes, p.blk_carry_out + (size_t) c * (size_t) p.blk_carry_row_bytes, lane, 64);
         }
     } else {
         float xr[P];
