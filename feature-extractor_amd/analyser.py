@@ -453,7 +453,9 @@ class HopStream:
 
     def push_samples(self, samples, fill_threads=1):
         """A block of n samples per channel, [C][n] with 0 <= n <= hops_per_batch * window_size / 2 (a device callback's block), into the
-        next slot: fx_stream_push_samples.  collect_samples() returns what the context's pending samples and the block yielded."""
+        next slot: fx_stream_push_samples.  collect_samples() returns what the context's pending samples and the block yielded.
+        (No sample_format argument, unlike BatchAnalyser.push_samples: a ring's format is fixed when it is created -- `dtype` of HopStream,
+        uint8 = packed 24-bit -- and the block is converted to it.)"""
         x = np.ascontiguousarray(samples, self.dtype)
         per = 3 if self.dtype == np.uint8 else 1
         C = self._shape[0]
