@@ -553,16 +553,22 @@ class LiveAnalyser
 public:
     typedef std::function<void (int frames, const float* raw, const float* smoothed)> FramesCallback;   // [channels][frames][12], worker thread
 
-    LiveAnalyser (RealTimeBatchAnalyser& analyserToFeed, int maxBlockSamples, int fifoBlocks = 8)
+    // sampleFormat: what pushBlock's blocks hold -- FX_SAMPLE_F32 (JUCE's float callbacks; audioDeviceIOCallback needs it), or the device's own
+    // integers as they are (FX_SAMPLE_S16, packed FX_SAMPLE_S24) or FX_SAMPLE_F16: half / three quarters of the bytes across the link, the same
+    // result bits as the floats JUCE would have made of them (fx.h, sample formats)
+    LiveAnalyser (RealTimeBatchAnalyser& analyserToFeed, int maxBlockSamples, int fifoBlocks = 8, int sampleFormat = FX_SAMPLE_F32)
         : analyser (analyserToFeed), channels (analyserToFeed.getNumChannels()), hop (analyserToFeed.getWindowSize() / 2),
-          maxBlock (maxBlockSamples), slots ((std::size_t) (fifoBlocks > 1 ? fifoBlocks : 2))
+          maxBlock (maxBlockSamples), format (sampleFormat),
+          sampleBytes (sampleFormat == FX_SAMPLE_F32 ? 4 : (sampleFormat == FX_SAMPLE_S24 ? 3 : 2)), slots ((std::size_t) (fifoBlocks > 1 ? fifoBlocks : 2))
     {
         if (maxBlockSamples < 1) throw Error (FX_ERR_INVALID_ARGUMENT, "maxBlockSamples must be positive");
+        if (sampleFormat != FX_SAMPLE_F32 && sampleFormat != FX_SAMPLE_F16 && sampleFormat != FX_SAMPLE_S16 && sampleFormat != FX_SAMPLE_S24)
+            throw Error (FX_ERR_INVALID_ARGUMENT, "unknown sample format");
         const std::size_t most = (std::size_t) ((maxBlockSamples + hop - 1) / hop + 1);            // frames a block plus the pending samples can complete
         const std::size_t values = (std::size_t) channels * most * FX_NUM_FEATURES * sizeof (float);
         try
         {
-            for (Slot& s : slots) { void* p = nullptr; check (fx_host_alloc (&p, sizeof (float) * (std::size_t) channels * (std::size_t) maxBlockSamples)); s.samples = static_cast<float*> (p); }
+            for (Slot& s : slots) { void* p = nullptr; check (fx_host_alloc (&p, sampleBytes * (std::size_t) channels * (std::size_t) maxBlockSamples)); s.samples = static_cast<unsigned char*> (p); }
             void* p = nullptr;
             check (fx_host_alloc (&p, values)); rawValues = static_cast<float*> (p);
             check (fx_host_alloc (&p, values)); smoothedValues = static_cast<float*> (p);
@@ -583,21 +589,21 @@ public:
     // AUDIO THREAD, ref AudioDataCollector.h:36-70: inputChannelData[c] -> numberOfSamples floats of channel c.  false: the block was dropped.
     bool audioDeviceIOCallback (const float* const* inputChannelData, int numInputChannels, int numberOfSamples)
     {
-        if (numInputChannels < channels || numberOfSamples < 0 || numberOfSamples > maxBlock) { dropped++; return false; }
+        if (format != FX_SAMPLE_F32 || numInputChannels < channels || numberOfSamples < 0 || numberOfSamples > maxBlock) { dropped++; return false; }
         Slot* s = claim();
         if (s == nullptr) return false;
         for (int c = 0; c < channels; ++c)
-            std::memcpy (s->samples + (std::size_t) c * (std::size_t) numberOfSamples, inputChannelData[c], sizeof (float) * (std::size_t) numberOfSamples);
+            std::memcpy (s->samples + sizeof (float) * (std::size_t) c * (std::size_t) numberOfSamples, inputChannelData[c], sizeof (float) * (std::size_t) numberOfSamples);
         publish (s, numberOfSamples);
         return true;
     }
-    // the same for a block that is already [channels][numberOfSamples] in one piece
-    bool pushBlock (const float* samples, int numberOfSamples)
+    // the same for a block that is already [channels][numberOfSamples] in one piece, in the engine's sample format
+    bool pushBlock (const void* samples, int numberOfSamples)
     {
         if (numberOfSamples < 0 || numberOfSamples > maxBlock) { dropped++; return false; }
         Slot* s = claim();
         if (s == nullptr) return false;
-        std::memcpy (s->samples, samples, sizeof (float) * (std::size_t) channels * (std::size_t) numberOfSamples);
+        std::memcpy (s->samples, samples, sampleBytes * (std::size_t) channels * (std::size_t) numberOfSamples);
         publish (s, numberOfSamples);
         return true;
     }
@@ -657,7 +663,7 @@ public:
 
 private:
     typedef std::chrono::steady_clock Clock;
-    struct Slot { float* samples = nullptr; int count = 0; Clock::time_point arrived; };
+    struct Slot { unsigned char* samples = nullptr; int count = 0; Clock::time_point arrived; };
 
     void release()
     {
@@ -692,7 +698,7 @@ private:
     void analyse (Slot& s)
     {
         int got = 0;
-        if (fx_push_samples (analyser.handle(), s.samples, s.count, FX_SAMPLE_F32, FX_MEM_HOST, rawValues, smoothedValues, &got) != FX_OK) { fail ("fx_push_samples"); return; }
+        if (fx_push_samples (analyser.handle(), s.samples, s.count, format, FX_MEM_HOST, rawValues, smoothedValues, &got) != FX_OK) { fail ("fx_push_samples"); return; }
         if (got <= 0) return;
         if (framesAnalysed) framesAnalysed (got, rawValues, smoothedValues);
         if (osc != nullptr)
@@ -737,7 +743,8 @@ private:
     }
 
     RealTimeBatchAnalyser& analyser;
-    int channels, hop, maxBlock;
+    int channels, hop, maxBlock, format;
+    std::size_t sampleBytes;
     std::vector<Slot> slots;
     std::atomic<long long> written { 0 }, consumed { 0 }, dropped { 0 };
     std::mutex wake;

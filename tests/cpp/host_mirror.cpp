@@ -429,6 +429,33 @@ int main (int argc, char** argv)
             }
         }
         fx_osc_receiver_destroy (rx);
+        // the same engine fed the device's own 16-bit integers: the vectors of pushHopsPCM16 on that stream, bit for bit
+        {
+            std::vector<std::int16_t> pcm (stream.size());
+            for (size_t i = 0; i < pcm.size(); i++) pcm[i] = (std::int16_t) std::lrint (stream[i] * 32767.0f);
+            std::vector<float> w16r (wr.size()), w16s (wr.size()), got ((size_t) C6 * T6 * 12, -1.0f);
+            fx::RealTimeBatchAnalyser ref16 (C6, N6), live16 (C6, N6);
+            ref16.pushHopsPCM16 (pcm.data(), T6, w16r.data(), w16s.data());
+            int seen = 0;
+            {
+                fx::LiveAnalyser live (live16, 512, 8, FX_SAMPLE_S16);
+                live.setFramesAnalysedCallback ([&] (int frames, const float*, const float* smoothed) {
+                    for (int c = 0; c < C6; c++) std::memcpy (&got[((size_t) c * T6 + seen) * 12], &smoothed[(size_t) c * frames * 12], sizeof (float) * 12 * (size_t) frames);
+                    seen += frames;
+                });
+                std::vector<std::int16_t> block ((size_t) C6 * B6);
+                for (size_t at = 0; at < (size_t) T6 * H6; at += B6)
+                {
+                    const size_t n = (size_t) T6 * H6 - at < (size_t) B6 ? (size_t) T6 * H6 - at : (size_t) B6;
+                    for (int c = 0; c < C6; c++) std::memcpy (&block[(size_t) c * n], &pcm[(size_t) c * T6 * H6 + at], n * sizeof (std::int16_t));
+                    while (! live.pushBlock (block.data(), (int) n)) std::this_thread::sleep_for (std::chrono::microseconds (200));
+                }
+                live.drain();
+                const float* none[1] = { nullptr };
+                EXPECT (! live.audioDeviceIOCallback (none, C6, 0));               // float callbacks are refused by an integer engine (and counted)
+            }
+            EXPECT (seen == T6 && std::memcmp (got.data(), w16s.data(), got.size() * sizeof (float)) == 0);
+        }
     }
     // the legacy offline analyser's mirror (ref AudioAnalysis.h)
     {
