@@ -159,9 +159,9 @@ static inline bool block_feed_valid(int n, const FrameParams& p)
 {
     const long long esz = p.sample_format == FX_SAMPLE_F32 ? 4 : (p.sample_format == FX_SAMPLE_S24 ? 3 : 2);
     const long long hop = (long long) (n / 2) * esz, total = (long long) p.blk_carry_bytes + p.blk_in_row_bytes;
-    return n >= 1024 && p.T == 1 && p.hop_mode == 1 && p.in && p.blk_carry_in && p.blk_carry_out && p.blk_carry_in != p.blk_carry_out &&
+    return n >= 1024 && p.T >= 1 && p.T <= 4096 && p.hop_mode == 1 && p.in && p.blk_carry_in && p.blk_carry_out && p.blk_carry_in != p.blk_carry_out &&
            p.blk_carry_bytes >= 0 && p.blk_carry_bytes < hop && p.blk_carry_bytes % esz == 0 && p.blk_in_row_bytes > 0 && p.blk_in_row_bytes % esz == 0 &&
-           p.blk_hop0 >= 0 && p.blk_hop0 < 4096 && total >= (p.blk_hop0 + 1) * hop && (!p.blk_keep_rest || total < (p.blk_hop0 + 2) * hop) &&
+           p.blk_hop0 >= 0 && p.blk_hop0 < 4096 && total >= (p.blk_hop0 + p.T) * hop && (!p.blk_keep_rest || total < (p.blk_hop0 + p.T + 1) * hop) &&
            (p.blk_carry_row_bytes & 15) == 0 && p.blk_carry_row_bytes >= (n / 2) * 4 &&
            (reinterpret_cast<uintptr_t>(p.in) & 3) == 0 && (reinterpret_cast<uintptr_t>(p.blk_carry_in) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.blk_carry_out) & 15) == 0;
 }

@@ -471,7 +471,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int in_ki
         if (reinterpret_cast<uintptr_t>(in) % (blocks ? 4 : 16) != 0)
             return fx_fail(FX_ERR_INVALID_ARGUMENT, "device input must be %d-byte aligned", blocks ? 4 : 16);
     }
-    if (blocks && (T < 1 || T > 2 || !hop_mode || in_kind != FX_MEM_DEVICE)) return fx_fail(FX_ERR_INVALID_ARGUMENT, "a block feed is one or two hops per channel from device memory");
+    if (blocks && (T < 1 || T > 4096 || !hop_mode || in_kind != FX_MEM_DEVICE)) return fx_fail(FX_ERR_INVALID_ARGUMENT, "a block feed is 1 .. 4096 hops per channel from device memory");
 
     // A call of TWO hops per channel (a 1024-sample device buffer against a 1024-point window, 960-sample blocks every other call ...) runs
     // as two one-frame launches over the same buffers -- the second reads hop 1 and writes frame 1 (FrameParams::in_hop_stride / in_hop0,
@@ -483,7 +483,8 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int in_ki
     // completes two hops is read by the kernels directly (1000-sample blocks at 8192 channels: 177 -> 132 us per call).
     const bool both = !(c->flags & (FX_SPECTRAL_ONLY | FX_HARMONIC_ONLY));
     const bool in_two = hop_mode && T == 2 && both && c->N >= 1024 && !uses_pairs(c, c->tuning.waves_per_frame) && !(c->test_hooks & FX_HOOK_NO_TWO_LAUNCHES);
-    const int parts = (blocks || in_two) ? T : 1, part_T = (blocks || in_two) ? 1 : T;
+    const bool one_frame_launches = in_two || (blocks && T <= 2);        // (a block feed of more hops is ONE launch of the batch kernel's block-fed form)
+    const int parts = one_frame_launches ? T : 1, part_T = one_frame_launches ? 1 : T;
 
     // The three events fx_last_kernel_ms() reads.  Each is a barrier packet between launches, which a call of milliseconds does not
     // notice and a one-frame call does (back to back 27 us per call with them, 14.6 without): those record none unless asked to.
@@ -512,7 +513,7 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int in_ki
     }
     if (blocks) {
         step.fp.block_mode = 1;
-        step.fp.blk_hop0 = part;
+        step.fp.blk_hop0 = one_frame_launches ? part : 0;
         step.fp.blk_keep_rest = last ? 1 : 0;
         step.fp.blk_carry_in = blocks->carry_in;
         step.fp.blk_carry_out = blocks->carry_out;
@@ -807,10 +808,11 @@ fx_status fx_push_samples(fx_context* c, const void* samples, int num_samples, i
     } else if (reinterpret_cast<uintptr_t>(samples) % 4 != 0) {
         return fx_fail(FX_ERR_INVALID_ARGUMENT, "device input must be 4-byte aligned (16-byte aligned to be analysed in place)");
     }
-    if ((hops == 1 || hops == 2) && blocks_feed_kernels(c)) {
-        // The live case -- a device block of 441 / 480 / 512 ... samples completes exactly one hop (or a 960- / 1000- / 1024-sample one two): the
-        // one-frame kernels read their window from [pending | block] directly, one launch per hop, and the last leaves the rest in the other
-        // carry buffer.  No pass over the samples beside the analysis.
+    if (hops >= 1 && hops <= (c->N == 1024 ? 4096 : 2) && blocks_feed_kernels(c)) {
+        // A block that completes hops is read by the analysis kernels directly from [pending | block]: the live case -- 441 / 480 / 512 ...
+        // samples, one hop; 960 / 1000 / 1024, two -- as one-frame launches, longer blocks (1024-point windows) as one launch of the batch
+        // kernel's block-fed form; the call's last frame leaves the rest in the other carry buffer.  No pass over the samples beside the
+        // analysis.  (Windows of 2048 / 4096 points re-block calls of more than two hops: measured faster there, fx_kernels.hip launch_t.)
         const BlockFeed feed = {c->d_carry[c->carry_cur], c->d_carry[c->carry_cur ^ 1], (int) ((size_t) c->carry_count * esz), H * 4,
                                 (long long) num_samples * (long long) esz};
         st = run(c, d_block, hops, sample_format, FX_MEM_DEVICE, mem_kind, 1, out_raw, out_smoothed, &feed);

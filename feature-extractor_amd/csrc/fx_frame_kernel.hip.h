@@ -112,16 +112,21 @@ __device__ __forceinline__ void load_half(const void* src, int sample_format, fl
 // fx_blocks.hip.h) instead of a hop at src_b.
 template <int N, int FMT_A, int FMT_B, bool BLOCKS = false>
 __device__ __forceinline__ double load_window(const void* src_a, const void* src_b, float gain_a, float gain_b,
-                                              float* rbuf, float* tail_out, int lane, const BlockStream* bs = nullptr, int hop0 = 0)
+                                              float* rbuf, float* tail_out, int lane, const BlockStream bs = BlockStream{}, const bool a_stream = false,
+                                              const BlockStream bs_a = BlockStream{})
 {
     double ssq = 0.0;           // this lane's share of getRMSLevel's sum (ref RealTimeAnalyser.h:207): float squares, double sum
     constexpr int HALF = N / 2, QH = HALF / 256;
     uint4 ra[QH], rb[QH];
 #pragma unroll
-    for (int q = 0; q < QH; q++) ra[q] = fetch_four<FMT_A>(src_a, 256 * q + 4 * lane);
+    for (int q = 0; q < QH; q++) {
+        // (BLOCKS, frames after a call's first: the first half is the hop before, out of the same stream -- bs_a, wave-uniform)
+        if (BLOCKS && a_stream) ra[q] = stream_four<sample_bytes(FMT_A)>(bs_a, 256 * q + 4 * lane);
+        else                           ra[q] = fetch_four<FMT_A>(src_a, 256 * q + 4 * lane);
+    }
 #pragma unroll
     for (int q = 0; q < QH; q++) {
-        if constexpr (BLOCKS) rb[q] = stream_four<sample_bytes(FMT_B)>(*bs, hop0 + 256 * q + 4 * lane);
+        if constexpr (BLOCKS) rb[q] = stream_four<sample_bytes(FMT_B)>(bs, 256 * q + 4 * lane);
         else                  rb[q] = fetch_four<FMT_B>(src_b, 256 * q + 4 * lane);
     }
 #pragma unroll
@@ -147,7 +152,8 @@ __device__ __forceinline__ double load_window(const void* src_a, const void* src
 // the spectral and the harmonic analyser need it).  For a fixed (g, j) the 64 lanes read 64 consecutive samples.
 template <int N, int FMT_A, int FMT_B, bool LAST_USE = false, bool BLOCKS = false>
 __device__ __forceinline__ void load_window_first_pass_order(const void* src_a, const void* src_b, float gain_a, float gain_b,
-                                                             int lane, float (&x)[Geo<N>::P], const BlockStream* bs = nullptr, int hop0 = 0)
+                                                             int lane, float (&x)[Geo<N>::P], const BlockStream bs = BlockStream{}, const bool a_stream = false,
+                                                             const BlockStream bs_a = BlockStream{})
 {
     typedef Geo<N> G;
     // sample index = rev4(lane + 64*g) + ITEMS_A*r(j), and rev4(lane + 64*g) = rev4(lane) + g (lane's three base-4 digits
@@ -168,7 +174,11 @@ __device__ __forceinline__ void load_window_first_pass_order(const void* src_a, 
             if constexpr (BLOCKS) {
                 if (second) {
                     // (the sample's place in the stream decides which of its two pieces holds it: a compare and two selects per load)
-                    x[g * G::RA + j] = widen_one<FMT_B, LAST_USE>(stream_sample<sample_bytes(FMT_B)>(*bs, hop0 + (int) low + k));
+                    x[g * G::RA + j] = widen_one<FMT_B, LAST_USE>(stream_sample<sample_bytes(FMT_B)>(bs, (int) low + k));
+                    continue;
+                }
+                if (a_stream) {
+                    x[g * G::RA + j] = widen_one<FMT_A, LAST_USE>(stream_sample<sample_bytes(FMT_A)>(bs_a, (int) low + k));
                     continue;
                 }
             }
@@ -361,7 +371,7 @@ template <int N, bool DIRECT = false, bool HOIST = false, bool WIDE = false, boo
     struct HarmonicSpectrum { float hre[U]; float left2, left1, right1; double sum, max; };
 
     // where the two halves of this frame's window come from (a1, ref RealTimeAudioAnalysis.h:205-219)
-    struct Sources { const void* a; const void* b; float gain_a, gain_b; int fmt_a, fmt_b; BlockStream bs; int hop0; };   // hop0: BLOCKS, first sample of the hop in the stream
+    struct Sources { const void* a; const void* b; float gain_a, gain_b; int fmt_a, fmt_b; BlockStream bs, bs_a; bool a_stream; };   // BLOCKS: bs / bs_a = the stream from this frame's hop / the hop before on
     __device__ __forceinline__ Sources sources() const
     {
         const size_t esz = (size_t) sample_bytes(p.sample_format);
@@ -369,16 +379,21 @@ template <int N, bool DIRECT = false, bool HOIST = false, bool WIDE = false, boo
         Sources s;
         s.fmt_a = s.fmt_b = p.sample_format;
         if constexpr (BLOCKS) {
-            // T == 1, t == 0: the carried-over tail and the stream's first hop
-            s.a = p.tail_in + (size_t) c * HALF; s.fmt_a = FX_SAMPLE_F32; s.gain_a = 1.0f;
+            // frame t's second half is hop blk_hop0 + t of the stream [pending | block], its first half the hop before -- the carried-over tail
+            // for the call's first frame.  The stream is shifted to the hop with wave-uniform arithmetic (stream_from).
+            const BlockStream base{p.blk_carry_in + (size_t) c * (size_t) p.blk_carry_row_bytes, in + (size_t) c * (size_t) p.blk_in_row_bytes,
+                                   p.blk_carry_bytes, p.blk_in_row_bytes};
+            const long long hop_bytes = (long long) HALF * (long long) esz;
+            // (the frame index is wave-uniform by construction; saying so keeps the shifted pointers in scalar registers)
+            const int tt = DIRECT ? 0 : __builtin_amdgcn_readfirstlane(t);
+            s.bs = stream_from(base, (long long) (p.blk_hop0 + tt) * hop_bytes);
             s.b = nullptr; s.gain_b = p.gain;
-            // (the stream from THIS launch's hop on: hop 0 of it is the hop analysed, what lies behind it is what the last launch keeps)
-            s.bs = stream_from(BlockStream{p.blk_carry_in + (size_t) c * (size_t) p.blk_carry_row_bytes, in + (size_t) c * (size_t) p.blk_in_row_bytes,
-                                           p.blk_carry_bytes, p.blk_in_row_bytes}, (long long) p.blk_hop0 * HALF * (long long) esz);
-            s.hop0 = 0;
+            s.a_stream = !DIRECT && tt > 0;                                      // (the one-frame forms only ever see a call's first frame)
+            if (DIRECT || tt == 0) { s.a = p.tail_in + (size_t) c * HALF; s.fmt_a = FX_SAMPLE_F32; s.gain_a = 1.0f; s.bs_a = s.bs; }
+            else        { s.a = nullptr; s.gain_a = p.gain; s.bs_a = stream_from(base, (long long) (p.blk_hop0 + tt - 1) * hop_bytes); }
             return s;
         }
-        s.hop0 = 0;
+        s.a_stream = false;
         if (p.hop_mode) {
             s.gain_a = s.gain_b = p.gain;
             const size_t row = (size_t) c * (size_t) (p.in_hop_stride ? p.in_hop_stride : T) + (size_t) p.in_hop0;    // (one-frame launches over several hops)
@@ -399,7 +414,7 @@ template <int N, bool DIRECT = false, bool HOIST = false, bool WIDE = false, boo
     {
         asm volatile("" ::: "memory");        // a fetch of its own each time: the point is not to keep x live in between
         const Sources s = sources();
-        FX_FORMATS(s.fmt_a, s.fmt_b, (load_window_first_pass_order<N, FA, FB, LAST_USE, BLOCKS>(s.a, s.b, s.gain_a, s.gain_b, lane, x, &s.bs, s.hop0)));
+        FX_FORMATS(s.fmt_a, s.fmt_b, (load_window_first_pass_order<N, FA, FB, LAST_USE, BLOCKS>(s.a, s.b, s.gain_a, s.gain_b, lane, x, s.bs, s.a_stream, s.bs_a)));
     }
 
     // returns the lane's share of the frame's sum of squares (split sizes only; otherwise sum_squares() computes it)
@@ -414,7 +429,7 @@ FX_MARK("load");
             const void* src_a = sr.a; const void* src_b = sr.b;
             const float gain_a = sr.gain_a, gain_b = sr.gain_b;
             if constexpr (N >= 512) {
-                FX_FORMATS(sr.fmt_a, sr.fmt_b, (ssq = load_window<N, FA, FB, BLOCKS>(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane, &sr.bs, sr.hop0)));
+                FX_FORMATS(sr.fmt_a, sr.fmt_b, (ssq = load_window<N, FA, FB, BLOCKS>(src_a, src_b, gain_a, gain_b, rbuf, tail_dst, lane, sr.bs, sr.a_stream, sr.bs_a)));
             } else {
                 load_half<N, HALF>(src_a, sr.fmt_a, gain_a, gain_a != 1.0f, rbuf, 0, nullptr, lane);
                 load_half<N, HALF>(src_b, sr.fmt_b, gain_b, gain_b != 1.0f, rbuf, HALF, tail_dst, lane);
@@ -1089,7 +1104,7 @@ FX_MARK("harm2");
 template <int N, bool SPEC, bool HARM, bool DIRECT, bool BLOCKS = false>
 __device__ __forceinline__ void frame_kernel_body(const FrameParams& p_arg)
 {
-    static_assert(!BLOCKS || (DIRECT && N >= 512), "the block-fed form is a one-frame form");
+    static_assert(!BLOCKS || N >= 512, "the block-fed forms exist from 512 points on (load_window)");
     FrameParams p = p_arg;
     if (p.dyn) { p.gain = p.dyn->gain; p.nyquist = p.dyn->nyquist; }         // captured step (hipGraph): per-call scalars
     typedef Geo<N> G;
@@ -1241,7 +1256,7 @@ __device__ __forceinline__ void frame_kernel_body(const FrameParams& p_arg)
         // the window's and its stores behind them (8 - 32 more registers across the load stage: scratch at 4096 points) -- 66.5 us per call
         // all three.  What did matter was the row's last piece (stream_piece16): byte by byte it cost 1.7 us per launch.
         if constexpr (BLOCKS)
-            if (p.blk_keep_rest)
+            if (p.blk_keep_rest && t == T - 1)                                  // (the wavefront that analyses the call's last frame)
                 stream_keep_rest(w.sources().bs, (long long) (N / 2) * sample_bytes(p.sample_format), p.blk_carry_out + (size_t) c * (size_t) p.blk_carry_row_bytes, lane, 64);
     }
 

@@ -126,6 +126,10 @@ template <int N> hipError_t prepare_t()
         // the block-fed one-frame forms (FrameParams::block_mode)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_tail_kernel<N, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
+        if constexpr (N == 1024) {           // the batch kernel's block-fed form: 1024 points only (see launch_t)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
         return hipFuncSetAttribute(reinterpret_cast<const void*>(&fx_frame_kernel<N, true, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     } else {
         return hipSuccess;
@@ -150,7 +154,18 @@ template <int N> hipError_t launch_t(const FrameParams& p, int analysers, hipStr
             hipLaunchKernelGGL((fx_frame_kernel<N, true, true, true>), grid, block, lds, stream, p);
         }
     }
-    else if (p.block_mode) return hipErrorInvalidValue;          // (only the one-frame forms read blocks)
+    else if (p.block_mode) {
+        // Calls of several frames: the batch kernel's block-fed form (both analysers).  Built for 1024 points only: the split sizes read a
+        // window three times, sample by sample, and the two-piece addressing costs them more than the re-blocking pass it saves (measured,
+        // us per call, block-fed / re-blocked: 4096 channels x 2048 points x 4000-sample blocks 302 / 293, 1024 x 4096 x 10 000 296 / 275;
+        // 8192 x 1024 points x 4097 samples 428 / 481, x 30 719 samples 2869 / 3193).
+        if constexpr (N == 1024) {
+            if (analysers != 3 || !block_feed_valid(N, p)) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((fx_frame_kernel<N, true, true, false, true>), grid, block, lds, stream, p);
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     else if (analysers == 3) hipLaunchKernelGGL((fx_frame_kernel<N, true, true>), grid, block, lds, stream, p);
     else if (analysers == 1) hipLaunchKernelGGL((fx_frame_kernel<N, true, false>), grid, block, lds, stream, p);
     else if (analysers == 2) hipLaunchKernelGGL((fx_frame_kernel<N, false, true>), grid, block, lds, stream, p);

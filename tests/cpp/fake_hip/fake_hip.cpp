@@ -198,17 +198,17 @@ fxk::FrameParams from_blocks(const fxk::FrameParams& p, int window)
         return q;
     }
     const size_t esz = p.sample_format == FX_SAMPLE_F32 ? 4 : (p.sample_format == FX_SAMPLE_S24 ? 3 : 2);
-    const size_t hop = (size_t) (window / 2) * esz;
+    const size_t hop = (size_t) (window / 2) * esz, hops = (size_t) p.T * hop;
     const size_t total = (size_t) p.blk_carry_bytes + (size_t) p.blk_in_row_bytes;
     const size_t from = (size_t) p.blk_hop0 * hop;
-    if (p.T != 1 || !p.hop_mode || total < from + hop || (p.blk_keep_rest && (total >= from + 2 * hop || total - from - hop > (size_t) p.blk_carry_row_bytes))) { fprintf(stderr, "fake hip: a block feed that is not one hop\n"); int* boom = nullptr; *boom = 1; }
-    g_block_hops.assign((size_t) p.C * hop, 0);
+    if (p.T < 1 || !p.hop_mode || total < from + hops || (p.blk_keep_rest && (total >= from + hops + hop || total - from - hops > (size_t) p.blk_carry_row_bytes))) { fprintf(stderr, "fake hip: a block feed that does not hold its hops\n"); int* boom = nullptr; *boom = 1; }
+    g_block_hops.assign((size_t) p.C * hops, 0);
     const unsigned char* in = static_cast<const unsigned char*>(p.in);
     for (int c = 0; c < p.C; c++)
-        for (size_t d = from; d < (p.blk_keep_rest ? total : from + hop); d++) {
+        for (size_t d = from; d < (p.blk_keep_rest ? total : from + hops); d++) {
             const unsigned char v = d < (size_t) p.blk_carry_bytes ? p.blk_carry_in[(size_t) c * p.blk_carry_row_bytes + d] : in[(size_t) c * (size_t) p.blk_in_row_bytes + (d - p.blk_carry_bytes)];
-            if (d < from + hop) g_block_hops[(size_t) c * hop + (d - from)] = v;
-            else p.blk_carry_out[(size_t) c * p.blk_carry_row_bytes + (d - from - hop)] = v;
+            if (d < from + hops) g_block_hops[(size_t) c * hops + (d - from)] = v;
+            else p.blk_carry_out[(size_t) c * p.blk_carry_row_bytes + (d - from - hops)] = v;
         }
     fxk::FrameParams q = p;
     q.in = g_block_hops.data();
