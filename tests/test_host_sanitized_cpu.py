@@ -122,18 +122,17 @@ def test_fill_pool_under_tsan(tmp_path, fake_rccl):
     assert any(line.startswith("live engine") and "clean run" in line for line in p.stdout.splitlines()), p.stdout
 
 
-@pytest.mark.parametrize("world, shards, sinks", [
-    (2, "8192,37", "0,0,0,1,0"),
-    (4, "8192,8191,1,37", "0,0,0,3,1,0"),
-    (8, "100,1,37,64,5,3,2,999", "0,0,7,0,3,3,0"),
+@pytest.mark.parametrize("world, shards, sinks, dst", [
+    (2, "8192,37", "0,0,0,1,0", "mixed"),
+    (4, "8192,8191,1,37", "0,0,0,3,1,0", "mixed"),
+    (4, "8192,8191,1,37", "0,0,0,3,1,0", "host"),           # (host-only / device-only destinations at one world size)
+    (4, "8192,8191,1,37", "0,0,0,3,1,0", "device"),
+    (8, "100,1,37,64,5,3,2,999", "0,0,7,0,3,3,0", "mixed"),
 ])
-@pytest.mark.parametrize("dst", ["mixed", "host", "device"])
 def test_comm_ranks_fake_rccl(comm_ranks, fake_rccl, world, shards, sinks, dst):
     """fx_comm.cpp with MORE THAN ONE rank: ragged shards, the sink moving between ranks, tables in host and in device memory, no
     fx_comm_sync until every round's gather has been issued.  The parent process compares each rank's block of every gathered table
     with what that rank held itself."""
-    if dst != "mixed" and world != 4:
-        pytest.skip("host-only / device-only destinations at one world size")
     p, tail = _ranks(comm_ranks, fake_rccl, world, "shards=" + shards, "sinks=" + sinks, "dst=" + dst)
     assert p.returncode == 0, tail
     assert "comm_ranks ok: %d ranks, %d channels, %d rounds" % (world, sum(map(int, shards.split(","))), len(sinks.split(","))) in p.stdout, tail
