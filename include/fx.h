@@ -141,8 +141,11 @@ fx_status fx_push_hops(fx_context* ctx, const void* hops, int num_hops, int samp
  *   out_raw / out_smoothed  [num_channels][frames][12] with frames = (fx_pending_samples() + num_samples) / (window_size/2),
  *                           or NULL;  *frames_out (may be NULL) receives that count (0 is not an error)
  * FX_MEM_DEVICE blocks must start on a 4-byte boundary (on a 16-byte boundary with whole hops and nothing pending they are
- * analysed in place).  A block that completes one or two hops -- an audio device's 441 / 480 / 512 / 960 / 1024 samples against windows
- * of 1024 points and more -- is read by the analysis kernels directly; other lengths pass through a re-blocking kernel first.  Every channel's block has the same length (one device callback feeds all collectors, AnalyserTrackController.h:31-41).
+ * analysed in place).  A block that completes one or two hops -- an audio device's 441 / 480 / 512 / 960 / 1024 samples against
+ * windows of 1024 points and more -- is read by the analysis kernels directly, and so is a block of any length up to 4096 hops
+ * against a 1024-point window; other calls pass through a re-blocking kernel first (same results, one more pass over the
+ * samples).  Every channel's block has the same length (one device callback feeds all collectors,
+ * AnalyserTrackController.h:31-41).
  * If the analysis of the completed hops fails (an allocation, a launch), the error is returned and those hops are lost -- the pending
  * samples have already moved on -- so the stream is no longer the caller's: fx_reset_state.  The sample format may change only while nothing is pending.  While samples are pending, fx_push_hops,
  * fx_process_frames and fx_stream_submit refuse (whole hops would overtake them); fx_reset_state drops them. */
