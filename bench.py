@@ -1064,8 +1064,8 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
     def offline():
         # The legacy offline analyser's three full-spectrum functions (ref AudioAnalysis.h:463-515, :566-609, :623-665) on
         # device-resident magnitude frames: a block per channel; since round 5 the per-bin TERMS (incl. the pow() calls) are formed by the whole
-        # block in parallel into LDS and only the additions / the IEEE product run serially, in the reference's bin order, on one thread --
-        # exact rather than fast.  Timed so that the cost of that choice is on record: calls per second of 1024 analysers x one 1025-bin
+        # block in parallel into LDS and only the additions / the IEEE product run serially, in the reference's bin order (round 6: a lane per
+        # chain, loads ahead of the additions) -- exact rather than fast.  Timed so that the cost of that choice is on record: calls per second of 1024 analysers x one 1025-bin
         # frame (a 2048-point window's magnitudes).  (Round 4's numbers were of the form where one thread did everything.)
         import ctypes
         lib = fx.load_library(build_if_missing=False)
@@ -1086,7 +1086,8 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
         }
         torch.cuda.synchronize(dev)
         res = {"workload": "%d analysers x one frame of %d magnitudes per call, device-resident" % (C5, B5),
-               "note": "a block per channel: per-bin terms formed in parallel into LDS, the additions / IEEE product serial in the reference's bin order on one thread (exactness over speed)"}
+               "note": "a block per channel: per-bin terms formed in parallel into LDS, every sum / the IEEE product serial in the reference's bin order on a lane of its own "
+                       "(exactness over speed: what is left is the latency of 2 x bins dependent fp64 additions, ~10 ns each)"}
         for name, call in calls.items():
             for _ in range(3):
                 fx.capi.check(call())

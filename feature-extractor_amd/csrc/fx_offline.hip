@@ -32,6 +32,58 @@ namespace {
 constexpr int NT = 256;
 constexpr int MAX_BINS = 4097;          // windowSize / 2 + 1 for windows up to 8192 (ref AudioAnalysis.h:113)
 
+// The reference's serial sums, as ONE LANE runs them: t[0] + t[1] + ... in index order, from 0.0, nothing re-associated.  What can be done for
+// speed without touching the order: the loads of a batch of eight terms are issued before the batch ahead of it is added, and independent chains
+// of one kernel run on different LANES of a wave (a lane per chain costs what one chain costs) or on different waves.  What is left is the
+// latency of a dependent v_add_f64, ~10 ns: measured (tools/offline_timing.py, 1024 analysers x 1025 bins, us per call, as shipped / with the
+// chains cut out): spectral characteristics 40.9 / 13.2 (round 5: 77), slope 40.2 / 5.1 (49), auto-correlation 10.4 (40: its 256-entry serial
+// maximum became a butterfly); at 4097 bins 424 / 70 and 357 / 26.  Batches of 16 / 32: 42.2 / 51.9 and 36.5 / 44.2 -- not kept.
+#ifndef FX_EXP_OFFLINE_BATCH
+#define FX_EXP_OFFLINE_BATCH 8
+#endif
+template <typename T, bool PRODUCT>
+__device__ __forceinline__ double serial_chain(const T* t, int n)
+{
+    constexpr int B = FX_EXP_OFFLINE_BATCH;
+    double acc = PRODUCT ? 1.0 : 0.0;
+    int i = 0;
+#ifdef FX_EXP_OFFLINE_NO_CHAIN                                               // (timing experiment: what the kernels cost without their serial parts)
+    return n > 0 ? (double) t[n - 1] : acc;
+#endif
+    if (n >= B) {
+        T cur[B], nxt[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) cur[u] = t[u];
+        for (; i + 2 * B <= n; i += B) {                                   // the next batch's loads are in flight while this batch is added
+#pragma unroll
+            for (int u = 0; u < B; u++) nxt[u] = t[i + B + u];
+#pragma unroll
+            for (int u = 0; u < B; u++) { if (PRODUCT) acc *= (double) cur[u]; else acc += (double) cur[u]; }
+#pragma unroll
+            for (int u = 0; u < B; u++) cur[u] = nxt[u];
+        }
+#pragma unroll
+        for (int u = 0; u < B; u++) { if (PRODUCT) acc *= (double) cur[u]; else acc += (double) cur[u]; }
+        i += B;
+    }
+    for (; i < n; i++) { if (PRODUCT) acc *= (double) t[i]; else acc += (double) t[i]; }
+    return acc;
+}
+template <typename T>
+__device__ __forceinline__ double serial_sum(const T* t, int n) { return serial_chain<T, false>(t, n); }
+__device__ __forceinline__ double serial_product(const double* t, int n) { return serial_chain<double, true>(t, n); }      // IEEE product in index order, from 1.0 (inf / 0 sticky as they fall)
+// order-free reductions (a maximum, an integer sum) over the block: butterflies inside a wave, the four wave results through LDS
+__device__ __forceinline__ float block_max(float v, float* s_wave /* [NT / 64] */)
+{
+    for (int o = 32; o > 0; o >>= 1) { const float w = __shfl_xor(v, o, 64); if (w > v) v = w; }
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float m = s_wave[0];
+    for (int w = 1; w < NT / 64; w++) if (s_wave[w] > m) m = s_wave[w];
+    __syncthreads();                                                      // (s_wave may be used again)
+    return m;
+}
+
 // ---- ref AudioAnalysis.h:517-541 analyseNormalisedZeroCrosses: block = (channel, downsample step) ----
 __global__ void __launch_bounds__(NT) zero_crosses_kernel(const float* audio, int num_samples, int num_downsamples, float* out)
 {
@@ -84,7 +136,7 @@ __global__ void __launch_bounds__(NT) log_attack_time_kernel(const float* env, i
 // ---- ref AudioAnalysis.h:543-564 calculateFFTLBP: block = channel ----
 __global__ void __launch_bounds__(NT) fft_lbp_kernel(const float* cur, const float* prev, int num_bins, unsigned char* bits, float* highest_ratio, float* activity_ratio)
 {
-    __shared__ int s_cnt[NT], s_hi[NT];
+    __shared__ int s_cnt[NT / 64], s_hi[NT / 64];
     const int c = blockIdx.x;
     const float threshold = 0.1f;                                          // :546
     int cnt = 0, hi = 0;
@@ -95,11 +147,12 @@ __global__ void __launch_bounds__(NT) fft_lbp_kernel(const float* cur, const flo
         cnt += b;
         if (b && i > hi) hi = i;                                           // :558-559: the last bin over the threshold
     }
-    s_cnt[threadIdx.x] = cnt; s_hi[threadIdx.x] = hi;
+    for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); const int h = __shfl_xor(hi, o, 64); if (h > hi) hi = h; }      // (integers: any order)
+    if ((threadIdx.x & 63) == 0) { s_cnt[threadIdx.x >> 6] = cnt; s_hi[threadIdx.x >> 6] = hi; }
     __syncthreads();
     if (threadIdx.x == 0) {
         int total = 0, highest = 0;
-        for (int k = 0; k < NT; k++) { total += s_cnt[k]; if (s_hi[k] > highest) highest = s_hi[k]; }
+        for (int k = 0; k < NT / 64; k++) { total += s_cnt[k]; if (s_hi[k] > highest) highest = s_hi[k]; }
         highest_ratio[c] = (float) highest / (float) num_bins;             // :563 (float counts are exact here)
         activity_ratio[c] = (float) total / (float) num_bins;
     }
@@ -144,9 +197,7 @@ __global__ void __launch_bounds__(NT) harmonic_characteristics_kernel(const floa
     for (int i = tid; i < num_bins; i += NT) { mag[i] = mags[(size_t) c * num_bins + i]; cnt[i] = 0; key[i] = 0x7fffffff; }
     __syncthreads();
     if (tid == 0) {                                                        // :264-268: the reference's serial sum (its last bit decides `mag > mean`)
-        double s = 0.0;
-        for (int i = 0; i < num_bins; i++) s += (double) mag[i];
-        s_sum = s;
+        s_sum = serial_sum(mag, num_bins);
     }
     __syncthreads();
     const double sum = s_sum;
@@ -239,7 +290,7 @@ __global__ void __launch_bounds__(NT) harmonic_characteristics_kernel(const floa
     __syncthreads();
     if (tid == 0) {
         double inh = 0.0;
-        if (f0 > 0.0) for (int k = 0; k < np; k++) inh += term[k];
+        if (f0 > 0.0) inh = serial_sum(term, np);
         out3[(size_t) c * 3 + 0] = (float) f0; out3[(size_t) c * 3 + 1] = (float) s_her; out3[(size_t) c * 3 + 2] = (float) inh;   // :302
     }
 }
@@ -283,21 +334,20 @@ fx_status check_args(fx_offline* o, const void* in, const void* out, int mem_kin
 // ---- ref AudioAnalysis.h:463-515 calculateSpectralCharacteristics: block = channel.  Every sum of the reference is a serial double
 // sum in bin order, and the product a serial IEEE product (inf / 0 sticky).  What is serial is only the ADDITIONS: each bin's terms --
 // the rectified difference, fc * m, the pow() of the spread -- are a function of that bin alone, so the whole block forms them side by side
-// into LDS (the same expressions, so the same roundings: no contraction in this file), and ONE thread then adds them up in bin order, four
-// independent chains per pass.  (Round 4 had that one thread evaluate everything, 1025 pow() calls in a row: 1.98 ms per call of 1024
-// analysers; bench.py `offline`.)
-// LDS: prev[bins] doubles | a[bins] doubles | b[bins] doubles | mag[bins] floats = 28 bytes per bin (115 KB at 4097 bins).
-constexpr size_t SPECTRAL_LDS_PER_BIN = 3 * sizeof(double) + sizeof(float);
+// into LDS (the same expressions, so the same roundings: no contraction in this file), and single lanes then add them up in bin order.
+// (Round 4 had one thread evaluate everything, 1025 pow() calls in a row: 1.98 ms per call of 1024 analysers; round 5, one thread adding four
+// chains with every LDS read waited for: 77 us; bench.py `offline`.)
+// Round 6: the three sums of the first pass run on three lanes of wave 0 and the product on a lane of wave 1, at the same time, each with its
+// loads ahead of its additions (serial_sum); "not added" became "+ 0.0" (the flux starts at +0.0 and only grows: x + 0.0 == x bit for bit).
+// LDS: a[bins] | b[bins] | m[bins], doubles = 24 bytes per bin (98 KB at 4097 bins).
+constexpr size_t SPECTRAL_LDS_PER_BIN = 3 * sizeof(double);
 __global__ void __launch_bounds__(NT) spectral_characteristics_kernel(const float* mags, int num_bins, double nyquist, double* prev_bins, float* out4)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double* prev = reinterpret_cast<double*>(smem);                         // [num_bins]
-    double* ta = prev + num_bins;                                           // per-bin terms, first pass: rectified difference; second: spread term
+    double* ta = reinterpret_cast<double*>(smem);                           // per-bin terms, first pass: rectified difference (or 0); second: spread term
     double* tb = ta + num_bins;                                             // first pass: fc * m
-    float* mag = reinterpret_cast<float*>(tb + num_bins);                   // [num_bins]
-    __shared__ int s_accepted;
-    __shared__ float s_centroid;
-    __shared__ double s_sum, s_flux, s_product;
+    double* tm = tb + num_bins;                                             // (double) mag
+    __shared__ double s_chain[4];                                           // flux, sum, weighted, product
     const int c = blockIdx.x;
     double* gprev = prev_bins + (size_t) c * num_bins;
     const size_t n = (size_t) num_bins;
@@ -305,50 +355,41 @@ __global__ void __launch_bounds__(NT) spectral_characteristics_kernel(const floa
     for (int i = threadIdx.x; i < num_bins; i += NT) {
         const float mf = mags[(size_t) c * num_bins + i];
         const double pv = gprev[i];
-        mag[i] = mf; prev[i] = pv;
         const double fc = (double) i * frpb + (frpb / 2.0);                 // :479-496, the per-bin part
         const double m = (double) mf;
         const double diff = fabs(m) - fabs(pv);
         const double rectified = (diff + fabs(diff)) / 2.0;
-        ta[i] = diff > 0.0 ? rectified : -1.0;                              // (-1: "not added", as the reference's `if (diff > 0.0)`)
+        ta[i] = diff > 0.0 ? rectified : 0.0;                               // (the reference's `if (diff > 0.0) flux += rectified`)
         tb[i] = fc * m;
+        tm[i] = m;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double weighted = 0.0, sum = 0.0, product = 1.0, flux = 0.0;
-        for (size_t i = 0; i < n; ++i) {                                    // the additions, in bin order
-            const double m = (double) mag[i];
-            if (ta[i] >= 0.0) flux += ta[i];
-            sum += m;
-            product *= m;
-            weighted += tb[i];
-        }
-        const bool accepted = sum > 0.001;                                  // :498-500
-        s_accepted = accepted ? 1 : 0;
-        s_centroid = accepted ? (float) (weighted / sum) : 0.0f;
-        s_sum = sum; s_flux = flux; s_product = product;
+    if (threadIdx.x < 3) {                                                  // the additions, in bin order: a lane per sum
+        const double* src = threadIdx.x == 0 ? ta : (threadIdx.x == 1 ? tm : tb);
+        s_chain[threadIdx.x] = serial_sum(src, num_bins);
+    } else if (threadIdx.x == 64) {
+        s_chain[3] = serial_product(tm, num_bins);
     }
     __syncthreads();
-    if (!s_accepted) {
+    const double flux = s_chain[0], sum = s_chain[1], weighted = s_chain[2], product = s_chain[3];
+    if (!(sum > 0.001)) {                                                   // :498-500
         if (threadIdx.x == 0) { out4[4 * c] = 0.0f; out4[4 * c + 1] = 0.0f; out4[4 * c + 2] = 0.0f; out4[4 * c + 3] = 0.0f; }
         return;
     }
-    const float centroid = s_centroid;
+    const float centroid = (float) (weighted / sum);
     for (int i = threadIdx.x; i < num_bins; i += NT) {
         const double fc = (double) i * frpb + (frpb / 2.0);                 // binCentreFrequencies[i], the same expression
-        ta[i] = pow((fc / nyquist) - (centroid / nyquist), 2.0) * (double) mag[i];       // :509, the per-bin part
+        ta[i] = pow((fc / nyquist) - (centroid / nyquist), 2.0) * tm[i];    // :509, the per-bin part
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double sum = s_sum;
-        double var = 0.0;
-        for (size_t i = 0; i < n; ++i) var += ta[i];
+        const double var = serial_sum(ta, num_bins);
         const double inv = 1.0 / n;
-        const float flatness = (float) (pow(s_product, inv) / (inv * sum));               // :505
+        const float flatness = (float) (pow(product, inv) / (inv * sum));                 // :505
         const float max_spread = (float) ((centroid / nyquist) * (1.0 - (centroid / nyquist)));
-        out4[4 * c] = centroid / (float) nyquist; out4[4 * c + 1] = (float) ((var / sum) / max_spread); out4[4 * c + 2] = flatness; out4[4 * c + 3] = (float) s_flux;
+        out4[4 * c] = centroid / (float) nyquist; out4[4 * c + 1] = (float) ((var / sum) / max_spread); out4[4 * c + 2] = flatness; out4[4 * c + 3] = (float) flux;
     }
-    for (int i = threadIdx.x; i < num_bins; i += NT) gprev[i] = (double) mag[i];          // :510
+    for (int i = threadIdx.x; i < num_bins; i += NT) gprev[i] = tm[i];                    // :510
 }
 
 // ---- ref AudioAnalysis.h:566-609 calculateNormalisedSpectralSlope: block = channel; the maximum in parallel (order does not matter),
@@ -361,20 +402,13 @@ __global__ void __launch_bounds__(NT) spectral_slope_kernel(const float* mags, i
     double* te = reinterpret_cast<double*>(smem);                           // e_i = mag[i] / magnitude
     double* tt = te + num_bins;                                             // first pass: i * e_i; second: (e_i - mean)^2
     float* mag = reinterpret_cast<float*>(tt + num_bins);
-    __shared__ float s_max[NT];
-    __shared__ double s_mean, s_prod;
-    __shared__ float s_peak;
+    __shared__ float s_wave[NT / 64];
+    __shared__ double s_chain[2];
     const int c = blockIdx.x;
     float peak = 0.0f;
     for (int i = threadIdx.x; i < num_bins; i += NT) { const float v = mags[(size_t) c * num_bins + i]; mag[i] = v; const float a = fabsf(v); if (a > peak) peak = a; }
-    s_max[threadIdx.x] = peak;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < NT; k++) if (s_max[k] > peak) peak = s_max[k];
-        s_peak = peak;
-    }
-    __syncthreads();
-    const double bins = (double) num_bins, mean_bin = 0.5, magnitude = (double) s_peak;      // getMagnitude, :573
+    peak = block_max(peak, s_wave);
+    const double bins = (double) num_bins, mean_bin = 0.5, magnitude = (double) peak;        // getMagnitude, :573
     if (!(magnitude > 0.0001)) { if (threadIdx.x == 0) out[c] = 0.0f; return; }
     for (int i = threadIdx.x; i < num_bins; i += NT) {
         const double e = mag[i] / magnitude;
@@ -382,29 +416,24 @@ __global__ void __launch_bounds__(NT) spectral_slope_kernel(const float* mags, i
         tt[i] = (double) i * e;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double mean_energy = 0.0, prod_sum = 0.0;
-        for (int i = 0; i < num_bins; i++) { mean_energy += te[i]; prod_sum += tt[i]; }
-        s_mean = mean_energy / bins; s_prod = prod_sum;
-    }
+    if (threadIdx.x < 2) s_chain[threadIdx.x] = serial_sum(threadIdx.x == 0 ? te : tt, num_bins);     // the two sums of :577-583, a lane each
     __syncthreads();
-    const double mean_energy = s_mean;
+    const double mean_energy = s_chain[0] / bins, prod_sum = s_chain[1];
+    __syncthreads();                                                        // (s_chain is written again below)
     for (int i = threadIdx.x; i < num_bins; i += NT) {
         const double e = te[i], ni = (double) i / bins;
         tt[i] = (e - mean_energy) * (e - mean_energy);
         te[i] = (ni - mean_bin) * (ni - mean_bin);                             // (e is not needed again)
     }
     __syncthreads();
+    if (threadIdx.x < 2) s_chain[threadIdx.x] = serial_sum(threadIdx.x == 0 ? te : tt, num_bins);
+    __syncthreads();
     if (threadIdx.x == 0) {
-        double bin_var = 0.0, energy_var = 0.0;
-        for (int i = 0; i < num_bins; i++) {
-            bin_var += te[i];
-            energy_var += tt[i];
-        }
+        double bin_var = s_chain[0], energy_var = s_chain[1];
         bin_var /= bins;
         energy_var /= bins;
         const double bin_std = sqrt(bin_var), energy_std = sqrt(energy_var);
-        const double r = (s_prod - (bins * mean_energy * mean_bin)) / (bins - 1.0f) * energy_std * bin_std;      // :602
+        const double r = (prod_sum - (bins * mean_energy * mean_bin)) / (bins - 1.0f) * energy_std * bin_std;      // :602
         out[c] = (float) (r * (bin_std / energy_std));
     }
 }
@@ -423,20 +452,25 @@ __global__ void __launch_bounds__(NT) conjugate_multiplication_kernel(float* dat
 // ---- ref AudioAnalysis.h:636-665 analyseAutoCorrelation + getMaxIndex: block = channel; the FIRST bin holding the largest real part ----
 __global__ void __launch_bounds__(NT) auto_correlation_kernel(const float* data, int num_items, double nyquist, int* peak_bin, double* frequency)
 {
-    __shared__ float s_val[NT];
-    __shared__ int s_idx[NT];
+    __shared__ float s_val[NT / 64];
+    __shared__ int s_idx[NT / 64];
     const int c = blockIdx.x;
     const float* d = data + (size_t) c * num_items * 2;
     float best = 0.0f; int at = -1;
     // ascending i: the first on ties.  NaNs are skipped as getMaxIndex skips them (`data[i] > currentMax` is false for one), so a NaN early in a
     // thread's stride cannot hide the maxima behind it; a NaN at data[0] is thread 0's business below
     for (int i = threadIdx.x; i < num_items; i += NT) { const float v = d[2 * i]; if (v == v && (at < 0 || v > best)) { best = v; at = i; } }
-    s_val[threadIdx.x] = best; s_idx[threadIdx.x] = at;
+    // (larger value, then smaller bin) is a total order on the candidates that exist (at >= 0; none of them a NaN): butterflies inside a wave
+    for (int o = 32; o > 0; o >>= 1) {
+        const float v = __shfl_xor(best, o, 64); const int k = __shfl_xor(at, o, 64);
+        if (k >= 0 && (at < 0 || v > best || (v == best && k < at))) { best = v; at = k; }
+    }
+    if ((threadIdx.x & 63) == 0) { s_val[threadIdx.x >> 6] = best; s_idx[threadIdx.x >> 6] = at; }
     __syncthreads();
     if (threadIdx.x == 0) {
         // getMaxIndex starts from data[0] and moves on `data[i] > currentMax` only: a NaN at 0 keeps bin 0, NaNs elsewhere never win
         int peak = 0; float current = d[0];
-        for (int k = 0; k < NT; k++)
+        for (int k = 0; k < NT / 64; k++)
             if (s_idx[k] >= 0 && (s_val[k] > current || (s_val[k] == current && s_idx[k] < peak))) { current = s_val[k]; peak = s_idx[k]; }
         const double frpb = nyquist / (double) num_items;
         peak_bin[c] = peak;
