@@ -141,6 +141,52 @@ def test_offline_round4_kernels_equal_the_reference_headers_vectors(gpu_fx, orac
 
 
 @pytest.mark.gpu
+def test_offline_serial_sums_at_every_batch_boundary_and_ties_across_waves(gpu_fx, oracle):
+    """Round 6: each serial sum runs on a lane of its own, eight loads ahead of the additions, and the maxima are butterflies.  Bin counts on
+    both sides of every batch boundary (so that the first batch, the pipelined middle and the tail are each empty once), signed magnitudes
+    (the sums are not monotone), and equal maxima placed in different lanes and different waves (the first one must win, +0.0 == -0.0)."""
+    rng = np.random.default_rng(61)
+    for B in (2, 7, 8, 9, 15, 16, 17, 23, 24, 25, 31, 32, 33, 255, 256, 257):
+        C, nyq = 5, 24000.0
+        an = gpu_fx.offline.AudioAnalyser(C, nyq)
+        pb = np.zeros((C, B))
+        for t in range(3):
+            mags = rng.normal(0, 1.0, (C, B)).astype(np.float32) * np.float32(10.0 ** rng.integers(-6, 6))
+            if t < 2:
+                mags = np.abs(mags)                 # (signed magnitudes once: the centroid can leave [0, nyquist] then, pow() of a negative base is the reference's business)
+            got, want = an.calculate_spectral_characteristics(mags), oracle.offline_spectral_characteristics(mags, nyq, pb)
+            assert same(got[:, [0, 3]], want[:, [0, 3]]), (B, t)
+            if t < 2:
+                np.testing.assert_allclose(got[:, [1, 2]], want[:, [1, 2]], rtol=2e-7, atol=0)
+            assert same(an.previous_bin_magnitudes, pb)
+            assert same(an.calculate_normalised_spectral_slope(mags), oracle.offline_spectral_slope(mags)), (B, t)
+            if B >= 4:
+                fresh = gpu_fx.offline.AudioAnalyser(C, nyq)
+                assert same(fresh.calculate_harmonic_characteristics(np.abs(mags)), oracle.offline_harmonic_characteristics(np.abs(mags), nyq, np.zeros(C))), (B, t)
+    # auto-correlation: the same largest real part at items that fall to different lanes (i, i + 1), different waves (i, i + 64) and a later
+    # stride of the same thread (i, i + 256): the first wins; all items zero with mixed signs: item 0
+    for n in (3, 64, 65, 300, 1024):
+        C = 6
+        data = rng.normal(0, 0.1, (C, n, 2)).astype(np.float32)
+        data[:, :, 1] = 0.0                         # real items: the product's real part is the square
+        for c, (i, j) in enumerate(((1, 2), (1, 65), (2, 258), (70, 71), (0, n - 1))):
+            if j < n:
+                data[c, i, 0] = 3.0; data[c, j, 0] = -3.0           # equal squares
+        data[5] = 0.0
+        data[5, ::2, 1] = -0.0
+        an = gpu_fx.offline.AudioAnalyser(C, 1000.0)
+        prod, peaks, freqs = an.analyse_auto_correlation(data)
+        want_prod = oracle.offline_conjugate_multiplication(data)
+        wp, wf = oracle.offline_auto_correlation(want_prod, 1000.0)
+        assert same(prod, want_prod) and same(peaks, wp) and same(freqs, wf), (n, peaks, wp)
+    # FFT-LBP counts / highest bin through the butterflies
+    for C, B in ((3, 63), (3, 64), (3, 65), (2, 300)):
+        cur = np.abs(rng.normal(0, 0.3, (C, B))).astype(np.float32)
+        prev = np.abs(rng.normal(0, 0.3, (C, B))).astype(np.float32)
+        assert all(same(a, b) for a, b in zip(gpu_fx.offline.AudioAnalyser(C).calculate_fft_lbp(cur, prev), oracle.offline_fft_lbp(cur, prev))), (C, B)
+
+
+@pytest.mark.gpu
 def test_offline_kernels_equal_the_oracle_on_random_inputs(gpu_fx, oracle):
     """Sizes and contents beyond the fixture: many channels, windows up to 8192 points (4097 magnitudes), spectra with thousands
     of peaks (a histogram of ~10^6 pairs), ties in the weighted counts, device-resident buffers."""
