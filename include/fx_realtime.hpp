@@ -572,11 +572,11 @@ public:
             void* p = nullptr;
             check (fx_host_alloc (&p, values)); rawValues = static_cast<float*> (p);
             check (fx_host_alloc (&p, values)); smoothedValues = static_cast<float*> (p);
+            latencies.reserve (1 << 20);
+            running = true;
+            worker = std::thread ([this] { run(); });
         }
-        catch (...) { release(); throw; }
-        latencies.reserve (1 << 20);
-        running = true;
-        worker = std::thread ([this] { run(); });
+        catch (...) { running = false; release(); throw; }           // (the destructor of a half-built engine never runs: give the page-locked memory back here)
     }
     ~LiveAnalyser()
     {
