@@ -329,6 +329,58 @@ def test_block_feed_of_every_one_frame_kernel_equals_the_reblocked_path_bitwise(
             an.close()
 
 
+@pytest.mark.parametrize("fmt", ["f32", "s16", "s24", "f16"])
+def test_long_blocks_through_the_batch_kernels_block_fed_form_equal_the_reblocked_path_bitwise(gpu_fx, fmt):
+    """Round 6, 1024-point windows: a call that completes MORE than two hops is one launch of fx_frame_kernel<1024, ..., blocks> -- every frame's
+    new half from hop t of [pending | block], its old half from hop t - 1, the last frame's wave writing the left-over.  Block lengths from three
+    hops to 273 per call, so that the launch is one unit, several units of the ticket queue (from ~48 hops) and the plan of thirds (from 256), with
+    the block row on every byte alignment: vectors, pending samples and the state afterwards are those of the same context with the feed switched
+    off (test hook 16), bit for bit, host and device blocks."""
+    import torch
+    N, H, C = 1024, 512, 13
+    lengths = [1537, 30719, 2000, 3, 70001, 4097, 511, 140003, 1024, 25601]
+    total = sum(lengths)
+    rng = np.random.default_rng(len(fmt) + 77)
+    base = signals.tone_vibrato_noise(C, 16, N, seed=5).reshape(C, -1)
+    reps = (total + base.shape[1] - 1) // base.shape[1]
+    x = (np.tile(base, (1, reps))[:, :total] * (0.6 + 0.4 * np.sin(np.arange(total) / 9973.0))[None, :]).astype(np.float32)
+    x += rng.normal(0, 0.01, x.shape).astype(np.float32)
+    if fmt == "s16":
+        stream, per = np.clip(np.round(x * 32768.0), -32768, 32767).astype(np.int16), 1
+    elif fmt == "f16":
+        stream, per = x.astype(np.float16), 1
+    elif fmt == "s24":
+        stream, per = np.asarray(gpu_fx.pack_s24(np.clip(np.round(x * 8388608.0), -2 ** 23, 2 ** 23 - 1).astype(np.int32))), 3
+    else:
+        stream, per = x, 1
+    sf = "s24" if fmt == "s24" else None
+
+    def feed(an, device):
+        raws, sms, at = [], [], 0
+        for n in lengths:
+            piece = np.ascontiguousarray(stream[:, per * at:per * (at + n)])
+            r, s = an.push_samples(torch.from_numpy(piece).cuda() if device else piece, sample_format=sf)
+            if hasattr(r, "cpu"):
+                r, s = r.cpu().numpy(), s.cpu().numpy()
+            raws.append(r); sms.append(s)
+            at += n
+        return np.concatenate(raws, 1), np.concatenate(sms, 1), an.pending_samples(), an.get_features()
+
+    ref = gpu_fx.BatchAnalyser(C, N)
+    ref.set_gain(0.75)
+    ref.set_test_hooks(16)
+    want = feed(ref, False)
+    ref.close()
+    assert want[0].shape[1] == total // H
+    for device in ((False, True) if fmt != "s24" else (False,)):
+        an = gpu_fx.BatchAnalyser(C, N)
+        an.set_gain(0.75)
+        got = feed(an, device)
+        an.close()
+        assert got[2] == want[2] == total % H
+        assert same(got[0], want[0]) and same(got[1], want[1]) and same(got[3], want[3]), (fmt, device)
+
+
 def test_the_applications_own_stepping_replayed_hop_by_hop(gpu_fx):
     """tests/golden/blocks/startup.npz: the reference's headers stepped the way the APPLICATION's threads step (one pass of the loop at thread
     start, one per audio callback; the reader running ahead of the writer as indexesOverlap lets it -- hops of zeros first, stale laps of the

@@ -109,6 +109,8 @@ def run(seconds=60.0, seed=0, max_cases=None, save_failures=True, verbose=True, 
             while at < total:
                 n = int(rng.choice([441, 480, 512, H, H - 1, H + 1, int(rng.integers(H // 2 + 1, H + H // 2))])) if live else \
                     int(rng.choice([1, 63, 441, 480, 512, 1000, 4097, int(rng.integers(1, 3 * N))]))
+                if st is None and not live and rng.random() < 0.25:
+                    n = int(rng.integers(3 * N, 70 * N))           # long blocks: at 1024 points one launch of the batch kernel's block-fed form, in units from ~48 hops
                 n = min(n, total - at)
                 piece = np.ascontiguousarray(flat[:, at * per:(at + n) * per])
                 if on_device:
