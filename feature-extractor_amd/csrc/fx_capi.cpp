@@ -504,63 +504,63 @@ fx_status run(fx_context* c, const void* in, int T, int sample_format, int in_ki
         last_valid = false;
     }
     for (int part = 0; part < parts; part++) {
-    const bool first = part == 0, last = part == parts - 1;       // (the events bracket the whole call: frame-kernel time is only split out of one-part calls)
-    Step step;
-    if ((st = prepare_step(c, d_in, part_T, sample_format, hop_mode, d_or, d_os, c->d_part, c->d_raw, nullptr, &step)) != FX_OK) return st;
-    if (parts > 1) {
-        step.fp.in_hop_stride = T; step.fp.in_hop0 = part;
-        step.ep.out_stride = T;    step.ep.out_t0 = part;
-    }
-    if (blocks) {
-        step.fp.block_mode = 1;
-        step.fp.blk_hop0 = one_frame_launches ? part : 0;
-        step.fp.blk_keep_rest = last ? 1 : 0;
-        step.fp.blk_carry_in = blocks->carry_in;
-        step.fp.blk_carry_out = blocks->carry_out;
-        step.fp.blk_carry_bytes = blocks->carry_bytes;
-        step.fp.blk_carry_row_bytes = blocks->carry_row_bytes;
-        step.fp.blk_in_row_bytes = blocks->in_row_bytes;
-        if (step.pair || step.analysers != 3) return fx_fail(FX_ERR_INVALID_ARGUMENT, "this context's kernels do not read blocks");
-    }
-    // ONE frame per channel -- the reference's own cadence, an analysis per hop as it arrives (AudioDataCollector.h:66-94,
-    // RealTimeAnalyser.h:201-234) -- is one launch of fx_hop_kernel: three wavefronts per channel (pitch / spectral /
-    // harmonic) and the hop's tail, instead of one wavefront per channel and a second launch.
-    // (measured, tools/live_cadence.py, profiles/r04_live_cadence.txt: once the call holds more than the chip takes in one round of
-    // workgroups -- 1024 channels of 1024 points, 512 of 2048, and 1024 of 4096 since a 4096-point workgroup is 80 KB and a CU holds two --
-    // the batch kernels take over: one wavefront per channel with the flux state left in global memory (prepare_step), then the fused
-    // tail on a quarter wavefront per channel: 63 against 120 us at 8192 channels x 1024-pt, 76 against 186 us at 2048 channels x 4096-pt;
-    // below it the hop kernel wins, 19.9 against 22.9 us at 1024 x 1024-pt, 58.7 against 61.8 us at 1024 x 4096-pt.  The pair family's
-    // hop kernel -- six wavefronts and 100 KB per channel -- keeps 2^20 at every size)
-    const bool one_hop = part_T == 1 && step.analysers == 3 && fxk::hop_kernel_available(c->N) &&
-                         (c->tuning.one_hop_kernel == 1 || (c->tuning.one_hop_kernel < 0 && (long long) c->C * c->N <= ((c->N == 4096 && !step.hop_pairs) ? (1ll << 22) : (1ll << 20))));
-    if (one_hop) {
-        const fxk::HopSignal none = {nullptr, nullptr, 0u, 0u, nullptr};
-        if (first) FX_EV(e0);
-        HIP_TRY(fxk::launch_hop_kernel(c->N, step.fp, step.ep, none, c->stream, step.hop_pairs));
-        if (last) { FX_EV(e1); FX_EV(e2); }
-    } else {
-        if (first) FX_EV(e0);
-        // One frame per channel through the batch kernels: frames and tails in ONE launch (fx_frame_tail_kernel) while the chip holds all
-        // of the call's workgroups at once -- two per CU at these sizes, one of eight channels at 4096 points.  Beyond that a workgroup whose
-        // first wavefronts are finishing its hops keeps the LDS the next workgroup is waiting for, and the tail is better off as a launch
-        // of its own.  Measured (us per call, one launch / two; profiles/r04_live_cadence.txt): 1024 points 2048 channels 26.8 / 28.6, 4096
-        // channels 41.0 / 41.7, 8192 channels 70.2 / 68.2; 2048 points 2048 channels 44.9 / 45.7, 4096 channels 77.5 / 73.8; windows of 512
-        // points and fewer lose either way (4096 channels 34.7 / 33.2): their frames are no longer than the tail.
-        const long long groups = ((long long) c->C + step.fp.ch_per_wg - 1) / step.fp.ch_per_wg;
-        const long long one_round = (long long) c->compute_units * ((c->N == 4096 && step.fp.ch_per_wg > 4) ? 1 : 2);
-        const bool one_launch = step.fp.direct_state && fxk::frame_tail_kernel_available(c->N) &&
-                                ((c->test_hooks & FX_HOOK_TAIL_ALWAYS_FUSED) || (!(c->test_hooks & FX_HOOK_TAIL_NEVER_FUSED) && groups <= one_round));
-        if (one_launch) {
-            HIP_TRY(fxk::launch_frame_tail_kernel(c->N, step.fp, step.ep, c->stream));
-            if (last) FX_EV(e1);
-        } else {
-            HIP_TRY(launch_frames(c, step));
-            if (last) FX_EV(e1);
-            HIP_TRY(fxk::launch_epilogue_kernels(step.ep, c->stream));
+        const bool first = part == 0, last = part == parts - 1;       // (the events bracket the whole call: frame-kernel time is only split out of one-part calls)
+        Step step;
+        if ((st = prepare_step(c, d_in, part_T, sample_format, hop_mode, d_or, d_os, c->d_part, c->d_raw, nullptr, &step)) != FX_OK) return st;
+        if (parts > 1) {
+            step.fp.in_hop_stride = T; step.fp.in_hop0 = part;
+            step.ep.out_stride = T;    step.ep.out_t0 = part;
         }
-        if (last) FX_EV(e2);
-    }
-    advance(c, part_T);
+        if (blocks) {
+            step.fp.block_mode = 1;
+            step.fp.blk_hop0 = one_frame_launches ? part : 0;
+            step.fp.blk_keep_rest = last ? 1 : 0;
+            step.fp.blk_carry_in = blocks->carry_in;
+            step.fp.blk_carry_out = blocks->carry_out;
+            step.fp.blk_carry_bytes = blocks->carry_bytes;
+            step.fp.blk_carry_row_bytes = blocks->carry_row_bytes;
+            step.fp.blk_in_row_bytes = blocks->in_row_bytes;
+            if (step.pair || step.analysers != 3) return fx_fail(FX_ERR_INVALID_ARGUMENT, "this context's kernels do not read blocks");
+        }
+        // ONE frame per channel -- the reference's own cadence, an analysis per hop as it arrives (AudioDataCollector.h:66-94,
+        // RealTimeAnalyser.h:201-234) -- is one launch of fx_hop_kernel: three wavefronts per channel (pitch / spectral /
+        // harmonic) and the hop's tail, instead of one wavefront per channel and a second launch.
+        // (measured, tools/live_cadence.py, profiles/r04_live_cadence.txt: once the call holds more than the chip takes in one round of
+        // workgroups -- 1024 channels of 1024 points, 512 of 2048, and 1024 of 4096 since a 4096-point workgroup is 80 KB and a CU holds two --
+        // the batch kernels take over: one wavefront per channel with the flux state left in global memory (prepare_step), then the fused
+        // tail on a quarter wavefront per channel: 63 against 120 us at 8192 channels x 1024-pt, 76 against 186 us at 2048 channels x 4096-pt;
+        // below it the hop kernel wins, 19.9 against 22.9 us at 1024 x 1024-pt, 58.7 against 61.8 us at 1024 x 4096-pt.  The pair family's
+        // hop kernel -- six wavefronts and 100 KB per channel -- keeps 2^20 at every size)
+        const bool one_hop = part_T == 1 && step.analysers == 3 && fxk::hop_kernel_available(c->N) &&
+                             (c->tuning.one_hop_kernel == 1 || (c->tuning.one_hop_kernel < 0 && (long long) c->C * c->N <= ((c->N == 4096 && !step.hop_pairs) ? (1ll << 22) : (1ll << 20))));
+        if (one_hop) {
+            const fxk::HopSignal none = {nullptr, nullptr, 0u, 0u, nullptr};
+            if (first) FX_EV(e0);
+            HIP_TRY(fxk::launch_hop_kernel(c->N, step.fp, step.ep, none, c->stream, step.hop_pairs));
+            if (last) { FX_EV(e1); FX_EV(e2); }
+        } else {
+            if (first) FX_EV(e0);
+            // One frame per channel through the batch kernels: frames and tails in ONE launch (fx_frame_tail_kernel) while the chip holds all
+            // of the call's workgroups at once -- two per CU at these sizes, one of eight channels at 4096 points.  Beyond that a workgroup whose
+            // first wavefronts are finishing its hops keeps the LDS the next workgroup is waiting for, and the tail is better off as a launch
+            // of its own.  Measured (us per call, one launch / two; profiles/r04_live_cadence.txt): 1024 points 2048 channels 26.8 / 28.6, 4096
+            // channels 41.0 / 41.7, 8192 channels 70.2 / 68.2; 2048 points 2048 channels 44.9 / 45.7, 4096 channels 77.5 / 73.8; windows of 512
+            // points and fewer lose either way (4096 channels 34.7 / 33.2): their frames are no longer than the tail.
+            const long long groups = ((long long) c->C + step.fp.ch_per_wg - 1) / step.fp.ch_per_wg;
+            const long long one_round = (long long) c->compute_units * ((c->N == 4096 && step.fp.ch_per_wg > 4) ? 1 : 2);
+            const bool one_launch = step.fp.direct_state && fxk::frame_tail_kernel_available(c->N) &&
+                                    ((c->test_hooks & FX_HOOK_TAIL_ALWAYS_FUSED) || (!(c->test_hooks & FX_HOOK_TAIL_NEVER_FUSED) && groups <= one_round));
+            if (one_launch) {
+                HIP_TRY(fxk::launch_frame_tail_kernel(c->N, step.fp, step.ep, c->stream));
+                if (last) FX_EV(e1);
+            } else {
+                HIP_TRY(launch_frames(c, step));
+                if (last) FX_EV(e1);
+                HIP_TRY(fxk::launch_epilogue_kernels(step.ep, c->stream));
+            }
+            if (last) FX_EV(e2);
+        }
+        advance(c, part_T);
     }
 #undef FX_EV
     c->ev_valid = last_valid;
