@@ -1076,6 +1076,7 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
         data = torch.randn((C5, B5 - 1, 2), generator=g, device="cuda:%d" % dev, dtype=torch.float32)
         out4 = torch.empty((C5, 4), device=mags.device, dtype=torch.float32)
         out1 = torch.empty((C5,), device=mags.device, dtype=torch.float32)
+        out3 = torch.empty((C5, 3), device=mags.device, dtype=torch.float32)
         peaks = torch.empty((C5,), device=mags.device, dtype=torch.int32)
         freqs = torch.empty((C5,), device=mags.device, dtype=torch.float64)
         vp = ctypes.c_void_p
@@ -1083,6 +1084,7 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
             "spectral_characteristics": lambda: lib.fx_offline_spectral_characteristics(an5._h, vp(mags.data_ptr()), B5, vp(out4.data_ptr()), fx.capi.MEM_DEVICE),
             "spectral_slope": lambda: lib.fx_offline_spectral_slope(an5._h, vp(mags.data_ptr()), B5, vp(out1.data_ptr()), fx.capi.MEM_DEVICE),
             "auto_correlation": lambda: lib.fx_offline_auto_correlation(an5._h, vp(data.data_ptr()), B5 - 1, vp(peaks.data_ptr()), vp(freqs.data_ptr()), fx.capi.MEM_DEVICE),
+            "harmonic_characteristics": lambda: lib.fx_offline_harmonic_characteristics(an5._h, vp(mags.data_ptr()), B5, vp(out3.data_ptr()), fx.capi.MEM_DEVICE),
         }
         torch.cuda.synchronize(dev)
         res = {"workload": "%d analysers x one frame of %d magnitudes per call, device-resident" % (C5, B5),

@@ -37,7 +37,8 @@ constexpr int MAX_BINS = 4097;          // windowSize / 2 + 1 for windows up to 
 // of one kernel run on different LANES of a wave (a lane per chain costs what one chain costs) or on different waves.  What is left is the
 // latency of a dependent v_add_f64, ~10 ns: measured (tools/offline_timing.py, 1024 analysers x 1025 bins, us per call, as shipped / with the
 // chains cut out): spectral characteristics 40.9 / 13.2 (round 5: 77), slope 40.2 / 5.1 (49), auto-correlation 10.4 (40: its 256-entry serial
-// maximum became a butterfly); at 4097 bins 424 / 70 and 357 / 26.  Batches of 16 / 32: 42.2 / 51.9 and 36.5 / 44.2 -- not kept.
+// maximum became a butterfly); at 4097 bins 424 / 70 and 357 / 26.  Batches of 16 / 32: 42.2 / 51.9 and 36.5 / 44.2 -- not kept.  The harmonic
+// characteristics (85 -> 53 us): peak positions by a shuffle prefix sum, the histogram's pairs a wave per new peak, the best candidate by butterflies.
 #ifndef FX_EXP_OFFLINE_BATCH
 #define FX_EXP_OFFLINE_BATCH 8
 #endif
@@ -190,10 +191,10 @@ __global__ void __launch_bounds__(NT) harmonic_characteristics_kernel(const floa
     int* key = cnt + num_bins + (num_bins & 1);                            // [num_bins] where the interval first entered the histogram
     double* term = reinterpret_cast<double*>(cnt);                         // [<= num_bins] inharmonicity terms (cnt / key are free by then)
     __shared__ double s_sum, s_f0, s_her;
-    __shared__ int s_chunk[NT], s_np;
-    __shared__ double s_w[NT], s_fr[NT], s_hr[NT];
-    __shared__ int s_k[NT];
-    const int c = blockIdx.x, tid = threadIdx.x;
+    __shared__ int s_wave_peaks[NT / 64];
+    __shared__ double s_w[NT / 64], s_fr[NT / 64], s_hr[NT / 64];
+    __shared__ int s_k[NT / 64];
+    const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < num_bins; i += NT) { mag[i] = mags[(size_t) c * num_bins + i]; cnt[i] = 0; key[i] = 0x7fffffff; }
     __syncthreads();
     if (tid == 0) {                                                        // :264-268: the reference's serial sum (its last bit decides `mag > mean`)
@@ -210,25 +211,29 @@ __global__ void __launch_bounds__(NT) harmonic_characteristics_kernel(const floa
     const int run = (num_bins + NT - 1) / NT, b0 = tid * run, b1 = min(num_bins, b0 + run);
     int mine = 0;
     for (int b = b0; b < b1; b++) mine += bin_is_peak(b, mag, num_bins, mean) ? 1 : 0;
-    s_chunk[tid] = mine;
+    int before = mine;                                                     // where this thread's peaks go: a prefix sum over the block (integers: any order)
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(before, o, 64); if (lane >= o) before += v; }
+    if (lane == 63) s_wave_peaks[wave] = before;
     __syncthreads();
-    if (tid == 0) { int acc = 0; for (int k = 0; k < NT; k++) { const int v = s_chunk[k]; s_chunk[k] = acc; acc += v; } s_np = acc; }
-    __syncthreads();
+    int np = 0;
     {
-        int at = s_chunk[tid];
+        int at = before - mine;
+        for (int w = 0; w < NT / 64; w++) { if (w < wave) at += s_wave_peaks[w]; np += s_wave_peaks[w]; }
         for (int b = b0; b < b1; b++) if (bin_is_peak(b, mag, num_bins, mean)) peaks[at++] = b;
     }
     __syncthreads();
-    const int np = s_np;
     // the frequency histogram (:395-408): one entry per distinct distance between two peaks, counting the pairs; the reference
     // appends an interval when it first meets it -- scanning new peaks j upwards and, for each, earlier peaks p upwards -- and
     // that order breaks ties below
-    for (int j = tid; j < np; j += NT)
-        for (int p = 0; p < j; p++) {
-            const int d = peaks[j] - peaks[p];
+    // (a wave per new peak j, its lanes across the earlier peaks p: the pairs of the longest rows are not one thread's)
+    for (int j = wave; j < np; j += NT / 64) {
+        const int pj = peaks[j];
+        for (int p = lane; p < j; p += 64) {
+            const int d = pj - peaks[p];
             atomicAdd(&cnt[d], 1);
             atomicMin(&key[d], j * 8192 + p);
         }
+    }
     __syncthreads();
     // estimateF0AndHERFromFrequencyHistogram (:419-441): the candidate with the largest count x harmonic energy ratio, the
     // first such in histogram order (`>` against a running maximum that starts at 0)
@@ -242,12 +247,19 @@ __global__ void __launch_bounds__(NT) harmonic_characteristics_kernel(const floa
         const double w = (double) cnt[d] * her;                            // :64-67
         if (w > best_w || (w == best_w && w > 0.0 && key[d] < best_k)) { best_w = w; best_f = freq; best_h = her; best_k = key[d]; }
     }
-    s_w[tid] = best_w; s_fr[tid] = best_f; s_hr[tid] = best_h; s_k[tid] = best_k;
+    // (largest weight, then first in histogram order) is a total order on the candidates with a weight above 0 -- the only ones ever taken; the
+    // others all read (0, 0, 0, max): butterflies inside a wave, then the four wave results
+    for (int o = 32; o > 0; o >>= 1) {
+        const double w = __shfl_xor(best_w, o, 64), f = __shfl_xor(best_f, o, 64), h = __shfl_xor(best_h, o, 64);
+        const int k = __shfl_xor(best_k, o, 64);
+        if (w > best_w || (w == best_w && w > 0.0 && k < best_k)) { best_w = w; best_f = f; best_h = h; best_k = k; }
+    }
+    if (lane == 0) { s_w[wave] = best_w; s_fr[wave] = best_f; s_hr[wave] = best_h; s_k[wave] = best_k; }
     __syncthreads();
     if (tid == 0) {
         double w = 0.0, f0 = 0.0, her = 0.0;
         int k = 0x7fffffff;
-        for (int q = 0; q < NT; q++)
+        for (int q = 0; q < NT / 64; q++)
             if (s_w[q] > w || (s_w[q] == w && w > 0.0 && s_k[q] < k)) { w = s_w[q]; f0 = s_fr[q]; her = s_hr[q]; k = s_k[q]; }
         const double previous = prev_f0[c];
         if (previous != f0 && previous > 10.0) {                           // :273-291
@@ -501,7 +513,7 @@ fx_status fx_offline_create(fx_offline** out, int device_id, int num_channels, d
     if (e == hipSuccess) e = hipMalloc((void**) &o->d_prev_f0, sizeof(double) * (size_t) num_channels);
     if (e == hipSuccess) e = hipMemsetAsync(o->d_prev_f0, 0, sizeof(double) * (size_t) num_channels, o->stream);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&harmonic_characteristics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   (int) harmonic_lds_bytes(MAX_BINS));      // (beside ~9 KB of static LDS)
+                                                   (int) harmonic_lds_bytes(MAX_BINS));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectral_characteristics_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int) (SPECTRAL_LDS_PER_BIN * MAX_BINS));
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&spectral_slope_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
