@@ -871,7 +871,8 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
                     d = time.perf_counter() - t_s
                     dt_ref = d if dt_ref is None or d < dt_ref else dt_ref
             rec["one_call"] = {"samples_per_channel": int(flat.shape[1] - 1), "ms_through_push_samples": dt_all * 1e3, "ms_as_whole_hops": dt_ref * 1e3,
-                               "reblocked_bytes": int(2 * (flat.shape[1] - 1) * c4 * 4)}
+                               "sample_bytes": int((flat.shape[1] - 1) * c4 * 4),
+                               "note": "1024-point windows: the batch kernel reads [pending | block] itself (no re-blocking pass since round 6)"}
             if c4 == 1024:
                 # the same blocks from HOST memory, where an audio callback has them: fx_push_samples on a host block (a synchronous call: copy in,
                 # analysis, vectors out) and the pinned ring's form (fx_stream_push_samples / fx_stream_collect_samples, three blocks in flight)
