@@ -4,10 +4,11 @@
 // (fewer than window/2, the `carry`: a 16-byte aligned row) followed by the block just delivered (a row of the caller's buffer, at
 // whatever alignment the block length gives it).
 //
-// Used by fx_reblock.hip (the byte mover behind calls that complete several hops, or none) and by the one-frame kernels' load stage
-// (BLOCKS forms of fx_hop_kernel / fx_frame_kernel<direct> / fx_frame_tail_kernel): a call that completes exactly one hop -- the live
-// case: 441 / 480 / 512-sample device blocks against hops of 512 .. 2048 -- reads its window straight from the two pieces and writes only
-// what is left over, so a sample crosses HBM once on its way in instead of three times.
+// Used by fx_reblock.hip (the byte mover behind the calls the kernels do not read themselves) and by the kernels' load stage (BLOCKS forms
+// of fx_hop_kernel / fx_frame_kernel<direct> / fx_frame_tail_kernel, one launch per hop of a call that completes one or two -- the live
+// case: 441 / 480 / 512 / 960 / 1024-sample device blocks against hops of 512 .. 2048 -- and, at 1024 points, of the batch kernel for calls of
+// any length): the window is read straight from the two pieces and only what is left over is written, so a sample crosses HBM once on
+// its way in instead of three times.
 // Included inside namespace fxk; not a stand-alone header.
 
 struct BlockStream {
