@@ -45,3 +45,12 @@ def test_no_frame_tail_kernel_below_1024_points(fx):
     names = [k["pretty"] for k in kr.kernels_of()]
     assert "fxk::fx_frame_tail_kernel<1024, false>" in names
     assert not any(n in names for n in ("fxk::fx_frame_tail_kernel<256, false>", "fxk::fx_frame_tail_kernel<512, false>", "fxk::fx_frame_tail_kernel<256>", "fxk::fx_frame_tail_kernel<512>"))
+
+
+def test_design_md_stays_a_design_document():
+    """Round 5's review: DESIGN.md had grown into a 900-line lab notebook of 200-900-character lines.  It is the design as it stands, in at most
+    300 lines of at most 120 columns; chronology lives in profiles/NOTEBOOK.md."""
+    lines = open(os.path.join(ROOT, "DESIGN.md"), encoding="utf-8").read().splitlines()
+    assert len(lines) <= 300, len(lines)
+    long = [(i, len(l)) for i, l in enumerate(lines, 1) if len(l) > 120]
+    assert not long, long
