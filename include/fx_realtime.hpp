@@ -500,8 +500,8 @@ public:
     OSCBatchSender (const OSCBatchSender&) = delete;
     OSCBatchSender& operator= (const OSCBatchSender&) = delete;
 
-    // publish formed messages: message i at datagrams + i * stride, lengths[i] bytes (copied)
-    void updateDatagrams (const unsigned char* datagrams, int stride, const int* lengths, int count) { check (fx_osc_sender_update (sender, datagrams, stride, lengths, count)); }
+    // publish formed messages: message i at datagrams + i * stride, messageLengths[i] bytes (copied)
+    void updateDatagrams (const unsigned char* datagrams, int stride, const int* messageLengths, int count) { check (fx_osc_sender_update (sender, datagrams, stride, messageLengths, count)); }
     // publish smoothed vectors [count][12] (AudioFeatures slot order) of tracks "<prefix><firstChannel + i>", formed on the host
     void updateFeatures (const std::string& prefix, int firstChannel, const float* smoothed12, int count)
     {
