@@ -35,22 +35,16 @@ constexpr int MAX_BINS = 4097;          // windowSize / 2 + 1 for windows up to 
 // The reference's serial sums, as ONE LANE runs them: t[0] + t[1] + ... in index order, from 0.0, nothing re-associated.  What can be done for
 // speed without touching the order: the loads of a batch of eight terms are issued before the batch ahead of it is added, and independent chains
 // of one kernel run on different LANES of a wave (a lane per chain costs what one chain costs) or on different waves.  What is left is the
-// latency of a dependent v_add_f64, ~10 ns: measured (tools/offline_timing.py, 1024 analysers x 1025 bins, us per call, as shipped / with the
-// chains cut out): spectral characteristics 40.9 / 13.2 (round 5: 77), slope 40.2 / 5.1 (49), auto-correlation 10.4 (40: its 256-entry serial
+// latency of a dependent v_add_f64, ~10 ns: measured (tools/offline_timing.py, 1024 analysers x 1025 bins, us per call, as shipped / in an
+// experiment build with the chains cut out): spectral characteristics 40.9 / 13.2 (round 5: 77), slope 40.2 / 5.1 (49), auto-correlation 10.4 (40: its 256-entry serial
 // maximum became a butterfly); at 4097 bins 424 / 70 and 357 / 26.  Batches of 16 / 32: 42.2 / 51.9 and 36.5 / 44.2 -- not kept.  The harmonic
 // characteristics (85 -> 53 us): peak positions by a shuffle prefix sum, the histogram's pairs a wave per new peak, the best candidate by butterflies.
-#ifndef FX_EXP_OFFLINE_BATCH
-#define FX_EXP_OFFLINE_BATCH 8
-#endif
 template <typename T, bool PRODUCT>
 __device__ __forceinline__ double serial_chain(const T* t, int n)
 {
-    constexpr int B = FX_EXP_OFFLINE_BATCH;
+    constexpr int B = 8;
     double acc = PRODUCT ? 1.0 : 0.0;
     int i = 0;
-#ifdef FX_EXP_OFFLINE_NO_CHAIN                                               // (timing experiment: what the kernels cost without their serial parts)
-    return n > 0 ? (double) t[n - 1] : acc;
-#endif
     if (n >= B) {
         T cur[B], nxt[B];
 #pragma unroll
