@@ -37,7 +37,7 @@ constexpr int MAX_BINS = 4097;          // windowSize / 2 + 1 for windows up to 
 // of one kernel run on different LANES of a wave (a lane per chain costs what one chain costs) or on different waves.  What is left is the
 // latency of a dependent v_add_f64, ~10 ns: measured (tools/offline_timing.py, 1024 analysers x 1025 bins, us per call, as shipped / in an
 // experiment build with the chains cut out): spectral characteristics 40.9 / 13.2 (round 5: 77), slope 40.2 / 5.1 (49), auto-correlation 10.4 (40: its 256-entry serial
-// maximum became a butterfly); at 4097 bins 424 / 70 and 357 / 26.  Batches of 16 / 32: 42.2 / 51.9 and 36.5 / 44.2 -- not kept.  The harmonic
+// maximum became a butterfly); at 4097 bins 424 / 70 and 357 / 26 (the slope 205 since its workgroup fits a CU twice: 16 bytes of LDS per bin).  Batches of 16 / 32: 42.2 / 51.9 and 36.5 / 44.2 -- not kept.  The harmonic
 // characteristics (85 -> 53 us): peak positions by a shuffle prefix sum, the histogram's pairs a wave per new peak, the best candidate by butterflies.
 template <typename T, bool PRODUCT>
 __device__ __forceinline__ double serial_chain(const T* t, int n)
@@ -400,19 +400,20 @@ __global__ void __launch_bounds__(NT) spectral_characteristics_kernel(const floa
 
 // ---- ref AudioAnalysis.h:566-609 calculateNormalisedSpectralSlope: block = channel; the maximum in parallel (order does not matter),
 // each bin's quotient and squares by the whole block, the double sums by one thread in the reference's order ----
-// LDS: e[bins] doubles | t[bins] doubles | mag[bins] floats = 20 bytes per bin
-constexpr size_t SLOPE_LDS_PER_BIN = 2 * sizeof(double) + sizeof(float);
+// LDS: e[bins] doubles | t[bins] doubles = 16 bytes per bin (66 KB at 4097 bins: two workgroups per CU; the magnitudes are read twice from
+// global memory -- the second time from the L2 -- instead of being kept)
+constexpr size_t SLOPE_LDS_PER_BIN = 2 * sizeof(double);
 __global__ void __launch_bounds__(NT) spectral_slope_kernel(const float* mags, int num_bins, float* out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* te = reinterpret_cast<double*>(smem);                           // e_i = mag[i] / magnitude
     double* tt = te + num_bins;                                             // first pass: i * e_i; second: (e_i - mean)^2
-    float* mag = reinterpret_cast<float*>(tt + num_bins);
     __shared__ float s_wave[NT / 64];
     __shared__ double s_chain[2];
     const int c = blockIdx.x;
+    const float* mag = mags + (size_t) c * num_bins;
     float peak = 0.0f;
-    for (int i = threadIdx.x; i < num_bins; i += NT) { const float v = mags[(size_t) c * num_bins + i]; mag[i] = v; const float a = fabsf(v); if (a > peak) peak = a; }
+    for (int i = threadIdx.x; i < num_bins; i += NT) { const float a = fabsf(mag[i]); if (a > peak) peak = a; }
     peak = block_max(peak, s_wave);
     const double bins = (double) num_bins, mean_bin = 0.5, magnitude = (double) peak;        // getMagnitude, :573
     if (!(magnitude > 0.0001)) { if (threadIdx.x == 0) out[c] = 0.0f; return; }
