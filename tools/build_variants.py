@@ -2,7 +2,8 @@
 GPU box spends its minutes measuring, not compiling.  Only the kernel unit the flags concern is recompiled (small = windows
 <= 1024, large = 2048 / 4096, hop); the rest is linked from the shipped objects.
 Usage: python tools/build_variants.py small|large|hop|offline name=flags [name=flags ...]        (flags: quoted, space separated)
-On the box: cp feature-extractor_amd/lib/variants/<name>.so feature-extractor_amd/lib/libfx_hip.so  (tools/section_costs.sh does)"""
+On the box a variant is selected by path: FX_LIBRARY_OVERRIDE=feature-extractor_amd/lib/variants/<name>.so (feature-extractor_amd/capi.py); the shipped
+library is never overwritten (tools/ab_variants.sh, ab_blocks.sh, section_costs.sh, fma_experiment.sh do that)."""
 import os, subprocess, sys
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
