@@ -767,7 +767,7 @@ def extras(out, args, engine, fx, an, frames, raw, sm, N, count, T, launch_bytes
             tf = flops_per_frame(n2) * c2 * t2 / (fms / 1e3) / 1e12
             others[str(n2)] = {"value": fps, "unit": "frames/s", "frame_kernel_ms": fms, "workload": "%s, %d frames per step" % (label, t2),
                                "hbm_frac": b2 / (fms / 1e3) / 1e9 / HBM_PEAK_GBPS, "achieved_tflops": tf, "compute_frac_no_fma": tf / FP32_NO_FMA_PEAK_TFLOPS}
-            # the same launches in the low-latency family: every frame on a PAIR of wavefronts (fx_pair_kernel, FX_LOW_LATENCY; DESIGN.md 3.1b)
+            # the same launches in the low-latency family: every frame on a PAIR of wavefronts (fx_pair_kernel, FX_LOW_LATENCY; DESIGN.md 3.3)
             an2 = fx.BatchAnalyser(c2, n2, device=dev, low_latency=True)
             fps_p, fms_p = max(time_steps(an2, fr2, None, None, 2 * extra_steps, warmup=5) for _ in range(2))
             an2.close()

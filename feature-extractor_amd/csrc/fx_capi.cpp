@@ -295,7 +295,7 @@ fx_status prepare_step(fx_context* c, const void* d_in, int T, int sample_format
     st->analysers = (c->flags & FX_SPECTRAL_ONLY) ? 1 : ((c->flags & FX_HARMONIC_ONLY) ? 2 : 3);
     // The low-latency family (opt-in: FX_LOW_LATENCY, or fx_tuning::waves_per_frame = 2): windows of 2048 / 4096 points with both
     // analysers run one frame across a PAIR of wavefronts -- fx_pair_kernel for calls of several frames, fx_hop_pair_kernel for
-    // one frame per call.  The default family keeps a frame in one wavefront at every size (pairs are the faster
+    // one frame per call.  The default family keeps a frame in one wavefront at every size (profiles/NOTEBOOK_design_r1-r5.md: pairs are the faster
     // path for one hop, not for throughput).
     st->pair = st->hop_pairs = uses_pairs(c, c->tuning.waves_per_frame);
     {

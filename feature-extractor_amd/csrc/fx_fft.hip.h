@@ -105,7 +105,7 @@ template <bool INV> __device__ __forceinline__ f2 twmul(f2 a, f2 t)
 #ifdef FX_EXP_FMA_TWIDDLES
     // EXPERIMENT BUILD ONLY (round 5, profiles/r05_fma_experiment.txt): the second product fused into the sum -- two packed instructions, one
     // rounding fewer per component, and spectra that are no longer the reference's.  What the FMA lever is worth on this chip, measured;
-    // the library is never built with it ("Round 5").
+    // the library is never built with it (profiles/r05_fma_experiment.txt).
     if (INV) {
         asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(p) : "v"(a), "v"(t));
         asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(t), "v"(p));

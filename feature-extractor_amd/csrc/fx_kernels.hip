@@ -17,7 +17,7 @@
 //   * reductions over bins run in fp64 (the reference accumulates in double) and are combined with
 //     DPP row operations; the few places where serial ORDER is semantics (flatness product, low-pass,
 //     lag scan, flat-spectrum ties) are handled exactly.
-//   * the kernel is bound by VALU issue first and the LDS pipe second (DESIGN.md 3.3), so values that only one
+//   * the kernel is bound by VALU issue first and the LDS pipe second (DESIGN.md 3.7), so values that only one
 //     lane produces go straight to global memory and lane-to-lane hand-overs use DPP / ds_bpermute where the
 //     data already sits in the right lane's registers.
 //   * fx_finalise_kernel (thread = frame) runs the scalar tail (logRMS, pow, log10, sqrt, divisions);

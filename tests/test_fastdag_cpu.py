@@ -1,4 +1,4 @@
-"""tools/fastdag/fastdag.c (the CPU study behind DESIGN.md 3.3 "Round 5") builds and runs: a few thousand frames of the stress mix through the
+"""tools/fastdag/fastdag.c (the CPU study behind DESIGN.md 3.7; profiles/r05_fastdag.txt) builds and runs: a few thousand frames of the stress mix through the
 oracle and the variant transform DAG.  The committed record of the full run is profiles/r05_fastdag.txt; this keeps the tool alive and checks
 the two facts the conclusion rests on at small scale: with FMA as the ONLY change a few per cent of the mix's frames already leave the 1e-5 bar,
 and on bench.py's own signal next to none do."""
